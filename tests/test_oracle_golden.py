@@ -1,0 +1,93 @@
+"""Pins the CPU oracle against the reference's golden vectors (tests/golden/*.npz,
+extracted by tests/golden/make_golden.py from the reference's own test files) and
+against outputs of the reference's neurst_pt front-end.  Tolerance is the
+reference's own: sum of squared differences < 1e-9 (literal vectors)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import neurst_oracle as O
+
+
+def _ssd(a, b):
+    return float(((a.detach().numpy().astype(np.float64) - b.astype(np.float64)) ** 2).sum())
+
+
+def test_mha_cross_golden():
+    # tests/neurst/layers/attentions/multi_head_attention_test.py:7-60
+    r, W = load_golden("mha_cross")
+    W = {"a/" + k: v for k, v in W.items()}
+    out = O.cross_attention(torch.from_numpy(r["query"]), torch.from_numpy(r["memory"]), W, "a",
+                            int(r["num_heads"]), None)
+    assert _ssd(out, r["expected"]) < 1e-9
+
+
+def test_mha_self_golden():
+    # tests/neurst/layers/attentions/multi_head_attention_test.py:63-111
+    r, W = load_golden("mha_self")
+    W = {"a/" + k: v for k, v in W.items()}
+    out = O.self_attention(torch.from_numpy(r["query"]), W, "a", int(r["num_heads"]), torch.from_numpy(r["bias"]))
+    assert _ssd(out, r["expected"]) < 1e-9
+
+
+def test_encoder_golden():
+    # tests/neurst/layers/encoders/transformer_encoder_test.py:21-122
+    r, W = load_golden("transformer_encoder")
+    W = O.fill_default_biases(W)
+    out = O.transformer_encoder(torch.from_numpy(r["inputs"]), torch.from_numpy(r["input_padding"]), W,
+                                "TransformerEncoder", int(r["num_layers"]), int(r["num_heads"]))
+    assert _ssd(out, r["expected"]) < 1e-9
+
+
+def test_decoder_golden():
+    # tests/neurst/layers/decoders/transformer_decoder_test.py:20-158
+    r, W = load_golden("transformer_decoder")
+    W = O.fill_default_biases(W)
+    out = O.transformer_decoder(torch.from_numpy(r["decoder_inputs"]), torch.from_numpy(r["encoder_outputs"]),
+                                torch.from_numpy(r["encoder_inputs_padding"]), W, "TransformerDecoder",
+                                int(r["num_layers"]), int(r["num_heads"]))
+    assert _ssd(out, r["expected"]) < 1e-9
+
+
+def test_position_embedding_golden():
+    # tests/neurst/layers/common_layers_test.py:96-152
+    r, _ = load_golden("position_embedding")
+    table = torch.from_numpy(r["table"])
+    out2d = O.position_embedding(O.word_embedding(torch.from_numpy(r["inputs2d"]), table))
+    assert _ssd(out2d, r["expected_2d"]) < 1e-9
+    out1d = O.position_embedding(O.word_embedding(torch.from_numpy(r["inputs1d"]), table), time=3)
+    assert _ssd(out1d, r["expected_1d_time3"]) < 1e-9
+
+
+def test_full_transformer_logits_golden():
+    # tests/neurst/models/transformer_test.py:23-666 (2+2 layers, d=8, H=2, ffn=10)
+    r, W = load_golden("transformer_toy_logits")
+    W = O.fill_default_biases(W)
+    inputs = {"src": torch.from_numpy(r["src"]), "src_padding": torch.from_numpy(r["src_padding"]),
+              "trg_input": torch.from_numpy(r["trg_input"])}
+    logits = O.transformer_logits(inputs, W, {"num_enc": 2, "num_dec": 2, "num_heads": 2})
+    assert _ssd(logits, r["expected"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["frontend_ln", "frontend_noln", "frontend_ragged"])
+def test_frontend_matches_reference_neurst_pt(tag):
+    # outputs of the reference's own neurst_pt AudioConvSubsamplingLayer
+    # (neurst_pt/layers/modalities/audio_modalities.py:22-100) run under the shim of make_golden.py;
+    # tolerance of tests/neurst_pt/modalities/audio_modalities_test.py (5e-5 with LN)
+    r, W = load_golden("neurst_pt_" + tag)
+    out = O.audio_conv_subsample(torch.from_numpy(r["src"]), W, "input_audio_modality", bool(int(r["layer_norm"])))
+    np.testing.assert_allclose(out.numpy(), r["expected"], atol=5e-5, rtol=0)
+
+
+def test_causal_bias_matrix():
+    # tests/neurst_pt/layers/layer_utils_test.py:20
+    b = O.lower_triangle_attention_bias(3)[0, 0]
+    assert torch.equal(b == 0, torch.tril(torch.ones(3, 3)).bool())
+    assert float(b[0, 1]) == -1e9
+
+
+def test_length_after_conv():
+    # neurst/models/speech_transformer.py:182-183
+    for l, e in [(1, 1), (2, 1), (3, 1), (4, 1), (5, 2), (11, 3), (900, 225), (899, 225), (897, 225), (896, 224)]:
+        assert O.length_after_conv(l) == e
