@@ -1,0 +1,223 @@
+/*
+ * libneurst_hip.so -- C ABI of the MI355X-native SpeechTransformer training hot path.
+ *
+ * The reference (bytedance/neurst) is pure Python on TensorFlow: it has no FFI
+ * boundary of its own.  Every entry point below REPLACES the third-party
+ * TensorFlow kernel (or Horovod call) that the cited reference line dispatches
+ * to; INTEGRATION.md shows the ctypes stub a NeurST maintainer binds them with.
+ * Citations are file:line relative to the reference repository root.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / STL types.
+ *  - every pointer is a DEVICE pointer owned by the caller (the PyTorch caching
+ *    allocator in our host); the library allocates nothing persistent.
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
+ *  - return 0 on success, a negative NST_ERR_* otherwise; the message is
+ *    available from nst_last_error_string() (thread local).  Never aborts,
+ *    never throws.
+ *  - row-major contiguous tensors unless a leading dimension is given.
+ *  - weights are in the reference's TensorFlow layout ([in,out] dense kernels,
+ *    q|k|v packed projection columns, [H*dh,out] output projection, HWIO conv
+ *    kernels, [V,d] shared embedding) so TF checkpoints map 1:1.
+ *  - dtype: NST_F32 or NST_BF16 activations; LayerNorm statistics, softmax,
+ *    loss, gradients of parameters and optimizer state are always fp32.
+ */
+#ifndef NEURST_HIP_H_
+#define NEURST_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NST_ABI_VERSION 1
+
+enum { NST_F32 = 0, NST_BF16 = 1 };
+
+enum {
+  NST_OK = 0,
+  NST_ERR_INVALID_ARG = -1,
+  NST_ERR_LAUNCH = -2,
+  NST_ERR_UNSUPPORTED = -3,
+  NST_ERR_WORKSPACE = -4
+};
+
+int nst_abi_version(void);
+const char* nst_last_error_string(void);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * tf.keras.layers.LayerNormalization(epsilon, dtype=float32) over the last axis:
+ *   neurst/layers/common_layers.py:64-65,77 (pre-norm), transformer_encoder.py:98-100,135,
+ *   transformer_decoder.py:99-101,225 (output_ln).
+ * x,y: [rows,d] dtype; gamma,beta: [d] f32; mean,rstd: [rows] f32 (saved for bwd). */
+int nst_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int d, float eps, int dtype, void* stream);
+/* dgamma/dbeta [d] f32 are ACCUMULATED into (+=) when accumulate!=0, else overwritten.
+ * dres (nullable, [rows,d] dtype) is added to dx: the gradient arriving through the residual branch of
+ * PrePostProcessingWrapper (inputs + y, common_layers.py:85), so no separate add pass is needed. */
+int nst_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                      int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ GEMM with fused epilogue
+ * Replaces tf.einsum/tf.matmul/Dense on the path:
+ *   MultiHeadDenseLayer.call  neurst/layers/common_layers.py:262-288 (qkv / q / kv / output projections)
+ *   TransformerFFN.call       neurst/layers/common_layers.py:156-159 (dense1+relu+dropout, dense2)
+ *   AudioConv2dSubsamplingLayer output_dense  neurst/layers/modalities/audio_modalities.py:107-108
+ *   WordEmbeddingSharedWeights._top  neurst/layers/modalities/text_modalities.py:103-108 (tied logits)
+ * and their gradients (TF autodiff of the same ops).
+ *
+ *   C[M,N] = epilogue( alpha * op(A)[M,K] @ op(B)[K,N] )
+ * trans_a==0: A stored [M,K] (lda); trans_a==1: A stored [K,M] (lda).
+ * trans_b==0: B stored [K,N] (ldb); trans_b==1: B stored [N,K] (ldb).
+ * Epilogue, applied in this order to v = alpha*acc:
+ *   +bias[col] (f32) -> relu -> dropout(p; Philox(seed,stream_id, row*N+col)) -> +residual[row,col]
+ *   -> *gate (gate_src[row,col] > 0 ? gate_scale : 0)   [backward of relu+dropout from the saved activation]
+ *   -> (v*emb_scale + posenc[row % posenc_period, col])   [PositionEmbeddingWrapper, common_layers.py:427-434]
+ *   -> C = v  or  C += v (accumulate)
+ * split_k > 1 partitions K over grid.z and adds partial products atomically into an f32 C
+ * (requires out_dtype==NST_F32 and no nonlinear epilogue; C is zeroed first unless accumulate). */
+typedef struct {
+  int M, N, K;
+  int trans_a, trans_b;
+  int64_t lda, ldb, ldc;
+  int in_dtype;   /* dtype of A and B */
+  int out_dtype;  /* dtype of C, residual and gate_src */
+  float alpha;
+  const float* bias;      /* [N] or NULL */
+  int relu;
+  float dropout_p;        /* 0 = off */
+  uint64_t seed, stream_id;
+  const void* residual;   /* [M,N] ld = ldr, or NULL */
+  int64_t ldr;
+  const void* gate_src;   /* [M,N] ld = ldg, or NULL */
+  int64_t ldg;
+  float gate_scale;
+  const float* posenc;    /* [posenc_period, N] f32 or NULL */
+  int posenc_period;
+  float emb_scale;
+  int accumulate;
+  int split_k;            /* <=1: off */
+} NstGemmDesc;
+
+int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
+
+/* Column sums: out[N] (f32) (+)= sum_rows x[rows,N] -- bias gradients. */
+int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ fused scaled-dot-product attention
+ * MultiHeadAttention.call / att_fn  neurst/layers/attentions/multi_head_attention.py:124-164, 203-215:
+ *   q *= dh^-0.5; logits = q.k^T + bias; softmax; dropout(p) on the probabilities; out = P.v
+ * q [B,Tq,H,dh] with row stride ldq (elements) between consecutive (b,t) rows (so the packed
+ * q|k|v projection output can be passed without a split copy); same for k,v (ldk, ldv) and out (ldo).
+ * key_bias: [B,Tk] f32 additive bias (padding * FLOAT_MIN, neurst/layers/layer_utils.py:19-32) or NULL.
+ * causal!=0 adds FLOAT_MIN where key > query (lower_triangle_attention_bias, layer_utils.py:35-53).
+ * lse [B,H,Tq] f32 = log-sum-exp of the biased logits, saved for backward. */
+typedef struct {
+  int B, H, Tq, Tk, dh;
+  int64_t ldq, ldk, ldv, ldo;
+  int dtype;
+  float scale;       /* dh^-0.5 */
+  int causal;
+  float float_min;   /* -1e9 (compat.FLOAT_MIN) */
+  float dropout_p;
+  uint64_t seed, stream_id;
+} NstAttnDesc;
+
+int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
+                      void* out, float* lse, void* stream);
+/* dq,dk,dv share the layouts/strides of q,k,v (ldq,ldk,ldv); dout that of out. delta [B,H,Tq] f32 workspace. */
+int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
+                      const void* out, const void* dout, const float* lse, float* delta, void* dq, void* dk,
+                      void* dv, void* stream);
+
+/* ------------------------------------------------------------------ conv2d-subsampling front end
+ * AudioConv2dSubsamplingLayer.call  neurst/layers/modalities/audio_modalities.py:84-109.
+ * Layer 1 (C_in = 1): pad 1 -> Conv2D 3x3 s2 VALID + bias -> LayerNorm(C, eps) -> ReLU, fused in one pass.
+ *   src [B,T,F] dtype f32 (the feature tensor is always f32), w1 [3,3,1,C] f32 (HWIO), out [B,T1,F1,C] dtype.
+ *   mean/rstd [B*T1*F1] f32 saved for backward (ignored / may be NULL when layer_norm==0). */
+int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const float* b1, const float* gamma,
+                          const float* beta, void* out, float* mean, float* rstd, int B, int T, int F, int C,
+                          int layer_norm, float eps, int out_dtype, void* stream);
+/* Recomputes the conv from src; dout is the gradient w.r.t. the ReLU output.  All parameter gradients f32,
+ * accumulated (+=) when accumulate!=0. */
+int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const float* b1, const float* gamma,
+                          const float* beta, const float* mean, const float* rstd, const void* dout, float* dw1,
+                          float* db1, float* dgamma, float* dbeta, int B, int T, int F, int C, int layer_norm,
+                          float eps, int dtype, int accumulate, void* stream);
+/* Layer 2 as an implicit GEMM on MFMA (M = B*T2*F2, N = C, K = 9*C), x [B,T1,F1,C] dtype, w2 [3,3,C,C] dtype (HWIO).
+ *   fwd:   y[B,T2,F2,C] = conv(x) + b2                    (LayerNorm+ReLU follow as nst_layernorm_fwd w/ relu)
+ *   dgrad: dx[B,T1,F1,C] = conv_transpose(dy, w2)
+ *   wgrad: dw2[3,3,C,C] f32 (+)= x (*) dy   */
+int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int dtype,
+                  void* stream);
+int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
+int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
+                    int accumulate, void* stream);
+
+/* LayerNorm + ReLU (second conv layer; audio_modalities.py:102-104) -- same contract as nst_layernorm_*,
+ * y = relu(LN(x)); backward takes dy w.r.t. the ReLU output and the saved y (gate y>0). */
+int nst_layernorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                           int64_t rows, int d, float eps, int dtype, void* stream);
+int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                           int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ target embedding
+ * WordEmbeddingSharedWeights._bottom + PositionEmbeddingWrapper.call
+ *   neurst/layers/modalities/text_modalities.py:84-93, neurst/layers/common_layers.py:415-434:
+ *   out[b,t,:] = table[ids[b,t],:] * emb_scale + posenc[t,:]   (then dropout p)
+ * table [V,d] dtype, ids int64 [rows], posenc [L,d] f32 or NULL, out [rows,d] dtype; rows = B*L. */
+int nst_embedding_fwd(const void* table, const int64_t* ids, const float* posenc, void* out, int64_t rows, int L,
+                      int d, int V, float emb_scale, float dropout_p, uint64_t seed, uint64_t stream_id, int dtype,
+                      void* stream);
+/* dtable [V,d] f32 += scatter-add of dout*emb_scale*(dropout mask) (sparse IndexedSlices made dense,
+ * neurst/training/hvd_utils.py:72-73).  Always accumulates (the tied logits GEMM writes the dense part first). */
+int nst_embedding_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t rows, int d, int V,
+                      float emb_scale, float dropout_p, uint64_t seed, uint64_t stream_id, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ elementwise dropout (+ scale, + posenc)
+ * tf.nn.dropout at transformer_encoder.py:125-127 / transformer_decoder.py:212-214 and the
+ * PositionEmbeddingWrapper scale+signal on the audio front-end output (common_layers.py:427-434):
+ *   y = dropout_p( x*scale + posenc[row % period, :] )          (posenc may be NULL)
+ * backward: dx = dy * mask * scale  (same Philox triple). */
+int nst_scale_posenc_dropout_fwd(const void* x, const float* posenc, void* y, int64_t rows, int d, int period,
+                                 float scale, float dropout_p, uint64_t seed, uint64_t stream_id, int dtype,
+                                 void* stream);
+int nst_scale_dropout_bwd(const void* dy, void* dx, int64_t n, float scale, float dropout_p, uint64_t seed,
+                          uint64_t stream_id, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ label-smoothed cross entropy
+ * LabelSmoothedCrossEntropy.__call__  neurst/criterions/label_smoothed_cross_entropy.py:94-157.
+ * logits [rows,V] dtype (ldl), labels int64 [rows], weights f32 [rows] (sequence_mask(trg_length)).
+ * fwd: xent[rows] f32 = (-(sum_v soft_v*log_softmax_v) - normalizing_constant) * weight ; lse[rows] f32 saved.
+ * bwd: dlogits[rows,V] dtype = (softmax - soft_target) * weight[row] * gscale    (gscale = 1/sum(n_tokens)) */
+int nst_ls_xent_fwd(const void* logits, const int64_t* labels, const float* weights, float* xent, float* lse,
+                    int64_t rows, int V, int64_t ldl, float label_smoothing, int dtype, void* stream);
+int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weights, const float* lse,
+                    void* dlogits, int64_t rows, int V, int64_t ldl, float label_smoothing, float gscale, int dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * Keras Adam (neurst/models/speech_transformer.py:265-279, neurst/optimizers/__init__.py) over ONE flat buffer:
+ *   m = b1*m+(1-b1)*g ; v = b2*v+(1-b2)*g^2 ; p -= lr_t * m/(sqrt(v)+eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+ * g is multiplied by grad_scale first (1/world_size for hvd.Average, neurst/training/hvd_utils.py:46-50).
+ * p,m,v,g f32 [n]; shadow (bf16 copy of p for the compute path) may be NULL. */
+int nst_adam_update(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n, float lr_t,
+                    float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* f32 -> bf16 cast (weight shadow refresh), bf16 -> f32, and fill. */
+int nst_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+int nst_cast_bf16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ probes (used by tests only)
+ * nst_probe_mfma: writes the raw lane->value maps of the MFMA / LDS-transpose-read instructions the
+ * kernels rely on, so the layout assumptions are verified on real hardware. */
+int nst_probe_mfma(float* out_c16, float* out_c16_f32, uint16_t* out_tr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURST_HIP_H_ */

@@ -1,0 +1,108 @@
+"""ctypes binding of libneurst_hip.so (include/neurst_hip.h).
+
+The library is the product: there is NO Python/CPU fallback.  If the shared
+object is missing or a symbol is absent the import raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
+
+NST_F32, NST_BF16 = 0, 1
+NST_ABI_VERSION = 1
+
+
+class NstGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("trans_a", C.c_int), ("trans_b", C.c_int),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("alpha", C.c_float),
+        ("bias", C.c_void_p),
+        ("relu", C.c_int),
+        ("dropout_p", C.c_float),
+        ("seed", C.c_uint64), ("stream_id", C.c_uint64),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("gate_src", C.c_void_p), ("ldg", C.c_int64),
+        ("gate_scale", C.c_float),
+        ("posenc", C.c_void_p), ("posenc_period", C.c_int),
+        ("emb_scale", C.c_float),
+        ("accumulate", C.c_int),
+        ("split_k", C.c_int),
+    ]
+
+
+class NstAttnDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("dh", C.c_int),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+        ("dtype", C.c_int),
+        ("scale", C.c_float),
+        ("causal", C.c_int),
+        ("float_min", C.c_float),
+        ("dropout_p", C.c_float),
+        ("seed", C.c_uint64), ("stream_id", C.c_uint64),
+    ]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> argtypes; every symbol declared in include/neurst_hip.h
+SIGNATURES = {
+    "nst_abi_version": [],
+    "nst_last_error_string": [],
+    "nst_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
+    "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P],
+    "nst_attention_fwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P],
+    "nst_attention_bwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nst_conv1_ln_relu_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nst_conv1_ln_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "nst_conv2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nst_conv2_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nst_conv2_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nst_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _U64, _U64, _I, _P],
+    "nst_embedding_bwd": [_P, _P, _P, _L, _I, _I, _F, _F, _U64, _U64, _I, _P],
+    "nst_scale_posenc_dropout_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _U64, _U64, _I, _P],
+    "nst_scale_dropout_bwd": [_P, _P, _L, _F, _F, _U64, _U64, _I, _P],
+    "nst_ls_xent_fwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _I, _P],
+    "nst_ls_xent_bwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _F, _I, _P],
+    "nst_adam_update": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
+    "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
+    "nst_cast_bf16_to_f32": [_P, _P, _L, _P],
+    "nst_probe_mfma": [_P, _P, _P, _P],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C neurst_amd/csrc -j8` (or `python -c 'import "
+            f"__graft_entry__ as g; g.build()'`).  neurst_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "nst_last_error_string" else C.c_int
+    ver = lib.nst_abi_version()
+    if ver != NST_ABI_VERSION:
+        raise ImportError(f"libneurst_hip.so ABI version {ver} != expected {NST_ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+class NstError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.nst_last_error_string()
+        raise NstError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,136 @@
+// Shared device/host helpers for libneurst_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/neurst_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float floatx4_t;
+
+#define NST_WAVE 64
+
+// ---------------------------------------------------------------------------
+// error plumbing: never abort, never throw across the ABI
+// ---------------------------------------------------------------------------
+void nst_set_error(const char* fmt, ...);
+
+#define NST_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      nst_set_error(__VA_ARGS__);                \
+      return NST_ERR_INVALID_ARG;                \
+    }                                            \
+  } while (0)
+
+#define NST_CHECK_LAUNCH(name)                                                    \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      nst_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+      return NST_ERR_LAUNCH;                                                      \
+    }                                                                             \
+  } while (0)
+
+#define NST_CHECK_HIP(expr)                                                       \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      nst_set_error("%s failed: %s", #expr, hipGetErrorString(e__));              \
+      return NST_ERR_LAUNCH;                                                      \
+    }                                                                             \
+  } while (0)
+
+static inline int nst_dtype_size(int dt) { return dt == NST_BF16 ? 2 : 4; }
+static inline bool nst_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------
+// bf16 <-> f32 (round to nearest even)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+// ---------------------------------------------------------------------------
+// wavefront (64-lane) reductions by shuffle
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter RNG for dropout.  One call yields 4 x u32 for the
+// element group (idx/4); element idx uses word idx%4.  The same
+// (seed, stream, idx) triple regenerates the same mask in backward.
+// ---------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t stream, uint64_t ctr) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+  return o;
+}
+// keep-multiplier for one element: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_keep_scale(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh,
+                                                    float inv_keep) {
+  Philox4 r = philox4x32_10(seed, stream, idx >> 2);
+  uint32_t sel = (uint32_t)(idx & 3);
+  uint32_t v = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+  return v >= thresh ? inv_keep : 0.0f;
+}
+static inline uint32_t nst_dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// sinusoid timing signal value for (position, channel) -- neurst/layers/common_layers.py:356-413
+__device__ __forceinline__ float sinusoid_value(int pos, int ch, int channels) {
+  int nts = channels >> 1;
+  if (ch >= 2 * nts) return 0.0f;  // odd channel count: zero pad
+  int i = ch < nts ? ch : ch - nts;
+  float inc = 9.210340371976184f / (float)(nts - 1);  // ln(1e4)/(nts-1)
+  float st = (float)pos * expf(-(float)i * inc);
+  return ch < nts ? sinf(st) : cosf(st);
+}

@@ -1,0 +1,536 @@
+// Conv2d-subsampling front end (AudioConv2dSubsamplingLayer.call, neurst/layers/modalities/audio_modalities.py:84-109).
+//
+// Layer 1 (C_in = 1, 9 taps): HBM-write bound -- one wavefront per output pixel, lanes own channels, the
+//   3x3 conv, LayerNorm over channels (wavefront shuffle reductions, fp32) and ReLU are fused so the largest
+//   activation of the model ([B, T/2, F/2, C]) is written exactly once and never re-read by a norm pass.
+//   Backward recomputes the conv from the (tiny) input instead of saving the pre-norm activation.
+// Layer 2 (C_in = C_out = C): implicit GEMM on MFMA (M = B*T2*F2 pixels, N = C, K = 9*C) through the loaders of
+//   nst_gemm_core.h: the im2col matrix is never materialised; out-of-image taps read zeros.
+//   dgrad splits the input pixels into the 4 stride-2 parity classes so every K step is a real tap
+//   (no multiply-by-zero work), wgrad reduces over the pixels with split-K.
+#include "nst_gemm_core.h"
+
+#include <stdlib.h>
+
+using namespace nstgemm;
+
+namespace {
+
+// =============================================================================================
+// layer 1
+// =============================================================================================
+constexpr int C1_SLOTS = 8;  // channels per lane (C <= 512)
+
+__device__ __forceinline__ int c1_channel(int lane, int s, int vec) { return vec ? lane * 4 + (s >> 2) * 256 + (s & 3) : lane + s * 64; }
+
+template <typename T, int S, bool VEC>
+__global__ void __launch_bounds__(256) conv1_fwd_kernel(const float* __restrict__ src, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ out,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
+                                                       int T_, int F, int C, int T1, int F1, int layer_norm, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[S][9], bias[S], g[S], be[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int c = c1_channel(lane, s, VEC);
+    const bool ok = c < C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[s][t] = ok ? w1[t * C + c] : 0.f;
+    bias[s] = ok ? b1[c] : 0.f;
+    g[s] = (ok && layer_norm) ? gamma[c] : 1.f;
+    be[s] = (ok && layer_norm) ? beta[c] : 0.f;
+  }
+  const int64_t npix = (int64_t)B * T1 * F1;
+  const float inv_c = 1.f / (float)C;
+  for (int64_t pix0 = (int64_t)blockIdx.x * 4 + wave; pix0 < npix; pix0 += (int64_t)gridDim.x * 4) {
+    const int64_t pix = pix0;
+    const int fo = (int)(pix % F1);
+    const int to = (int)((pix / F1) % T1);
+    const int b = (int)(pix / ((int64_t)F1 * T1));
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
+        x[kh * 3 + kw] = (ti >= 0 && ti < T_ && fi >= 0 && fi < F) ? src[((int64_t)b * T_ + ti) * F + fi] : 0.f;
+      }
+    float z[S];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float a = bias[s];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
+      z[s] = a;
+      sum += c1_channel(lane, s, VEC) < C ? a : 0.f;
+    }
+    if (layer_norm) {
+      const float mean = wave_sum(sum) * inv_c;
+      float sq = 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float d = c1_channel(lane, s, VEC) < C ? z[s] - mean : 0.f;
+        sq += d * d;
+      }
+      const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+#pragma unroll
+      for (int s = 0; s < S; ++s) z[s] = (z[s] - mean) * rstd * g[s] + be[s];
+      if (lane == 0) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
+    }
+    T* o = out + pix * C;
+    if (VEC) {
+#pragma unroll
+      for (int k = 0; k < S / 4; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c < C) {
+          const float v0 = fmaxf(z[k * 4], 0.f), v1 = fmaxf(z[k * 4 + 1], 0.f), v2 = fmaxf(z[k * 4 + 2], 0.f), v3 = fmaxf(z[k * 4 + 3], 0.f);
+          if (sizeof(T) == 2) {
+            uint2 raw;
+            raw.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+            raw.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+            *reinterpret_cast<uint2*>(o + c) = raw;
+          } else {
+            *reinterpret_cast<float4*>(o + c) = make_float4(v0, v1, v2, v3);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int c = lane + s * 64;
+        if (c < C) o[c] = from_f32<T>(fmaxf(z[s], 0.f));
+      }
+    }
+  }
+}
+
+// backward: accumulators per lane for its channels: dw[9], db, dgamma, dbeta
+template <typename T, int S, bool VEC>
+__global__ void __launch_bounds__(256) conv1_bwd_kernel(const float* __restrict__ src, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean_in,
+                                                       const float* __restrict__ rstd_in, const T* __restrict__ dout,
+                                                       float* __restrict__ dw1, float* __restrict__ db1,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T_,
+                                                       int F, int C, int T1, int F1, int layer_norm) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[S][9], bias[S], g[S], be[S];
+  float aw[S][9], ab[S], ag[S], abe[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int c = c1_channel(lane, s, VEC);
+    const bool ok = c < C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w[s][t] = ok ? w1[t * C + c] : 0.f; aw[s][t] = 0.f; }
+    bias[s] = ok ? b1[c] : 0.f;
+    g[s] = (ok && layer_norm) ? gamma[c] : 1.f;
+    be[s] = (ok && layer_norm) ? beta[c] : 0.f;
+    ab[s] = 0.f; ag[s] = 0.f; abe[s] = 0.f;
+  }
+  const int64_t npix = (int64_t)B * T1 * F1;
+  const float inv_c = 1.f / (float)C;
+  for (int64_t pix = (int64_t)blockIdx.x * 4 + wave; pix < npix; pix += (int64_t)gridDim.x * 4) {
+    const int fo = (int)(pix % F1);
+    const int to = (int)((pix / F1) % T1);
+    const int b = (int)(pix / ((int64_t)F1 * T1));
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
+        x[kh * 3 + kw] = (ti >= 0 && ti < T_ && fi >= 0 && fi < F) ? src[((int64_t)b * T_ + ti) * F + fi] : 0.f;
+      }
+    const float mean = layer_norm ? mean_in[pix] : 0.f;
+    const float rstd = layer_norm ? rstd_in[pix] : 1.f;
+    const T* go = dout + pix * C;
+    float xh[S], dxh[S];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int c = c1_channel(lane, s, VEC);
+      float a = bias[s];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
+      float gy = 0.f;
+      if (c < C) gy = to_f32<T>(go[c]);
+      if (layer_norm) {
+        const float xhat = (a - mean) * rstd;
+        const float y = xhat * g[s] + be[s];
+        gy = y > 0.f ? gy : 0.f;
+        ag[s] += gy * xhat;
+        abe[s] += gy;
+        const float d = gy * g[s];
+        xh[s] = xhat;
+        dxh[s] = d;
+        s1 += d;
+        s2 += d * xhat;
+      } else {
+        dxh[s] = a > 0.f ? gy : 0.f;
+        xh[s] = 0.f;
+      }
+    }
+    float c1 = 0.f, c2 = 0.f;
+    if (layer_norm) { c1 = wave_sum(s1) * inv_c; c2 = wave_sum(s2) * inv_c; }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float dz = layer_norm ? rstd * (dxh[s] - c1 - xh[s] * c2) : dxh[s];
+      const float dzc = c1_channel(lane, s, VEC) < C ? dz : 0.f;
+      ab[s] += dzc;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) aw[s][t] = fmaf(dzc, x[t], aw[s][t]);
+    }
+  }
+  // reduce the 4 waves of the block, then one atomic per (tap, channel) per block
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int c = c1_channel(lane, s, VEC);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float v = q < 9 ? aw[s][q < 9 ? q : 0] : (q == 9 ? ab[s] : (q == 10 ? ag[s] : abe[s]));
+      __syncthreads();
+      red[wave][lane] = v;
+      __syncthreads();
+      if (wave == 0 && c < C) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (q < 9) atomicAdd(dw1 + q * C + c, t);
+        else if (q == 9) atomicAdd(db1 + c, t);
+        else if (layer_norm) atomicAdd((q == 10 ? dgamma : dbeta) + c, t);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// layer 2 loaders
+// =============================================================================================
+// im2col element (pixel m, kk = tap*C + c) of a stride-2, pad-1, 3x3 conv over x [B,T1,F1,C].
+// Serves the forward A operand (RC: outer = pixel, contig = kk) and the wgrad A operand (OC: outer = pixel, contig = kk).
+template <typename T>
+struct Im2colLoader {
+  const T* x;
+  int B, T1, F1, C, T2, F2;
+  int outer_limit, contig_limit;  // pixels, 9*C
+  int vec;                        // C % E == 0 and 16-byte aligned base
+  __device__ __forceinline__ const T* addr(int b, int to, int fo, int kk, bool& ok) const {
+    const int tap = kk / C, c = kk - tap * C;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
+    ok = ti >= 0 && ti < T1 && fi >= 0 && fi < F1;
+    return x + (((int64_t)b * T1 + ti) * F1 + fi) * C + c;
+  }
+  __device__ __forceinline__ uint4 load(int outer, int contig) const {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (outer >= outer_limit || contig >= contig_limit) return r;
+    const int fo = outer % F2, to = (outer / F2) % T2, b = outer / (F2 * T2);
+    if (vec) {
+      bool ok;
+      const T* p = addr(b, to, fo, contig, ok);
+      if (ok) r = *reinterpret_cast<const uint4*>(p);
+      return r;
+    }
+    T tmp[Tile<T>::E];
+#pragma unroll
+    for (int e = 0; e < Tile<T>::E; ++e) {
+      tmp[e] = (T)0;
+      if (contig + e < contig_limit) {
+        bool ok;
+        const T* p = addr(b, to, fo, contig + e, ok);
+        if (ok) tmp[e] = *p;
+      }
+    }
+    memcpy(&r, tmp, 16);
+    return r;
+  }
+};
+
+// dgrad, one stride parity class (pt, pf): logical row = (b, th, fh) with ti = 2*th+pt, fi = 2*fh+pf.
+// Reduction index r = tapidx*C + co over the class's valid taps: kh in {1} (pt=0) or {0,2} (pt=1), same for kw.
+template <typename T>
+struct DgradALoader {  // RC: outer = class row, contig = r
+  const T* dy;
+  int B, C, T2, F2, ct, cf, pt, pf, nkw;
+  int outer_limit, contig_limit, vec;
+  __device__ __forceinline__ const T* addr(int b, int th, int fh, int r, bool& ok) const {
+    const int tapidx = r / C, co = r - tapidx * C;
+    const int ih = tapidx / nkw, iw = tapidx - ih * nkw;
+    // pt=0: kh=1 -> to = th ; pt=1: kh=0 -> to = th+1 (ih=0), kh=2 -> to = th (ih=1)
+    const int to = pt ? (ih == 0 ? th + 1 : th) : th;
+    const int fo = pf ? (iw == 0 ? fh + 1 : fh) : fh;
+    ok = to < T2 && fo < F2;
+    return dy + (((int64_t)b * T2 + to) * F2 + fo) * C + co;
+  }
+  __device__ __forceinline__ uint4 load(int outer, int contig) const {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (outer >= outer_limit || contig >= contig_limit) return r;
+    const int fh = outer % cf, th = (outer / cf) % ct, b = outer / (cf * ct);
+    if (vec) {
+      bool ok;
+      const T* p = addr(b, th, fh, contig, ok);
+      if (ok) r = *reinterpret_cast<const uint4*>(p);
+      return r;
+    }
+    T tmp[Tile<T>::E];
+#pragma unroll
+    for (int e = 0; e < Tile<T>::E; ++e) {
+      tmp[e] = (T)0;
+      if (contig + e < contig_limit) {
+        bool ok;
+        const T* p = addr(b, th, fh, contig + e, ok);
+        if (ok) tmp[e] = *p;
+      }
+    }
+    memcpy(&r, tmp, 16);
+    return r;
+  }
+};
+template <typename T>
+struct DgradBLoader {  // RC: outer = ci, contig = r ; element = w2[tap][ci][co]
+  const T* w2;
+  int C, pt, pf, nkw;
+  int outer_limit, contig_limit, vec;
+  __device__ __forceinline__ const T* addr(int ci, int r) const {
+    const int tapidx = r / C, co = r - tapidx * C;
+    const int ih = tapidx / nkw, iw = tapidx - ih * nkw;
+    const int kh = pt ? (ih == 0 ? 0 : 2) : 1;
+    const int kw = pf ? (iw == 0 ? 0 : 2) : 1;
+    return w2 + ((int64_t)(kh * 3 + kw) * C + ci) * C + co;
+  }
+  __device__ __forceinline__ uint4 load(int outer, int contig) const {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (outer >= outer_limit || contig >= contig_limit) return r;
+    if (vec) return *reinterpret_cast<const uint4*>(addr(outer, contig));
+    T tmp[Tile<T>::E];
+#pragma unroll
+    for (int e = 0; e < Tile<T>::E; ++e) tmp[e] = (contig + e < contig_limit) ? *addr(outer, contig + e) : (T)0;
+    memcpy(&r, tmp, 16);
+    return r;
+  }
+};
+struct DgradRowMap {  // class row -> pixel row of dx [B*T1*F1]
+  int T1, F1, ct, cf, pt, pf;
+  __device__ __forceinline__ int64_t operator()(int row) const {
+    const int fh = row % cf, th = (row / cf) % ct, b = row / (cf * ct);
+    return ((int64_t)b * T1 + (2 * th + pt)) * F1 + (2 * fh + pf);
+  }
+};
+
+template <typename T, typename OutT, int AMODE, int BMODE, bool USE_TR, typename AL, typename BL, typename RM>
+__global__ void __launch_bounds__(THREADS) conv_gemm_kernel(AL la, BL lb, OutT* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                           int tiles_n, int ntiles, int kt_per_split, Epilogue ep, RM rm) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * Tile<T>::LDS_BYTES];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  const int kt_first = blockIdx.z * kt_per_split;
+  int kt_count = kt_total - kt_first;
+  if (kt_count > kt_per_split) kt_count = kt_per_split;
+  if (kt_count <= 0) return;
+  gemm_block<T, OutT, AMODE, BMODE, USE_TR, AL, BL, RM>(la, lb, C, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem, rm);
+}
+
+bool conv_use_tr() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+Epilogue plain_epilogue() {
+  Epilogue ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.alpha = 1.f;
+  ep.drop_inv_keep = 1.f;
+  ep.posenc_period = 1;
+  ep.emb_scale = 1.f;
+  return ep;
+}
+
+template <typename T>
+int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, hipStream_t st) {
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  const int M = B * T2 * F2, N = C, K = 9 * C;
+  Im2colLoader<T> la;
+  la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
+  la.outer_limit = M; la.contig_limit = K;
+  la.vec = nst_aligned16(x) && (C % Tile<T>::E == 0);
+  DenseLoader<T> lb;  // Bop[j=co][r] = w2[r*C + co]  (OC: outer = r, contig = co)
+  lb.base = (const T*)w2; lb.ld = C; lb.outer_limit = K; lb.contig_limit = N;
+  lb.vec = nst_aligned16(w2) && (C % Tile<T>::E == 0);
+  Epilogue ep = plain_epilogue();
+  ep.bias = b2;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  dim3 grid(ntiles, 1, 1);
+  if (conv_use_tr())
+    conv_gemm_kernel<T, T, MODE_RC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
+  else
+    conv_gemm_kernel<T, T, MODE_RC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
+  return 0;
+}
+
+template <typename T>
+int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  for (int pt = 0; pt < 2; ++pt)
+    for (int pf = 0; pf < 2; ++pf) {
+      const int ct = (T1 - pt + 1) / 2, cf = (F1 - pf + 1) / 2;  // rows / cols of this parity
+      if (ct <= 0 || cf <= 0) continue;
+      const int nkh = pt ? 2 : 1, nkw = pf ? 2 : 1;
+      const int M = B * ct * cf, N = C, K = nkh * nkw * C;
+      DgradALoader<T> la;
+      la.dy = (const T*)dy; la.B = B; la.C = C; la.T2 = T2; la.F2 = F2; la.ct = ct; la.cf = cf; la.pt = pt; la.pf = pf; la.nkw = nkw;
+      la.outer_limit = M; la.contig_limit = K; la.vec = nst_aligned16(dy) && (C % Tile<T>::E == 0);
+      DgradBLoader<T> lb;
+      lb.w2 = (const T*)w2; lb.C = C; lb.pt = pt; lb.pf = pf; lb.nkw = nkw;
+      lb.outer_limit = N; lb.contig_limit = K; lb.vec = nst_aligned16(w2) && (C % Tile<T>::E == 0);
+      DgradRowMap rm;
+      rm.T1 = T1; rm.F1 = F1; rm.ct = ct; rm.cf = cf; rm.pt = pt; rm.pf = pf;
+      Epilogue ep = plain_epilogue();
+      const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+      const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+      dim3 grid(ntiles, 1, 1);
+      conv_gemm_kernel<T, T, MODE_RC, MODE_RC, true, DgradALoader<T>, DgradBLoader<T>, DgradRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)dx, C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
+    }
+  return 0;
+}
+
+template <typename T>
+int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int accumulate, hipStream_t st) {
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  const int P = B * T2 * F2;          // reduction: pixels
+  const int M = 9 * C, N = C, K = P;  // dw2[kk][co] = sum_p im2col[p][kk] * dy[p][co]
+  Im2colLoader<T> la;                 // OC: outer = pixel (reduction), contig = kk (output row)
+  la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
+  la.outer_limit = P; la.contig_limit = M;
+  la.vec = nst_aligned16(x) && (C % Tile<T>::E == 0);
+  DenseLoader<T> lb;                  // Bop[j=co][r=p] = dy[p*C + co] (OC)
+  lb.base = (const T*)dy; lb.ld = C; lb.outer_limit = P; lb.contig_limit = N;
+  lb.vec = nst_aligned16(dy) && (C % Tile<T>::E == 0);
+  Epilogue ep = plain_epilogue();
+  ep.atomic = 1;
+  if (!accumulate) {
+    if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
+  }
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  int split = (1024 + ntiles - 1) / ntiles;  // ~4 workgroups per CU
+  if (split > kt_total) split = kt_total;
+  if (split < 1) split = 1;
+  const int kt_per_split = (kt_total + split - 1) / split;
+  split = (kt_total + kt_per_split - 1) / kt_per_split;
+  dim3 grid(ntiles, 1, split);
+  if (conv_use_tr())
+    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, dw2, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+  else
+    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, dw2, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+  return 0;
+}
+
+int check_conv_dims(const char* name, int B, int T, int F, int C) {
+  NST_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0, "%s: bad dims B=%d T=%d F=%d C=%d", name, B, T, F, C);
+  NST_CHECK_ARG((int64_t)B * T * F * 9 * C < ((int64_t)1 << 31), "%s: problem too large for 32-bit tile indices", name);
+  return NST_OK;
+}
+
+}  // namespace
+
+extern "C" int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const float* b1, const float* gamma,
+                                     const float* beta, void* out, float* mean, float* rstd, int B, int T, int F, int C,
+                                     int layer_norm, float eps, int out_dtype, void* stream) {
+  NST_CHECK_ARG(src && w1 && b1 && out, "conv1_fwd: null pointer");
+  NST_CHECK_ARG(!layer_norm || (gamma && beta && mean && rstd), "conv1_fwd: LayerNorm needs gamma/beta/mean/rstd");
+  NST_CHECK_ARG(C > 0 && C <= 64 * C1_SLOTS, "conv1_fwd: C=%d unsupported (1..%d)", C, 64 * C1_SLOTS);
+  NST_CHECK_ARG(B > 0 && T > 0 && F > 0, "conv1_fwd: bad dims");
+  NST_CHECK_ARG(out_dtype == NST_F32 || out_dtype == NST_BF16, "conv1_fwd: bad dtype %d", out_dtype);
+  const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  int blocks = (int)((npix + 3) / 4 > 4096 ? 4096 : (npix + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+#define NST_C1F(TT, S, V) conv1_fwd_kernel<TT, S, V><<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, (TT*)out, mean, rstd, B, T, F, C, T1, F1, layer_norm, eps)
+  if (out_dtype == NST_F32) {
+    if (vec) { if (C <= 256) NST_C1F(float, 4, true); else NST_C1F(float, 8, true); }
+    else { if (C <= 256) NST_C1F(float, 4, false); else NST_C1F(float, 8, false); }
+  } else {
+    if (vec) { if (C <= 256) NST_C1F(bf16_t, 4, true); else NST_C1F(bf16_t, 8, true); }
+    else { if (C <= 256) NST_C1F(bf16_t, 4, false); else NST_C1F(bf16_t, 8, false); }
+  }
+#undef NST_C1F
+  NST_CHECK_LAUNCH("conv1_fwd");
+  return NST_OK;
+}
+
+extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const float* b1, const float* gamma,
+                                     const float* beta, const float* mean, const float* rstd, const void* dout,
+                                     float* dw1, float* db1, float* dgamma, float* dbeta, int B, int T, int F, int C,
+                                     int layer_norm, float eps, int dtype, int accumulate, void* stream) {
+  (void)eps;
+  NST_CHECK_ARG(src && w1 && b1 && dout && dw1 && db1, "conv1_bwd: null pointer");
+  NST_CHECK_ARG(!layer_norm || (gamma && beta && mean && rstd && dgamma && dbeta), "conv1_bwd: LayerNorm pointers missing");
+  NST_CHECK_ARG(C > 0 && C <= 64 * C1_SLOTS, "conv1_bwd: C=%d unsupported", C);
+  NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "conv1_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    NST_CHECK_HIP(hipMemsetAsync(dw1, 0, sizeof(float) * 9 * C, st));
+    NST_CHECK_HIP(hipMemsetAsync(db1, 0, sizeof(float) * C, st));
+    if (layer_norm) {
+      NST_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+      NST_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, st));
+    }
+  }
+  const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  int blocks = (int)((npix + 3) / 4 > 1024 ? 1024 : (npix + 3) / 4);
+  const bool vec = (C % 4 == 0);
+#define NST_C1B(TT, S, V) conv1_bwd_kernel<TT, S, V><<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, mean, rstd, (const TT*)dout, dw1, db1, dgamma, dbeta, B, T, F, C, T1, F1, layer_norm)
+  if (dtype == NST_F32) {
+    if (vec) { if (C <= 256) NST_C1B(float, 4, true); else NST_C1B(float, 8, true); }
+    else { if (C <= 256) NST_C1B(float, 4, false); else NST_C1B(float, 8, false); }
+  } else {
+    if (vec) { if (C <= 256) NST_C1B(bf16_t, 4, true); else NST_C1B(bf16_t, 8, true); }
+    else { if (C <= 256) NST_C1B(bf16_t, 4, false); else NST_C1B(bf16_t, 8, false); }
+  }
+#undef NST_C1B
+  NST_CHECK_LAUNCH("conv1_bwd");
+  return NST_OK;
+}
+
+extern "C" int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int dtype,
+                             void* stream) {
+  NST_CHECK_ARG(x && w2 && y, "conv2_fwd: null pointer");
+  int rc = check_conv_dims("conv2_fwd", B, T1, F1, C);
+  if (rc) return rc;
+  if (dtype == NST_F32) conv2_fwd_t<float>(x, w2, b2, y, B, T1, F1, C, (hipStream_t)stream);
+  else if (dtype == NST_BF16) conv2_fwd_t<bf16_t>(x, w2, b2, y, B, T1, F1, C, (hipStream_t)stream);
+  else { nst_set_error("conv2_fwd: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
+  NST_CHECK_LAUNCH("conv2_fwd");
+  return NST_OK;
+}
+
+extern "C" int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, int dtype, void* stream) {
+  NST_CHECK_ARG(dy && w2 && dx, "conv2_dgrad: null pointer");
+  int rc = check_conv_dims("conv2_dgrad", B, T1, F1, C);
+  if (rc) return rc;
+  if (dtype == NST_F32) conv2_dgrad_t<float>(dy, w2, dx, B, T1, F1, C, (hipStream_t)stream);
+  else if (dtype == NST_BF16) conv2_dgrad_t<bf16_t>(dy, w2, dx, B, T1, F1, C, (hipStream_t)stream);
+  else { nst_set_error("conv2_dgrad: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
+  NST_CHECK_LAUNCH("conv2_dgrad");
+  return NST_OK;
+}
+
+extern "C" int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
+                               int accumulate, void* stream) {
+  NST_CHECK_ARG(x && dy && dw2, "conv2_wgrad: null pointer");
+  int rc = check_conv_dims("conv2_wgrad", B, T1, F1, C);
+  if (rc) return rc;
+  int r = 0;
+  if (dtype == NST_F32) r = conv2_wgrad_t<float>(x, dy, dw2, B, T1, F1, C, accumulate, (hipStream_t)stream);
+  else if (dtype == NST_BF16) r = conv2_wgrad_t<bf16_t>(x, dy, dw2, B, T1, F1, C, accumulate, (hipStream_t)stream);
+  else { nst_set_error("conv2_wgrad: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
+  if (r) { nst_set_error("conv2_wgrad: memset failed"); return NST_ERR_LAUNCH; }
+  NST_CHECK_LAUNCH("conv2_wgrad");
+  return NST_OK;
+}

@@ -1,0 +1,123 @@
+// Dense GEMM entry point (projections, FFN, front-end dense, tied logits and all their gradients).
+#include "nst_gemm_core.h"
+
+#include <stdlib.h>
+
+using namespace nstgemm;
+
+namespace {
+
+template <typename T, typename OutT, int AMODE, int BMODE, bool USE_TR>
+__global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, DenseLoader<T> lb, OutT* __restrict__ C,
+                                                            int64_t ldc, int M, int N, int K, int tiles_n, int ntiles,
+                                                            int kt_per_split, Epilogue ep) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * Tile<T>::LDS_BYTES];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  const int kt_first = blockIdx.z * kt_per_split;
+  int kt_count = kt_total - kt_first;
+  if (kt_count > kt_per_split) kt_count = kt_per_split;
+  if (kt_count <= 0) return;
+  gemm_block<T, OutT, AMODE, BMODE, USE_TR>(la, lb, C, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem);
+}
+
+template <typename T>
+DenseLoader<T> make_loader(const void* base, int64_t ld, int mode, int out_extent, int k_extent) {
+  DenseLoader<T> l;
+  l.base = (const T*)base;
+  l.ld = ld;
+  if (mode == MODE_RC) { l.outer_limit = out_extent; l.contig_limit = k_extent; }
+  else { l.outer_limit = k_extent; l.contig_limit = out_extent; }
+  l.vec = nst_aligned16(base) && ((ld * (int64_t)sizeof(T)) % 16 == 0) && (l.contig_limit % Tile<T>::E == 0);
+  return l;
+}
+
+bool use_tr() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+template <typename T, typename OutT>
+int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Epilogue& ep, int split, hipStream_t st) {
+  // Aop[i][r]: trans_a==0 -> A[i*lda + r] (RC);  trans_a==1 -> A[r*lda + i] (OC)
+  // Bop[j][r]: trans_b==1 -> B[j*ldb + r] (RC);  trans_b==0 -> B[r*ldb + j] (OC)
+  const int amode = d->trans_a ? MODE_OC : MODE_RC;
+  const int bmode = d->trans_b ? MODE_RC : MODE_OC;
+  DenseLoader<T> la = make_loader<T>(A, d->lda, amode, d->M, d->K);
+  DenseLoader<T> lb = make_loader<T>(B, d->ldb, bmode, d->N, d->K);
+  const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+  const int kt_total = (d->K + Tile<T>::BK - 1) / Tile<T>::BK;
+  if (split > kt_total) split = kt_total;
+  if (split < 1) split = 1;
+  const int kt_per_split = (kt_total + split - 1) / split;
+  split = (kt_total + kt_per_split - 1) / kt_per_split;
+  dim3 grid(ntiles, 1, split);
+  const bool tr = use_tr();
+#define NST_GEMM_LAUNCH(AM, BMO, TR)                                                                                   \
+  dense_gemm_kernel<T, OutT, AM, BMO, TR><<<grid, THREADS, 0, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, \
+                                                                   ntiles, kt_per_split, ep)
+  if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH(MODE_RC, MODE_RC, true);
+  else if (amode == MODE_RC && bmode == MODE_OC) { if (tr) NST_GEMM_LAUNCH(MODE_RC, MODE_OC, true); else NST_GEMM_LAUNCH(MODE_RC, MODE_OC, false); }
+  else if (amode == MODE_OC && bmode == MODE_RC) { if (tr) NST_GEMM_LAUNCH(MODE_OC, MODE_RC, true); else NST_GEMM_LAUNCH(MODE_OC, MODE_RC, false); }
+  else { if (tr) NST_GEMM_LAUNCH(MODE_OC, MODE_OC, true); else NST_GEMM_LAUNCH(MODE_OC, MODE_OC, false); }
+#undef NST_GEMM_LAUNCH
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void* C, void* stream) {
+  NST_CHECK_ARG(d && A && B && C, "gemm: null pointer");
+  NST_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "gemm: negative dims");
+  NST_CHECK_ARG(d->in_dtype == NST_F32 || d->in_dtype == NST_BF16, "gemm: bad in_dtype %d", d->in_dtype);
+  NST_CHECK_ARG(d->out_dtype == NST_F32 || d->out_dtype == NST_BF16, "gemm: bad out_dtype %d", d->out_dtype);
+  NST_CHECK_ARG(!(d->in_dtype == NST_F32 && d->out_dtype == NST_BF16), "gemm: f32 inputs with bf16 output unsupported");
+  NST_CHECK_ARG(d->lda >= (d->trans_a ? d->M : d->K), "gemm: lda=%lld too small", (long long)d->lda);
+  NST_CHECK_ARG(d->ldb >= (d->trans_b ? d->K : d->N), "gemm: ldb=%lld too small", (long long)d->ldb);
+  NST_CHECK_ARG(d->ldc >= d->N, "gemm: ldc=%lld too small", (long long)d->ldc);
+  NST_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm: dropout_p=%f", d->dropout_p);
+  NST_CHECK_ARG(!d->posenc || d->posenc_period > 0, "gemm: posenc needs posenc_period > 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->M == 0 || d->N == 0) return NST_OK;
+
+  Epilogue ep;
+  ep.alpha = d->alpha;
+  ep.bias = d->bias;
+  ep.relu = d->relu;
+  ep.drop_thresh = nst_dropout_threshold(d->dropout_p);
+  ep.drop_inv_keep = 1.f / (1.f - d->dropout_p);
+  ep.seed = d->seed;
+  ep.stream_id = d->stream_id;
+  ep.residual = d->residual;
+  ep.ldr = d->ldr;
+  ep.gate_src = d->gate_src;
+  ep.ldg = d->ldg;
+  ep.gate_scale = d->gate_scale;
+  ep.posenc = d->posenc;
+  ep.posenc_period = d->posenc_period > 0 ? d->posenc_period : 1;
+  ep.emb_scale = d->emb_scale;
+  ep.accumulate = d->accumulate;
+  ep.atomic = 0;
+
+  int split = d->split_k > 1 ? d->split_k : 1;
+  if (split > 1) {
+    NST_CHECK_ARG(d->out_dtype == NST_F32, "gemm: split_k requires an f32 output");
+    NST_CHECK_ARG(!d->relu && d->dropout_p == 0.f && !d->gate_src && !d->posenc && !d->bias && !d->residual,
+                  "gemm: split_k supports only the plain alpha*A*B (+accumulate) epilogue");
+    if (!d->accumulate)
+      NST_CHECK_HIP(hipMemset2DAsync(C, d->ldc * sizeof(float), 0, (size_t)d->N * sizeof(float), d->M, st));
+    ep.atomic = 1;
+    ep.accumulate = 0;
+  }
+  if (d->K == 0) {  // empty reduction: C = epilogue(0)
+    nst_set_error("gemm: K == 0 unsupported");
+    return NST_ERR_UNSUPPORTED;
+  }
+  if (d->in_dtype == NST_F32) launch<float, float>(d, A, B, C, ep, split, st);
+  else if (d->out_dtype == NST_BF16) launch<bf16_t, bf16_t>(d, A, B, C, ep, split, st);
+  else launch<bf16_t, float>(d, A, B, C, ep, split, st);
+  NST_CHECK_LAUNCH("gemm");
+  return NST_OK;
+}

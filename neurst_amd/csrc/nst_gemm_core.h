@@ -1,0 +1,304 @@
+// MFMA GEMM core shared by the dense projections/FFN/logits GEMMs and the implicit-GEMM conv.
+//
+//   C[i][j] = epilogue( alpha * sum_r Aop[i][r] * Bop[j][r] )        i<M, j<N, r<K
+//
+// Each operand is described by a LOADER (where element (outer, contig) lives in HBM) and a
+// storage MODE:
+//   RC  reduction-contiguous : tile staged in LDS as [BM rows i][BK r]   -> fragments by ds_read_b128
+//   OC  output-contiguous    : tile staged in LDS as [BK rows r][BM i]   -> fragments by
+//                              ds_read_b64_tr_b16 (bf16, the gfx950 LDS transpose read) or ds_read_b32 (f32)
+// Staging is global -> VGPR -> LDS in 16-byte chunks along the contiguous dimension with the next tile's
+// loads issued before the MFMAs of the current tile (register double buffering).  LDS rows are padded by
+// 16 bytes so the 16-lane groups of ds_read_b128 hit distinct banks.
+//
+// Block = 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 4x4 MFMA 16x16 fragments,
+// K step = 128 bytes of the reduction dimension (64 bf16 / 32 f32).
+//   bf16: v_mfma_f32_16x16x32_bf16      f32: v_mfma_f32_16x16x4_f32 (exact fp32, 1/16 of the bf16 rate)
+// Fragment maps (verified on hardware by nst_probe_mfma / tests/test_gpu_probe.py):
+//   A/B: lane l holds row (l&15), reduction elements (l>>4)*8..+7 (bf16) or (l>>4) (f32)
+//   C/D: lane l, reg j holds row (l>>4)*4+j, col (l&15)
+#pragma once
+#include "nst_common.h"
+
+namespace nstgemm {
+
+constexpr int BM = 128, BN = 128, KBYTES = 128, THREADS = 256;
+constexpr int RS_RC = KBYTES + 16;  // LDS row stride (bytes) of an RC tile
+
+enum { MODE_RC = 0, MODE_OC = 1 };
+
+template <typename T>
+struct Tile {
+  static constexpr int BK = KBYTES / (int)sizeof(T);          // reduction elements per K step
+  static constexpr int E = 16 / (int)sizeof(T);               // elements per 16-byte chunk
+  static constexpr int RS_OC = BM * (int)sizeof(T) + 16;      // LDS row stride (bytes) of an OC tile
+  static constexpr int OC_CPR = BM * (int)sizeof(T) / 16;     // chunks per OC row
+  static constexpr int LDS_BYTES = (BM * RS_RC > BK * RS_OC) ? BM * RS_RC : BK * RS_OC;
+};
+
+struct Epilogue {
+  float alpha;
+  const float* bias;
+  int relu;
+  uint32_t drop_thresh;
+  float drop_inv_keep;
+  uint64_t seed, stream_id;
+  const void* residual;
+  int64_t ldr;
+  const void* gate_src;
+  int64_t ldg;
+  float gate_scale;
+  const float* posenc;
+  int posenc_period;
+  float emb_scale;
+  int accumulate;
+  int atomic;  // split-K: atomicAdd into an f32 C
+};
+
+// ---------------------------------------------------------------------------------------------
+// dense loader: element (outer, contig) at base[outer*ld + contig]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct DenseLoader {
+  const T* base;
+  int64_t ld;
+  int outer_limit, contig_limit;
+  int vec;  // 16-byte loads are legal (alignment + contig_limit % E == 0)
+  __device__ __forceinline__ uint4 load(int outer, int contig) const {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (outer >= outer_limit || contig >= contig_limit) return r;
+    const T* p = base + (int64_t)outer * ld + contig;
+    if (vec) return *reinterpret_cast<const uint4*>(p);
+    T tmp[Tile<T>::E];
+#pragma unroll
+    for (int e = 0; e < Tile<T>::E; ++e) tmp[e] = (contig + e < contig_limit) ? p[e] : (T)0;
+    memcpy(&r, tmp, 16);
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// fragment readers
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool USE_TR>
+struct FragReader;
+
+template <bool USE_TR>
+struct FragReader<bf16_t, MODE_RC, USE_TR> {
+  typedef bf16x8_t Frag;
+  // row = tile row (i), kk = reduction offset of this MFMA step inside the tile
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    const char* p = tile + (row + (lane & 15)) * RS_RC + (kk + (lane >> 4) * 8) * 2;
+    return *reinterpret_cast<const Frag*>(p);
+  }
+};
+template <>
+struct FragReader<bf16_t, MODE_OC, true> {
+  typedef bf16x8_t Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    const int ii = lane & 15;
+    const int r = kk + (lane >> 4) * 8 + (ii >> 2);
+    const char* p = tile + r * Tile<bf16_t>::RS_OC + (row + (ii & 3) * 4) * 2;
+    typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+    short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
+    short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p + 4 * Tile<bf16_t>::RS_OC));
+    union { short s[8]; Frag f; } u;
+    u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+    u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+    return u.f;
+  }
+};
+template <>
+struct FragReader<bf16_t, MODE_OC, false> {
+  typedef bf16x8_t Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    const char* p = tile + (kk + (lane >> 4) * 8) * Tile<bf16_t>::RS_OC + (row + (lane & 15)) * 2;
+    union { short s[8]; Frag f; } u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.s[j] = *reinterpret_cast<const short*>(p + j * Tile<bf16_t>::RS_OC);
+    return u.f;
+  }
+};
+template <bool USE_TR>
+struct FragReader<float, MODE_RC, USE_TR> {
+  typedef float Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    return *reinterpret_cast<const float*>(tile + (row + (lane & 15)) * RS_RC + (kk + (lane >> 4)) * 4);
+  }
+};
+template <bool USE_TR>
+struct FragReader<float, MODE_OC, USE_TR> {
+  typedef float Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    return *reinterpret_cast<const float*>(tile + (kk + (lane >> 4)) * Tile<float>::RS_OC + (row + (lane & 15)) * 4);
+  }
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  static constexpr int KS = 32;
+  static __device__ __forceinline__ floatx4_t run(bf16x8_t a, bf16x8_t b, floatx4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  static constexpr int KS = 4;
+  static __device__ __forceinline__ floatx4_t run(float a, float b, floatx4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// staging: every thread moves 4 x 16-byte chunks per operand per K step
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE, typename Loader>
+__device__ __forceinline__ void stage_load(const Loader& ld, int o0, int r0, int tid, uint4 (&regs)[4]) {
+  // o0 = first output index (i or j) of the tile, r0 = first reduction index of the K step
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = tid + s * THREADS;
+    if (MODE == MODE_RC) {
+      const int row = c >> 3, cc = c & 7;  // 8 chunks per 128-byte row
+      regs[s] = ld.load(o0 + row, r0 + cc * Tile<T>::E);
+    } else {
+      const int row = c / Tile<T>::OC_CPR, cc = c % Tile<T>::OC_CPR;
+      regs[s] = ld.load(r0 + row, o0 + cc * Tile<T>::E);
+    }
+  }
+}
+template <typename T, int MODE>
+__device__ __forceinline__ void stage_store(char* tile, int tid, const uint4 (&regs)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = tid + s * THREADS;
+    if (MODE == MODE_RC) {
+      const int row = c >> 3, cc = c & 7;
+      *reinterpret_cast<uint4*>(tile + row * RS_RC + cc * 16) = regs[s];
+    } else {
+      const int row = c / Tile<T>::OC_CPR, cc = c % Tile<T>::OC_CPR;
+      *reinterpret_cast<uint4*>(tile + row * Tile<T>::RS_OC + cc * 16) = regs[s];
+    }
+  }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, OutT* __restrict__ C, int64_t ldc, int row, int col,
+                                               int N, float acc, int64_t out_row) {
+  float v = acc * ep.alpha;
+  if (ep.bias) v += ep.bias[col];
+  if (ep.relu) v = fmaxf(v, 0.f);
+  if (ep.drop_thresh)
+    v *= dropout_keep_scale(ep.seed, ep.stream_id, (uint64_t)row * (uint64_t)N + (uint64_t)col, ep.drop_thresh,
+                            ep.drop_inv_keep);
+  if (ep.residual) v += to_f32<OutT>(reinterpret_cast<const OutT*>(ep.residual)[(int64_t)row * ep.ldr + col]);
+  if (ep.gate_src)
+    v *= to_f32<OutT>(reinterpret_cast<const OutT*>(ep.gate_src)[(int64_t)row * ep.ldg + col]) > 0.f ? ep.gate_scale : 0.f;
+  if (ep.posenc) v = v * ep.emb_scale + ep.posenc[(int64_t)(row % ep.posenc_period) * N + col];
+  OutT* p = C + out_row * ldc + col;
+  if (ep.atomic) {
+    atomicAdd(reinterpret_cast<float*>(p), v);  // only instantiated meaningfully for OutT=float (host enforces)
+  } else {
+    if (ep.accumulate) v += to_f32<OutT>(*p);
+    *p = from_f32<OutT>(v);
+  }
+}
+
+// k_tiles_of(z, &first, &count): the K steps this block (blockIdx.z) owns.
+struct IdentityRowMap {
+  __device__ __forceinline__ int64_t operator()(int row) const { return row; }
+};
+
+// RowMap: logical output row -> row index in C (identity for dense GEMMs; the conv dgrad scatters its
+// parity-class rows back to pixel order).
+template <typename T, typename OutT, int AMODE, int BMODE, bool USE_TR, typename ALoader, typename BLoader,
+          typename RowMap = IdentityRowMap>
+__device__ __forceinline__ void gemm_block(const ALoader& la, const BLoader& lb, OutT* __restrict__ C, int64_t ldc, int M,
+                                           int N, int m0, int n0, int kt_first, int kt_count, const Epilogue& ep,
+                                           char* smem, const RowMap rowmap = RowMap()) {
+  typedef FragReader<T, AMODE, USE_TR> RA;
+  typedef FragReader<T, BMODE, USE_TR> RB;
+  constexpr int BK = Tile<T>::BK;
+  constexpr int KS = Mma<T>::KS;
+  char* As = smem;
+  char* Bs = smem + Tile<T>::LDS_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  floatx4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  if (kt_count > 0) {
+    stage_load<T, AMODE>(la, m0, kt_first * BK, tid, ra);
+    stage_load<T, BMODE>(lb, n0, kt_first * BK, tid, rb);
+  }
+  for (int kt = 0; kt < kt_count; ++kt) {
+    stage_store<T, AMODE>(As, tid, ra);
+    stage_store<T, BMODE>(Bs, tid, rb);
+    __syncthreads();
+    if (kt + 1 < kt_count) {
+      stage_load<T, AMODE>(la, m0, (kt_first + kt + 1) * BK, tid, ra);
+      stage_load<T, BMODE>(lb, n0, (kt_first + kt + 1) * BK, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += KS) {
+      typename RA::Frag a[4];
+      typename RB::Frag b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = RA::read(As, wm + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = RB::read(Bs, wn + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that the
+  // global stores (and residual / gate reads) are row-contiguous: lane = column, 64 consecutive columns per row.
+  constexpr int EPI_LD = 65;  // floats; +1 pad keeps the 4 row groups of a fragment on distinct banks
+  float* epi = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+  const int lr = (lane >> 4) * 4, lc = lane & 15;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const floatx4_t a4 = acc[half * 2 + ii][j];
+        epi[(ii * 16 + lr + 0) * EPI_LD + j * 16 + lc] = a4[0];
+        epi[(ii * 16 + lr + 1) * EPI_LD + j * 16 + lc] = a4[1];
+        epi[(ii * 16 + lr + 2) * EPI_LD + j * 16 + lc] = a4[2];
+        epi[(ii * 16 + lr + 3) * EPI_LD + j * 16 + lc] = a4[3];
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+    const int col = n0 + wn + lane;
+    const int row_base = m0 + wm + half * 32;
+    if (col < N) {
+      for (int r = 0; r < 32; ++r) {
+        const int row = row_base + r;
+        if (row < M) epilogue_store<OutT>(ep, C, ldc, row, col, N, epi[r * EPI_LD + lane], rowmap(row));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// XCD-aware tile order: consecutive block ids land on different XCDs (id % 8); give each XCD a contiguous
+// run of tiles so neighbouring tiles (which share an A row panel) hit the same L2.  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+}  // namespace nstgemm

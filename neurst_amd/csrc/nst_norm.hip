@@ -1,0 +1,285 @@
+// LayerNorm forward/backward (optionally fused with ReLU) -- HBM-bound, one wavefront per row,
+// wavefront-shuffle reductions, fp32 statistics.
+//   replaces tf.keras.layers.LayerNormalization at neurst/layers/common_layers.py:64-65,77,
+//   transformer_encoder.py:98-100,135, transformer_decoder.py:99-101,225 and (with ReLU)
+//   audio_modalities.py:102-104.
+#include "nst_common.h"
+
+namespace {
+
+constexpr int LN_MAX_PER_LANE = 16;  // d <= 64*16 = 1024
+constexpr int LN_WAVES = 4;
+
+// Values are cached in registers with STATIC indices (runtime-indexed register arrays go to scratch):
+// slot c of a lane holds element elem_index(lane, c); slots past the row end are zero and never stored.
+template <int VEC>
+__device__ __forceinline__ int elem_index(int lane, int c) {
+  return VEC == 4 ? (lane * 4 + (c >> 2) * 256 + (c & 3)) : (lane + c * 64);
+}
+
+template <typename T, int VEC, int S>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, int d, int lane, float (&v)[S]) {
+  if (VEC == 4) {
+#pragma unroll
+    for (int k = 0; k < S / 4; ++k) {
+      const int e = lane * 4 + k * 256;
+      if (e < d) {
+        if (sizeof(T) == 2) {
+          uint2 raw = *reinterpret_cast<const uint2*>(p + e);
+          v[k * 4 + 0] = bf16_to_f32((bf16_t)(raw.x & 0xffff));
+          v[k * 4 + 1] = bf16_to_f32((bf16_t)(raw.x >> 16));
+          v[k * 4 + 2] = bf16_to_f32((bf16_t)(raw.y & 0xffff));
+          v[k * 4 + 3] = bf16_to_f32((bf16_t)(raw.y >> 16));
+        } else {
+          float4 raw = *reinterpret_cast<const float4*>(p + e);
+          v[k * 4 + 0] = raw.x; v[k * 4 + 1] = raw.y; v[k * 4 + 2] = raw.z; v[k * 4 + 3] = raw.w;
+        }
+      } else {
+        v[k * 4 + 0] = 0.f; v[k * 4 + 1] = 0.f; v[k * 4 + 2] = 0.f; v[k * 4 + 3] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      const int e = lane + k * 64;
+      v[k] = e < d ? to_f32<T>(p[e]) : 0.f;
+    }
+  }
+}
+
+template <typename T, int VEC, int S>
+__device__ __forceinline__ void store_row(T* __restrict__ p, int d, int lane, const float (&v)[S]) {
+  if (VEC == 4) {
+#pragma unroll
+    for (int k = 0; k < S / 4; ++k) {
+      const int e = lane * 4 + k * 256;
+      if (e < d) {
+        if (sizeof(T) == 2) {
+          uint2 raw;
+          raw.x = (uint32_t)f32_to_bf16(v[k * 4 + 0]) | ((uint32_t)f32_to_bf16(v[k * 4 + 1]) << 16);
+          raw.y = (uint32_t)f32_to_bf16(v[k * 4 + 2]) | ((uint32_t)f32_to_bf16(v[k * 4 + 3]) << 16);
+          *reinterpret_cast<uint2*>(p + e) = raw;
+        } else {
+          *reinterpret_cast<float4*>(p + e) = make_float4(v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      const int e = lane + k * 64;
+      if (e < d) p[e] = from_f32<T>(v[k]);
+    }
+  }
+}
+
+template <typename T, int VEC, bool RELU, int S>
+__global__ void __launch_bounds__(LN_WAVES * 64) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, T* __restrict__ y,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                              int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
+    float v[S];
+    load_row<T, VEC, S>(x + row * d, d, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < S; ++c) s += v[c];
+    const float mean = wave_sum(s) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      const float t = elem_index<VEC>(lane, c) < d ? v[c] - mean : 0.f;
+      sq += t * t;
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      const int e = elem_index<VEC>(lane, c);
+      if (e < d) {
+        float o = (v[c] - mean) * rstd * gamma[e] + beta[e];
+        if (RELU) o = fmaxf(o, 0.f);
+        v[c] = o;
+      }
+    }
+    store_row<T, VEC, S>(y + row * d, d, lane, v);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+template <typename T, int VEC, bool RELU, int S>
+__global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const T* __restrict__ yout, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                              const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int64_t rows, int d) {
+  __shared__ float red[LN_WAVES][256];  // reused twice (dgamma then dbeta) in 4 slices
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_d = 1.0f / (float)d;
+  float g_acc[S], b_acc[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) { g_acc[c] = 0.f; b_acc[c] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
+    float xv[S], gv[S];
+    load_row<T, VEC, S>(x + row * d, d, lane, xv);
+    load_row<T, VEC, S>(dy + row * d, d, lane, gv);
+    if (RELU) {
+      float yv[S];
+      load_row<T, VEC, S>(yout + row * d, d, lane, yv);
+#pragma unroll
+      for (int c = 0; c < S; ++c) gv[c] = yv[c] > 0.f ? gv[c] : 0.f;
+    }
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+      const int e = elem_index<VEC>(lane, c);
+      if (e < d) {
+        const float xhat = (xv[c] - mean) * rstd;
+        const float dxh = gv[c] * gamma[e];
+        g_acc[c] += gv[c] * xhat;
+        b_acc[c] += gv[c];
+        s1 += dxh;
+        s2 += dxh * xhat;
+        xv[c] = xhat;
+        gv[c] = dxh;
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_d, c2m = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int c = 0; c < S; ++c) xv[c] = rstd * (gv[c] - c1 - xv[c] * c2m);
+    if (dres) {
+      load_row<T, VEC, S>(dres + row * d, d, lane, gv);
+#pragma unroll
+      for (int c = 0; c < S; ++c) xv[c] += gv[c];
+    }
+    store_row<T, VEC, S>(dx + row * d, d, lane, xv);
+  }
+  // cross-wave reduction in LDS, 4 cached values at a time, then one atomic per column per block
+#pragma unroll
+  for (int base = 0; base < S; base += 4) {
+    if (elem_index<VEC>(0, base) >= d) break;  // block-uniform: no lane owns a column in this slice
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = pass == 0 ? g_acc[base + j] : b_acc[base + j];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = elem_index<VEC>(lane, base + j);
+          if (e < d) {
+            float t = red[0][lane * 4 + j] + red[1][lane * 4 + j] + red[2][lane * 4 + j] + red[3][lane * 4 + j];
+            atomicAdd((pass == 0 ? dgamma : dbeta) + e, t);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+bool vec_ok(const void* a, const void* b, const void* c, int d) {
+  const uintptr_t al = sizeof(T) == 2 ? 7 : 15;
+  return d % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & al) == 0;
+}
+
+template <typename T, bool RELU>
+int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+               int d, float eps, hipStream_t st) {
+  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+#define NST_LN_FWD(V, S) ln_fwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)x, gamma, beta, (T*)y, mean, rstd, rows, d, eps)
+  if (vec_ok<T>(x, y, nullptr, d)) {
+    if (d <= 256) NST_LN_FWD(4, 4); else if (d <= 512) NST_LN_FWD(4, 8); else NST_LN_FWD(4, 16);
+  } else {
+    if (d <= 256) NST_LN_FWD(1, 4); else if (d <= 512) NST_LN_FWD(1, 8); else NST_LN_FWD(1, 16);
+  }
+#undef NST_LN_FWD
+  return 0;
+}
+
+template <typename T, bool RELU>
+int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
+               const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, hipStream_t st) {
+  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+#define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d)
+  if (vec_ok<T>(x, dy, dx, d) && vec_ok<T>(y, dres, nullptr, d)) {
+    if (d <= 256) NST_LN_BWD(4, 4); else if (d <= 512) NST_LN_BWD(4, 8); else NST_LN_BWD(4, 16);
+  } else {
+    if (d <= 256) NST_LN_BWD(1, 4); else if (d <= 512) NST_LN_BWD(1, 8); else NST_LN_BWD(1, 16);
+  }
+#undef NST_LN_BWD
+  return 0;
+}
+
+int ln_fwd_common(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                  int d, float eps, int dtype, void* stream, bool relu) {
+  NST_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_fwd: d=%d unsupported (1..%d)", d, 64 * LN_MAX_PER_LANE);
+  NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "layernorm_fwd: bad dtype %d", dtype);
+  if (rows <= 0) return NST_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NST_F32) {
+    if (relu) launch_fwd<float, true>(x, gamma, beta, y, mean, rstd, rows, d, eps, st);
+    else launch_fwd<float, false>(x, gamma, beta, y, mean, rstd, rows, d, eps, st);
+  } else {
+    if (relu) launch_fwd<bf16_t, true>(x, gamma, beta, y, mean, rstd, rows, d, eps, st);
+    else launch_fwd<bf16_t, false>(x, gamma, beta, y, mean, rstd, rows, d, eps, st);
+  }
+  NST_CHECK_LAUNCH("layernorm_fwd");
+  return NST_OK;
+}
+
+int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                  int accumulate, void* stream, bool relu) {
+  NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
+  NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
+  NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "layernorm_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    NST_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * d, st));
+    NST_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * d, st));
+  }
+  if (rows <= 0) return NST_OK;
+  if (dtype == NST_F32) {
+    if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+    else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+  } else {
+    if (relu) launch_bwd<bf16_t, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+    else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+  }
+  NST_CHECK_LAUNCH("layernorm_bwd");
+  return NST_OK;
+}
+
+}  // namespace
+
+extern "C" int nst_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 int64_t rows, int d, float eps, int dtype, void* stream) {
+  return ln_fwd_common(x, gamma, beta, y, mean, rstd, rows, d, eps, dtype, stream, false);
+}
+extern "C" int nst_layernorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                      float* rstd, int64_t rows, int d, float eps, int dtype, void* stream) {
+  return ln_fwd_common(x, gamma, beta, y, mean, rstd, rows, d, eps, dtype, stream, true);
+}
+extern "C" int nst_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                                 int accumulate, void* stream) {
+  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, stream, false);
+}
+extern "C" int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d,
+                                      int dtype, int accumulate, void* stream) {
+  return ln_bwd_common(dy, x, y, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, d, dtype, accumulate, stream, true);
+}

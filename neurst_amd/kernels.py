@@ -1,0 +1,273 @@
+"""Thin tensor-level wrappers over the C ABI of libneurst_hip.so.
+
+PyTorch is used only as the owner of device memory and streams: every function
+passes raw device pointers and the current HIP stream to the library.  All
+inputs must live on a ROCm device; nothing here falls back to torch math.
+"""
+import ctypes as C
+
+import torch
+
+from neurst_amd._lib import NST_BF16, NST_F32, NstAttnDesc, NstGemmDesc, check, lib
+
+FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return NST_F32
+    if t.dtype == torch.bfloat16:
+        return NST_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("neurst_amd kernels need ROCm device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows2d(t):
+    """View [..., d] as rows with unit inner stride; returns (tensor, rows, d, ld)."""
+    assert t.stride(-1) == 1
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, relu=False):
+    assert x.is_contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    fn = lib.nst_layernorm_relu_fwd if relu else lib.nst_layernorm_fwd
+    check(fn(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, d, float(eps), _dt(x), _stream()),
+          "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None):
+    """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x))."""
+    assert dy.is_contiguous() and x.is_contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    if y is not None:
+        assert dres is None
+        check(lib.nst_layernorm_relu_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                         _p(dbeta), rows, d, _dt(x), int(accumulate), _stream()), "layernorm_relu_bwd")
+    else:
+        if dres is not None:
+            assert dres.is_contiguous() and dres.dtype == x.dtype
+        check(lib.nst_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma),
+                                    _p(dbeta), rows, d, _dt(x), int(accumulate), _stream()), "layernorm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
+         dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
+         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1):
+    """C[M,N] = epilogue(alpha * op(A) @ op(B)); A/B are 2-D views with unit inner stride (see neurst_hip.h)."""
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
+    assert A.dtype == B.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or A.dtype, device=A.device)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] == N
+    d = NstGemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), out.stride(0)
+    d.in_dtype, d.out_dtype = _dt(A), _dt(out)
+    d.alpha = alpha
+    d.bias = _p(bias)
+    d.relu = int(relu)
+    d.dropout_p = dropout_p
+    d.seed, d.stream_id = seed, stream_id
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.stride(1) == 1
+        d.residual, d.ldr = _p(residual), residual.stride(0)
+    if gate_src is not None:
+        assert gate_src.dtype == out.dtype and gate_src.stride(1) == 1
+        d.gate_src, d.ldg = _p(gate_src), gate_src.stride(0)
+    d.gate_scale = gate_scale
+    if posenc is not None:
+        assert posenc.dtype == torch.float32 and posenc.is_contiguous() and posenc.shape[1] == N
+        d.posenc, d.posenc_period = _p(posenc), posenc_period or posenc.shape[0]
+    d.emb_scale = emb_scale
+    d.accumulate = int(accumulate)
+    d.split_k = split_k
+    check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
+    return out
+
+
+def colsum(x, out, accumulate=False):
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    check(lib.nst_colsum(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), _dt(x), int(accumulate), _stream()),
+          "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id):
+    # q [B,Tq,*] k,v [B,Tk,*] views whose last dim starts at this tensor's head 0 (row stride = stride(1))
+    d = NstAttnDesc()
+    d.B, d.Tq, d.Tk, d.H, d.dh = q.shape[0], q.shape[1], k.shape[1], H, dh
+    for t in (q, k, v, out):
+        assert t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "batch stride must be T*row stride"
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    d.dtype = _dt(q)
+    d.scale = float(dh) ** -0.5
+    d.causal = int(causal)
+    d.float_min = FLOAT_MIN
+    d.dropout_p = dropout_p
+    d.seed, d.stream_id = seed, stream_id
+    return d
+
+
+def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0):
+    """q [B,Tq,H*dh-view], k/v [B,Tk,H*dh-view] (may be column slices of a packed projection)."""
+    B, Tq = q.shape[0], q.shape[1]
+    out = torch.empty(B, Tq, H * dh, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    check(lib.nst_attention_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(lse), _stream()),
+          "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
+                  stream_id=0):
+    assert dout.is_contiguous() and out.is_contiguous()
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    delta = torch.empty_like(lse)
+    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(dout), _p(lse), _p(delta),
+                                _p(dq), _p(dk), _p(dv), _stream()), "attention_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ conv front end
+def conv1_ln_relu_fwd(src, w1, b1, gamma, beta, layer_norm, eps, out_dtype):
+    B, T, F = src.shape
+    Cc = w1.shape[-1]
+    T1, F1 = (T + 1) // 2, (F + 1) // 2
+    out = torch.empty(B, T1, F1, Cc, dtype=out_dtype, device=src.device)
+    mean = torch.empty(B * T1 * F1, dtype=torch.float32, device=src.device) if layer_norm else None
+    rstd = torch.empty(B * T1 * F1, dtype=torch.float32, device=src.device) if layer_norm else None
+    assert src.is_contiguous() and src.dtype == torch.float32 and w1.is_contiguous()
+    check(lib.nst_conv1_ln_relu_fwd(_p(src), _p(w1), _p(b1), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), B, T, F,
+                                    Cc, int(layer_norm), float(eps), _dt(out), _stream()), "conv1_fwd")
+    return out, mean, rstd
+
+
+def conv1_ln_relu_bwd(src, w1, b1, gamma, beta, mean, rstd, dout, dw1, db1, dgamma, dbeta, layer_norm, eps,
+                      accumulate=False):
+    B, T, F = src.shape
+    Cc = w1.shape[-1]
+    assert dout.is_contiguous()
+    check(lib.nst_conv1_ln_relu_bwd(_p(src), _p(w1), _p(b1), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dout),
+                                    _p(dw1), _p(db1), _p(dgamma), _p(dbeta), B, T, F, Cc, int(layer_norm), float(eps),
+                                    _dt(dout), int(accumulate), _stream()), "conv1_bwd")
+
+
+def conv2_fwd(x, w2, b2):
+    B, T1, F1, Cc = x.shape
+    assert x.is_contiguous() and w2.is_contiguous() and w2.dtype == x.dtype
+    y = torch.empty(B, (T1 + 1) // 2, (F1 + 1) // 2, Cc, dtype=x.dtype, device=x.device)
+    check(lib.nst_conv2_fwd(_p(x), _p(w2), _p(b2), _p(y), B, T1, F1, Cc, _dt(x), _stream()), "conv2_fwd")
+    return y
+
+
+def conv2_dgrad(dy, w2, T1, F1):
+    B, T2, F2, Cc = dy.shape
+    assert dy.is_contiguous() and w2.dtype == dy.dtype
+    dx = torch.empty(B, T1, F1, Cc, dtype=dy.dtype, device=dy.device)
+    check(lib.nst_conv2_dgrad(_p(dy), _p(w2), _p(dx), B, T1, F1, Cc, _dt(dy), _stream()), "conv2_dgrad")
+    return dx
+
+
+def conv2_wgrad(x, dy, dw2, accumulate=False):
+    B, T1, F1, Cc = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
+    check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), B, T1, F1, Cc, _dt(x), int(accumulate), _stream()), "conv2_wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ embedding / elementwise
+def embedding_fwd(table, ids, posenc, L, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
+    V, d = table.shape
+    ids = ids.contiguous()
+    rows = ids.numel()
+    out = torch.empty(*ids.shape, d, dtype=table.dtype, device=table.device)
+    assert ids.dtype == torch.int64
+    check(lib.nst_embedding_fwd(_p(table), _p(ids), _p(posenc), _p(out), rows, L, d, V, emb_scale, dropout_p, seed,
+                                stream_id, _dt(table), _stream()), "embedding_fwd")
+    return out
+
+
+def embedding_bwd(dout, ids, dtable, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
+    V, d = dtable.shape
+    assert dout.is_contiguous() and dtable.dtype == torch.float32
+    check(lib.nst_embedding_bwd(_p(dout), _p(ids.contiguous()), _p(dtable), ids.numel(), d, V, emb_scale, dropout_p,
+                                seed, stream_id, _dt(dout), _stream()), "embedding_bwd")
+
+
+def scale_posenc_dropout_fwd(x, posenc, period, scale, dropout_p=0.0, seed=0, stream_id=0):
+    assert x.is_contiguous()
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.nst_scale_posenc_dropout_fwd(_p(x), _p(posenc), _p(y), x.numel() // d, d, period, scale, dropout_p, seed,
+                                           stream_id, _dt(x), _stream()), "scale_posenc_dropout_fwd")
+    return y
+
+
+def scale_dropout_bwd(dy, scale, dropout_p=0.0, seed=0, stream_id=0):
+    assert dy.is_contiguous()
+    dx = torch.empty_like(dy)
+    check(lib.nst_scale_dropout_bwd(_p(dy), _p(dx), dy.numel(), scale, dropout_p, seed, stream_id, _dt(dy), _stream()),
+          "scale_dropout_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ criterion / optimizer
+def ls_xent_fwd(logits, labels, weights, label_smoothing):
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    xent = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    check(lib.nst_ls_xent_fwd(_p(logits), _p(labels), _p(weights), _p(xent), _p(lse), rows, V, logits.stride(0),
+                              label_smoothing, _dt(logits), _stream()), "ls_xent_fwd")
+    return xent, lse
+
+
+def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None):
+    rows, V = logits.shape
+    dlogits = out if out is not None else torch.empty_like(logits)
+    assert dlogits.stride(0) == logits.stride(0)
+    check(lib.nst_ls_xent_bwd(_p(logits), _p(labels), _p(weights), _p(lse), _p(dlogits), rows, V, logits.stride(0),
+                              label_smoothing, gscale, _dt(logits), _stream()), "ls_xent_bwd")
+    return dlogits
+
+
+def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    n = p.numel()
+    check(lib.nst_adam_update(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, lr_t, beta1, beta2, eps, grad_scale,
+                              _stream()), "adam_update")
+
+
+def cast_f32_to_bf16(src, dst):
+    check(lib.nst_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_f32_to_bf16")
+
+
+def probe_mfma(device):
+    c16 = torch.zeros(256, dtype=torch.float32, device=device)
+    c16f = torch.zeros(256, dtype=torch.float32, device=device)
+    tr = torch.zeros(512, dtype=torch.int16, device=device)
+    check(lib.nst_probe_mfma(_p(c16), _p(c16f), _p(tr), _stream()), "probe_mfma")
+    return c16, c16f, tr

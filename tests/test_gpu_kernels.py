@@ -1,0 +1,438 @@
+"""Parity of every HIP kernel (called through the C ABI of libneurst_hip.so) against the CPU oracle /
+plain torch fp64 math on the same seeded inputs.  Tolerances are the north-star ones:
+1e-3 (fp32 path) and 1e-2 (bf16 path), relative to the magnitude of the reference tensor.
+
+All tests need a real MI355X: run with  pytest -m gpu.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import neurst_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def K():
+    from neurst_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    tag = "notr" if os.environ.get("NST_GEMM_NO_TR") == "1" else "tr"
+    with open(os.path.join(out, f"kernel_report_{tag}.json"), "w") as fp:
+        json.dump(REPORT, fp, indent=1, sort_keys=True)
+
+
+def close(name, got, ref, dtype, scale=1.0):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    denom = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max()) / denom
+    REPORT[name] = err
+    assert math.isfinite(err) and err <= TOL[dtype] * scale, f"{name}: rel err {err:.3e} > {TOL[dtype] * scale:.1e}"
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(*shape, generator=g) * scale
+    return t.to(dtype)
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------------------------ probes
+def test_mfma_fragment_maps(K):
+    c16, c16f, tr = K.probe_mfma(DEV)
+    i = np.arange(16)
+    A32 = ((i[:, None] * 37 + np.arange(32)[None, :] * 11) % 17 - 8) / 8.0
+    B32 = ((np.arange(32)[:, None] * 13 + i[None, :] * 7) % 19 - 9) / 16.0
+    np.testing.assert_allclose(c16.cpu().numpy().reshape(16, 16), A32 @ B32, atol=1e-5)
+    A4 = ((i[:, None] * 37 + np.arange(4)[None, :] * 11) % 17 - 8) / 8.0
+    B4 = ((np.arange(4)[:, None] * 13 + i[None, :] * 7) % 19 - 9) / 16.0
+    np.testing.assert_allclose(c16f.cpu().numpy().reshape(16, 16), A4 @ B4, atol=1e-6)
+
+
+def test_lds_transpose_read_map(K):
+    _, _, tr = K.probe_mfma(DEV)
+    got = tr.cpu().numpy().astype(np.int64).reshape(64, 8)
+    lane = np.arange(64)[:, None]
+    j = np.arange(8)[None, :]
+    expect = ((lane >> 4) * 8 + j) * 16 + (lane & 15)
+    REPORT["tr_read_mismatches"] = int((got != expect).sum())
+    np.testing.assert_array_equal(got, expect)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(7, 4), (37, 8), (300, 256), (100, 512), (33, 1024), (5, 250)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layernorm(K, dtype, rows, d, relu):
+    x = rnd(rows, d, dtype=dtype, seed=1)
+    gamma = rnd(d, seed=2) * 0.2 + 1.0
+    beta = rnd(d, seed=3) * 0.1
+    dy = rnd(rows, d, dtype=dtype, seed=4)
+    dres = rnd(rows, d, dtype=dtype, seed=5)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br, 1e-6)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+    y, mean, rstd = K.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, relu=relu)
+    tag = f"ln{'_relu' if relu else ''}[{dtype},{rows}x{d}]"
+    close(tag + ".y", y, yr, dtype)
+    dgamma = torch.full((d,), 7.0, device=DEV)
+    dbeta = torch.full((d,), 7.0, device=DEV)
+    if relu:
+        dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, y=y)
+        close(tag + ".dx", dx, xr.grad, dtype, scale=3.0)
+    else:
+        dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, dres=dres.to(DEV))
+        close(tag + ".dx", dx, xr.grad + dres.double(), dtype, scale=2.0)
+    if not relu or dtype == torch.float32:  # relu gate on a bf16-rounded y can flip near zero
+        close(tag + ".dgamma", dgamma, gr.grad, dtype, scale=2.0)
+        close(tag + ".dbeta", dbeta, br.grad, dtype, scale=2.0)
+    # accumulate
+    before = dgamma.clone()
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, accumulate=True,
+                    y=y if relu else None)
+    close(tag + ".dgamma_acc", dgamma, 2 * before.cpu().double(), torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(5, 7, 3), (16, 16, 32), (128, 128, 64), (130, 136, 72), (300, 256, 256), (257, 120, 513),
+               (64, 520, 40), (1000, 256, 2048)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
+def test_gemm_plain(K, dtype, ta, tb, M, N, K_):
+    A = rnd(*((K_, M) if ta else (M, K_)), dtype=dtype, seed=11)
+    B = rnd(*((N, K_) if tb else (K_, N)), dtype=dtype, seed=12)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    C_ = K.gemm(A.to(DEV), B.to(DEV), M, N, K_, trans_a=ta, trans_b=tb)
+    close(f"gemm[{dtype},{ta}{tb},{M}x{N}x{K_}]", C_, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(K, dtype):
+    M, N, K_ = 150, 264, 96
+    A, B = rnd(M, K_, dtype=dtype, seed=1), rnd(K_, N, dtype=dtype, seed=2)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    gate = rnd(M, N, dtype=dtype, seed=5)
+    pos = rnd(50, N, seed=6)
+    base = A.double() @ B.double()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    out = K.gemm(Ad, Bd, M, N, K_, alpha=0.5, bias=bias.to(DEV), relu=True)
+    close(f"gemm_bias_relu[{dtype}]", out, torch.relu(0.5 * base + bias.double()), dtype)
+    out = K.gemm(Ad, Bd, M, N, K_, bias=bias.to(DEV), residual=res.to(DEV))
+    close(f"gemm_residual[{dtype}]", out, base + bias.double() + res.double(), dtype)
+    out = K.gemm(Ad, Bd, M, N, K_, gate_src=gate.to(DEV), gate_scale=1.25)
+    close(f"gemm_gate[{dtype}]", out, base * (gate.double() > 0) * 1.25, dtype)
+    out = K.gemm(Ad, Bd, M, N, K_, bias=bias.to(DEV), posenc=pos.to(DEV), posenc_period=50, emb_scale=4.0)
+    rows = torch.arange(M) % 50
+    close(f"gemm_posenc[{dtype}]", out, (base + bias.double()) * 4.0 + pos.double()[rows], dtype)
+    c0 = rnd(M, N, dtype=dtype, seed=7)
+    out = c0.to(DEV).clone()
+    K.gemm(Ad, Bd, M, N, K_, out=out, accumulate=True)
+    close(f"gemm_accumulate[{dtype}]", out, base + c0.double(), dtype)
+    # strided views: A / out are column slices of wider buffers
+    wideA = rnd(M, K_ + 40, dtype=dtype, seed=8).to(DEV)
+    wideC = torch.zeros(M, N + 24, dtype=dtype, device=DEV)
+    K.gemm(wideA[:, 8:8 + K_], Bd, M, N, K_, out=wideC[:, 16:16 + N])
+    close(f"gemm_strided[{dtype}]", wideC[:, 16:16 + N], wideA[:, 8:8 + K_].cpu().double() @ B.double(), dtype)
+    assert float(wideC[:, :16].abs().max()) == 0.0 and float(wideC[:, 16 + N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_splitk_wgrad(K, dtype):
+    # dW[Kin,N] = X^T[Kin,rows] @ dY[rows,N], fp32 output, reduction over many rows
+    rows, Kin, N = 3000, 136, 264
+    X, dY = rnd(rows, Kin, dtype=dtype, seed=1), rnd(rows, N, dtype=dtype, seed=2)
+    ref = X.double().t() @ dY.double()
+    for split in (1, 7, 64):
+        out = torch.full((Kin, N), 3.0, dtype=torch.float32, device=DEV)
+        K.gemm(X.to(DEV), dY.to(DEV), Kin, N, rows, trans_a=True, out=out, split_k=split)
+        close(f"gemm_wgrad[{dtype},split{split}]", out, ref, torch.float32 if dtype == torch.float32 else dtype)
+    out = torch.full((Kin, N), 3.0, dtype=torch.float32, device=DEV)
+    K.gemm(X.to(DEV), dY.to(DEV), Kin, N, rows, trans_a=True, out=out, split_k=16, accumulate=True)
+    close(f"gemm_wgrad_acc[{dtype}]", out, ref + 3.0, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dropout_epilogue(K, dtype):
+    M, N, K_ = 256, 256, 64
+    A, B = rnd(M, K_, dtype=dtype, seed=1), rnd(K_, N, dtype=dtype, seed=2)
+    base = (A.double() @ B.double())
+    out = K.gemm(A.to(DEV), B.to(DEV), M, N, K_, dropout_p=0.25, seed=123, stream_id=9).float().cpu().double()
+    kept = out != 0
+    frac = float(kept.double().mean())
+    REPORT[f"gemm_dropout_keepfrac[{dtype}]"] = frac
+    assert abs(frac - 0.75) < 0.02
+    close(f"gemm_dropout_vals[{dtype}]", torch.where(kept, out, torch.zeros_like(out)),
+          torch.where(kept, base / 0.75, torch.zeros_like(base)), dtype)
+    # backward mask regeneration: scale_dropout_bwd with the same (seed, stream) gives the same mask
+    ones = torch.ones(M, N, dtype=dtype, device=DEV)
+    mask = K.scale_dropout_bwd(ones, 1.0, 0.25, 123, 9).float().cpu()
+    assert torch.equal(mask != 0, kept)
+    out2 = K.gemm(A.to(DEV), B.to(DEV), M, N, K_, dropout_p=0.25, seed=123, stream_id=10).float().cpu()
+    assert not torch.equal(out2 != 0, kept)
+
+
+def test_colsum(K):
+    for dtype in DTYPES:
+        x = rnd(1000, 264, dtype=dtype, seed=3)
+        out = torch.full((264,), 2.0, device=DEV)
+        K.colsum(x.to(DEV), out)
+        close(f"colsum[{dtype}]", out, x.double().sum(0), dtype)
+        K.colsum(x.to(DEV), out, accumulate=True)
+        close(f"colsum_acc[{dtype}]", out, 2 * x.double().sum(0), dtype)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, bias, causal, H, dh, keep=None, p=0.0):
+    B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+    q4, k4, v4 = q.reshape(B, Tq, H, dh), k.reshape(B, Tk, H, dh), v.reshape(B, Tk, H, dh)
+    logits = torch.einsum("bthd,bfhd->bhft", k4, q4 * dh ** -0.5)
+    if bias is not None:
+        logits = logits + bias[:, None, None, :]
+    if causal:
+        logits = logits + O.lower_triangle_attention_bias(Tq, q.dtype)
+    w = torch.softmax(logits, -1)
+    if keep is not None:
+        w = w * keep / (1.0 - p)
+    return torch.einsum("bhft,bthd->bfhd", w, v4).reshape(B, Tq, H * dh)
+
+
+ATTN_CASES = [  # B, H, Tq, Tk, dh, causal, key-padding
+    (1, 2, 2, 2, 2, False, False), (2, 2, 5, 7, 4, False, True), (2, 2, 3, 3, 4, True, False),
+    (2, 4, 225, 225, 64, False, True), (2, 4, 75, 75, 64, True, False), (2, 4, 75, 225, 64, False, True),
+    (1, 3, 130, 70, 24, False, True), (1, 2, 64, 64, 64, True, False)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal,pad", ATTN_CASES)
+def test_attention(K, dtype, B, H, Tq, Tk, dh, causal, pad):
+    d = H * dh
+    self_att = Tq == Tk
+    bias = None
+    if pad:
+        lens = torch.tensor([Tk - (i * Tk) // (2 * B) for i in range(B)])
+        bias = (O.length_to_padding(lens, Tk) * O.FLOAT_MIN).float()
+    if self_att:  # packed q|k|v projection output, as produced by the qkv GEMM
+        qkv = rnd(B, Tq, 3 * d, dtype=dtype, seed=5)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        qkv_d = qkv.to(DEV)
+        qd, kd, vd = qkv_d[..., :d], qkv_d[..., d:2 * d], qkv_d[..., 2 * d:]
+    else:
+        q = rnd(B, Tq, d, dtype=dtype, seed=5)
+        kv = rnd(B, Tk, 2 * d, dtype=dtype, seed=6)
+        k, v = kv[..., :d], kv[..., d:]
+        qd = q.to(DEV)
+        kv_d = kv.to(DEV)
+        kd, vd = kv_d[..., :d], kv_d[..., d:]
+    dout = rnd(B, Tq, d, dtype=dtype, seed=7)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, None if bias is None else bias.double(), causal, H, dh)
+    ref.backward(dout.double())
+    out, lse = K.attention_fwd(qd, kd, vd, H, dh, key_bias=None if bias is None else bias.to(DEV), causal=causal)
+    tag = f"attn[{dtype},B{B}H{H}q{Tq}k{Tk}d{dh}{'c' if causal else ''}{'p' if pad else ''}]"
+    close(tag + ".out", out, ref, dtype)
+    if self_att:
+        dqkv = torch.zeros_like(qkv_d)
+        dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+    else:
+        dq = torch.zeros_like(qd)
+        dkv = torch.zeros_like(kv_d)
+        dk, dv = dkv[..., :d], dkv[..., d:]
+    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dk, dv, H, dh,
+                    key_bias=None if bias is None else bias.to(DEV), causal=causal)
+    close(tag + ".dq", dq, qr.grad, dtype, scale=3.0)
+    close(tag + ".dk", dk, kr.grad, dtype, scale=3.0)
+    close(tag + ".dv", dv, vr.grad, dtype, scale=3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_dropout(K, dtype):
+    # V = identity exposes the (dropped) probability matrix as the output, which yields the mask itself.
+    B, H, T, dh, p = 2, 2, 32, 32, 0.3
+    d = H * dh
+    q, k = rnd(B, T, d, dtype=dtype, seed=1), rnd(B, T, d, dtype=dtype, seed=2)
+    eye = torch.eye(T).reshape(1, T, 1, dh).expand(B, T, H, dh).reshape(B, T, d).to(dtype).contiguous()
+    out, lse = K.attention_fwd(q.to(DEV), k.to(DEV), eye.to(DEV), H, dh, dropout_p=p, seed=77, stream_id=3)
+    P = out.float().cpu().reshape(B, T, H, T).permute(0, 2, 1, 3)  # [B,H,Tq,Tk]
+    keep = (P != 0).double()
+    frac = float(keep.mean())
+    REPORT[f"attn_dropout_keepfrac[{dtype}]"] = frac
+    assert abs(frac - (1 - p)) < 0.03
+    v = rnd(B, T, d, dtype=dtype, seed=3)
+    dout = rnd(B, T, d, dtype=dtype, seed=4)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, None, False, H, dh, keep=keep, p=p)
+    ref.backward(dout.double())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out, lse = K.attention_fwd(qd, kd, vd, H, dh, dropout_p=p, seed=77, stream_id=3)
+    close(f"attn_dropout[{dtype}].out", out, ref, dtype)
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dk, dv, H, dh, dropout_p=p, seed=77, stream_id=3)
+    close(f"attn_dropout[{dtype}].dq", dq, qr.grad, dtype, scale=3.0)
+    close(f"attn_dropout[{dtype}].dk", dk, kr.grad, dtype, scale=3.0)
+    close(f"attn_dropout[{dtype}].dv", dv, vr.grad, dtype, scale=3.0)
+
+
+# ------------------------------------------------------------------------------------------------ conv front end
+def _conv1_ref(src, w1, b1, gamma, beta, ln):
+    x = torch.nn.functional.conv2d(src[:, None], w1.permute(3, 2, 0, 1), b1, stride=2, padding=1)  # [B,C,T1,F1]
+    x = x.permute(0, 2, 3, 1)
+    if ln:
+        x = O.layer_norm(x, gamma, beta, 1e-6)
+    return torch.relu(x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,F,C,ln", [(1, 11, 80, 5, True), (2, 33, 16, 8, True), (2, 14, 12, 6, False),
+                                        (2, 50, 80, 256, True), (1, 9, 20, 512, True), (3, 23, 16, 64, False)])
+def test_conv1(K, dtype, B, T, F, C, ln):
+    src = rnd(B, T, F, seed=1)
+    w1 = rnd(3, 3, 1, C, seed=2) * 0.4
+    b1 = rnd(C, seed=3) * 0.1
+    gamma, beta = rnd(C, seed=4) * 0.2 + 1.0, rnd(C, seed=5) * 0.1
+    T1, F1 = (T + 1) // 2, (F + 1) // 2
+    dout = rnd(B, T1, F1, C, dtype=dtype, seed=6)
+    pr = [t.double().requires_grad_(True) for t in (w1, b1, gamma, beta)]
+    ref = _conv1_ref(src.double(), *pr, ln)
+    ref.backward(dout.double())
+    dv = lambda t: t.to(DEV)
+    out, mean, rstd = K.conv1_ln_relu_fwd(dv(src), dv(w1), dv(b1), dv(gamma), dv(beta), ln, 1e-6, dtype)
+    tag = f"conv1[{dtype},B{B}T{T}F{F}C{C}{'ln' if ln else ''}]"
+    close(tag + ".out", out, ref, dtype)
+    dw1, db1 = torch.full((3, 3, 1, C), 5.0, device=DEV), torch.full((C,), 5.0, device=DEV)
+    dg, dbe = torch.full((C,), 5.0, device=DEV), torch.full((C,), 5.0, device=DEV)
+    K.conv1_ln_relu_bwd(dv(src), dv(w1), dv(b1), dv(gamma), dv(beta), mean, rstd, dv(dout), dw1, db1, dg, dbe, ln, 1e-6)
+    close(tag + ".dw1", dw1, pr[0].grad, dtype, scale=2.0)
+    close(tag + ".db1", db1, pr[1].grad, dtype, scale=2.0)
+    if ln:
+        close(tag + ".dgamma", dg, pr[2].grad, dtype, scale=2.0)
+        close(tag + ".dbeta", dbe, pr[3].grad, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T1,F1,C", [(1, 6, 40, 5), (2, 9, 7, 8), (2, 12, 8, 64), (2, 25, 40, 256), (1, 5, 6, 40)])
+def test_conv2(K, dtype, B, T1, F1, C):
+    x = rnd(B, T1, F1, C, dtype=dtype, seed=1)
+    w2 = (rnd(3, 3, C, C, seed=2) * (1.0 / math.sqrt(9 * C))).to(dtype)
+    b2 = rnd(C, seed=3) * 0.1
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    dy = rnd(B, T2, F2, C, dtype=dtype, seed=4)
+    xr, wr = x.double().requires_grad_(True), w2.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), b2.double(), stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    ref.backward(dy.double())
+    tag = f"conv2[{dtype},B{B}T{T1}F{F1}C{C}]"
+    y = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV))
+    close(tag + ".y", y, ref, dtype)
+    dx = K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1)
+    close(tag + ".dx", dx, xr.grad, dtype, scale=2.0)
+    dw2 = torch.full((3, 3, C, C), 2.0, device=DEV)
+    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2)
+    close(tag + ".dw2", dw2, wr.grad, dtype, scale=2.0)
+    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, accumulate=True)
+    close(tag + ".dw2_acc", dw2, 2 * wr.grad, dtype, scale=2.0)
+
+
+# ------------------------------------------------------------------------------------------------ embedding / elementwise
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding(K, dtype):
+    V, d, B, L = 50, 24, 3, 7
+    table = rnd(V, d, dtype=dtype, seed=1)
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(2))
+    pos = O.sinusoid_signal(L, d)
+    ref = O.position_embedding(O.word_embedding(ids, table.double()))
+    out = K.embedding_fwd(table.to(DEV), ids.to(DEV), pos.to(DEV), L, d ** 0.5)
+    close(f"embedding[{dtype}].fwd", out, ref, dtype)
+    dout = rnd(B, L, d, dtype=dtype, seed=3)
+    dtab = torch.full((V, d), 1.0, device=DEV)
+    K.embedding_bwd(dout.to(DEV), ids.to(DEV), dtab, d ** 0.5)
+    refg = torch.ones(V, d, dtype=torch.float64)
+    refg.index_put_((ids.reshape(-1),), dout.double().reshape(-1, d) * d ** 0.5, accumulate=True)
+    close(f"embedding[{dtype}].bwd", dtab, refg, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_scale_posenc_dropout(K, dtype):
+    B, T, d = 3, 10, 24
+    x = rnd(B, T, d, dtype=dtype, seed=1)
+    pos = O.sinusoid_signal(T, d)
+    y = K.scale_posenc_dropout_fwd(x.to(DEV), pos.to(DEV), T, d ** 0.5)
+    close(f"scale_posenc[{dtype}]", y, O.position_embedding(x.double()), dtype)
+    y = K.scale_posenc_dropout_fwd(x.to(DEV), None, 1, 1.0, dropout_p=0.5, seed=5, stream_id=1).float().cpu()
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.5) < 0.1
+    g = K.scale_dropout_bwd(torch.ones_like(x).to(DEV), 1.0, 0.5, 5, 1).float().cpu()
+    assert torch.equal(g != 0, kept)
+    close(f"dropout_scale[{dtype}]", y[kept], x.double()[kept] * 2.0, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,V,ls", [(6, 5, 0.1), (64, 8008, 0.1), (10, 1000, 0.0), (33, 300, 0.3)])
+def test_ls_xent(K, dtype, rows, V, ls):
+    logits = (rnd(rows, V, seed=1) * 2.0).to(dtype)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
+    B = 2 if rows % 2 == 0 else 1
+    L = rows // B
+    lens = torch.tensor([L - i for i in range(B)])
+    lr = logits.double().reshape(B, L, V).requires_grad_(True)
+    nll, _, ntok = O.label_smoothed_cross_entropy(lr, labels.reshape(B, L), lens, ls)
+    loss = O.reduce_loss(nll, ntok)
+    loss.backward()
+    weights = (1.0 - O.length_to_padding(lens, L)).reshape(-1).float()
+    xent, lse = K.ls_xent_fwd(logits.to(DEV), labels.to(DEV), weights.to(DEV), ls)
+    tag = f"xent[{dtype},{rows}x{V},ls{ls}]"
+    close(tag + ".nll", xent.reshape(B, L).sum(1), nll, torch.float32, scale=5.0)
+    dl = K.ls_xent_bwd(logits.to(DEV), labels.to(DEV), weights.to(DEV), lse, ls, 1.0 / float(ntok.sum()))
+    close(tag + ".dlogits", dl, lr.grad.reshape(rows, V), dtype)
+
+
+def test_adam_and_cast(K):
+    n = 10007
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    m, v = rnd(n, seed=3) * 0.1, rnd(n, seed=4).abs() * 0.01
+    lr, t = 3e-4, 7
+    pr, mr, vr = O.keras_adam_step(p.double(), g.double() * 0.5, m.double(), v.double(), t, lr)
+    pd, md, vd, gd = p.to(DEV), m.to(DEV), v.to(DEV), g.to(DEV)
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    lr_t = lr * math.sqrt(1 - 0.98 ** t) / (1 - 0.9 ** t)
+    K.adam_update(pd, md, vd, gd, shadow, lr_t, 0.9, 0.98, 1e-9, grad_scale=0.5)
+    close("adam.p", pd, pr, torch.float32, scale=0.01)
+    close("adam.m", md, mr, torch.float32, scale=0.01)
+    close("adam.v", vd, vr, torch.float32, scale=0.01)
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+    out = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    K.cast_f32_to_bf16(gd, out)
+    assert torch.equal(out.cpu(), g.to(torch.bfloat16))
+
+
+def test_errors_are_reported_not_fatal(K):
+    from neurst_amd._lib import NstError
+    with pytest.raises(NstError):
+        K.layernorm_fwd(torch.zeros(2, 5000, device=DEV), torch.ones(5000, device=DEV), torch.zeros(5000, device=DEV), 1e-6)
+    with pytest.raises(RuntimeError):
+        K.layernorm_fwd(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)  # CPU tensors: no fallback
