@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/sec of SpeechTransformer-base (speech_transformer_s) bf16 TRAINING steps
+(forward + label-smoothed CE + backward + gradient all-reduce + Adam) on synthetic MuST-C-shaped batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).  `value` is the whole-job
+frames/s with the inputs already resident in HBM.  `roofline` is measured live with HIP events around the launches
+of the dominant kernel (the conv2 implicit-GEMM forward: the largest single launch of the step) during the timed
+steps, on the stream they are launched on.  `cpu_baseline` times the CPU oracle (oracle/neurst_oracle.py, a torch-CPU
+restatement of the reference math -- TensorFlow is not installable here) on the host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="speech_transformer_s")
+    ap.add_argument("--batch", type=int, default=128, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=900)
+    ap.add_argument("--vocab", type=int, default=8008)
+    ap.add_argument("--dropout", type=float, default=None, help="override the hparams set's dropout (0.1)")
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def algorithmic_flops(model_args, B, T, F, L, V):
+    """Forward FLOPs per step (SURVEY §8(d) formula); training = 3x."""
+    d, C = model_args["modality.dim"], model_args["modality.source.channels"]
+    H, ffn = model_args["encoder.num_attention_heads"], model_args["encoder.filter_size"]
+    Ne, Nd = model_args["encoder.num_layers"], model_args["decoder.num_layers"]
+    T1, F1 = (T + 1) // 2, (F + 1) // 2
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    M, Md, dh = B * T2, B * L, d // H
+    conv1 = 2 * B * T1 * F1 * 9 * C
+    conv2 = 2 * B * T2 * F2 * 9 * C * C
+    dense = 2 * M * F2 * C * d
+    enc = Ne * (2 * M * d * 3 * d + 4 * B * H * T2 * T2 * dh + 2 * M * d * d + 4 * M * d * ffn)
+    dec = Nd * (2 * Md * d * 3 * d + 4 * B * H * L * L * dh + 2 * Md * d * d + 2 * Md * d * d + 2 * M * d * 2 * d
+                + 4 * B * H * L * T2 * dh + 2 * Md * d * d + 4 * Md * d * ffn)
+    logits = 2 * Md * d * V
+    return {"conv1": conv1, "conv2": conv2, "dense": dense, "encoder": enc, "decoder": dec, "logits": logits,
+            "forward": conv1 + conv2 + dense + enc + dec + logits}
+
+
+def cpu_baseline(hp, args, T, F, L, V):
+    """Oracle (port of the reference math) fwd+bwd+Adam on the host cores, bounded sample."""
+    from oracle import neurst_oracle as O
+    p = hp["model.params"]
+    cfg = {"num_enc": p["encoder.num_layers"], "num_dec": p["decoder.num_layers"],
+           "num_heads": p["encoder.num_attention_heads"], "layer_norm": True, "d_model": p["modality.dim"],
+           "channels": p["modality.source.channels"], "ffn": p["encoder.filter_size"]}
+    B = args.cpu_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    W = O.init_speech_transformer_weights(cfg, V, F, 1, seed=42)
+    g = torch.Generator().manual_seed(1234)
+    trg = torch.randint(0, V - 3, (B, L), generator=g)
+    trg[:, -1] = V - 1
+    inputs = {"src": torch.randn(B, T, F, 1, generator=g), "src_length": torch.full((B,), T), "trg": trg,
+              "trg_length": torch.full((B,), L), "trg_input": torch.cat([torch.full((B, 1), V - 2), trg[:, :-1]], 1)}
+    m = {k: torch.zeros_like(v) for k, v in W.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in W.items()}
+    times = []
+    for t in range(1, 5):
+        t0 = time.perf_counter()
+        _, _, grads = O.train_step_reference(W, inputs, cfg, 0.1)
+        for k in W:
+            W[k], m[k], v_[k] = O.keras_adam_step(W[k], grads[k], m[k], v_[k], t, 1e-4)
+        times.append(time.perf_counter() - t0)
+    dt = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": B * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd+Adam, fp32, batch {B} x {T} frames, best of {len(times) - 1} timed steps "
+                      f"({dt * 1e3:.0f} ms/step); torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    args = parse()
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
+    from neurst_amd.models import build_model  # noqa: F401
+    from neurst_amd.optimizers import build_lr_schedule, build_optimizer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.training.distributed import GradientReducer, init_distributed
+    from neurst_amd.training.train_step import TrainStep
+    from neurst_amd.utils import compat
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    import torch.distributed as dist
+
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = f"cuda:{local_rank}"
+    dtype = "bfloat16" if args.dtype == "bf16" else "float32"
+    hp = get_hyper_parameters(args.model)
+    if args.dropout is not None:
+        for k in list(hp["model.params"]):
+            if k.endswith("dropout_rate"):
+                hp["model.params"][k] = args.dropout
+    B, T, F, V = args.batch, args.frames, 80, args.vocab
+    L = max(1, T // 12)
+    task = build_task({"task.class": "speech2text", "task.params": {"audio_feature_dim": F, "vocab_size": V}})
+    model = task.build_model(hp, device=dev, dtype=dtype, seed=1234 + rank, init_seed=42)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = build_optimizer({"optimizer.class": hp["optimizer.class"], "optimizer.params": hp["optimizer.params"]})
+    opt.bind(model.store)
+    opt.learning_rate = build_lr_schedule({"lr_schedule.class": hp["lr_schedule.class"],
+                                           "lr_schedule.params": hp["lr_schedule.params"]})
+    reducer = GradientReducer(model.store)
+    reducer.broadcast_parameters(0)
+    step_fn = TrainStep(model, crit, opt, reducer)
+    ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
+                                 "ragged": args.ragged, "seed": 1234})
+    it = ds.build_iterator(map_func=lambda b: task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
+                           total_shards=world, device=dev)
+    batches = [next(it) for _ in range(4)]  # resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step_fn(batches[i % len(batches)])
+    barrier()
+    K.PROBE.start("conv2_fwd")
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = step_fn(batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    probe_ms = K.PROBE.stop()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss)
+
+    if rank != 0:
+        return
+    frames = world * B * T * args.steps
+    fl = algorithmic_flops(hp["model.params"], B, T, F, L, V)
+    step_flops = 3 * fl["forward"]
+    value = frames / elapsed
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    conv2_ms = sum(probe_ms) / max(len(probe_ms), 1) if probe_ms else None
+    roofline = {"kernel": "conv_gemm_kernel (conv2 implicit-GEMM forward, M=B*T2*F2, N=C, K=9C)", "bound": "mfma",
+                "achieved": (fl["conv2"] / (conv2_ms * 1e-3) / 1e12) if conv2_ms else None, "peak": peak,
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_timed": len(probe_ms),
+                "avg_launch_ms": conv2_ms, "algorithmic_flops_per_launch": fl["conv2"]}
+    if roofline["achieved"]:
+        roofline["frac"] = roofline["achieved"] / peak
+    out = {
+        "metric": "audio frames/sec, SpeechTransformer-base (speech_transformer_s) training, whole job",
+        "value": value, "unit": "frames/s", "value_per_gpu": value / world, "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.model} train step: B={B}/GPU x T={T} frames x F={F} mel, L={L}, V={V}, "
+                               f"dropout {hp['model.params']['encoder.ffn_dropout_rate']}, label smoothing 0.1, "
+                               f"Adam+Noam, {'ragged' if args.ragged else 'full-length'} inputs",
+                   "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+        "model_tflops_per_s": step_flops * args.steps * world / elapsed / 1e12,
+        "model_mfma_frac": step_flops * args.steps / elapsed / 1e12 / peak,
+        "final_loss": loss_val,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(hp, args, T, F, L, V)
+        except Exception as e:  # the baseline is informational; never lose the GPU line because of it
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e}"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -148,11 +148,12 @@ int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const float* b1, co
                           float* db1, float* dgamma, float* dbeta, int B, int T, int F, int C, int layer_norm,
                           float eps, int dtype, int accumulate, void* stream);
 /* Layer 2 as an implicit GEMM on MFMA (M = B*T2*F2, N = C, K = 9*C), x [B,T1,F1,C] dtype, w2 [3,3,C,C] dtype (HWIO).
- *   fwd:   y[B,T2,F2,C] = conv(x) + b2                    (LayerNorm+ReLU follow as nst_layernorm_fwd w/ relu)
+ *   fwd:   y[B,T2,F2,C] = conv(x) + b2, ReLU fused when relu!=0 (layer_norm=False recipe); with LayerNorm the
+ *          LN+ReLU follow as nst_layernorm_relu_fwd
  *   dgrad: dx[B,T1,F1,C] = conv_transpose(dy, w2)
  *   wgrad: dw2[3,3,C,C] f32 (+)= x (*) dy   */
-int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int dtype,
-                  void* stream);
+int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu,
+                  int dtype, void* stream);
 int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
 int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
                     int accumulate, void* stream);
@@ -193,12 +194,14 @@ int nst_scale_dropout_bwd(const void* dy, void* dx, int64_t n, float scale, floa
  * LabelSmoothedCrossEntropy.__call__  neurst/criterions/label_smoothed_cross_entropy.py:94-157.
  * logits [rows,V] dtype (ldl), labels int64 [rows], weights f32 [rows] (sequence_mask(trg_length)).
  * fwd: xent[rows] f32 = (-(sum_v soft_v*log_softmax_v) - normalizing_constant) * weight ; lse[rows] f32 saved.
- * bwd: dlogits[rows,V] dtype = (softmax - soft_target) * weight[row] * gscale    (gscale = 1/sum(n_tokens)) */
+ * bwd: dlogits[rows,V] dtype = (softmax - soft_target) * weight[row] * gscale * (gscale_dev ? *gscale_dev : 1)
+ *      (reduce_loss = sum(nll)/sum(n_tokens), label_smoothed_cross_entropy.py:46-53: pass 1/sum(n_tokens) either as
+ *      the host value gscale or, to avoid a device->host sync, as the device scalar gscale_dev) */
 int nst_ls_xent_fwd(const void* logits, const int64_t* labels, const float* weights, float* xent, float* lse,
                     int64_t rows, int V, int64_t ldl, float label_smoothing, int dtype, void* stream);
 int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weights, const float* lse,
-                    void* dlogits, int64_t rows, int V, int64_t ldl, float label_smoothing, float gscale, int dtype,
-                    void* stream);
+                    void* dlogits, int64_t rows, int V, int64_t ldl, float label_smoothing, float gscale,
+                    const float* gscale_dev, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * Keras Adam (neurst/models/speech_transformer.py:265-279, neurst/optimizers/__init__.py) over ONE flat buffer:

@@ -63,7 +63,7 @@ SIGNATURES = {
     "nst_attention_bwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_conv1_ln_relu_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "nst_conv1_ln_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "nst_conv2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nst_conv2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nst_conv2_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nst_conv2_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nst_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _U64, _U64, _I, _P],
@@ -71,7 +71,7 @@ SIGNATURES = {
     "nst_scale_posenc_dropout_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _U64, _U64, _I, _P],
     "nst_scale_dropout_bwd": [_P, _P, _L, _F, _F, _U64, _U64, _I, _P],
     "nst_ls_xent_fwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _I, _P],
-    "nst_ls_xent_bwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _F, _I, _P],
+    "nst_ls_xent_bwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _F, _P, _I, _P],
     "nst_adam_update": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
     "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
     "nst_cast_bf16_to_f32": [_P, _P, _L, _P],

@@ -1,0 +1,44 @@
+"""Criterion base + registry (neurst/criterions/criterion.py:20-82, neurst/criterions/__init__.py)."""
+from abc import ABCMeta, abstractmethod
+
+from neurst_amd.utils.registry import setup_registry
+
+
+class Criterion(metaclass=ABCMeta):
+    REGISTRY_NAME = "criterion"
+
+    def __init__(self):
+        self._model = None
+
+    @staticmethod
+    def class_or_method_args():
+        return []
+
+    @abstractmethod
+    def __call__(self, model_inp, model_out):
+        raise NotImplementedError
+
+    @abstractmethod
+    def reduce_loss(self, model_inp, model_out):
+        raise NotImplementedError
+
+    @abstractmethod
+    def reduce_metrics(self, eval_res_list):
+        raise NotImplementedError
+
+    def reduce_sample_metrics(self, eval_res):
+        raise NotImplementedError
+
+    @abstractmethod
+    def as_metric(self):
+        raise NotImplementedError
+
+    def set_model(self, model):
+        self._model = model
+
+    @property
+    def model(self):
+        return self._model
+
+
+build_criterion, register_criterion = setup_registry(Criterion.REGISTRY_NAME, base_class=Criterion, backend="pt")

@@ -1,0 +1,88 @@
+"""LabelSmoothedCrossEntropy (neurst/criterions/label_smoothed_cross_entropy.py:27-157) on the HIP path.
+
+One fused kernel pass computes, per target position, the smoothed cross entropy minus the normalising constant
+times the length mask (no one_hot / softmax tensors are materialised); a second fused pass writes
+d(reduce_loss)/d(logits) = (softmax - soft_target) * weight / sum(n_tokens), with 1/sum(n_tokens) read from a device
+scalar so the training step never synchronises with the host.
+"""
+import collections
+
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.criterions.criterion import Criterion, register_criterion
+from neurst_amd.models.model_utils import input_length_to_nonpadding
+from neurst_amd.utils.flags_core import Flag
+
+MetricWrapper = collections.namedtuple("MetricWrapper", "flag greater_is_better")
+
+
+@register_criterion
+class LabelSmoothedCrossEntropy(Criterion):
+    def __init__(self, args=None):
+        super().__init__()
+        self._label_smoothing = float((args or {}).get("label_smoothing", 0.) or 0.)
+        self._saved = None
+
+    @staticmethod
+    def class_or_method_args():
+        return [Flag("label_smoothing", dtype=Flag.TYPE.FLOAT, default=0., help="The label smoothing constant.")]
+
+    def _weights(self, model_inp, labels):
+        padding = model_inp.get("trg_padding", None)
+        if padding is None:
+            padding = model_inp.get("padding", None)
+        length = model_inp.get("trg_length", None)
+        if length is None:
+            length = model_inp.get("length", None)
+        if padding is None:
+            weights = input_length_to_nonpadding(length, labels.shape[1], torch.float32)
+        else:
+            weights = (1 - padding).float()
+        if model_inp.get("mask", None) is not None:
+            weights = weights * model_inp["mask"].float()
+        return weights
+
+    def __call__(self, model_inp, model_out):
+        """-> (nll_sum [B], n_samples [1], n_tokens [B]), float32 device tensors."""
+        logits = model_out["logits"] if isinstance(model_out, dict) else model_out
+        if not torch.is_tensor(logits):
+            raise ValueError("Not supported type of model_out: {}".format(type(model_out)))
+        labels = model_inp["trg"].long().contiguous()
+        B, L, V = logits.shape
+        weights = self._weights(model_inp, labels).contiguous()
+        l2 = logits.reshape(B * L, V)
+        xent, lse = K.ls_xent_fwd(l2, labels.view(-1), weights.view(-1), self._label_smoothing)
+        nll_sum = xent.view(B, L).sum(dim=1)
+        n_tokens = weights.sum(dim=1)
+        n_samples = torch.full((1,), float(B), dtype=torch.float32, device=logits.device)
+        self._saved = (l2, labels.view(-1), weights.view(-1), lse, n_tokens, (B, L, V))
+        return nll_sum, n_samples, n_tokens
+
+    def reduce_loss(self, model_inp, model_out):
+        """sum(nll_sum) / sum(n_tokens)  (label_smoothed_cross_entropy.py:46-53), a device scalar."""
+        nll_sum, _, n_tokens = self(model_inp, model_out)
+        return nll_sum.sum() / n_tokens.sum()
+
+    def backward(self, loss_scale=1.0):
+        """d(reduce_loss * loss_scale)/d(logits) for the logits of the last __call__; [B, L, V] in the logits dtype."""
+        l2, labels, weights, lse, n_tokens, (B, L, V) = self._saved
+        self._saved = None
+        inv = (1.0 / n_tokens.sum()).reshape(1).contiguous()
+        return K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), gscale_dev=inv).view(B, L, V)
+
+    def reduce_metrics(self, eval_res_list):
+        nll_sum = nll_samples = nll_tokens = 0.
+        for _nll_sum, _nll_samples, _nll_tokens in eval_res_list:
+            nll_sum += float(torch.as_tensor(_nll_sum).sum())
+            nll_samples += float(torch.as_tensor(_nll_samples).sum())
+            nll_tokens += float(torch.as_tensor(_nll_tokens).sum())
+        return {"NLL": nll_sum / nll_samples, "PPL": 2. ** (nll_sum / nll_tokens)}
+
+    def reduce_sample_metrics(self, eval_res):
+        nll_sum, _, nll_tokens = eval_res
+        return [{"nll": float(n), "ppl": 2. ** (float(n) / float(t)), "nll_per_token": float(n) / float(t)}
+                for n, t in zip(nll_sum.tolist(), nll_tokens.tolist())]
+
+    def as_metric(self):
+        return MetricWrapper(flag="NLL", greater_is_better=False)

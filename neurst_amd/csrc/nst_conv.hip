@@ -349,7 +349,7 @@ Epilogue plain_epilogue() {
 }
 
 template <typename T>
-int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, hipStream_t st) {
+int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int M = B * T2 * F2, N = C, K = 9 * C;
   Im2colLoader<T> la;
@@ -361,6 +361,7 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   lb.vec = nst_aligned16(w2) && (C % Tile<T>::E == 0);
   Epilogue ep = plain_epilogue();
   ep.bias = b2;
+  ep.relu = relu;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   dim3 grid(ntiles, 1, 1);
@@ -498,13 +499,13 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
   return NST_OK;
 }
 
-extern "C" int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int dtype,
-                             void* stream) {
+extern "C" int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu,
+                             int dtype, void* stream) {
   NST_CHECK_ARG(x && w2 && y, "conv2_fwd: null pointer");
   int rc = check_conv_dims("conv2_fwd", B, T1, F1, C);
   if (rc) return rc;
-  if (dtype == NST_F32) conv2_fwd_t<float>(x, w2, b2, y, B, T1, F1, C, (hipStream_t)stream);
-  else if (dtype == NST_BF16) conv2_fwd_t<bf16_t>(x, w2, b2, y, B, T1, F1, C, (hipStream_t)stream);
+  if (dtype == NST_F32) conv2_fwd_t<float>(x, w2, b2, y, B, T1, F1, C, relu, (hipStream_t)stream);
+  else if (dtype == NST_BF16) conv2_fwd_t<bf16_t>(x, w2, b2, y, B, T1, F1, C, relu, (hipStream_t)stream);
   else { nst_set_error("conv2_fwd: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("conv2_fwd");
   return NST_OK;

@@ -149,12 +149,12 @@ template <typename T>
 __global__ void __launch_bounds__(256) ls_xent_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                                          const float* __restrict__ weights, const float* __restrict__ lse_in,
                                                          T* __restrict__ dlogits, int V, int64_t ldl, float conf, float low,
-                                                         float gscale) {
+                                                         float gscale, const float* __restrict__ gscale_dev) {
   const int64_t row = blockIdx.x;
   const T* x = logits + row * ldl;
   T* dx = dlogits + row * ldl;
   const float lse = lse_in[row];
-  const float w = weights[row] * gscale;
+  const float w = weights[row] * gscale * (gscale_dev ? gscale_dev[0] : 1.f);
   int64_t lab = labels[row];
   lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
@@ -329,7 +329,7 @@ extern "C" int nst_ls_xent_fwd(const void* logits, const int64_t* labels, const 
 
 extern "C" int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weights, const float* lse,
                                void* dlogits, int64_t rows, int V, int64_t ldl, float label_smoothing, float gscale,
-                               int dtype, void* stream) {
+                               const float* gscale_dev, int dtype, void* stream) {
   NST_CHECK_ARG(logits && labels && weights && lse && dlogits, "ls_xent_bwd: null pointer");
   NST_CHECK_ARG(V > 0 && ldl >= V, "ls_xent_bwd: bad V=%d ldl=%lld", V, (long long)ldl);
   if (rows <= 0) return NST_OK;
@@ -337,9 +337,9 @@ extern "C" int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const 
   xent_consts(V, label_smoothing, &conf, &low, &norm);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == NST_F32)
-    ls_xent_bwd_kernel<float><<<(unsigned)rows, 256, 0, st>>>((const float*)logits, labels, weights, lse, (float*)dlogits, V, ldl, conf, low, gscale);
+    ls_xent_bwd_kernel<float><<<(unsigned)rows, 256, 0, st>>>((const float*)logits, labels, weights, lse, (float*)dlogits, V, ldl, conf, low, gscale, gscale_dev);
   else if (dtype == NST_BF16)
-    ls_xent_bwd_kernel<bf16_t><<<(unsigned)rows, 256, 0, st>>>((const bf16_t*)logits, labels, weights, lse, (bf16_t*)dlogits, V, ldl, conf, low, gscale);
+    ls_xent_bwd_kernel<bf16_t><<<(unsigned)rows, 256, 0, st>>>((const bf16_t*)logits, labels, weights, lse, (bf16_t*)dlogits, V, ldl, conf, low, gscale, gscale_dev);
   else { nst_set_error("ls_xent_bwd: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("ls_xent_bwd");
   return NST_OK;

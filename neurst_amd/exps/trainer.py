@@ -1,0 +1,104 @@
+"""Trainer (neurst/exps/trainer.py:38-315), registered as entry.class=trainer.
+
+run(): criterion / optimizer / lr schedule construction, rank-0 weight broadcast, the training loop with the
+reference's logging (steps/sec, src_real_tokens_per_sec == audio frames/sec summed over workers,
+training/callbacks.py:209-245), checkpoint save of model weights + model_configs.yml on rank 0.
+"""
+import logging
+import os
+import time
+
+import torch
+
+from neurst_amd.criterions import Criterion, build_criterion
+from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
+from neurst_amd.optimizers import build_lr_schedule, build_optimizer
+from neurst_amd.training.distributed import GradientReducer
+from neurst_amd.training.train_step import TrainStep
+from neurst_amd.utils import compat
+from neurst_amd.utils.configurable import ModelConfigs
+from neurst_amd.utils.flags_core import Flag, ModuleFlag
+
+
+@register_exp(["train", "training"])
+class Trainer(BaseExperiment):
+    def __init__(self, args, **kwargs):
+        super().__init__(**kwargs)
+        self._args = args
+        self._criterion = build_criterion(args)
+        self._train_steps = args["train_steps"]
+        self._summary_steps = args["summary_steps"]
+        self._save_checkpoint_steps = args["save_checkpoint_steps"]
+        self._update_cycle = args["update_cycle"] or 1
+        self._optimizer_args = {"optimizer.class": args["optimizer.class"], "optimizer.params": args["optimizer.params"]}
+        self._lr_args = {"lr_schedule.class": args["lr_schedule.class"], "lr_schedule.params": args["lr_schedule.params"]}
+        self._bucket_mb = args.get("allreduce_bucket_mb", 32) or 32
+
+    @staticmethod
+    def class_or_method_args():
+        return [
+            ModuleFlag(Criterion.REGISTRY_NAME, default="label_smoothed_cross_entropy", help="The training criterion."),
+            ModuleFlag("optimizer", default="Adam", help="The optimizer for training."),
+            ModuleFlag("lr_schedule", default=None, help="The learning schedule for training."),
+            Flag("train_steps", dtype=Flag.TYPE.INTEGER, default=10000000, help="The maximum steps for training."),
+            Flag("summary_steps", dtype=Flag.TYPE.INTEGER, default=200, help="Doing summary (logging) every N steps."),
+            Flag("save_checkpoint_steps", dtype=Flag.TYPE.INTEGER, default=1000, help="Saving checkpoints every N steps."),
+            Flag("checkpoints_max_to_keep", dtype=Flag.TYPE.INTEGER, default=8, help="Number of checkpoints to keep."),
+            Flag("update_cycle", dtype=Flag.TYPE.INTEGER, default=1, help="Gradient accumulation micro steps."),
+            Flag("allreduce_bucket_mb", dtype=Flag.TYPE.INTEGER, default=32,
+                 help="Size of one RCCL all-reduce message of the flat gradient buffer."),
+        ]
+
+    def _save(self, step):
+        if not self.model_dir:
+            return
+        os.makedirs(self.model_dir, exist_ok=True)
+        path = os.path.join(self.model_dir, f"ckpt-{step}.pt")
+        try:
+            torch.save({"step": step, "variables": self.model.store.state_dict()}, path)
+            with open(os.path.join(self.model_dir, "checkpoint"), "w") as fp:
+                fp.write(f'model_checkpoint_path: "ckpt-{step}.pt"\n')
+        except Exception as e:  # the reference also only warns (callbacks.py:88-92)
+            logging.warning("fail to save checkpoint: %s", e)
+
+    def run(self):
+        rank, world, _ = compat.get_distributed_worker_setting()
+        model, rt = self.model, self.model.rt
+        lr = build_lr_schedule(self._lr_args) if self._lr_args["lr_schedule.class"] else None
+        opt_params = dict(self._optimizer_args["optimizer.params"] or {})
+        optimizer = build_optimizer({"optimizer.class": self._optimizer_args["optimizer.class"],
+                                     "optimizer.params": opt_params})
+        optimizer.bind(model.store)
+        if lr is not None:
+            optimizer.learning_rate = lr
+        reducer = GradientReducer(model.store, bucket_bytes=self._bucket_mb << 20)
+        reducer.broadcast_parameters(0)
+        step_fn = TrainStep(model, self._criterion, optimizer, reducer, self._update_cycle)
+        if rank == 0 and self.model_dir:
+            ModelConfigs.dump({"model.class": model.__class__.__name__, "model.params": model.args,
+                               "task.class": self.task.__class__.__name__, "task.params": self.task.get_config()},
+                              self.model_dir)
+        it = self.custom_dataset.build_iterator(
+            map_func=lambda b: self.task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
+            total_shards=world, device=rt.device)
+        t0, frames, last_loss = time.time(), 0.0, None
+        for step in range(1, self._train_steps + 1):
+            try:
+                batches = [next(it) for _ in range(self._update_cycle)]
+            except StopIteration:
+                break
+            frames_dev = sum(b["src_length"].sum() for b in batches)
+            last_loss = step_fn(batches)
+            if step % self._summary_steps == 0 or step == self._train_steps:
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                m = reducer.reduce_metrics({"loss": float(last_loss) / world, "src_real_tokens": float(frames_dev) + frames})
+                if rank == 0:
+                    logging.info("step %d: loss=%.4f  %.3f steps/sec  %.1f src_real_tokens_per_sec  lr=%.3e", step,
+                                 m["loss"], self._summary_steps / dt, m["src_real_tokens"] / dt, optimizer.current_lr())
+                t0, frames = time.time(), 0.0
+            else:
+                frames = frames + float(0)  # keep host free of syncs between summaries
+            if rank == 0 and self._save_checkpoint_steps and step % self._save_checkpoint_steps == 0:
+                self._save(step)
+        return last_loss

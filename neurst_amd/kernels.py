@@ -33,10 +33,37 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _rows2d(t):
-    """View [..., d] as rows with unit inner stride; returns (tensor, rows, d, ld)."""
-    assert t.stride(-1) == 1
-    return t
+class _KernelProbe(object):
+    """HIP-event timing of one named kernel entry point on the stream it is launched on (bench.py's roofline).
+    Inactive unless start(name) was called; events are only read back in stop()."""
+
+    def __init__(self):
+        self.name, self.events = None, []
+
+    def start(self, name):
+        self.name, self.events = name, []
+
+    def stop(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        self.name, self.events = None, []
+        return ms
+
+    def begin(self, name):
+        if self.name != name:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, ev):
+        if ev is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record(torch.cuda.current_stream())
+            self.events.append((ev, e2))
+
+
+PROBE = _KernelProbe()
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
@@ -177,11 +204,13 @@ def conv1_ln_relu_bwd(src, w1, b1, gamma, beta, mean, rstd, dout, dw1, db1, dgam
                                     _dt(dout), int(accumulate), _stream()), "conv1_bwd")
 
 
-def conv2_fwd(x, w2, b2):
+def conv2_fwd(x, w2, b2, relu=False):
     B, T1, F1, Cc = x.shape
     assert x.is_contiguous() and w2.is_contiguous() and w2.dtype == x.dtype
     y = torch.empty(B, (T1 + 1) // 2, (F1 + 1) // 2, Cc, dtype=x.dtype, device=x.device)
-    check(lib.nst_conv2_fwd(_p(x), _p(w2), _p(b2), _p(y), B, T1, F1, Cc, _dt(x), _stream()), "conv2_fwd")
+    ev = PROBE.begin("conv2_fwd")
+    check(lib.nst_conv2_fwd(_p(x), _p(w2), _p(b2), _p(y), B, T1, F1, Cc, int(relu), _dt(x), _stream()), "conv2_fwd")
+    PROBE.end(ev)
     return y
 
 
@@ -246,12 +275,12 @@ def ls_xent_fwd(logits, labels, weights, label_smoothing):
     return xent, lse
 
 
-def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None):
+def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None, gscale_dev=None):
     rows, V = logits.shape
     dlogits = out if out is not None else torch.empty_like(logits)
     assert dlogits.stride(0) == logits.stride(0)
     check(lib.nst_ls_xent_bwd(_p(logits), _p(labels), _p(weights), _p(lse), _p(dlogits), rows, V, logits.stride(0),
-                              label_smoothing, gscale, _dt(logits), _stream()), "ls_xent_bwd")
+                              label_smoothing, gscale, _p(gscale_dev), _dt(logits), _stream()), "ls_xent_bwd")
     return dlogits
 
 

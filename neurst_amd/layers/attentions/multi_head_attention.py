@@ -1,0 +1,112 @@
+"""MultiHeadAttention / MultiHeadSelfAttention (neurst/layers/attentions/multi_head_attention.py:21-290),
+training path (no decode cache).
+
+forward : packed projection GEMM (bias fused) -> fused flash attention kernel reading q|k|v as strided column
+          views of the projection output (no split / transpose copies) -> output projection GEMM whose epilogue
+          carries the wrapper's dropout + residual.
+backward: hand scheduled; dq|dk|dv are written by the attention backward kernels directly into one packed
+          buffer that feeds the projection wgrad / dgrad GEMMs.
+"""
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.layers.common_layers import Layer, MultiHeadDenseLayer
+
+
+class MultiHeadAttention(Layer):
+    """Cross attention: q from `query`, k|v from `memory` (variables q_transform, kv_transform, output_transform)."""
+
+    def __init__(self, rt, name, num_heads, num_units, attention_dropout_rate, gen, attention_type="dot_product",
+                 output_depth=None, input_depth=None, memory_depth=None):
+        super().__init__(rt, name)
+        if attention_type != "dot_product":
+            raise NotImplementedError(f"att_fn for \"{attention_type}\" not implemented.")
+        if num_units % num_heads != 0:
+            raise ValueError("query depth ({}) must be divisible by the number of "
+                             "attention heads ({}).".format(num_units, num_heads))
+        self.num_heads, self.num_units = num_heads, num_units
+        self.dh = num_units // num_heads
+        self.rate = attention_dropout_rate
+        self.site = self._site()
+        self.input_depth, self.memory_depth = input_depth or num_units, memory_depth or input_depth or num_units
+        self.output_depth = output_depth or num_units
+        self._build_projections(gen, self.output_depth)
+
+    def _build_projections(self, gen, output_depth):
+        d, H = self.num_units, self.num_heads
+        # creation order follows the reference: output_transform in __init__, the others in build()
+        self.output_transform = MultiHeadDenseLayer(self.rt, self.name + "/output_transform", d, output_depth, H, gen,
+                                                    is_output_transform=True)
+        self.q_transform = MultiHeadDenseLayer(self.rt, self.name + "/q_transform", self.input_depth, d, H, gen)
+        self.kv_transform = MultiHeadDenseLayer(self.rt, self.name + "/kv_transform", self.memory_depth, [d, d], H, gen)
+
+    def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None):
+        """query [B*Tq, d], memory [B*Tk, d]; memory_bias [B,Tk] f32 (padding*FLOAT_MIN) or None."""
+        d, H, dh = self.num_units, self.num_heads, self.dh
+        p = self.rate if is_training else 0.0
+        q = self.q_transform.forward(query)
+        kv = self.kv_transform.forward(memory)
+        q3, kv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d)
+        ctx, lse = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=False,
+                                   dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        out = self.output_transform.forward(ctx.view(B * Tq, d), **(epilogue or {}))
+        if is_training:
+            self._saved = (query, memory, q, kv, ctx, lse, memory_bias, B, Tq, Tk, p)
+        return out
+
+    def backward(self, dz, dmemory=None, dmemory_accumulate=False):
+        """Returns d(query); d(memory) is written (or accumulated) into `dmemory` [B*Tk, d]."""
+        query, memory, q, kv, ctx, lse, bias, B, Tq, Tk, p = self._saved
+        self._saved = None
+        d, H, dh = self.num_units, self.num_heads, self.dh
+        ctx2 = ctx.view(B * Tq, d)
+        self.output_transform.backward_params(ctx2, dz)
+        dctx = self.output_transform.backward_input(dz)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        q3, kv3, dq3, dkv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d), dq.view(B, Tq, d), dkv.view(B, Tk, 2 * d)
+        K.attention_bwd(q3, kv3[..., :d], kv3[..., d:], ctx, dctx.view(B, Tq, d), lse, dq3, dkv3[..., :d],
+                        dkv3[..., d:], H, dh, key_bias=bias, causal=False, dropout_p=p, seed=self.rt.step_seed,
+                        stream_id=self.site)
+        self.q_transform.backward_params(query, dq)
+        self.kv_transform.backward_params(memory, dkv)
+        if dmemory is not None:
+            self.kv_transform.backward_input(dkv, out=dmemory, accumulate=dmemory_accumulate)
+        return self.q_transform.backward_input(dq)
+
+
+class MultiHeadSelfAttention(MultiHeadAttention):
+    """Self attention with one packed qkv_transform (multi_head_attention.py:226-290)."""
+
+    def _build_projections(self, gen, output_depth):
+        d, H = self.num_units, self.num_heads
+        self.output_transform = MultiHeadDenseLayer(self.rt, self.name + "/output_transform", d, output_depth, H, gen,
+                                                    is_output_transform=True)
+        self.qkv_transform = MultiHeadDenseLayer(self.rt, self.name + "/qkv_transform", self.input_depth, [d, d, d], H, gen)
+
+    def forward(self, x, B, T, bias=None, causal=False, is_training=True, epilogue=None):
+        """x [B*T, d]; bias [B,T] f32 key-padding bias or None; causal=True is the decoder's lower-triangle bias."""
+        d, H, dh = self.num_units, self.num_heads, self.dh
+        p = self.rate if is_training else 0.0
+        qkv = self.qkv_transform.forward(x)
+        v3 = qkv.view(B, T, 3 * d)
+        ctx, lse = K.attention_fwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], H, dh, key_bias=bias, causal=causal,
+                                   dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        out = self.output_transform.forward(ctx.view(B * T, d), **(epilogue or {}))
+        if is_training:
+            self._saved = (x, qkv, ctx, lse, bias, causal, B, T, p)
+        return out
+
+    def backward(self, dz):
+        x, qkv, ctx, lse, bias, causal, B, T, p = self._saved
+        self._saved = None
+        d, H, dh = self.num_units, self.num_heads, self.dh
+        self.output_transform.backward_params(ctx.view(B * T, d), dz)
+        dctx = self.output_transform.backward_input(dz)
+        dqkv = torch.empty_like(qkv)
+        v3, g3 = qkv.view(B, T, 3 * d), dqkv.view(B, T, 3 * d)
+        K.attention_bwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], ctx, dctx.view(B, T, d), lse, g3[..., :d],
+                        g3[..., d:2 * d], g3[..., 2 * d:], H, dh, key_bias=bias, causal=causal, dropout_p=p,
+                        seed=self.rt.step_seed, stream_id=self.site)
+        self.qkv_transform.backward_params(x, dqkv)
+        return self.qkv_transform.backward_input(dqkv)

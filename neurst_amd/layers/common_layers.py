@@ -1,0 +1,191 @@
+"""MI355X-native restatement of neurst/layers/common_layers.py.
+
+Every layer owns its parameters (TF variable names, TF layouts) in the runtime's flat ParamStore and
+exposes an explicit ``forward`` / ``backward`` pair: the backward pass is hand-scheduled (no autograd
+tape), writes parameter gradients straight into the flat gradient buffer and returns the input gradient.
+Activations are 2-D ``[B*T, d]`` row-major tensors.
+
+  PrePostProcessingWrapper   neurst/layers/common_layers.py:23-92   (LN -> layer -> dropout -> residual)
+  TransformerFFN             neurst/layers/common_layers.py:95-160
+  MultiHeadDenseLayer        neurst/layers/common_layers.py:163-295
+  PositionEmbeddingWrapper   neurst/layers/common_layers.py:298-446
+"""
+import math
+
+import torch
+
+from neurst_amd import kernels as K
+
+
+def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
+    """Keras glorot_uniform: U(-l, l), l = sqrt(6/(fan_in+fan_out))."""
+    if fan_in is None:
+        if len(shape) == 1:
+            fan_in = fan_out = shape[0]
+        elif len(shape) == 2:
+            fan_in, fan_out = shape
+        else:  # conv HWIO
+            rf = int(math.prod(shape[:-2]))
+            fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(*shape, generator=gen, dtype=torch.float64) * 2 - 1).mul_(lim).float()
+
+
+def _wgrad_split(rows, k_in, n_out, dtype):
+    """split-K factor for dW[k_in, n_out] = X^T dY reduced over `rows`."""
+    tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    kt = (rows + bk - 1) // bk
+    return max(1, min(1024 // max(tiles, 1), kt // 8))
+
+
+class Layer(object):
+    """Base: keeps the runtime and a name scope."""
+
+    def __init__(self, rt, name):
+        self.rt, self.name = rt, name
+
+    def _site(self):
+        return self.rt.new_dropout_site()
+
+
+class LayerNorm(Layer):
+    """tf.keras.layers.LayerNormalization(epsilon, dtype=float32): variables <name>/gamma, <name>/beta."""
+
+    def __init__(self, rt, name, dim, epsilon):
+        super().__init__(rt, name)
+        self.eps = epsilon
+        self.gamma = rt.store.add(name + "/gamma", (dim,), torch.ones(dim))
+        self.beta = rt.store.add(name + "/beta", (dim,), torch.zeros(dim))
+
+    def forward(self, x, save=True):
+        y, mean, rstd = K.layernorm_fwd(x, self.gamma.data, self.beta.data, self.eps)
+        if save:
+            self._saved = (x, mean, rstd)
+        return y
+
+    def backward(self, dy, dres=None):
+        x, mean, rstd = self._saved
+        self._saved = None
+        st = self.rt.store
+        acc = st.acc_flag(self.gamma)
+        st.acc_flag(self.beta)
+        return K.layernorm_bwd(dy, x, self.gamma.data, mean, rstd, self.gamma.grad, self.beta.grad, accumulate=acc,
+                               dres=dres)
+
+
+class Dense(Layer):
+    """y = x @ kernel + bias with kernel [in, out] (tf.keras Dense / QuantDense layout).
+    Variables <name>/kernel, <name>/bias."""
+
+    def __init__(self, rt, name, in_dim, out_dim, gen, use_bias=True):
+        super().__init__(rt, name)
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.kernel = rt.store.add(name + "/kernel", (in_dim, out_dim), glorot_uniform((in_dim, out_dim), gen))
+        self.bias = rt.store.add(name + "/bias", (out_dim,), torch.zeros(out_dim)) if use_bias else None
+
+    def forward(self, x, **epi):
+        return K.gemm(x, self.kernel.compute, x.shape[0], self.out_dim, self.in_dim,
+                      bias=None if self.bias is None else self.bias.data, **epi)
+
+    def backward_params(self, x, dz):
+        """dkernel (+)= x^T dz ; dbias (+)= colsum(dz)."""
+        st = self.rt.store
+        rows = x.shape[0]
+        K.gemm(x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad,
+               accumulate=st.acc_flag(self.kernel), split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype))
+        if self.bias is not None:
+            K.colsum(dz, self.bias.grad, accumulate=st.acc_flag(self.bias))
+
+    def backward_input(self, dz, **epi):
+        """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""
+        return K.gemm(dz, self.kernel.compute, dz.shape[0], self.in_dim, self.out_dim, trans_b=True, **epi)
+
+
+class MultiHeadDenseLayer(Dense):
+    """MultiHeadDenseLayer (common_layers.py:163-295).  The kernel is stored exactly as the reference stores it
+    (non-output: [in, sum(units)] with column blocks q|k|v, each head-major; output: [H*dh, out]); head
+    split/merge are views on the 2-D GEMM output, never copies."""
+
+    def __init__(self, rt, name, in_dim, output_units, num_heads, gen, is_output_transform=False):
+        units = output_units if isinstance(output_units, (list, tuple)) else [output_units]
+        super().__init__(rt, name, in_dim, sum(units), gen)
+        self.units, self.num_heads, self.is_output_transform = list(units), num_heads, is_output_transform
+
+
+class TransformerFFN(Layer):
+    """TransformerFFN (common_layers.py:95-160): dense1 + relu -> dropout -> dense2.
+    forward fuses bias+relu+dropout into the first GEMM epilogue and bias(+post dropout + residual, supplied by
+    the wrapper) into the second; backward recovers relu'/dropout from the saved hidden activation (h > 0)."""
+
+    def __init__(self, rt, name, hidden_size, filter_size, dropout_rate, gen):
+        super().__init__(rt, name)
+        self.dense1 = Dense(rt, name + "/dense1", hidden_size, filter_size, gen)
+        self.dense2 = Dense(rt, name + "/dense2", filter_size, hidden_size, gen)
+        self.rate = dropout_rate
+        self.site = self._site()
+
+    def forward(self, x, is_training, epilogue=None):
+        p = self.rate if is_training else 0.0
+        h = self.dense1.forward(x, relu=True, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        y = self.dense2.forward(h, **(epilogue or {}))
+        if is_training:
+            self._saved = (x, h, p)
+        return y
+
+    def backward(self, dz):
+        x, h, p = self._saved
+        self._saved = None
+        self.dense2.backward_params(h, dz)
+        dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=1.0 / (1.0 - p))
+        self.dense1.backward_params(x, dh)
+        return self.dense1.backward_input(dh)
+
+
+class PrePostProcessingWrapper(Layer):
+    """PrePostProcessingWrapper, pre-norm branch (common_layers.py:73-85):  inputs + dropout(layer(LN(inputs))).
+    The dropout and the residual add are fused into the wrapped layer's last GEMM epilogue; in backward the
+    residual gradient is fused into the LayerNorm backward kernel."""
+
+    def __init__(self, rt, name, layer, dim, dropout_rate, epsilon):
+        super().__init__(rt, name)
+        self.layer = layer
+        self.norm = LayerNorm(rt, name + "/ln", dim, epsilon)
+        self.rate = dropout_rate
+        self.site = self._site()
+
+    def forward(self, x, is_training, **kwargs):
+        p = self.rate if is_training else 0.0
+        y = self.norm.forward(x, save=is_training)
+        epi = dict(residual=x, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        self._p = p
+        return self.layer.forward(y, is_training=is_training, epilogue=epi, **kwargs)
+
+    def backward(self, dy):
+        p = self._p
+        dz = K.scale_dropout_bwd(dy, 1.0, p, self.rt.step_seed, self.site) if p > 0 else dy
+        dn = self.layer.backward(dz)
+        return self.norm.backward(dn, dres=dy)
+
+
+class PositionEmbeddingWrapper(Layer):
+    """PositionEmbeddingWrapper, timing="sinusoids" (common_layers.py:415-434): emb*sqrt(d) + signal.
+    The wrapped embedding layer applies scale+signal inside its own kernel (GEMM epilogue for the audio
+    front end, gather kernel for word embeddings); mode="linear" bypasses the timing like the reference."""
+
+    def __init__(self, rt, name, embedding_layer, timing="sinusoids"):
+        super().__init__(rt, name)
+        assert timing in (None, "sinusoids"), f"Unknown position embedding type: \"{timing}\""
+        self.embedding_layer, self.timing = embedding_layer, timing
+
+    @property
+    def embedding_dim(self):
+        return self.embedding_layer.embedding_dim
+
+    def forward(self, inputs, mode="embedding", **kw):
+        if mode != "embedding":
+            return self.embedding_layer.forward(inputs, mode=mode, **kw)
+        return self.embedding_layer.forward(inputs, timing=self.timing, **kw)
+
+    def backward(self, dy, mode="embedding"):
+        return self.embedding_layer.backward(dy, mode=mode)

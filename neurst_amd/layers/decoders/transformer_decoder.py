@@ -1,0 +1,91 @@
+"""TransformerDecoder (neurst/layers/decoders/transformer_decoder.py:23-228), training branch
+(cache["decoding_states"] is None; wait-k lagging and incremental decoding are off the hot path)."""
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.layers import layer_utils
+from neurst_amd.layers.common_layers import LayerNorm
+from neurst_amd.layers.decoders.decoder import Decoder, register_decoder
+from neurst_amd.layers.transformer_layers import TransformerDecoderLayer
+
+
+@register_decoder
+class TransformerDecoder(Decoder):
+    def __init__(self, num_layers, hidden_size, num_attention_heads, filter_size, ffn_activation="relu",
+                 attention_dropout_rate=0., attention_type="dot_product", ffn_dropout_rate=0.,
+                 layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False,
+                 no_cross_attn_layer_list=None, name=None):
+        super().__init__(num_layers=num_layers, hidden_size=hidden_size, num_attention_heads=num_attention_heads,
+                         filter_size=filter_size, ffn_activation=ffn_activation,
+                         attention_dropout_rate=attention_dropout_rate, attention_type=attention_type,
+                         ffn_dropout_rate=ffn_dropout_rate,
+                         layer_postprocess_dropout_rate=layer_postprocess_dropout_rate,
+                         layer_postprocess_epsilon=layer_postprocess_epsilon, post_normalize=post_normalize,
+                         no_cross_attn_layer_list=no_cross_attn_layer_list or [])
+        if post_normalize:
+            raise NotImplementedError("post_normalize=True is off the hot path")
+        self.name = name or self.__class__.__name__
+
+    def build(self, rt, gen):
+        p = self._params
+        self.rt = rt
+        self._stacking_layers = [
+            TransformerDecoderLayer(rt, f"{self.name}/layer_{i}", p["hidden_size"], p["num_attention_heads"],
+                                    p["filter_size"], gen, p["ffn_activation"], p["attention_dropout_rate"],
+                                    p["attention_type"], p["ffn_dropout_rate"], p["layer_postprocess_dropout_rate"],
+                                    p["layer_postprocess_epsilon"], p["post_normalize"],
+                                    with_cross_attention=(i not in p["no_cross_attn_layer_list"]))
+            for i in range(p["num_layers"])]
+        self._output_norm_layer = LayerNorm(rt, f"{self.name}/output_ln", p["hidden_size"],
+                                            p["layer_postprocess_epsilon"])
+        self._site = rt.new_dropout_site()
+        return self
+
+    def create_decoding_internal_cache(self, encoder_outputs, encoder_inputs_padding, is_inference=False,
+                                       decode_padded_length=None):
+        """transformer_decoder.py:105-147, training branch: {"decoding_states": None, "memory", "memory_bias"}."""
+        if is_inference:
+            raise NotImplementedError("incremental decoding cache is not on the training hot path")
+        cache = dict(decoding_states=None)
+        if encoder_inputs_padding is not None:
+            cache["memory"] = encoder_outputs
+            cache["memory_bias"] = layer_utils.input_padding_to_bias(encoder_inputs_padding)
+        return cache
+
+    def forward(self, decoder_inputs, cache, decode_lagging=None, is_training=True, decode_loop_step=None):
+        """decoder_inputs [B,L,d]; cache from create_decoding_internal_cache -> [B,L,d]."""
+        if decode_lagging is not None or decode_loop_step is not None:
+            raise NotImplementedError("wait-k / static-shape decoding are off the hot path")
+        B, L, d = decoder_inputs.shape
+        memory = cache.get("memory", None)
+        memory_bias = cache.get("memory_bias", None)
+        Tm = memory.shape[1] if memory is not None else 0
+        mem2 = memory.reshape(B * Tm, d) if memory is not None else None
+        x = decoder_inputs.reshape(B * L, d)
+        p = self._params["layer_postprocess_dropout_rate"] if is_training else 0.0
+        self._p = p
+        if p > 0:
+            x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
+        for layer in self._stacking_layers:
+            x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training)
+        out = self._output_norm_layer.forward(x, save=is_training)
+        self._shapes = (B, L, d, Tm)
+        return out.view(B, L, d)
+
+    __call__ = forward
+
+    def backward(self, dout):
+        """Returns (d decoder_inputs [B,L,d], d memory [B,Tm,d])."""
+        B, L, d, Tm = self._shapes
+        dmemory = torch.empty(B * Tm, d, dtype=dout.dtype, device=dout.device) if Tm else None
+        dx = self._output_norm_layer.backward(dout.reshape(B * L, d))
+        first = True
+        for layer in reversed(self._stacking_layers):
+            dx = layer.backward(dx, dmemory, dmemory_accumulate=not first)
+            if layer._with_cross_attention:
+                first = False
+        if self._p > 0:
+            dx = K.scale_dropout_bwd(dx, 1.0, self._p, self.rt.step_seed, self._site)
+        if dmemory is not None and first:
+            dmemory.zero_()
+        return dx.view(B, L, d), (dmemory.view(B, Tm, d) if dmemory is not None else None)

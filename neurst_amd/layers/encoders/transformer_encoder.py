@@ -1,0 +1,68 @@
+"""TransformerEncoder (neurst/layers/encoders/transformer_encoder.py:23-136), training/eval path."""
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.layers import layer_utils
+from neurst_amd.layers.common_layers import LayerNorm
+from neurst_amd.layers.encoders.encoder import Encoder, register_encoder
+from neurst_amd.layers.transformer_layers import TransformerEncoderLayer
+
+
+@register_encoder
+class TransformerEncoder(Encoder):
+    def __init__(self, num_layers, hidden_size, num_attention_heads, filter_size, ffn_activation="relu",
+                 attention_dropout_rate=0., attention_type="dot_product", ffn_dropout_rate=0.,
+                 layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False,
+                 attention_monotonic=False, return_all_layers=False, name=None):
+        super().__init__(num_layers=num_layers, hidden_size=hidden_size, num_attention_heads=num_attention_heads,
+                         filter_size=filter_size, ffn_activation=ffn_activation,
+                         attention_dropout_rate=attention_dropout_rate, attention_type=attention_type,
+                         ffn_dropout_rate=ffn_dropout_rate,
+                         layer_postprocess_dropout_rate=layer_postprocess_dropout_rate,
+                         layer_postprocess_epsilon=layer_postprocess_epsilon, post_normalize=post_normalize,
+                         attention_monotonic=attention_monotonic, return_all_layers=return_all_layers)
+        if attention_monotonic or return_all_layers or post_normalize:
+            raise NotImplementedError("attention_monotonic / return_all_layers / post_normalize are off the hot path")
+        self.name = name or self.__class__.__name__
+        self._built = False
+
+    def build(self, rt, gen):
+        """Creates variables (the reference does this lazily in Keras build(); here it is explicit)."""
+        p = self._params
+        self.rt = rt
+        self._stacking_layers = [
+            TransformerEncoderLayer(rt, f"{self.name}/layer_{i}", p["hidden_size"], p["num_attention_heads"],
+                                    p["filter_size"], gen, p["ffn_activation"], p["attention_dropout_rate"],
+                                    p["attention_type"], p["ffn_dropout_rate"], p["layer_postprocess_dropout_rate"],
+                                    p["layer_postprocess_epsilon"], p["post_normalize"])
+            for i in range(p["num_layers"])]
+        self._output_norm_layer = LayerNorm(rt, f"{self.name}/output_ln", p["hidden_size"],
+                                            p["layer_postprocess_epsilon"])
+        self._site = rt.new_dropout_site()
+        self._built = True
+        return self
+
+    def forward(self, inputs, inputs_padding, is_training=True):
+        """inputs [B,T,d] (device, compute dtype), inputs_padding [B,T] float (1.0 = pad) -> [B,T,d]."""
+        B, T, d = inputs.shape
+        bias = layer_utils.input_padding_to_bias(inputs_padding)
+        x = inputs.reshape(B * T, d)
+        p = self._params["layer_postprocess_dropout_rate"] if is_training else 0.0
+        self._p = p
+        if p > 0:
+            x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
+        for layer in self._stacking_layers:
+            x = layer.forward(x, B, T, bias, is_training=is_training)
+        out = self._output_norm_layer.forward(x, save=is_training)
+        return out.view(B, T, d)
+
+    __call__ = forward
+
+    def backward(self, dout):
+        B, T, d = dout.shape
+        dx = self._output_norm_layer.backward(dout.reshape(B * T, d))
+        for layer in reversed(self._stacking_layers):
+            dx = layer.backward(dx)
+        if self._p > 0:
+            dx = K.scale_dropout_bwd(dx, 1.0, self._p, self.rt.step_seed, self._site)
+        return dx.view(B, T, d)

@@ -1,0 +1,69 @@
+"""WordEmbeddingSharedWeights (neurst/layers/modalities/text_modalities.py:21-134) on the HIP path.
+
+mode="embedding": gather (+ *sqrt(d) + sinusoid when wrapped by PositionEmbeddingWrapper) in one kernel;
+mode="linear"   : tied logits  x @ W^T + b  on MFMA, reading the [V,d] table as the [N,K] operand (no transpose).
+Variables: shared/weights [V,d] + shared/bias [V] when the softmax weights are shared, else emb/weights.
+"""
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.layers.common_layers import Layer, _wgrad_split, glorot_uniform
+
+
+class WordEmbeddingSharedWeights(Layer):
+    def __init__(self, rt, name, embedding_dim, vocab_size, gen, share_softmax_weights=False, use_bias=True):
+        super().__init__(rt, name)
+        self._embedding_dim, self._vocab_size = embedding_dim, vocab_size
+        self._share_softmax_weights = share_softmax_weights
+        scope = "shared" if share_softmax_weights else "emb"
+        init = torch.randn(vocab_size, embedding_dim, generator=gen, dtype=torch.float64) * embedding_dim ** -0.5
+        self._shared_weights = rt.store.add(f"{name}/{scope}/weights", (vocab_size, embedding_dim), init.float())
+        self._bias = None
+        if share_softmax_weights and use_bias:
+            # created without an initializer in the reference => Keras default glorot_uniform on shape [V]
+            self._bias = rt.store.add(f"{name}/{scope}/bias", (vocab_size,), glorot_uniform((vocab_size,), gen))
+        self._stack = []
+
+    embedding_dim = property(lambda self: self._embedding_dim)
+    vocab_size = property(lambda self: self._vocab_size)
+
+    def forward(self, inputs, mode="embedding", timing=None, is_training=True, **kw):
+        d, V = self._embedding_dim, self._vocab_size
+        if mode == "embedding":
+            ids = inputs.long()
+            L = ids.shape[-1]
+            scale = float(d) ** 0.5 if timing == "sinusoids" else 1.0
+            pos = self.rt.posenc(L, d) if timing == "sinusoids" else None
+            out = K.embedding_fwd(self._shared_weights.compute, ids, pos, L, scale)
+            if is_training:
+                self._stack.append(("embedding", ids, scale))
+            return out
+        if mode == "linear":
+            x2 = inputs.reshape(-1, d)
+            logits = K.gemm(x2, self._shared_weights.compute, x2.shape[0], V, d, trans_b=True,
+                            bias=None if self._bias is None else self._bias.data)
+            if is_training:
+                self._stack.append(("linear", x2))
+            return logits.view(*inputs.shape[:-1], V)
+        raise ValueError("mode = {} is not valid.".format(mode))
+
+    def backward(self, dy, mode="embedding"):
+        st = self.rt.store
+        d, V = self._embedding_dim, self._vocab_size
+        W = self._shared_weights
+        if mode == "linear":
+            idx = max(i for i, s in enumerate(self._stack) if s[0] == "linear")
+            _, x2 = self._stack.pop(idx)
+            dl = dy.reshape(-1, V)
+            rows = dl.shape[0]
+            K.gemm(dl, x2, V, d, rows, trans_a=True, out=W.grad, accumulate=st.acc_flag(W),
+                   split_k=_wgrad_split(rows, V, d, dl.dtype))
+            if self._bias is not None:
+                K.colsum(dl, self._bias.grad, accumulate=st.acc_flag(self._bias))
+            return K.gemm(dl, W.compute, rows, d, V).view(*dy.shape[:-1], d)
+        idx = max(i for i, s in enumerate(self._stack) if s[0] == "embedding")
+        _, ids, scale = self._stack.pop(idx)
+        if not st.acc_flag(W):
+            W.grad.zero_()
+        K.embedding_bwd(dy.contiguous(), ids, W.grad, scale)
+        return None

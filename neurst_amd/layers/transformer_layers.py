@@ -1,0 +1,87 @@
+"""TransformerEncoderLayer / TransformerDecoderLayer (neurst/layers/transformer_layers.py:21-234), pre-norm."""
+from neurst_amd.layers.attentions.multi_head_attention import MultiHeadAttention, MultiHeadSelfAttention
+from neurst_amd.layers.common_layers import Layer, PrePostProcessingWrapper, TransformerFFN
+
+
+class TransformerEncoderLayer(Layer):
+    def __init__(self, rt, name, hidden_size, num_attention_heads, filter_size, gen, ffn_activation="relu",
+                 attention_dropout_rate=0., attention_type="dot_product", ffn_dropout_rate=0.,
+                 layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False):
+        super().__init__(rt, name)
+        if post_normalize:
+            raise NotImplementedError("post_normalize=True is not on the hot path (hparams sets use pre-norm)")
+        if ffn_activation != "relu":
+            raise NotImplementedError(f"ffn_activation={ffn_activation}")
+        self._selfatt_layer = PrePostProcessingWrapper(
+            rt, name + "/self_attention_prepost_wrapper",
+            MultiHeadSelfAttention(rt, name + "/self_attention_prepost_wrapper/self_attention", num_attention_heads,
+                                   hidden_size, attention_dropout_rate, gen, attention_type),
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+        self._ffn_layer = PrePostProcessingWrapper(
+            rt, name + "/ffn_prepost_wrapper",
+            TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+
+    def forward(self, x, B, T, x_bias, is_training=True):
+        y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=False)
+        return self._ffn_layer.forward(y, is_training)
+
+    def backward(self, dy):
+        return self._selfatt_layer.backward(self._ffn_layer.backward(dy))
+
+
+class _CrossAttentionAdapter(object):
+    """Binds the memory arguments so the generic PrePostProcessingWrapper can drive MultiHeadAttention."""
+
+    def __init__(self, att):
+        self.att = att
+        self.dmemory, self.dmemory_accumulate = None, False
+
+    def forward(self, y, is_training, epilogue, memory, B, Tq, Tk, memory_bias):
+        return self.att.forward(y, memory, B, Tq, Tk, memory_bias=memory_bias, is_training=is_training,
+                                epilogue=epilogue)
+
+    def backward(self, dz):
+        return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate)
+
+
+class TransformerDecoderLayer(Layer):
+    def __init__(self, rt, name, hidden_size, num_attention_heads, filter_size, gen, ffn_activation="relu",
+                 attention_dropout_rate=0., attention_type="dot_product", ffn_dropout_rate=0.,
+                 layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False,
+                 with_cross_attention=True):
+        super().__init__(rt, name)
+        if post_normalize:
+            raise NotImplementedError("post_normalize=True is not on the hot path")
+        if ffn_activation != "relu":
+            raise NotImplementedError(f"ffn_activation={ffn_activation}")
+        self._with_cross_attention = with_cross_attention
+        self._selfatt_layer = PrePostProcessingWrapper(
+            rt, name + "/self_attention_prepost_wrapper",
+            MultiHeadSelfAttention(rt, name + "/self_attention_prepost_wrapper/self_attention", num_attention_heads,
+                                   hidden_size, attention_dropout_rate, gen, attention_type),
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+        if with_cross_attention:
+            self._cross = _CrossAttentionAdapter(
+                MultiHeadAttention(rt, name + "/encdec_attention_prepost_wrapper/encdec_attention",
+                                   num_attention_heads, hidden_size, attention_dropout_rate, gen, attention_type))
+            self._crossatt_layer = PrePostProcessingWrapper(
+                rt, name + "/encdec_attention_prepost_wrapper", self._cross, hidden_size,
+                layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+        self._ffn_layer = PrePostProcessingWrapper(
+            rt, name + "/ffn_prepost_wrapper",
+            TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+
+    def forward(self, x, B, L, memory, Tm, memory_bias, is_training=True):
+        y = self._selfatt_layer.forward(x, is_training, B=B, T=L, bias=None, causal=True)
+        if self._with_cross_attention:
+            y = self._crossatt_layer.forward(y, is_training, memory=memory, B=B, Tq=L, Tk=Tm, memory_bias=memory_bias)
+        return self._ffn_layer.forward(y, is_training)
+
+    def backward(self, dy, dmemory, dmemory_accumulate):
+        d = self._ffn_layer.backward(dy)
+        if self._with_cross_attention:
+            self._cross.dmemory, self._cross.dmemory_accumulate = dmemory, dmemory_accumulate
+            d = self._crossatt_layer.backward(d)
+        return self._selfatt_layer.backward(d)

@@ -1,0 +1,45 @@
+"""Keras-semantics Adam over the flat parameter buffer (the optimizer the reference's hparams sets select,
+neurst/models/speech_transformer.py:265-279; neurst/optimizers/__init__.py registers tf.keras Adam).
+
+    lr_t = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t);  m, v EMAs;  p -= lr_t * m / (sqrt(v) + epsilon)
+
+One fused kernel launch updates fp32 master weights, both moments and the bf16 compute shadow for all parameters;
+the data-parallel 1/world_size average is folded in as `grad_scale` (hvd.Average, neurst/training/hvd_utils.py:46-50).
+"""
+import math
+
+import torch
+
+from neurst_amd import kernels as K
+from neurst_amd.optimizers.registries import register_optimizer
+
+
+@register_optimizer("Adam")
+class Adam(object):
+    def __init__(self, store=None, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **unused):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.store = None
+        if store is not None:
+            self.bind(store)
+
+    def bind(self, store):
+        self.store = store
+        self.m = torch.zeros_like(store.master)
+        self.v = torch.zeros_like(store.master)
+        return self
+
+    def current_lr(self):
+        lr = self.learning_rate
+        return float(lr(self.iterations)) if callable(lr) else float(lr)
+
+    def apply_gradients(self, grad_scale=1.0):
+        t = self.iterations + 1
+        lr_t = self.current_lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        st = self.store
+        K.adam_update(st.master, self.m, self.v, st.grad, st.shadow, lr_t, self.beta_1, self.beta_2, self.epsilon,
+                      grad_scale)
+        self.iterations = t
+
+    def get_config(self):
+        return {"beta_1": self.beta_1, "beta_2": self.beta_2, "epsilon": self.epsilon}

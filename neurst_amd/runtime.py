@@ -1,0 +1,150 @@
+"""Execution context of the MI355X path: device, compute dtype, parameter store, dropout streams.
+
+One process drives one GPU.  Parameters live in flat fp32 buffers (master weights, gradients, Adam
+moments) plus -- in bf16 mode -- a flat bf16 shadow that the MFMA kernels read and the fused Adam kernel
+rewrites.  Gradients are written by the backward kernels straight into the flat gradient buffer, in
+forward registration order, so the data-parallel reducer can all-reduce contiguous buckets as soon as the
+backward pass has finished the layers they cover (neurst_amd/training/distributed.py).
+"""
+import collections
+import math
+
+import torch
+
+_ALIGN = 8  # elements: keeps every parameter 32-byte (fp32) / 16-byte (bf16) aligned for vector loads
+
+
+class Param(object):
+    __slots__ = ("name", "shape", "offset", "numel", "data", "grad", "compute", "_init")
+
+    def __init__(self, name, shape, init):
+        self.name, self.shape = name, tuple(shape)
+        self.numel = int(math.prod(self.shape)) if len(self.shape) else 1
+        self._init = init
+        self.offset = -1
+        self.data = self.grad = self.compute = None
+
+    def __repr__(self):
+        return f"Param({self.name}, {self.shape})"
+
+
+class ParamStore(object):
+    def __init__(self):
+        self.params = collections.OrderedDict()
+        self.finalized = False
+        self._touched = set()
+        self.accumulate_all = False
+
+    def add(self, name, shape, init):
+        """init: CPU float tensor of `shape` (the reference's initializer already applied)."""
+        if self.finalized:
+            raise RuntimeError("ParamStore already finalized")
+        if name in self.params:
+            raise ValueError(f"duplicate variable name: {name}")
+        init = torch.as_tensor(init, dtype=torch.float32).reshape(shape)
+        p = Param(name, shape, init)
+        self.params[name] = p
+        return p
+
+    def finalize(self, device, compute_dtype):
+        off = 0
+        for p in self.params.values():
+            p.offset = off
+            off += (p.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.device, self.compute_dtype = torch.device(device), compute_dtype
+        host = torch.zeros(off, dtype=torch.float32)
+        for p in self.params.values():
+            host[p.offset:p.offset + p.numel] = p._init.reshape(-1)
+            p._init = None
+        self.master = host.to(self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.shadow = None
+        if compute_dtype == torch.bfloat16:
+            self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        for p in self.params.values():
+            sl = slice(p.offset, p.offset + p.numel)
+            p.data = self.master[sl].view(p.shape)
+            p.grad = self.grad[sl].view(p.shape)
+            p.compute = (self.shadow if self.shadow is not None else self.master)[sl].view(p.shape)
+        self.finalized = True
+        self.refresh_shadow()
+        return self
+
+    def refresh_shadow(self):
+        if self.shadow is not None:
+            if self.master.is_cuda:
+                from neurst_amd import kernels
+                kernels.cast_f32_to_bf16(self.master, self.shadow)
+            else:  # host-side unit tests of the store itself
+                self.shadow.copy_(self.master.to(torch.bfloat16))
+
+    # --- gradient bookkeeping: the first kernel that writes a parameter's gradient in a backward pass
+    # overwrites, later writers (tied embedding, gradient accumulation micro-steps) accumulate.
+    def begin_backward(self, accumulate=False):
+        self._touched.clear()
+        self.accumulate_all = accumulate
+
+    def acc_flag(self, p):
+        if self.accumulate_all or p.name in self._touched:
+            return True
+        self._touched.add(p.name)
+        return False
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def state_dict(self):
+        return {n: p.data.detach().cpu().clone() for n, p in self.params.items()}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n in self.params if n not in sd]
+        if strict and missing:
+            raise KeyError(f"missing variables: {missing[:5]}...")
+        for n, p in self.params.items():
+            if n in sd:
+                p.data.copy_(torch.as_tensor(sd[n], dtype=torch.float32).reshape(p.shape))
+        self.refresh_shadow()
+
+    def num_parameters(self):
+        return sum(p.numel for p in self.params.values())
+
+
+class Runtime(object):
+    """Per-process execution context shared by all layers of a model."""
+
+    def __init__(self, device="cuda:0", dtype="float32", seed=1234):
+        self.device = torch.device(device)
+        if isinstance(dtype, str):
+            dtype = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16,
+                     "bf16": torch.bfloat16}[dtype]
+        self.dtype = dtype
+        self.store = ParamStore()
+        self.base_seed = int(seed)
+        self.step = 0
+        self._sites = 0
+        self._posenc_cache = {}
+
+    def new_dropout_site(self):
+        self._sites += 1
+        return self._sites
+
+    @property
+    def step_seed(self):
+        return self.base_seed * 1000003 + self.step
+
+    def posenc(self, length, channels):
+        """Sinusoid timing table [length, channels] f32 (neurst/layers/common_layers.py:356-413), built on
+        the host exactly like the reference and cached on the device."""
+        key = (length, channels)
+        if key not in self._posenc_cache:
+            position = torch.arange(0, length, dtype=torch.float32)
+            nts = channels // 2
+            inc = math.log(1.0e4 / 1.0) / (float(nts) - 1)
+            inv = torch.exp(torch.arange(nts, dtype=torch.float32) * -inc)
+            scaled = position[:, None] * inv[None, :]
+            sig = torch.cat([torch.sin(scaled), torch.cos(scaled)], dim=1)
+            if channels % 2:
+                sig = torch.nn.functional.pad(sig, (0, 1))
+            self._posenc_cache[key] = sig.contiguous().to(self.device)
+        return self._posenc_cache[key]

@@ -33,8 +33,16 @@ def _dump_report():
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     tag = "notr" if os.environ.get("NST_GEMM_NO_TR") == "1" else "tr"
-    with open(os.path.join(out, f"kernel_report_{tag}.json"), "w") as fp:
-        json.dump(REPORT, fp, indent=1, sort_keys=True)
+    path = os.path.join(out, f"kernel_report_{tag}.json")
+    merged = {}
+    if os.path.exists(path):
+        try:
+            merged = json.load(open(path))
+        except Exception:
+            merged = {}
+    merged.update(REPORT)
+    with open(path, "w") as fp:
+        json.dump(merged, fp, indent=1, sort_keys=True)
 
 
 def close(name, got, ref, dtype, scale=1.0):
