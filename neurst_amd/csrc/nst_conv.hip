@@ -432,7 +432,7 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int 
 
 int check_conv_dims(const char* name, int B, int T, int F, int C) {
   NST_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0, "%s: bad dims B=%d T=%d F=%d C=%d", name, B, T, F, C);
-  NST_CHECK_ARG((int64_t)B * T * F * 9 * C < ((int64_t)1 << 31), "%s: problem too large for 32-bit tile indices", name);
+  NST_CHECK_ARG((int64_t)B * T * F < ((int64_t)1 << 30) && (int64_t)9 * C < ((int64_t)1 << 24), "%s: problem too large for 32-bit row indices", name);
   return NST_OK;
 }
 

@@ -1,0 +1,213 @@
+"""CPU tests of the host side: C-ABI surface, registry / flag semantics of the reference, variable naming,
+parameter store, schedule, task glue.  No kernel is launched (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "neurst_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nst_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neurst_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in include/neurst_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.lib.nst_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (nst_[a-z0-9_]+)", out))
+    assert exported == set(syms)
+
+
+def test_struct_layouts_match_header_sizes():
+    from neurst_amd import _lib
+    # field order/types mirror the header; sizes guard against silent drift (x86-64 SysV layout)
+    assert ctypes.sizeof(_lib.NstGemmDesc) == 160
+    assert ctypes.sizeof(_lib.NstAttnDesc) == 96
+
+
+def test_kernels_refuse_cpu_tensors():
+    from neurst_amd import kernels as K
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.layernorm_fwd(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ registry / flags
+def test_registry_semantics():
+    from neurst_amd.utils.registry import setup_registry
+
+    class Base(object):
+        pass
+
+    build, register = setup_registry("thing_t", base_class=Base, backend="pt")
+
+    @register
+    class MyThing(Base):
+        def __init__(self, a=1, b=2):
+            self.a, self.b = a, b
+
+    @register(["alias1", "alias2"])
+    class OtherThing(Base):
+        def __init__(self, **kw):
+            self.kw = kw
+
+    for name in ("MyThing", "mything", "my_thing"):
+        assert isinstance(build({"thing_t.class": name, "thing_t.params": {"a": 5}}), MyThing)
+    assert build({"class": "alias2", "params": {"x": 1}}).kw == {"x": 1}
+    assert build("MyThing", b=7).b == 7
+    assert build({"thing_t.class": None}) is None and build("none") is None
+    with pytest.raises(ValueError, match="Not registered class name"):
+        build({"thing_t.class": "nope"})
+    with pytest.raises(ValueError, match="must extend"):
+        register(type("Bad", (), {}))
+    with pytest.raises(ValueError, match="Cannot register duplicate"):
+        register("alias1")(type("Third", (Base,), {}))
+
+
+def test_flag_precedence_cli_over_config_over_hparams(tmp_path):
+    import neurst_amd.cli.run_exp as run_exp
+    import neurst_amd.utils.flags_core as fc
+    cfg = tmp_path / "cfg.yml"
+    cfg.write_text("dtype: float32\nmodel.params:\n  encoder.num_layers: 3\n  decoder.num_layers: 4\n"
+                   "entry.class: trainer\nentry.params:\n  train_steps: 77\ntask.class: speech2text\n"
+                   "dataset.class: synthetic_speech\ndataset.params:\n  frames: 120\n")
+    argv = ["--config_paths", str(cfg), "--hparams_set", "speech_transformer_s", "--encoder.num_layers", "5",
+            "--summary_steps", "9", "--batch_per_gpu", "16"]
+    parser = fc.define_flags(run_exp.FLAG_LIST, argv=argv)
+    args, rest = fc.intelligent_parse_flags(run_exp.FLAG_LIST, parser, run_exp._pre_load_args, argv=argv)
+    assert args["dtype"] == "float32"                                  # config file beats the flag default
+    assert args["model.class"] == "SpeechTransformer"                  # from the hparams set
+    assert args["model.params"]["encoder.num_layers"] == 5             # CLI beats config beats hparams (12)
+    assert args["model.params"]["decoder.num_layers"] == 4             # config beats hparams (6)
+    assert args["model.params"]["encoder.hidden_size"] == 256          # hparams set
+    assert args["entry.params"]["train_steps"] == 77
+    assert args["entry.params"]["summary_steps"] == 9                  # nested class flag given flat on the CLI
+    assert args["entry.params"]["optimizer.class"] == "Adam"           # hparams set's entry params survive
+    assert args["entry.params"]["lr_schedule.params"]["warmup_steps"] == 25000
+    assert args["dataset.params"]["frames"] == 120 and args["dataset.params"]["batch_per_gpu"] == 16
+    assert rest == []
+
+
+def test_hparams_sets_match_reference_tables():
+    from neurst_amd.models import build_model  # noqa: F401 (registers the models)
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    s = get_hyper_parameters("speech_transformer_s")  # neurst/models/speech_transformer.py:209-216
+    p = s["model.params"]
+    assert (p["modality.dim"], p["encoder.num_attention_heads"], p["encoder.num_layers"], p["decoder.num_layers"],
+            p["encoder.filter_size"], p["modality.source.channels"]) == (256, 4, 12, 6, 2048, 256)
+    assert s["lr_schedule.params"]["initial_factor"] == 3.5 and s["optimizer.params"]["beta_2"] == 0.98
+    m = get_hyper_parameters("speech_transformer_m")["model.params"]
+    assert (m["modality.dim"], m["encoder.num_attention_heads"]) == (512, 8)
+    big = get_hyper_parameters("transformer_big")["model.params"]
+    assert (big["modality.dim"], big["encoder.num_attention_heads"], big["encoder.attention_dropout_rate"]) == (1024, 16, 0.3)
+    assert get_hyper_parameters("no_such_set") == {}
+
+
+# ------------------------------------------------------------------------------------------------ variables
+def test_speech_transformer_variable_names_and_counts():
+    """TF variable names / layouts the reference's tests address (tests/neurst_pt/models/speech_transformer_test.py:57-152)."""
+    from neurst_amd.models import build_model
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    hp = get_hyper_parameters("speech_transformer_s")
+    m = build_model(hp, {"audio_feature_dim": 80, "audio_feature_channels": 1},
+                    {"vocab_size": 8008, "eos_id": 8007, "bos_id": 8006, "unk_id": 8005}, device="cpu", dtype="bfloat16")
+    P = m.store.params
+    assert P["input_audio_modality/conv1/kernel"].shape == (3, 3, 1, 256)
+    assert P["input_audio_modality/conv2/kernel"].shape == (3, 3, 256, 256)
+    assert P["input_audio_modality/output_dense/kernel"].shape == (5120, 256)
+    assert P["target_symbol_modality/shared/weights"].shape == (8008, 256)
+    assert P["target_symbol_modality/shared/bias"].shape == (8008,)
+    e = "TransformerEncoder/layer_11/self_attention_prepost_wrapper/"
+    assert P[e + "self_attention/qkv_transform/kernel"].shape == (256, 768)
+    assert P[e + "self_attention/output_transform/kernel"].shape == (256, 256)
+    assert P[e + "ln/gamma"].shape == (256,)
+    assert P["TransformerEncoder/layer_0/ffn_prepost_wrapper/ffn/dense1/kernel"].shape == (256, 2048)
+    d = "TransformerDecoder/layer_5/encdec_attention_prepost_wrapper/encdec_attention/"
+    assert P[d + "q_transform/kernel"].shape == (256, 256) and P[d + "kv_transform/kernel"].shape == (256, 512)
+    assert "TransformerEncoder/output_ln/gamma" in P and "TransformerDecoder/output_ln/beta" in P
+    n = m.store.num_parameters()
+    assert abs(n - 29.2e6) < 0.1e6, n              # 29.2 M parameters
+    assert m.store.shadow.dtype == torch.bfloat16 and m.store.grad.dtype == torch.float32
+    for p in P.values():                             # every parameter 16-byte aligned in the bf16 shadow
+        assert p.offset % 8 == 0
+    assert torch.equal(m.store.shadow[:100].float(), m.store.master[:100].to(torch.bfloat16).float())
+
+
+def test_param_store_gradient_bookkeeping():
+    from neurst_amd.runtime import ParamStore
+    st = ParamStore()
+    a = st.add("a", (3,), torch.arange(3.0))
+    b = st.add("b", (2, 2), torch.ones(2, 2))
+    with pytest.raises(ValueError, match="duplicate"):
+        st.add("a", (1,), torch.zeros(1))
+    st.finalize("cpu", torch.float32)
+    assert a.compute.data_ptr() == a.data.data_ptr()   # fp32 mode: no shadow
+    st.begin_backward()
+    assert st.acc_flag(a) is False and st.acc_flag(a) is True and st.acc_flag(b) is False
+    st.begin_backward(accumulate=True)
+    assert st.acc_flag(a) is True
+    sd = st.state_dict()
+    sd["b"] = torch.full((2, 2), 5.0)
+    st.load_state_dict(sd)
+    assert float(b.data.sum()) == 20.0
+
+
+def test_noam_schedule_matches_oracle():
+    from neurst_amd.optimizers import build_lr_schedule
+    from oracle import neurst_oracle as O
+    kw = dict(dmodel=256, warmup_steps=25000, initial_factor=3.5, end_factor=1.5, start_decay_at=50000, decay_steps=50000)
+    s = build_lr_schedule({"lr_schedule.class": "noam", "lr_schedule.params": kw})
+    for step in (0, 1, 100, 24999, 25000, 60000, 99999, 150000):
+        assert abs(s(step) - O.noam_lr(step, **kw)) < 1e-15
+    s2 = build_lr_schedule({"lr_schedule.class": "noam", "lr_schedule.params": {"dmodel": 8, "warmup_steps": 4000}})
+    assert abs(s2(0) - O.noam_lr(0, dmodel=8, warmup_steps=4000)) < 1e-15
+
+
+def test_example_to_input_matches_oracle():
+    from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils import compat
+    from oracle import neurst_oracle as O
+    task = build_task({"task.class": "AudioToText", "task.params": {"audio_feature_dim": 16, "vocab_size": 30}})
+    ds = SyntheticSpeechDataset({"batch_per_gpu": 5, "frames": 48, "feature_dim": 16, "vocab_size": 30, "ragged": True})
+    raw = ds.make_batch(torch.Generator().manual_seed(0))
+    got = task.example_to_input(raw, compat.ModeKeys.TRAIN)
+    ref = O.example_to_input(raw["audio"], raw["audio_length"], raw["transcript"], 16, 1, 28, 29)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    assert got["src"].shape == (5, 48, 16, 1) and int(got["trg"][0, -1]) == 29
+    # every transcript ends with EOS and is padded with EOS; length counts the first EOS
+    assert all(int(got["trg"][i, int(got["trg_length"][i]) - 1]) == 29 for i in range(5))
+    # different ranks draw different data, same rank reproduces
+    a = next(ds.build_iterator(shard_id=0))["audio"]
+    b = next(ds.build_iterator(shard_id=1))["audio"]
+    assert not torch.equal(a, b) and torch.equal(a, next(ds.build_iterator(shard_id=0))["audio"])
+
+
+def test_length_masks():
+    from neurst_amd.models.model_utils import deduce_text_length, input_length_to_padding
+    from neurst_amd.utils.compat import PaddingMode
+    pad = input_length_to_padding(torch.tensor([3, 1]), 4)
+    assert pad.tolist() == [[0, 0, 0, 1], [0, 1, 1, 1]]
+    t = torch.tensor([[5, 6, 9, 9], [9, 9, 9, 9], [1, 2, 3, 9]])
+    assert deduce_text_length(t, 9, PaddingMode.EOS_AS_PADDING).tolist() == [3, 1, 4]
+    assert deduce_text_length(t, 9, PaddingMode.DEFAULT).tolist() == [2, 0, 3]
+
+
+def test_graft_entry_build_runs():
+    import __graft_entry__ as g
+    g.build()
