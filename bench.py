@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -64,15 +65,36 @@ def algorithmic_flops(model_args, B, T, F, L, V):
             "forward": conv1 + conv2 + dense + enc + dec + logits}
 
 
-def cpu_baseline(hp, args, T, F, L, V):
-    """Oracle (port of the reference math) fwd+bwd+Adam on the host cores, bounded sample."""
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    host's cores inside a container, and oversubscribing torch's thread pool slows the oracle by orders of magnitude)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_worker(model_name, B, T, F, L, V):
+    """Oracle (port of the reference math) fwd+bwd+Adam on the host cores, bounded sample.  Runs in a child
+    process (see cpu_baseline) so that it can never stall the GPU measurement."""
+    import neurst_amd.models  # noqa: F401  (registers the hparams sets)
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
     from oracle import neurst_oracle as O
-    p = hp["model.params"]
+    p = get_hyper_parameters(model_name)["model.params"]
     cfg = {"num_enc": p["encoder.num_layers"], "num_dec": p["decoder.num_layers"],
            "num_heads": p["encoder.num_attention_heads"], "layer_norm": True, "d_model": p["modality.dim"],
            "channels": p["modality.source.channels"], "ffn": p["encoder.filter_size"]}
-    B = args.cpu_batch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     W = O.init_speech_transformer_weights(cfg, V, F, 1, seed=42)
     g = torch.Generator().manual_seed(1234)
@@ -83,20 +105,46 @@ def cpu_baseline(hp, args, T, F, L, V):
     m = {k: torch.zeros_like(v) for k, v in W.items()}
     v_ = {k: torch.zeros_like(v) for k, v in W.items()}
     times = []
+    t_start = time.perf_counter()
     for t in range(1, 5):
         t0 = time.perf_counter()
         _, _, grads = O.train_step_reference(W, inputs, cfg, 0.1)
         for k in W:
             W[k], m[k], v_[k] = O.keras_adam_step(W[k], grads[k], m[k], v_[k], t, 1e-4)
         times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 40 and len(times) >= 2:
+            break
     dt = min(times[1:]) if len(times) > 1 else times[0]
     return {"value": B * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd+Adam, fp32, batch {B} x {T} frames, best of {len(times) - 1} timed steps "
+            "sample": f"oracle fwd+bwd+Adam, fp32, batch {B} x {T} frames, best of {max(len(times) - 1, 1)} timed steps "
                       f"({dt * 1e3:.0f} ms/step); torch {torch.__version__} CPU, {cores} threads"}
+
+
+def cpu_baseline(args, T, F, L, V, timeout=150):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model,
+           "--cpu-batch", str(args.cpu_batch), "--frames", str(T), "--vocab", str(V)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                "sample": "failed: " + (out.stderr.strip().splitlines() or ["no output"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"timed out after {timeout}s"}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_worker(args.model, args.cpu_batch, args.frames, 80, max(1, args.frames // 12),
+                                             args.vocab)))
+        return
     from neurst_amd import kernels as K
     from neurst_amd.criterions import build_criterion
     from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
@@ -188,11 +236,7 @@ def main():
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(hp, args, T, F, L, V)
-        except Exception as e:  # the baseline is informational; never lose the GPU line because of it
-            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"failed: {e}"}
+        out["cpu_baseline"] = cpu_baseline(args, T, F, L, V)
     print(json.dumps(out))
 
 

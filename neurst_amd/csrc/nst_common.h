@@ -82,6 +82,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Fast all-lanes sum: 4 DPP steps reduce each 16-lane row in place (no LDS crossbar: __shfl_xor lowers to
+// ds_bpermute, ~100 cycles of dependent latency per step), then the 4 row totals are read with v_readlane.
+// The result is wave-uniform (lives in an SGPR).
+__device__ __forceinline__ float dpp_add(float v, const int ctrl) {
+  switch (ctrl) {  // dpp_ctrl must be an immediate
+    case 0: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    case 1: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    case 2: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    default: return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true)); // row_mirror
+  }
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -23,13 +23,30 @@ constexpr int C1_SLOTS = 8;  // channels per lane (C <= 512)
 
 __device__ __forceinline__ int c1_channel(int lane, int s, int vec) { return vec ? lane * 4 + (s >> 2) * 256 + (s & 3) : lane + s * 64; }
 
+constexpr int C1_MAXF = 254;  // feature bins: three padded source rows per wave live in LDS
+
+// Stages the three source rows (ti = 2*to-1 .. 2*to+1) of one output row into wave-private LDS with a zero column
+// on both sides, so tap (kh,kw) of output pixel fo is xs[kh][2*fo + kw] with no bounds checks.
+__device__ __forceinline__ void c1_stage_rows(float (*xs)[C1_MAXF + 2], const float* __restrict__ src, int b, int to,
+                                              int T_, int F, int lane) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int ti = 2 * to + r - 1;
+    const bool rok = ti >= 0 && ti < T_;
+    const float* p = src + ((int64_t)b * T_ + (rok ? ti : 0)) * F;
+    for (int f = lane; f < F + 2; f += 64) xs[r][f] = (rok && f >= 1 && f <= F) ? p[f - 1] : 0.f;
+  }
+}
+
 template <typename T, int S, bool VEC>
 __global__ void __launch_bounds__(256) conv1_fwd_kernel(const float* __restrict__ src, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* __restrict__ out,
                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
                                                        int T_, int F, int C, int T1, int F1, int layer_norm, float eps) {
+  __shared__ float xs_all[4][3][C1_MAXF + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float(*xs)[C1_MAXF + 2] = xs_all[wave];
   float w[S][9], bias[S], g[S], be[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -41,68 +58,68 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(const float* __restrict_
     g[s] = (ok && layer_norm) ? gamma[c] : 1.f;
     be[s] = (ok && layer_norm) ? beta[c] : 0.f;
   }
-  const int64_t npix = (int64_t)B * T1 * F1;
+  const int nrows = B * T1;
   const float inv_c = 1.f / (float)C;
-  for (int64_t pix0 = (int64_t)blockIdx.x * 4 + wave; pix0 < npix; pix0 += (int64_t)gridDim.x * 4) {
-    const int64_t pix = pix0;
-    const int fo = (int)(pix % F1);
-    const int to = (int)((pix / F1) % T1);
-    const int b = (int)(pix / ((int64_t)F1 * T1));
-    float x[9];
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int b = row / T1, to = row - b * T1;
+    c1_stage_rows(xs, src, b, to, T_, F, lane);
+    __builtin_amdgcn_wave_barrier();
+    for (int fo = 0; fo < F1; ++fo) {
+      float x[9];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
-        x[kh * 3 + kw] = (ti >= 0 && ti < T_ && fi >= 0 && fi < F) ? src[((int64_t)b * T_ + ti) * F + fi] : 0.f;
-      }
-    float z[S];
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      float a = bias[s];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
-      z[s] = a;
-      sum += c1_channel(lane, s, VEC) < C ? a : 0.f;
-    }
-    if (layer_norm) {
-      const float mean = wave_sum(sum) * inv_c;
-      float sq = 0.f;
+        for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = xs[kh][2 * fo + kw];
+      float z[S];
+      float sum = 0.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const float d = c1_channel(lane, s, VEC) < C ? z[s] - mean : 0.f;
-        sq += d * d;
+        float a = bias[s];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
+        z[s] = a;
+        sum += c1_channel(lane, s, VEC) < C ? a : 0.f;
       }
-      const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+      const int64_t pix = (int64_t)row * F1 + fo;
+      if (layer_norm) {
+        const float mean = wave_sum_fast(sum) * inv_c;
+        float sq = 0.f;
 #pragma unroll
-      for (int s = 0; s < S; ++s) z[s] = (z[s] - mean) * rstd * g[s] + be[s];
-      if (lane == 0) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
-    }
-    T* o = out + pix * C;
-    if (VEC) {
+        for (int s = 0; s < S; ++s) {
+          const float d = c1_channel(lane, s, VEC) < C ? z[s] - mean : 0.f;
+          sq += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum_fast(sq) * inv_c + eps);
 #pragma unroll
-      for (int k = 0; k < S / 4; ++k) {
-        const int c = lane * 4 + k * 256;
-        if (c < C) {
-          const float v0 = fmaxf(z[k * 4], 0.f), v1 = fmaxf(z[k * 4 + 1], 0.f), v2 = fmaxf(z[k * 4 + 2], 0.f), v3 = fmaxf(z[k * 4 + 3], 0.f);
-          if (sizeof(T) == 2) {
-            uint2 raw;
-            raw.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-            raw.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-            *reinterpret_cast<uint2*>(o + c) = raw;
-          } else {
-            *reinterpret_cast<float4*>(o + c) = make_float4(v0, v1, v2, v3);
+        for (int s = 0; s < S; ++s) z[s] = (z[s] - mean) * rstd * g[s] + be[s];
+        if (lane == 0) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
+      }
+      T* o = out + pix * C;
+      if (VEC) {
+#pragma unroll
+        for (int k = 0; k < S / 4; ++k) {
+          const int c = lane * 4 + k * 256;
+          if (c < C) {
+            const float v0 = fmaxf(z[k * 4], 0.f), v1 = fmaxf(z[k * 4 + 1], 0.f), v2 = fmaxf(z[k * 4 + 2], 0.f), v3 = fmaxf(z[k * 4 + 3], 0.f);
+            if (sizeof(T) == 2) {
+              uint2 raw;
+              raw.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+              raw.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+              *reinterpret_cast<uint2*>(o + c) = raw;
+            } else {
+              *reinterpret_cast<float4*>(o + c) = make_float4(v0, v1, v2, v3);
+            }
           }
         }
-      }
-    } else {
+      } else {
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const int c = lane + s * 64;
-        if (c < C) o[c] = from_f32<T>(fmaxf(z[s], 0.f));
+        for (int s = 0; s < S; ++s) {
+          const int c = lane + s * 64;
+          if (c < C) o[c] = from_f32<T>(fmaxf(z[s], 0.f));
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -115,8 +132,10 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const float* __restrict_
                                                        float* __restrict__ dw1, float* __restrict__ db1,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T_,
                                                        int F, int C, int T1, int F1, int layer_norm) {
+  __shared__ float xs_all[4][3][C1_MAXF + 2];
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float(*xs)[C1_MAXF + 2] = xs_all[wave];
   float w[S][9], bias[S], g[S], be[S];
   float aw[S][9], ab[S], ag[S], abe[S];
 #pragma unroll
@@ -130,59 +149,83 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const float* __restrict_
     be[s] = (ok && layer_norm) ? beta[c] : 0.f;
     ab[s] = 0.f; ag[s] = 0.f; abe[s] = 0.f;
   }
-  const int64_t npix = (int64_t)B * T1 * F1;
+  const int nrows = B * T1;
   const float inv_c = 1.f / (float)C;
-  for (int64_t pix = (int64_t)blockIdx.x * 4 + wave; pix < npix; pix += (int64_t)gridDim.x * 4) {
-    const int fo = (int)(pix % F1);
-    const int to = (int)((pix / F1) % T1);
-    const int b = (int)(pix / ((int64_t)F1 * T1));
-    float x[9];
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int b = row / T1, to = row - b * T1;
+    c1_stage_rows(xs, src, b, to, T_, F, lane);
+    __builtin_amdgcn_wave_barrier();
+    for (int fo = 0; fo < F1; ++fo) {
+      float x[9];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
-        x[kh * 3 + kw] = (ti >= 0 && ti < T_ && fi >= 0 && fi < F) ? src[((int64_t)b * T_ + ti) * F + fi] : 0.f;
-      }
-    const float mean = layer_norm ? mean_in[pix] : 0.f;
-    const float rstd = layer_norm ? rstd_in[pix] : 1.f;
-    const T* go = dout + pix * C;
-    float xh[S], dxh[S];
-    float s1 = 0.f, s2 = 0.f;
+        for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = xs[kh][2 * fo + kw];
+      const int64_t pix = (int64_t)row * F1 + fo;
+      const float mean = layer_norm ? mean_in[pix] : 0.f;
+      const float rstd = layer_norm ? rstd_in[pix] : 1.f;
+      const T* go = dout + pix * C;
+      float gy[S];
+      if (VEC) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int c = c1_channel(lane, s, VEC);
-      float a = bias[s];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
-      float gy = 0.f;
-      if (c < C) gy = to_f32<T>(go[c]);
-      if (layer_norm) {
-        const float xhat = (a - mean) * rstd;
-        const float y = xhat * g[s] + be[s];
-        gy = y > 0.f ? gy : 0.f;
-        ag[s] += gy * xhat;
-        abe[s] += gy;
-        const float d = gy * g[s];
-        xh[s] = xhat;
-        dxh[s] = d;
-        s1 += d;
-        s2 += d * xhat;
+        for (int k = 0; k < S / 4; ++k) {
+          const int c = lane * 4 + k * 256;
+          if (c < C) {
+            if (sizeof(T) == 2) {
+              uint2 raw = *reinterpret_cast<const uint2*>(go + c);
+              gy[k * 4 + 0] = bf16_to_f32((bf16_t)(raw.x & 0xffff)); gy[k * 4 + 1] = bf16_to_f32((bf16_t)(raw.x >> 16));
+              gy[k * 4 + 2] = bf16_to_f32((bf16_t)(raw.y & 0xffff)); gy[k * 4 + 3] = bf16_to_f32((bf16_t)(raw.y >> 16));
+            } else {
+              float4 raw = *reinterpret_cast<const float4*>(go + c);
+              gy[k * 4 + 0] = raw.x; gy[k * 4 + 1] = raw.y; gy[k * 4 + 2] = raw.z; gy[k * 4 + 3] = raw.w;
+            }
+          } else {
+            gy[k * 4 + 0] = 0.f; gy[k * 4 + 1] = 0.f; gy[k * 4 + 2] = 0.f; gy[k * 4 + 3] = 0.f;
+          }
+        }
       } else {
-        dxh[s] = a > 0.f ? gy : 0.f;
-        xh[s] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int c = lane + s * 64;
+          gy[s] = c < C ? to_f32<T>(go[c]) : 0.f;
+        }
+      }
+      float xh[S], dxh[S];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float a = bias[s];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
+        float gv = gy[s];
+        if (layer_norm) {
+          const float xhat = (a - mean) * rstd;
+          const float y = xhat * g[s] + be[s];
+          gv = y > 0.f ? gv : 0.f;
+          ag[s] += gv * xhat;
+          abe[s] += gv;
+          const float d = gv * g[s];
+          xh[s] = xhat;
+          dxh[s] = d;
+          s1 += d;
+          s2 += d * xhat;
+        } else {
+          dxh[s] = a > 0.f ? gv : 0.f;
+          xh[s] = 0.f;
+        }
+      }
+      float c1 = 0.f, c2 = 0.f;
+      if (layer_norm) { c1 = wave_sum_fast(s1) * inv_c; c2 = wave_sum_fast(s2) * inv_c; }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float dz = layer_norm ? rstd * (dxh[s] - c1 - xh[s] * c2) : dxh[s];
+        const float dzc = c1_channel(lane, s, VEC) < C ? dz : 0.f;
+        ab[s] += dzc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) aw[s][t] = fmaf(dzc, x[t], aw[s][t]);
       }
     }
-    float c1 = 0.f, c2 = 0.f;
-    if (layer_norm) { c1 = wave_sum(s1) * inv_c; c2 = wave_sum(s2) * inv_c; }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float dz = layer_norm ? rstd * (dxh[s] - c1 - xh[s] * c2) : dxh[s];
-      const float dzc = c1_channel(lane, s, VEC) < C ? dz : 0.f;
-      ab[s] += dzc;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) aw[s][t] = fmaf(dzc, x[t], aw[s][t]);
-    }
+    __builtin_amdgcn_wave_barrier();
   }
   // reduce the 4 waves of the block, then one atomic per (tap, channel) per block
 #pragma unroll
@@ -213,22 +256,27 @@ template <typename T>
 struct Im2colLoader {
   const T* x;
   int B, T1, F1, C, T2, F2;
+  FastDiv dF2, dT2, dC;
   int outer_limit, contig_limit;  // pixels, 9*C
   int vec;                        // C % E == 0 and 16-byte aligned base
+  void init_divs() { dF2.init(F2); dT2.init(T2); dC.init(C); }
   __device__ __forceinline__ const T* addr(int b, int to, int fo, int kk, bool& ok) const {
-    const int tap = kk / C, c = kk - tap * C;
-    const int kh = tap / 3, kw = tap - kh * 3;
+    uint32_t tap, c;
+    dC.divmod((uint32_t)kk, tap, c);
+    const int kh = (int)tap / 3, kw = (int)tap - kh * 3;
     const int ti = 2 * to + kh - 1, fi = 2 * fo + kw - 1;
     ok = ti >= 0 && ti < T1 && fi >= 0 && fi < F1;
-    return x + (((int64_t)b * T1 + ti) * F1 + fi) * C + c;
+    return x + (((int64_t)b * T1 + ti) * F1 + fi) * C + (int)c;
   }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
-    const int fo = outer % F2, to = (outer / F2) % T2, b = outer / (F2 * T2);
+    uint32_t q, fo, b, to;
+    dF2.divmod((uint32_t)outer, q, fo);
+    dT2.divmod(q, b, to);
     if (vec) {
       bool ok;
-      const T* p = addr(b, to, fo, contig, ok);
+      const T* p = addr((int)b, (int)to, (int)fo, contig, ok);
       if (ok) r = *reinterpret_cast<const uint4*>(p);
       return r;
     }
@@ -238,7 +286,7 @@ struct Im2colLoader {
       tmp[e] = (T)0;
       if (contig + e < contig_limit) {
         bool ok;
-        const T* p = addr(b, to, fo, contig + e, ok);
+        const T* p = addr((int)b, (int)to, (int)fo, contig + e, ok);
         if (ok) tmp[e] = *p;
       }
     }
@@ -253,23 +301,28 @@ template <typename T>
 struct DgradALoader {  // RC: outer = class row, contig = r
   const T* dy;
   int B, C, T2, F2, ct, cf, pt, pf, nkw;
+  FastDiv dcf, dct, dC;
   int outer_limit, contig_limit, vec;
+  void init_divs() { dcf.init(cf); dct.init(ct); dC.init(C); }
   __device__ __forceinline__ const T* addr(int b, int th, int fh, int r, bool& ok) const {
-    const int tapidx = r / C, co = r - tapidx * C;
-    const int ih = tapidx / nkw, iw = tapidx - ih * nkw;
+    uint32_t tapidx, co;
+    dC.divmod((uint32_t)r, tapidx, co);
+    const int ih = nkw == 2 ? (int)(tapidx >> 1) : (int)tapidx, iw = nkw == 2 ? (int)(tapidx & 1) : 0;
     // pt=0: kh=1 -> to = th ; pt=1: kh=0 -> to = th+1 (ih=0), kh=2 -> to = th (ih=1)
     const int to = pt ? (ih == 0 ? th + 1 : th) : th;
     const int fo = pf ? (iw == 0 ? fh + 1 : fh) : fh;
     ok = to < T2 && fo < F2;
-    return dy + (((int64_t)b * T2 + to) * F2 + fo) * C + co;
+    return dy + (((int64_t)b * T2 + to) * F2 + fo) * C + (int)co;
   }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
-    const int fh = outer % cf, th = (outer / cf) % ct, b = outer / (cf * ct);
+    uint32_t q, fh, b, th;
+    dcf.divmod((uint32_t)outer, q, fh);
+    dct.divmod(q, b, th);
     if (vec) {
       bool ok;
-      const T* p = addr(b, th, fh, contig, ok);
+      const T* p = addr((int)b, (int)th, (int)fh, contig, ok);
       if (ok) r = *reinterpret_cast<const uint4*>(p);
       return r;
     }
@@ -279,7 +332,7 @@ struct DgradALoader {  // RC: outer = class row, contig = r
       tmp[e] = (T)0;
       if (contig + e < contig_limit) {
         bool ok;
-        const T* p = addr(b, th, fh, contig + e, ok);
+        const T* p = addr((int)b, (int)th, (int)fh, contig + e, ok);
         if (ok) tmp[e] = *p;
       }
     }
@@ -291,13 +344,16 @@ template <typename T>
 struct DgradBLoader {  // RC: outer = ci, contig = r ; element = w2[tap][ci][co]
   const T* w2;
   int C, pt, pf, nkw;
+  FastDiv dC;
   int outer_limit, contig_limit, vec;
+  void init_divs() { dC.init(C); }
   __device__ __forceinline__ const T* addr(int ci, int r) const {
-    const int tapidx = r / C, co = r - tapidx * C;
-    const int ih = tapidx / nkw, iw = tapidx - ih * nkw;
+    uint32_t tapidx, co;
+    dC.divmod((uint32_t)r, tapidx, co);
+    const int ih = nkw == 2 ? (int)(tapidx >> 1) : (int)tapidx, iw = nkw == 2 ? (int)(tapidx & 1) : 0;
     const int kh = pt ? (ih == 0 ? 0 : 2) : 1;
     const int kw = pf ? (iw == 0 ? 0 : 2) : 1;
-    return w2 + ((int64_t)(kh * 3 + kw) * C + ci) * C + co;
+    return w2 + ((int64_t)(kh * 3 + kw) * C + ci) * C + (int)co;
   }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
@@ -312,9 +368,13 @@ struct DgradBLoader {  // RC: outer = ci, contig = r ; element = w2[tap][ci][co]
 };
 struct DgradRowMap {  // class row -> pixel row of dx [B*T1*F1]
   int T1, F1, ct, cf, pt, pf;
+  FastDiv dcf, dct;
+  void init_divs() { dcf.init(cf); dct.init(ct); }
   __device__ __forceinline__ int64_t operator()(int row) const {
-    const int fh = row % cf, th = (row / cf) % ct, b = row / (cf * ct);
-    return ((int64_t)b * T1 + (2 * th + pt)) * F1 + (2 * fh + pf);
+    uint32_t q, fh, b, th;
+    dcf.divmod((uint32_t)row, q, fh);
+    dct.divmod(q, b, th);
+    return ((int64_t)b * T1 + (2 * (int)th + pt)) * F1 + (2 * (int)fh + pf);
   }
 };
 
@@ -356,12 +416,14 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
   la.outer_limit = M; la.contig_limit = K;
   la.vec = nst_aligned16(x) && (C % Tile<T>::E == 0);
+  la.init_divs();
   DenseLoader<T> lb;  // Bop[j=co][r] = w2[r*C + co]  (OC: outer = r, contig = co)
   lb.base = (const T*)w2; lb.ld = C; lb.outer_limit = K; lb.contig_limit = N;
   lb.vec = nst_aligned16(w2) && (C % Tile<T>::E == 0);
   Epilogue ep = plain_epilogue();
   ep.bias = b2;
   ep.relu = relu;
+  ep.vec = nst_aligned16(y) && (C % 8 == 0);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   dim3 grid(ntiles, 1, 1);
@@ -384,12 +446,16 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
       DgradALoader<T> la;
       la.dy = (const T*)dy; la.B = B; la.C = C; la.T2 = T2; la.F2 = F2; la.ct = ct; la.cf = cf; la.pt = pt; la.pf = pf; la.nkw = nkw;
       la.outer_limit = M; la.contig_limit = K; la.vec = nst_aligned16(dy) && (C % Tile<T>::E == 0);
+      la.init_divs();
       DgradBLoader<T> lb;
       lb.w2 = (const T*)w2; lb.C = C; lb.pt = pt; lb.pf = pf; lb.nkw = nkw;
       lb.outer_limit = N; lb.contig_limit = K; lb.vec = nst_aligned16(w2) && (C % Tile<T>::E == 0);
+      lb.init_divs();
       DgradRowMap rm;
       rm.T1 = T1; rm.F1 = F1; rm.ct = ct; rm.cf = cf; rm.pt = pt; rm.pf = pf;
+      rm.init_divs();
       Epilogue ep = plain_epilogue();
+      ep.vec = nst_aligned16(dx) && (C % 8 == 0);
       const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
       const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
       dim3 grid(ntiles, 1, 1);
@@ -407,11 +473,13 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int 
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
   la.outer_limit = P; la.contig_limit = M;
   la.vec = nst_aligned16(x) && (C % Tile<T>::E == 0);
+  la.init_divs();
   DenseLoader<T> lb;                  // Bop[j=co][r=p] = dy[p*C + co] (OC)
   lb.base = (const T*)dy; lb.ld = C; lb.outer_limit = P; lb.contig_limit = N;
   lb.vec = nst_aligned16(dy) && (C % Tile<T>::E == 0);
   Epilogue ep = plain_epilogue();
   ep.atomic = 1;
+  ep.vec = nst_aligned16(dw2) && (C % 8 == 0);
   if (!accumulate) {
     if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
   }
@@ -446,9 +514,10 @@ extern "C" int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const fl
   NST_CHECK_ARG(C > 0 && C <= 64 * C1_SLOTS, "conv1_fwd: C=%d unsupported (1..%d)", C, 64 * C1_SLOTS);
   NST_CHECK_ARG(B > 0 && T > 0 && F > 0, "conv1_fwd: bad dims");
   NST_CHECK_ARG(out_dtype == NST_F32 || out_dtype == NST_BF16, "conv1_fwd: bad dtype %d", out_dtype);
+  NST_CHECK_ARG(F <= C1_MAXF, "conv1_fwd: F=%d unsupported (<= %d)", F, C1_MAXF);
   const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
-  const int64_t npix = (int64_t)B * T1 * F1;
-  int blocks = (int)((npix + 3) / 4 > 4096 ? 4096 : (npix + 3) / 4);
+  const int64_t nrows = (int64_t)B * T1;
+  int blocks = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (C % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
 #define NST_C1F(TT, S, V) conv1_fwd_kernel<TT, S, V><<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, (TT*)out, mean, rstd, B, T, F, C, T1, F1, layer_norm, eps)
@@ -482,10 +551,11 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
       NST_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, st));
     }
   }
+  NST_CHECK_ARG(F <= C1_MAXF, "conv1_bwd: F=%d unsupported (<= %d)", F, C1_MAXF);
   const int T1 = (T + 1) / 2, F1 = (F + 1) / 2;
-  const int64_t npix = (int64_t)B * T1 * F1;
-  int blocks = (int)((npix + 3) / 4 > 1024 ? 1024 : (npix + 3) / 4);
-  const bool vec = (C % 4 == 0);
+  const int64_t nrows = (int64_t)B * T1;
+  int blocks = (int)((nrows + 3) / 4 > 1024 ? 1024 : (nrows + 3) / 4);
+  const bool vec = (C % 4 == 0) && ((((uintptr_t)dout) & 15) == 0);
 #define NST_C1B(TT, S, V) conv1_bwd_kernel<TT, S, V><<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, mean, rstd, (const TT*)dout, dw1, db1, dgamma, dbeta, B, T, F, C, T1, F1, layer_norm)
   if (dtype == NST_F32) {
     if (vec) { if (C <= 256) NST_C1B(float, 4, true); else NST_C1B(float, 8, true); }

@@ -167,21 +167,50 @@ __global__ void __launch_bounds__(256) ls_xent_bwd_kernel(const T* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // column sums (bias gradients): out[c] += sum_r x[r, c]
 // ---------------------------------------------------------------------------------------------
+// Each thread owns CPT consecutive columns (16 bytes of a row) so a wave reads whole 128-byte lines; the block's
+// 256 threads cover (256*CPT/ncols_tile) rows per iteration; rows are strided over gridDim.y strips.
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows, int n,
-                                                    int64_t ldx, int64_t rows_per_block) {
-  __shared__ float sh[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+                                                    int64_t ldx, int64_t rows_per_block, int vec) {
+  constexpr int CPT = 16 / (int)sizeof(T);  // columns per thread
+  constexpr int TPR = 32;                   // threads per row -> a block tile is 8 rows x (32*CPT) columns
+  __shared__ float sh[8][TPR * CPT + 1];
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  const int col0 = blockIdx.x * (TPR * CPT) + tc * CPT;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  float acc = 0.f;
-  if (col < n)
-    for (int64_t r = r0 + wave; r < r1; r += 4) acc += to_f32<T>(x[r * ldx + col]);
-  sh[wave][lane] = acc;
+  float acc[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+  if (col0 < n) {
+    for (int64_t r = r0 + tr; r < r1; r += 8) {
+      const T* p = x + r * ldx + col0;
+      if (vec) {
+        uint4 raw = *reinterpret_cast<const uint4*>(p);
+        T tmp[CPT];
+        memcpy(tmp, &raw, 16);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] += to_f32<T>(tmp[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+          if (col0 + j < n) acc[j] += to_f32<T>(p[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) sh[tr][tc * CPT + j] = acc[j];
   __syncthreads();
-  if (wave == 0 && col < n) atomicAdd(out + col, sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+  for (int c = threadIdx.x; c < TPR * CPT; c += 256) {
+    const int col = blockIdx.x * (TPR * CPT) + c;
+    if (col < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += sh[q][c];
+      atomicAdd(out + col, t);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,12 +381,15 @@ extern "C" int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) NST_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, st));
   if (rows <= 0) return NST_OK;
-  int64_t strips = (rows + 255) / 256;
-  if (strips > 1024) strips = 1024;
+  const int esz = dtype == NST_BF16 ? 2 : 4;
+  const int cpt = 16 / esz, tile_cols = 32 * cpt;
+  int64_t strips = (rows + 63) / 64;
+  if (strips > 256) strips = 256;
   const int64_t rpb = (rows + strips - 1) / strips;
-  dim3 grid((n + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
-  if (dtype == NST_F32) colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)x, out, rows, n, ldx, rpb);
-  else if (dtype == NST_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, out, rows, n, ldx, rpb);
+  dim3 grid((n + tile_cols - 1) / tile_cols, (unsigned)((rows + rpb - 1) / rpb));
+  const int vec = nst_aligned16(x) && ((ldx * esz) % 16 == 0) && (n % cpt == 0);
+  if (dtype == NST_F32) colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)x, out, rows, n, ldx, rpb, vec);
+  else if (dtype == NST_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, out, rows, n, ldx, rpb, vec);
   else { nst_set_error("colsum: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("colsum");
   return NST_OK;

@@ -83,6 +83,15 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   if (d->M == 0 || d->N == 0) return NST_OK;
 
   Epilogue ep;
+  {
+    const int osz = nst_dtype_size(d->out_dtype);
+    bool v = nst_aligned16(C) && ((d->ldc * osz) % 16 == 0) && (d->N % 8 == 0);
+    if (d->residual) v = v && nst_aligned16(d->residual) && ((d->ldr * osz) % 16 == 0);
+    if (d->gate_src) v = v && nst_aligned16(d->gate_src) && ((d->ldg * osz) % 16 == 0);
+    if (d->posenc) v = v && nst_aligned16(d->posenc);
+    if (d->bias) v = v && ((((uintptr_t)d->bias) & 3) == 0);
+    ep.vec = v ? 1 : 0;
+  }
   ep.alpha = d->alpha;
   ep.bias = d->bias;
   ep.relu = d->relu;

@@ -36,7 +36,30 @@ struct Tile {
   static constexpr int LDS_BYTES = (BM * RS_RC > BK * RS_OC) ? BM * RS_RC : BK * RS_OC;
 };
 
+// Division by a runtime-constant divisor without the ~40-instruction integer divide (Granlund-Montgomery
+// round-up method, exact for all 32-bit n): the conv loaders decompose pixel / tap indices with it every K step.
+struct FastDiv {
+  uint32_t d, mul, sh1, sh2;
+  void init(uint32_t div) {
+    d = div;
+    uint32_t l = 0;
+    while ((1ull << l) < div) ++l;
+    mul = (uint32_t)(((1ull << 32) * ((1ull << l) - div)) / div + 1);
+    sh1 = l < 1 ? l : 1;
+    sh2 = l > 0 ? l - 1 : 0;
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const {
+    const uint32_t t = __umulhi(mul, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+  }
+  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+    q = div(n);
+    r = n - q * d;
+  }
+};
+
 struct Epilogue {
+  int vec;  // 16-byte vector epilogue is legal (host-checked alignment of C / residual / gate, N % 8 == 0)
   float alpha;
   const float* bias;
   int relu;
@@ -207,6 +230,65 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, OutT* __restr
 }
 
 // k_tiles_of(z, &first, &count): the K steps this block (blockIdx.z) owns.
+// Vector epilogue: one lane finishes 8 consecutive columns of one row (16-byte bf16 / 2x16-byte f32 accesses);
+// every optional stage is a wave-uniform branch taken once per 8 elements instead of once per element.
+template <typename OutT>
+__device__ __forceinline__ void epilogue_store8(const Epilogue& ep, OutT* __restrict__ C, int64_t ldc, int row, int col,
+                                                int N, float (&v)[8], const float (&bias8)[8], int64_t out_row) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = v[j] * ep.alpha + bias8[j];
+  if (ep.relu) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  if (ep.drop_thresh) {
+    const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)col;  // multiple of 8 -> two aligned Philox groups
+    const Philox4 r0 = philox4x32_10(ep.seed, ep.stream_id, idx >> 2);
+    const Philox4 r1 = philox4x32_10(ep.seed, ep.stream_id, (idx >> 2) + 1);
+    const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= rr[j] >= ep.drop_thresh ? ep.drop_inv_keep : 0.f;
+  }
+  OutT tmp[8];
+  if (ep.residual) {
+    const OutT* p = reinterpret_cast<const OutT*>(ep.residual) + (int64_t)row * ep.ldr + col;
+    *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(p);
+    if (sizeof(OutT) == 4) *reinterpret_cast<uint4*>(tmp + 4) = *reinterpret_cast<const uint4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += to_f32<OutT>(tmp[j]);
+  }
+  if (ep.gate_src) {
+    const OutT* p = reinterpret_cast<const OutT*>(ep.gate_src) + (int64_t)row * ep.ldg + col;
+    *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(p);
+    if (sizeof(OutT) == 4) *reinterpret_cast<uint4*>(tmp + 4) = *reinterpret_cast<const uint4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= to_f32<OutT>(tmp[j]) > 0.f ? ep.gate_scale : 0.f;
+  }
+  if (ep.posenc) {
+    const float* p = ep.posenc + (int64_t)(row % ep.posenc_period) * N + col;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    const float pe[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * ep.emb_scale + pe[j];
+  }
+  OutT* o = C + out_row * ldc + col;
+  if (ep.atomic) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(reinterpret_cast<float*>(o) + j, v[j]);
+    return;
+  }
+  if (ep.accumulate) {
+    *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(o);
+    if (sizeof(OutT) == 4) *reinterpret_cast<uint4*>(tmp + 4) = *reinterpret_cast<const uint4*>(o + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += to_f32<OutT>(tmp[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tmp[j] = from_f32<OutT>(v[j]);
+  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(tmp);
+  if (sizeof(OutT) == 4) *reinterpret_cast<uint4*>(o + 4) = *reinterpret_cast<uint4*>(tmp + 4);
+}
+
 struct IdentityRowMap {
   __device__ __forceinline__ int64_t operator()(int row) const { return row; }
 };
@@ -262,11 +344,17 @@ __device__ __forceinline__ void gemm_block(const ALoader& la, const BLoader& lb,
     __syncthreads();
   }
 
-  // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that the
-  // global stores (and residual / gate reads) are row-contiguous: lane = column, 64 consecutive columns per row.
-  constexpr int EPI_LD = 65;  // floats; +1 pad keeps the 4 row groups of a fragment on distinct banks
+  // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that global
+  // accesses are row-contiguous.  Fast path (interior tile, aligned): a lane finishes 8 consecutive columns with
+  // 16-byte accesses; edge tiles fall back to one element per lane.
+  constexpr int EPI_LD = 68;  // floats; multiple of 4 keeps the float4 reads 16-byte aligned
   float* epi = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
   const int lr = (lane >> 4) * 4, lc = lane & 15;
+  const bool fast = ep.vec && (m0 + BM <= M) && (n0 + BN <= N);
+  const int vrow = lane >> 3, vcol = (lane & 7) * 8;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias8[j] = (fast && ep.bias) ? ep.bias[n0 + wn + vcol + j] : 0.f;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -281,12 +369,24 @@ __device__ __forceinline__ void gemm_block(const ALoader& la, const BLoader& lb,
       }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
     __builtin_amdgcn_wave_barrier();
-    const int col = n0 + wn + lane;
     const int row_base = m0 + wm + half * 32;
-    if (col < N) {
-      for (int r = 0; r < 32; ++r) {
-        const int row = row_base + r;
-        if (row < M) epilogue_store<OutT>(ep, C, ldc, row, col, N, epi[r * EPI_LD + lane], rowmap(row));
+    if (fast) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 8 + vrow;
+        const float4 x0 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol);
+        const float4 x1 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const int row = row_base + rl;
+        epilogue_store8<OutT>(ep, C, ldc, row, n0 + wn + vcol, N, v, bias8, rowmap(row));
+      }
+    } else {
+      const int col = n0 + wn + lane;
+      if (col < N) {
+        for (int r = 0; r < 32; ++r) {
+          const int row = row_base + r;
+          if (row < M) epilogue_store<OutT>(ep, C, ldc, row, col, N, epi[r * EPI_LD + lane], rowmap(row));
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();

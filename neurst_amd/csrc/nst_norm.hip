@@ -86,14 +86,14 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_fwd_kernel(const T* __restri
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < S; ++c) s += v[c];
-    const float mean = wave_sum(s) * inv_d;
+    const float mean = wave_sum_fast(s) * inv_d;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < S; ++c) {
       const float t = elem_index<VEC>(lane, c) < d ? v[c] - mean : 0.f;
       sq += t * t;
     }
-    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    const float rstd = rsqrtf(wave_sum_fast(sq) * inv_d + eps);
 #pragma unroll
     for (int c = 0; c < S; ++c) {
       const int e = elem_index<VEC>(lane, c);
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
         gv[c] = dxh;
       }
     }
-    const float c1 = wave_sum(s1) * inv_d, c2m = wave_sum(s2) * inv_d;
+    const float c1 = wave_sum_fast(s1) * inv_d, c2m = wave_sum_fast(s2) * inv_d;
 #pragma unroll
     for (int c = 0; c < S; ++c) xv[c] = rstd * (gv[c] - c1 - xv[c] * c2m);
     if (dres) {
@@ -209,7 +209,7 @@ template <typename T, bool RELU>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, hipStream_t st) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;  // one atomic per column per block: keep the fan-in per address small
   if (blocks < 1) blocks = 1;
 #define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d)
   if (vec_ok<T>(x, dy, dx, d) && vec_ok<T>(y, dres, nullptr, d)) {

@@ -156,10 +156,12 @@ def test_param_store_gradient_bookkeeping():
         st.add("a", (1,), torch.zeros(1))
     st.finalize("cpu", torch.float32)
     assert a.compute.data_ptr() == a.data.data_ptr()   # fp32 mode: no shadow
-    st.begin_backward()
-    assert st.acc_flag(a) is False and st.acc_flag(a) is True and st.acc_flag(b) is False
-    st.begin_backward(accumulate=True)
-    assert st.acc_flag(a) is True
+    a.grad.fill_(3.0)
+    st.begin_backward()                      # zeroes the flat gradient once; every kernel then accumulates
+    assert float(st.grad.abs().sum()) == 0.0 and st.acc_flag(a) is True and st.acc_flag(b) is True
+    a.grad.fill_(3.0)
+    st.begin_backward(accumulate=True)       # gradient accumulation micro step: keep what is there
+    assert float(a.grad.sum()) == 9.0 and st.acc_flag(a) is True
     sd = st.state_dict()
     sd["b"] = torch.full((2, 2), 5.0)
     st.load_state_dict(sd)
