@@ -77,8 +77,10 @@ int nst_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  *   -> *gate (gate_src[row,col] > 0 ? gate_scale : 0)   [backward of relu+dropout from the saved activation]
  *   -> (v*emb_scale + posenc[row % posenc_period, col])   [PositionEmbeddingWrapper, common_layers.py:427-434]
  *   -> C = v  or  C += v (accumulate)
- * split_k > 1 partitions K over grid.z and adds partial products atomically into an f32 C
- * (requires out_dtype==NST_F32 and no nonlinear epilogue; C is zeroed first unless accumulate). */
+ * split_k > 1 partitions K over grid.z (weight gradients: small output, very long reduction).  Requires
+ * out_dtype==NST_F32 and the plain alpha*A*B (+accumulate) epilogue.  With a caller-provided workspace of at least
+ * split_k*M*N*4 bytes every split writes its partial tile with plain coalesced stores and a second kernel sums the
+ * slabs into C; without one the partials are added atomically (much slower: ~36 G atomic elements/s). */
 typedef struct {
   int M, N, K;
   int trans_a, trans_b;
@@ -100,6 +102,8 @@ typedef struct {
   float emb_scale;
   int accumulate;
   int split_k;            /* <=1: off */
+  void* workspace;        /* split-K slabs (device), or NULL */
+  int64_t workspace_bytes;
 } NstGemmDesc;
 
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
@@ -155,8 +159,10 @@ int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const float* b1, co
 int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu,
                   int dtype, void* stream);
 int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
+/* workspace (nullable): split-K slabs, see nst_gemm; needs splits*9*C*C*4 bytes (query with workspace==NULL is
+ * not needed: 64 MiB covers every supported shape; smaller workspaces fall back to atomic accumulation). */
 int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
-                    int accumulate, void* stream);
+                    int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* LayerNorm + ReLU (second conv layer; audio_modalities.py:102-104) -- same contract as nst_layernorm_*,
  * y = relu(LN(x)); backward takes dy w.r.t. the ReLU output and the saved y (gate y>0). */

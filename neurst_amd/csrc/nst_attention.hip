@@ -131,6 +131,18 @@ struct AttnParams {
   int vq, vk, vv, vo;  // 16-byte vector loads legal for q / k / v / (out,dout)
 };
 
+// Dropout mask of attention probabilities.  One Philox call serves the 4 keys {64*kt + 16*f + lc, f = 0..3} of one
+// query row -- exactly the 4 C-fragment columns a lane owns in the forward / dQ kernels -- so those kernels pay one
+// Philox per 4 probabilities.  counter = ((bh*Tq + q) * ceil(Tk/64) + kt) * 16 + lc ; word f.
+__device__ __forceinline__ Philox4 attn_drop4(const AttnParams& p, int64_t bh_row_base, int qg, int kt, int lc) {
+  const int nkt = (p.Tk + TR - 1) / TR;
+  const uint64_t ctr = (uint64_t)(((bh_row_base + qg) * nkt + kt) * 16 + lc);
+  return philox4x32_10(p.seed, p.stream_id, ctr);
+}
+__device__ __forceinline__ float drop_scale(const AttnParams& p, uint32_t word) {
+  return word >= p.drop_thresh ? p.drop_inv_keep : 0.f;
+}
+
 // biased logit of (query qg, key kg) from the raw dot product -- the reference's fp32 order of operations
 __device__ __forceinline__ float biased_logit(const AttnParams& p, float raw, float kbias, int qg, int kg) {
   float v = raw * p.scale + kbias;
@@ -209,18 +221,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
       rsum[r] = 0.f;
     }
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int kg = k0 + f * 16 + lc;
+    for (int r = 0; r < 4; ++r) {
+      const int qg = q0 + wave * 16 + lq * 4 + r;
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.drop_thresh) {
+        const Philox4 w4 = attn_drop4(p, drop_row_base, qg, kt, lc);
+        keep[0] = drop_scale(p, w4.x); keep[1] = drop_scale(p, w4.y); keep[2] = drop_scale(p, w4.z); keep[3] = drop_scale(p, w4.w);
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pv = __expf(s[f][r] - m_run[r]);
+      for (int f = 0; f < 4; ++f) {
+        const float pv = __expf(s[f][r] - m_run[r]);
         rsum[r] += pv;
-        if (p.drop_thresh) {
-          const int qg = q0 + wave * 16 + lq * 4 + r;
-          pv *= dropout_keep_scale(p.seed, p.stream_id, (uint64_t)((drop_row_base + qg) * p.Tk + kg), p.drop_thresh,
-                                   p.drop_inv_keep);
-        }
-        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(pv);
+        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(pv * keep[f]);
       }
     }
 #pragma unroll
@@ -351,9 +363,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
         float pv = 0.f, keep = 1.f;
         if (qvalid && kvalid[r]) {
           pv = __expf(biased_logit(p, st[f][r], kbias[r], qg, kg) - lse);
-          if (p.drop_thresh)
-            keep = dropout_keep_scale(p.seed, p.stream_id, (uint64_t)((stat_base + qg) * p.Tk + kg), p.drop_thresh,
-                                      p.drop_inv_keep);
+          if (p.drop_thresh) {
+            const Philox4 w4 = attn_drop4(p, stat_base, qg, blockIdx.x, lq * 4 + r);
+            const uint32_t wsel = wave == 0 ? w4.x : (wave == 1 ? w4.y : (wave == 2 ? w4.z : w4.w));
+            keep = drop_scale(p, wsel);
+          }
         }
         *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(pv * keep);
         st[f][r] = pv * (keep * dp[f][r] - dl) * p.scale;  // dS^T (scaled), kept for the second product
@@ -460,22 +474,29 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
         s[f] = Mma<T>::run(qf[st], rc_frag<T>(Ks, f * 16, st * AT<T>::KS, lane), s[f]);
         dp[f] = Mma<T>::run(gf[st], rc_frag<T>(Vs, f * 16, st * AT<T>::KS, lane), dp[f]);
       }
+    float kbias4[4];
+    bool kvalid4[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int kg = k0 + f * 16 + lc;
-      const bool kvalid = kg < p.Tk;
-      const float kbias = (kvalid && p.key_bias) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
+      kvalid4[f] = kg < p.Tk;
+      kbias4[f] = (kvalid4[f] && p.key_bias) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qg = q0 + wave * 16 + lq * 4 + r;
+    for (int r = 0; r < 4; ++r) {
+      const int qg = q0 + wave * 16 + lq * 4 + r;
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.drop_thresh) {
+        const Philox4 w4 = attn_drop4(p, stat_base, qg, kt, lc);
+        keep[0] = drop_scale(p, w4.x); keep[1] = drop_scale(p, w4.y); keep[2] = drop_scale(p, w4.z); keep[3] = drop_scale(p, w4.w);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int kg = k0 + f * 16 + lc;
         float ds = 0.f;
-        if (kvalid && qvalid[r]) {
-          const float pv = __expf(biased_logit(p, s[f][r], kbias, qg, kg) - lse[r]);
-          float keep = 1.f;
-          if (p.drop_thresh)
-            keep = dropout_keep_scale(p.seed, p.stream_id, (uint64_t)((stat_base + qg) * p.Tk + kg), p.drop_thresh,
-                                      p.drop_inv_keep);
-          ds = pv * (keep * dp[f][r] - dl[r]) * p.scale;
+        if (kvalid4[f] && qvalid[r]) {
+          const float pv = __expf(biased_logit(p, s[f][r], kbias4[f], qg, kg) - lse[r]);
+          ds = pv * (keep[f] * dp[f][r] - dl[r]) * p.scale;
         }
         *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(ds);
       }

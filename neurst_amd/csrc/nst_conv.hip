@@ -268,6 +268,15 @@ struct Im2colLoader {
     ok = ti >= 0 && ti < T1 && fi >= 0 && fi < F1;
     return x + (((int64_t)b * T1 + ti) * F1 + fi) * C + (int)c;
   }
+  __device__ __forceinline__ const T* ptr(int outer, int contig) const {
+    if (outer >= outer_limit || contig >= contig_limit) return nullptr;
+    uint32_t q, fo, b, to;
+    dF2.divmod((uint32_t)outer, q, fo);
+    dT2.divmod(q, b, to);
+    bool ok;
+    const T* p = addr((int)b, (int)to, (int)fo, contig, ok);
+    return ok ? p : nullptr;
+  }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
@@ -314,6 +323,15 @@ struct DgradALoader {  // RC: outer = class row, contig = r
     ok = to < T2 && fo < F2;
     return dy + (((int64_t)b * T2 + to) * F2 + fo) * C + (int)co;
   }
+  __device__ __forceinline__ const T* ptr(int outer, int contig) const {
+    if (outer >= outer_limit || contig >= contig_limit) return nullptr;
+    uint32_t q, fh, b, th;
+    dcf.divmod((uint32_t)outer, q, fh);
+    dct.divmod(q, b, th);
+    bool ok;
+    const T* p = addr((int)b, (int)th, (int)fh, contig, ok);
+    return ok ? p : nullptr;
+  }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
@@ -355,6 +373,10 @@ struct DgradBLoader {  // RC: outer = ci, contig = r ; element = w2[tap][ci][co]
     const int kw = pf ? (iw == 0 ? 0 : 2) : 1;
     return w2 + ((int64_t)(kh * 3 + kw) * C + ci) * C + (int)co;
   }
+  __device__ __forceinline__ const T* ptr(int outer, int contig) const {
+    if (outer >= outer_limit || contig >= contig_limit) return nullptr;
+    return addr(outer, contig);
+  }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
@@ -389,8 +411,71 @@ __global__ void __launch_bounds__(THREADS) conv_gemm_kernel(AL la, BL lb, OutT* 
   int kt_count = kt_total - kt_first;
   if (kt_count > kt_per_split) kt_count = kt_per_split;
   if (kt_count <= 0) return;
-  gemm_block<T, OutT, AMODE, BMODE, USE_TR, AL, BL, RM>(la, lb, C, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem, rm);
+  gemm_block<T, OutT, AMODE, BMODE, USE_TR, AL, BL, RM>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM,
+                                                        tn * BN, kt_first, kt_count, ep, smem, rm);
 }
+
+template <typename T, typename OutT, int AMODE, int BMODE, int NST, typename AL, typename BL, typename RM>
+__global__ void __launch_bounds__(THREADS) conv_gemm_kernel_v2(AL la, BL lb, OutT* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                              int tiles_n, int ntiles, int kt_per_split, Epilogue ep, RM rm) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  const int kt_first = blockIdx.z * kt_per_split;
+  int kt_count = kt_total - kt_first;
+  if (kt_count > kt_per_split) kt_count = kt_per_split;
+  if (kt_count <= 0) return;
+  gemm_block_v2<T, OutT, AMODE, BMODE, NST, AL, BL, RM>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM,
+                                                        tn * BN, kt_first, kt_count, ep, smem_dyn, rm);
+}
+
+// dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output)
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                int64_t total4, int split, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < split; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + ((int64_t)z * total4 + i) * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* o = out + i * 4;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    *reinterpret_cast<float4*>(o) = acc;
+  }
+}
+
+bool conv_use_v2() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_V1"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+template <typename KernelT>
+void conv_allow_big_lds(KernelT kernel, int bytes) {
+  static thread_local const void* done[32];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kernel) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 32) done[ndone++] = (const void*)kernel;
+}
+
+#define NST_CONV_LAUNCH_V2(T_, OutT_, AM, BMO, AL, BL, RM, grid, ktps, ...)                                   \
+  do {                                                                                                        \
+    if ((ktps) >= 3) {                                                                                        \
+      auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 3, AL, BL, RM>;                                      \
+      conv_allow_big_lds(kfn, 3 * V2_STAGE_BYTES);                                                            \
+      kfn<<<grid, THREADS, 3 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                            \
+    } else {                                                                                                  \
+      auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 2, AL, BL, RM>;                                      \
+      conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);                                                            \
+      kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                            \
+    }                                                                                                         \
+  } while (0)
 
 bool conv_use_tr() {
   static int v = -1;
@@ -405,6 +490,7 @@ Epilogue plain_epilogue() {
   ep.drop_inv_keep = 1.f;
   ep.posenc_period = 1;
   ep.emb_scale = 1.f;
+  ep.slab_stride = 0;
   return ep;
 }
 
@@ -427,7 +513,10 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   dim3 grid(ntiles, 1, 1);
-  if (conv_use_tr())
+  if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
+    NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_total, la, lb, (T*)y,
+                       (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
+  else if (conv_use_tr())
     conv_gemm_kernel<T, T, MODE_RC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
   else
     conv_gemm_kernel<T, T, MODE_RC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
@@ -459,13 +548,18 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
       const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
       const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
       dim3 grid(ntiles, 1, 1);
-      conv_gemm_kernel<T, T, MODE_RC, MODE_RC, true, DgradALoader<T>, DgradBLoader<T>, DgradRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)dx, C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
+      if (conv_use_v2() && la.vec && lb.vec)
+        NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_RC, DgradALoader<T>, DgradBLoader<T>, DgradRowMap, grid, kt_total, la, lb, (T*)dx,
+                           (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
+      else
+        conv_gemm_kernel<T, T, MODE_RC, MODE_RC, true, DgradALoader<T>, DgradBLoader<T>, DgradRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)dx, C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
     }
   return 0;
 }
 
 template <typename T>
-int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int accumulate, hipStream_t st) {
+int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int accumulate, void* ws,
+                  int64_t ws_bytes, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int P = B * T2 * F2;          // reduction: pixels
   const int M = 9 * C, N = C, K = P;  // dw2[kk][co] = sum_p im2col[p][kk] * dy[p][co]
@@ -478,23 +572,39 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int 
   lb.base = (const T*)dy; lb.ld = C; lb.outer_limit = P; lb.contig_limit = N;
   lb.vec = nst_aligned16(dy) && (C % Tile<T>::E == 0);
   Epilogue ep = plain_epilogue();
-  ep.atomic = 1;
   ep.vec = nst_aligned16(dw2) && (C % 8 == 0);
-  if (!accumulate) {
-    if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
-  }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
-  int split = (1024 + ntiles - 1) / ntiles;  // ~4 workgroups per CU
+  int split = (512 + ntiles - 1) / ntiles;  // ~2 workgroups per CU
   if (split > kt_total) split = kt_total;
   if (split < 1) split = 1;
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
-  if (conv_use_tr())
-    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, dw2, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+  const bool slab = ws && nst_aligned16(ws) && ws_bytes >= (int64_t)split * M * N * 4 && (N % 8 == 0) && nst_aligned16(dw2);
+  float* out = dw2;
+  if (slab) {
+    ep.slab_stride = (int64_t)M * N;
+    ep.vec = 1;
+    out = (float*)ws;
+  } else {
+    ep.atomic = 1;
+    if (!accumulate) {
+      if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
+    }
+  }
+  if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
+    NST_CONV_LAUNCH_V2(T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_per_split, la, lb, out,
+                       (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+  else if (conv_use_tr())
+    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, out, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
   else
-    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, dw2, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, out, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+  if (slab) {
+    const int64_t total4 = (int64_t)M * N / 4;
+    int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    conv_splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)ws, dw2, total4, split, accumulate);
+  }
   return 0;
 }
 
@@ -593,13 +703,13 @@ extern "C" int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, 
 }
 
 extern "C" int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
-                               int accumulate, void* stream) {
+                               int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   NST_CHECK_ARG(x && dy && dw2, "conv2_wgrad: null pointer");
   int rc = check_conv_dims("conv2_wgrad", B, T1, F1, C);
   if (rc) return rc;
   int r = 0;
-  if (dtype == NST_F32) r = conv2_wgrad_t<float>(x, dy, dw2, B, T1, F1, C, accumulate, (hipStream_t)stream);
-  else if (dtype == NST_BF16) r = conv2_wgrad_t<bf16_t>(x, dy, dw2, B, T1, F1, C, accumulate, (hipStream_t)stream);
+  if (dtype == NST_F32) r = conv2_wgrad_t<float>(x, dy, dw2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+  else if (dtype == NST_BF16) r = conv2_wgrad_t<bf16_t>(x, dy, dw2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
   else { nst_set_error("conv2_wgrad: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   if (r) { nst_set_error("conv2_wgrad: memset failed"); return NST_ERR_LAUNCH; }
   NST_CHECK_LAUNCH("conv2_wgrad");

@@ -19,7 +19,61 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, 
   int kt_count = kt_total - kt_first;
   if (kt_count > kt_per_split) kt_count = kt_per_split;
   if (kt_count <= 0) return;
-  gemm_block<T, OutT, AMODE, BMODE, USE_TR>(la, lb, C, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem);
+  gemm_block<T, OutT, AMODE, BMODE, USE_TR>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN,
+                                            kt_first, kt_count, ep, smem);
+}
+
+template <typename T, typename OutT, int AMODE, int BMODE, int NST>
+__global__ void __launch_bounds__(THREADS) dense_gemm_kernel_v2(DenseLoader<T> la, DenseLoader<T> lb, OutT* __restrict__ C,
+                                                               int64_t ldc, int M, int N, int K, int tiles_n, int ntiles,
+                                                               int kt_per_split, Epilogue ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  const int kt_first = blockIdx.z * kt_per_split;
+  int kt_count = kt_total - kt_first;
+  if (kt_count > kt_per_split) kt_count = kt_per_split;
+  if (kt_count <= 0) return;
+  gemm_block_v2<T, OutT, AMODE, BMODE, NST>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN,
+                                            kt_first, kt_count, ep, smem_dyn);
+}
+
+template <typename KernelT>
+void allow_big_lds(KernelT kernel, int bytes) {
+  static thread_local const void* done[64];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kernel) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 64) done[ndone++] = (const void*)kernel;
+}
+
+bool use_v2() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_V1"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+// C[i] (+)= sum_z slabs[z][i]   (split-K second stage; slabs are [split][M][N] f32, C has leading dimension ldc)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+                                                           int64_t ldc, int split, int accumulate) {
+  const int64_t total4 = (int64_t)M * N / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < split; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + ((int64_t)z * M * N + i * 4));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int64_t e = i * 4;
+    const int row = (int)(e / N), col = (int)(e - (int64_t)row * N);
+    float* o = C + (int64_t)row * ldc + col;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    *reinterpret_cast<float4*>(o) = acc;
+  }
 }
 
 template <typename T>
@@ -55,6 +109,26 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
   const bool tr = use_tr();
+  if (use_v2() && tr && la.vec && lb.vec) {  // LDS-DMA pipeline: needs 16-byte aligned, 8-element granular operands
+#define NST_GEMM_LAUNCH2(AM, BMO, NS)                                                                                  \
+  do {                                                                                                               \
+    auto kfn = dense_gemm_kernel_v2<T, OutT, AM, BMO, NS>;                                                            \
+    allow_big_lds(kfn, NS * V2_STAGE_BYTES);                                                                          \
+    kfn<<<grid, THREADS, NS * V2_STAGE_BYTES, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, ntiles,      \
+                                                    kt_per_split, ep);                                                \
+  } while (0)
+#define NST_GEMM_MODES(NS)                                                                 \
+  do {                                                                                     \
+    if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_RC, MODE_RC, NS);      \
+    else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH2(MODE_RC, MODE_OC, NS); \
+    else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_OC, MODE_RC, NS); \
+    else NST_GEMM_LAUNCH2(MODE_OC, MODE_OC, NS);                                           \
+  } while (0)
+    if (kt_per_split >= 3) NST_GEMM_MODES(3); else NST_GEMM_MODES(2);
+#undef NST_GEMM_MODES
+#undef NST_GEMM_LAUNCH2
+    return 0;
+  }
 #define NST_GEMM_LAUNCH(AM, BMO, TR)                                                                                   \
   dense_gemm_kernel<T, OutT, AM, BMO, TR><<<grid, THREADS, 0, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, \
                                                                    ntiles, kt_per_split, ep)
@@ -109,12 +183,37 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   ep.emb_scale = d->emb_scale;
   ep.accumulate = d->accumulate;
   ep.atomic = 0;
+  ep.slab_stride = 0;
 
   int split = d->split_k > 1 ? d->split_k : 1;
   if (split > 1) {
     NST_CHECK_ARG(d->out_dtype == NST_F32, "gemm: split_k requires an f32 output");
     NST_CHECK_ARG(!d->relu && d->dropout_p == 0.f && !d->gate_src && !d->posenc && !d->bias && !d->residual,
                   "gemm: split_k supports only the plain alpha*A*B (+accumulate) epilogue");
+    const int kt_total = (d->K + (d->in_dtype == NST_BF16 ? 64 : 32) - 1) / (d->in_dtype == NST_BF16 ? 64 : 32);
+    if (split > kt_total) split = kt_total;
+    const int kps = (kt_total + split - 1) / split;
+    split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
+    const int64_t need = (int64_t)split * d->M * d->N * 4;
+    const bool slab = split > 1 && d->workspace && d->workspace_bytes >= need && nst_aligned16(d->workspace) &&
+                      (d->N % 4 == 0) && ((d->ldc * 4) % 16 == 0) && nst_aligned16(C);
+    if (slab) {
+      Epilogue eps = ep;
+      eps.accumulate = 0;
+      eps.slab_stride = (int64_t)d->M * d->N;
+      eps.vec = (d->N % 8 == 0) ? 1 : 0;
+      NstGemmDesc ds = *d;
+      ds.ldc = d->N;  // slabs are dense [M][N]
+      if (d->in_dtype == NST_F32) launch<float, float>(&ds, A, B, d->workspace, eps, split, st);
+      else launch<bf16_t, float>(&ds, A, B, d->workspace, eps, split, st);
+      NST_CHECK_LAUNCH("gemm(split-K partials)");
+      const int64_t total4 = (int64_t)d->M * d->N / 4;
+      int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+      splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)d->workspace, (float*)C, d->M, d->N, d->ldc, split,
+                                                  d->accumulate);
+      NST_CHECK_LAUNCH("gemm(split-K reduce)");
+      return NST_OK;
+    }
     if (!d->accumulate)
       NST_CHECK_HIP(hipMemset2DAsync(C, d->ldc * sizeof(float), 0, (size_t)d->N * sizeof(float), d->M, st));
     ep.atomic = 1;

@@ -76,6 +76,7 @@ struct Epilogue {
   float emb_scale;
   int accumulate;
   int atomic;  // split-K: atomicAdd into an f32 C
+  int64_t slab_stride;  // split-K with workspace: split z stores its partial tile at C + z*slab_stride (elements)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -87,6 +88,11 @@ struct DenseLoader {
   int64_t ld;
   int outer_limit, contig_limit;
   int vec;  // 16-byte loads are legal (alignment + contig_limit % E == 0)
+  // address of the 16-byte chunk (vector-legal loaders only), nullptr when it lies outside the matrix
+  __device__ __forceinline__ const T* ptr(int outer, int contig) const {
+    if (outer >= outer_limit || contig >= contig_limit) return nullptr;
+    return base + (int64_t)outer * ld + contig;
+  }
   __device__ __forceinline__ uint4 load(int outer, int contig) const {
     uint4 r = make_uint4(0, 0, 0, 0);
     if (outer >= outer_limit || contig >= contig_limit) return r;
@@ -293,6 +299,61 @@ struct IdentityRowMap {
   __device__ __forceinline__ int64_t operator()(int row) const { return row; }
 };
 
+// Shared epilogue of both main loops (see gemm_block).
+template <typename OutT, typename RowMap>
+__device__ __forceinline__ void gemm_epilogue(floatx4_t (&acc)[4][4], OutT* __restrict__ C, int64_t ldc, int M, int N, int m0,
+                                              int n0, const Epilogue& ep, char* smem, const RowMap& rowmap) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that global
+  // accesses are row-contiguous.  Fast path (interior tile, aligned): a lane finishes 8 consecutive columns with
+  // 16-byte accesses; edge tiles fall back to one element per lane.
+  constexpr int EPI_LD = 68;  // floats; multiple of 4 keeps the float4 reads 16-byte aligned
+  float* epi = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+  const int lr = (lane >> 4) * 4, lc = lane & 15;
+  const bool fast = ep.vec && (m0 + BM <= M) && (n0 + BN <= N);
+  const int vrow = lane >> 3, vcol = (lane & 7) * 8;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias8[j] = (fast && ep.bias) ? ep.bias[n0 + wn + vcol + j] : 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const floatx4_t a4 = acc[half * 2 + ii][j];
+        epi[(ii * 16 + lr + 0) * EPI_LD + j * 16 + lc] = a4[0];
+        epi[(ii * 16 + lr + 1) * EPI_LD + j * 16 + lc] = a4[1];
+        epi[(ii * 16 + lr + 2) * EPI_LD + j * 16 + lc] = a4[2];
+        epi[(ii * 16 + lr + 3) * EPI_LD + j * 16 + lc] = a4[3];
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+    const int row_base = m0 + wm + half * 32;
+    if (fast) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 8 + vrow;
+        const float4 x0 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol);
+        const float4 x1 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const int row = row_base + rl;
+        epilogue_store8<OutT>(ep, C, ldc, row, n0 + wn + vcol, N, v, bias8, rowmap(row));
+      }
+    } else {
+      const int col = n0 + wn + lane;
+      if (col < N) {
+        for (int r = 0; r < 32; ++r) {
+          const int row = row_base + r;
+          if (row < M) epilogue_store<OutT>(ep, C, ldc, row, col, N, epi[r * EPI_LD + lane], rowmap(row));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // RowMap: logical output row -> row index in C (identity for dense GEMMs; the conv dgrad scatters its
 // parity-class rows back to pixel order).
 template <typename T, typename OutT, int AMODE, int BMODE, bool USE_TR, typename ALoader, typename BLoader,
@@ -344,53 +405,184 @@ __device__ __forceinline__ void gemm_block(const ALoader& la, const BLoader& lb,
     __syncthreads();
   }
 
-  // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that global
-  // accesses are row-contiguous.  Fast path (interior tile, aligned): a lane finishes 8 consecutive columns with
-  // 16-byte accesses; edge tiles fall back to one element per lane.
-  constexpr int EPI_LD = 68;  // floats; multiple of 4 keeps the float4 reads 16-byte aligned
-  float* epi = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
-  const int lr = (lane >> 4) * 4, lc = lane & 15;
-  const bool fast = ep.vec && (m0 + BM <= M) && (n0 + BN <= N);
-  const int vrow = lane >> 3, vcol = (lane & 7) * 8;
-  float bias8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bias8[j] = (fast && ep.bias) ? ep.bias[n0 + wn + vcol + j] : 0.f;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const floatx4_t a4 = acc[half * 2 + ii][j];
-        epi[(ii * 16 + lr + 0) * EPI_LD + j * 16 + lc] = a4[0];
-        epi[(ii * 16 + lr + 1) * EPI_LD + j * 16 + lc] = a4[1];
-        epi[(ii * 16 + lr + 2) * EPI_LD + j * 16 + lc] = a4[2];
-        epi[(ii * 16 + lr + 3) * EPI_LD + j * 16 + lc] = a4[3];
-      }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
-    __builtin_amdgcn_wave_barrier();
-    const int row_base = m0 + wm + half * 32;
-    if (fast) {
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int rl = pass * 8 + vrow;
-        const float4 x0 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol);
-        const float4 x1 = *reinterpret_cast<const float4*>(epi + rl * EPI_LD + vcol + 4);
-        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        const int row = row_base + rl;
-        epilogue_store8<OutT>(ep, C, ldc, row, n0 + wn + vcol, N, v, bias8, rowmap(row));
-      }
-    } else {
-      const int col = n0 + wn + lane;
-      if (col < N) {
-        for (int r = 0; r < 32; ++r) {
-          const int row = row_base + r;
-          if (row < M) epilogue_store<OutT>(ep, C, ldc, row, col, N, epi[r * EPI_LD + lane], rowmap(row));
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  gemm_epilogue<OutT, RowMap>(acc, C, ldc, M, N, m0, n0, ep, smem, rowmap);
+}
+// =============================================================================================
+// v2 main loop: global -> LDS by LDS-DMA (global_load_lds_dwordx4), NST-stage ring, counted vmcnt.
+//
+//  * no VGPR staging and no ds_write pass: a lane only computes the global address of its 16-byte chunk; the chunk
+//    lands at LDS byte (wave-uniform base + lane*16), i.e. the stage image is lane-linear and UNPADDED;
+//  * bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk index and to the fragment read address
+//    (same involution on both sides):  RC tile (128-byte rows): 16-byte slot ^= (row>>1)&7
+//                                      OC tile (BM*sizeof(T)-byte rows): 32-byte pair ^= (r&3) | ((r>>3)&1)<<2
+//  * the loads of tile t+NST-1 are issued right after the barrier that starts tile t, so NST-1 tiles are in flight
+//    while tile t is multiplied; the wait before the barrier is a COUNTED s_waitcnt vmcnt(N), never a drain;
+//  * the DMA is issued from inline asm so that hipcc's own waitcnt insertion (which would drain vmcnt(0) in front of
+//    every ds_read it cannot prove disjoint) does not see it; out-of-range chunks read a 16-byte zero block.
+// =============================================================================================
+__device__ __attribute__((aligned(16))) const uint4 g_nst_zero16[1] = {{0u, 0u, 0u, 0u}};
+
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_byte_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr_uniform)
+      : "memory");
+}
+
+template <typename T, int MODE>
+struct SwzFrag;  // fragment readers for the unpadded, swizzled stage images
+template <>
+struct SwzFrag<bf16_t, MODE_RC> {
+  typedef bf16x8_t Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    const int r = row + (lane & 15);
+    const int slot = ((kk >> 3) + (lane >> 4)) ^ ((r >> 1) & 7);
+    return *reinterpret_cast<const Frag*>(tile + r * KBYTES + slot * 16);
   }
+};
+template <>
+struct SwzFrag<bf16_t, MODE_OC> {
+  typedef bf16x8_t Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    constexpr int RB = BM * 2;  // row bytes
+    const int ii = lane & 15;
+    const int r0 = kk + (lane >> 4) * 8 + (ii >> 2), r1 = r0 + 4;
+    const int off = (row + (ii & 3) * 4) * 2;
+    const int s0 = ((r0 & 3) | (((r0 >> 3) & 1) << 2)) << 5, s1 = ((r1 & 3) | (((r1 >> 3) & 1) << 2)) << 5;
+    typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+    short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + r0 * RB + (off ^ s0)));
+    short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + r1 * RB + (off ^ s1)));
+    union { short s[8]; Frag f; } u;
+    u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+    u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+    return u.f;
+  }
+};
+template <>
+struct SwzFrag<float, MODE_RC> {
+  typedef float Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    const int r = row + (lane & 15), k = kk + (lane >> 4);
+    const int slot = (k >> 2) ^ ((r >> 1) & 7);
+    return *reinterpret_cast<const float*>(tile + r * KBYTES + slot * 16 + (k & 3) * 4);
+  }
+};
+template <>
+struct SwzFrag<float, MODE_OC> {
+  typedef float Frag;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int kk, int lane) {
+    constexpr int RB = BM * 4;
+    const int r = kk + (lane >> 4);
+    const int off = (row + (lane & 15)) * 4;
+    const int s = ((r & 3) | (((r >> 3) & 1) << 2)) << 5;
+    return *reinterpret_cast<const float*>(tile + r * RB + (off ^ s));
+  }
+};
+
+// issue the LDS-DMA of one operand tile (16 KB = 4 wave-instructions per wave)
+template <typename T, int MODE, typename Loader>
+__device__ __forceinline__ void dma_tile(const Loader& ld, int o0, int r0, uint32_t tile_lds_addr, int wave, int lane) {
+  constexpr int E = Tile<T>::E;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cbase = (s * 4 + wave) * 64;  // first chunk of this wave-instruction (wave uniform)
+    const int c = cbase + lane;
+    const T* p;
+    if (MODE == MODE_RC) {
+      const int row = c >> 3, slot = c & 7;
+      const int kchunk = slot ^ ((row >> 1) & 7);
+      p = ld.ptr(o0 + row, r0 + kchunk * E);
+    } else {
+      constexpr int CPR = Tile<T>::OC_CPR;
+      const int r = c / CPR, c16 = c % CPR;
+      const int g = (r & 3) | (((r >> 3) & 1) << 2);
+      p = ld.ptr(r0 + r, o0 + (c16 ^ (g << 1)) * E);
+    }
+    const void* src = p ? (const void*)p : (const void*)g_nst_zero16;
+    glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)cbase * 16u));
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+constexpr int V2_STAGE_BYTES = 2 * BM * KBYTES;  // A tile + B tile, 32 KB
+
+template <typename T, typename OutT, int AMODE, int BMODE, int NST, typename ALoader, typename BLoader,
+          typename RowMap = IdentityRowMap>
+__device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& lb, OutT* __restrict__ C, int64_t ldc, int M,
+                                              int N, int m0, int n0, int kt_first, int kt_count, const Epilogue& ep,
+                                              char* smem, const RowMap rowmap = RowMap()) {
+  typedef SwzFrag<T, AMODE> RA;
+  typedef SwzFrag<T, BMODE> RB;
+  constexpr int BK = Tile<T>::BK;
+  constexpr int KS = Mma<T>::KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+
+  floatx4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: NST-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    if (s < kt_count) {
+      dma_tile<T, AMODE>(la, m0, (kt_first + s) * BK, smem_addr + s * V2_STAGE_BYTES, wave, lane);
+      dma_tile<T, BMODE>(lb, n0, (kt_first + s) * BK, smem_addr + s * V2_STAGE_BYTES + BM * KBYTES, wave, lane);
+    }
+  }
+  int stage = 0;
+  for (int kt = 0; kt < kt_count; ++kt) {
+    // tile kt must have landed; tiles kt+1 .. kt+NST-2 (8 DMA instructions each) may stay in flight
+    const int ahead = (kt_count - 1 - kt) < (NST - 2) ? (kt_count - 1 - kt) : (NST - 2);
+    if (ahead <= 0) wait_vmcnt<0>();
+    else if (ahead == 1) wait_vmcnt<8>();
+    else wait_vmcnt<16>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int nxt = kt + NST - 1;
+    if (nxt < kt_count) {
+      int st2 = stage + NST - 1;
+      if (st2 >= NST) st2 -= NST;
+      dma_tile<T, AMODE>(la, m0, (kt_first + nxt) * BK, smem_addr + st2 * V2_STAGE_BYTES, wave, lane);
+      dma_tile<T, BMODE>(lb, n0, (kt_first + nxt) * BK, smem_addr + st2 * V2_STAGE_BYTES + BM * KBYTES, wave, lane);
+    }
+    const char* As = smem + stage * V2_STAGE_BYTES;
+    const char* Bs = As + BM * KBYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += KS) {
+      typename RA::Frag a[4];
+      typename RB::Frag b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = RA::read(As, wm + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = RB::read(Bs, wn + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the epilogue reuses the LDS
+  asm volatile("" ::: "memory");
+  gemm_epilogue<OutT, RowMap>(acc, C, ldc, M, N, m0, n0, ep, smem, rowmap);
 }
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (id % 8); give each XCD a contiguous

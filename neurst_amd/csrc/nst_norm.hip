@@ -80,33 +80,43 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_fwd_kernel(const T* __restri
                                                               int64_t rows, int d, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_d = 1.0f / (float)d;
-  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
-    float v[S];
-    load_row<T, VEC, S>(x + row * d, d, lane, v);
-    float s = 0.f;
+  // two rows in flight per wave: both rows' loads are issued before either reduction chain starts
+  const int64_t stride = (int64_t)gridDim.x * LN_WAVES;
+  for (int64_t row0 = (int64_t)blockIdx.x * LN_WAVES + wave; row0 < rows; row0 += 2 * stride) {
+    const int64_t row1 = row0 + stride;
+    const bool has1 = row1 < rows;
+    float v[2][S];
+    load_row<T, VEC, S>(x + row0 * d, d, lane, v[0]);
+    if (has1) load_row<T, VEC, S>(x + row1 * d, d, lane, v[1]);
 #pragma unroll
-    for (int c = 0; c < S; ++c) s += v[c];
-    const float mean = wave_sum_fast(s) * inv_d;
-    float sq = 0.f;
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !has1) break;
+      const int64_t row = u == 0 ? row0 : row1;
+      float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < S; ++c) {
-      const float t = elem_index<VEC>(lane, c) < d ? v[c] - mean : 0.f;
-      sq += t * t;
-    }
-    const float rstd = rsqrtf(wave_sum_fast(sq) * inv_d + eps);
+      for (int c = 0; c < S; ++c) s += v[u][c];
+      const float mean = wave_sum_fast(s) * inv_d;
+      float sq = 0.f;
 #pragma unroll
-    for (int c = 0; c < S; ++c) {
-      const int e = elem_index<VEC>(lane, c);
-      if (e < d) {
-        float o = (v[c] - mean) * rstd * gamma[e] + beta[e];
-        if (RELU) o = fmaxf(o, 0.f);
-        v[c] = o;
+      for (int c = 0; c < S; ++c) {
+        const float t = elem_index<VEC>(lane, c) < d ? v[u][c] - mean : 0.f;
+        sq += t * t;
       }
-    }
-    store_row<T, VEC, S>(y + row * d, d, lane, v);
-    if (lane == 0) {
-      if (mean_out) mean_out[row] = mean;
-      if (rstd_out) rstd_out[row] = rstd;
+      const float rstd = rsqrtf(wave_sum_fast(sq) * inv_d + eps);
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        const int e = elem_index<VEC>(lane, c);
+        if (e < d) {
+          float o = (v[u][c] - mean) * rstd * gamma[e] + beta[e];
+          if (RELU) o = fmaxf(o, 0.f);
+          v[u][c] = o;
+        }
+      }
+      store_row<T, VEC, S>(y + row * d, d, lane, v[u]);
+      if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+      }
     }
   }
 }
@@ -123,41 +133,53 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
   float g_acc[S], b_acc[S];
 #pragma unroll
   for (int c = 0; c < S; ++c) { g_acc[c] = 0.f; b_acc[c] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * LN_WAVES + wave; row < rows; row += (int64_t)gridDim.x * LN_WAVES) {
-    float xv[S], gv[S];
-    load_row<T, VEC, S>(x + row * d, d, lane, xv);
-    load_row<T, VEC, S>(dy + row * d, d, lane, gv);
-    if (RELU) {
-      float yv[S];
-      load_row<T, VEC, S>(yout + row * d, d, lane, yv);
+  const int64_t stride = (int64_t)gridDim.x * LN_WAVES;
+  for (int64_t row0 = (int64_t)blockIdx.x * LN_WAVES + wave; row0 < rows; row0 += 2 * stride) {
+    const int64_t row1 = row0 + stride;
+    const bool has1 = row1 < rows;
+    float xv[2][S], gv[2][S], rv[2][S];
 #pragma unroll
-      for (int c = 0; c < S; ++c) gv[c] = yv[c] > 0.f ? gv[c] : 0.f;
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !has1) break;
+      const int64_t row = u == 0 ? row0 : row1;
+      load_row<T, VEC, S>(x + row * d, d, lane, xv[u]);
+      load_row<T, VEC, S>(dy + row * d, d, lane, gv[u]);
+      if (RELU) load_row<T, VEC, S>(yout + row * d, d, lane, rv[u]);
+      else if (dres) load_row<T, VEC, S>(dres + row * d, d, lane, rv[u]);
     }
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < S; ++c) {
-      const int e = elem_index<VEC>(lane, c);
-      if (e < d) {
-        const float xhat = (xv[c] - mean) * rstd;
-        const float dxh = gv[c] * gamma[e];
-        g_acc[c] += gv[c] * xhat;
-        b_acc[c] += gv[c];
-        s1 += dxh;
-        s2 += dxh * xhat;
-        xv[c] = xhat;
-        gv[c] = dxh;
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !has1) break;
+      const int64_t row = u == 0 ? row0 : row1;
+      if (RELU) {
+#pragma unroll
+        for (int c = 0; c < S; ++c) gv[u][c] = rv[u][c] > 0.f ? gv[u][c] : 0.f;
       }
-    }
-    const float c1 = wave_sum_fast(s1) * inv_d, c2m = wave_sum_fast(s2) * inv_d;
+      const float mean = mean_in[row], rstd = rstd_in[row];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < S; ++c) xv[c] = rstd * (gv[c] - c1 - xv[c] * c2m);
-    if (dres) {
-      load_row<T, VEC, S>(dres + row * d, d, lane, gv);
+      for (int c = 0; c < S; ++c) {
+        const int e = elem_index<VEC>(lane, c);
+        if (e < d) {
+          const float xhat = (xv[u][c] - mean) * rstd;
+          const float dxh = gv[u][c] * gamma[e];
+          g_acc[c] += gv[u][c] * xhat;
+          b_acc[c] += gv[u][c];
+          s1 += dxh;
+          s2 += dxh * xhat;
+          xv[u][c] = xhat;
+          gv[u][c] = dxh;
+        }
+      }
+      const float c1 = wave_sum_fast(s1) * inv_d, c2m = wave_sum_fast(s2) * inv_d;
 #pragma unroll
-      for (int c = 0; c < S; ++c) xv[c] += gv[c];
+      for (int c = 0; c < S; ++c) xv[u][c] = rstd * (gv[u][c] - c1 - xv[u][c] * c2m);
+      if (!RELU && dres) {
+#pragma unroll
+        for (int c = 0; c < S; ++c) xv[u][c] += rv[u][c];
+      }
+      store_row<T, VEC, S>(dx + row * d, d, lane, xv[u]);
     }
-    store_row<T, VEC, S>(dx + row * d, d, lane, xv);
   }
   // cross-wave reduction in LDS, 4 cached values at a time, then one atomic per column per block
 #pragma unroll

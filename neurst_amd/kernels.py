@@ -99,6 +99,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Persistent split-K slab workspace (grown on demand; all launches are ordered on one stream)."""
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
+
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
          posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1):
@@ -131,6 +143,9 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     d.emb_scale = emb_scale
     d.accumulate = int(accumulate)
     d.split_k = split_k
+    if split_k > 1:
+        ws = _workspace(split_k * M * N * 4, A.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
     return out
 
@@ -225,7 +240,9 @@ def conv2_dgrad(dy, w2, T1, F1):
 def conv2_wgrad(x, dy, dw2, accumulate=False):
     B, T1, F1, Cc = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
-    check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), B, T1, F1, Cc, _dt(x), int(accumulate), _stream()), "conv2_wgrad")
+    ws = _workspace(64 << 20, x.device)
+    check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), B, T1, F1, Cc, _dt(x), int(accumulate), ws.data_ptr(), ws.numel(),
+                              _stream()), "conv2_wgrad")
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise

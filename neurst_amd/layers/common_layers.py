@@ -36,7 +36,7 @@ def _wgrad_split(rows, k_in, n_out, dtype):
     tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
     bk = 64 if dtype == torch.bfloat16 else 32
     kt = (rows + bk - 1) // bk
-    return max(1, min(1024 // max(tiles, 1), kt // 8))
+    return max(1, min(512 // max(tiles, 1), kt // 8))
 
 
 class Layer(object):
