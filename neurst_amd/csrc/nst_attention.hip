@@ -106,6 +106,47 @@ __device__ __forceinline__ void stage_tile(char* lds, const T* __restrict__ base
   }
 }
 
+// register-staged variant: issue the global loads of a tile early (tile_load), write them to LDS later (tile_store),
+// so the HBM/L2 latency of tile t+1 hides under the MFMAs of tile t.
+template <typename T>
+struct TileRegs {
+  uint4 v[TR * AT<T>::CPR / 256];
+};
+template <typename T>
+__device__ __forceinline__ void tile_load(TileRegs<T>& regs, const T* __restrict__ base, int64_t ld, int row0, int nrows, int dh,
+                                          int vec, int tid) {
+  constexpr int N = TR * AT<T>::CPR / 256;
+#pragma unroll
+  for (int s = 0; s < N; ++s) {
+    const int c = tid + s * 256;
+    const int row = c / AT<T>::CPR, cc = c % AT<T>::CPR;
+    const int col = cc * AT<T>::E;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + row < nrows && col < dh) {
+      const T* p = base + (int64_t)(row0 + row) * ld + col;
+      if (vec) {
+        v = *reinterpret_cast<const uint4*>(p);
+      } else {
+        T tmp[AT<T>::E];
+#pragma unroll
+        for (int e = 0; e < AT<T>::E; ++e) tmp[e] = (col + e < dh) ? p[e] : (T)0;
+        memcpy(&v, tmp, 16);
+      }
+    }
+    regs.v[s] = v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(char* lds, const TileRegs<T>& regs, int tid) {
+  constexpr int N = TR * AT<T>::CPR / 256;
+#pragma unroll
+  for (int s = 0; s < N; ++s) {
+    const int c = tid + s * 256;
+    const int row = c / AT<T>::CPR, cc = c % AT<T>::CPR;
+    *reinterpret_cast<uint4*>(lds + row * AT<T>::RS + cc * 16) = regs.v[s];
+  }
+}
+
 __device__ __forceinline__ float group16_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
   v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
@@ -185,11 +226,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   if (p.causal) { const int lim = (q0 + TR - 1) / TR + 1; if (lim < nkt) nkt = lim; }
   const int64_t drop_row_base = ((int64_t)b * p.H + h) * p.Tq;
 
+  TileRegs<T> kreg, vreg;
+  tile_load<T>(kreg, kb, p.ldk, 0, p.Tk, p.dh, p.vk, tid);
+  tile_load<T>(vreg, vb, p.ldv, 0, p.Tk, p.dh, p.vv, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
-    stage_tile<T>(Ks, kb, p.ldk, k0, p.Tk, p.dh, p.vk, tid);
-    stage_tile<T>(Vs, vb, p.ldv, k0, p.Tk, p.dh, p.vv, tid);
+    tile_store<T>(Ks, kreg, tid);
+    tile_store<T>(Vs, vreg, tid);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_load<T>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, p.vk, tid);
+      tile_load<T>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, p.vv, tid);
+    }
     floatx4_t s[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) s[f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -335,11 +383,20 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
   const int qt_first = p.causal ? k0 / TR : 0;  // queries before the key tile never see it
   const int64_t stat_base = ((int64_t)b * p.H + h) * p.Tq;
 
+  TileRegs<T> qreg, greg;
+  if (qt_first < nqt) {
+    tile_load<T>(qreg, qb, p.ldq, qt_first * TR, p.Tq, p.dh, p.vq, tid);
+    tile_load<T>(greg, gb, p.ldo, qt_first * TR, p.Tq, p.dh, p.vo, tid);
+  }
   for (int qt = qt_first; qt < nqt; ++qt) {
     const int q0 = qt * TR;
-    stage_tile<T>(Qs, qb, p.ldq, q0, p.Tq, p.dh, p.vq, tid);
-    stage_tile<T>(Gs, gb, p.ldo, q0, p.Tq, p.dh, p.vo, tid);
+    tile_store<T>(Qs, qreg, tid);
+    tile_store<T>(Gs, greg, tid);
     __syncthreads();
+    if (qt + 1 < nqt) {
+      tile_load<T>(qreg, qb, p.ldq, q0 + TR, p.Tq, p.dh, p.vq, tid);
+      tile_load<T>(greg, gb, p.ldo, q0 + TR, p.Tq, p.dh, p.vo, tid);
+    }
     floatx4_t st[4], dp[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { st[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
@@ -459,11 +516,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
 
   int nkt = (p.Tk + TR - 1) / TR;
   if (p.causal) { const int lim = (q0 + TR - 1) / TR + 1; if (lim < nkt) nkt = lim; }
+  TileRegs<T> kreg, vreg;
+  tile_load<T>(kreg, kb, p.ldk, 0, p.Tk, p.dh, p.vk, tid);
+  tile_load<T>(vreg, vb, p.ldv, 0, p.Tk, p.dh, p.vv, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
-    stage_tile<T>(Ks, kb, p.ldk, k0, p.Tk, p.dh, p.vk, tid);
-    stage_tile<T>(Vs, vb, p.ldv, k0, p.Tk, p.dh, p.vv, tid);
+    tile_store<T>(Ks, kreg, tid);
+    tile_store<T>(Vs, vreg, tid);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_load<T>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, p.vk, tid);
+      tile_load<T>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, p.vv, tid);
+    }
     floatx4_t s[4], dp[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { s[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }

@@ -111,7 +111,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10 counter RNG for dropout.  One call yields 4 x u32 for the
+// Philox4x32-7 counter RNG for dropout (7 rounds pass BigCrush; the 10-round default only adds safety margin).  One call yields 4 x u32 for the
 // element group (idx/4); element idx uses word idx%4.  The same
 // (seed, stream, idx) triple regenerates the same mask in backward.
 // ---------------------------------------------------------------------------
@@ -122,7 +122,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t stream,
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < 7; ++r) {
     uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -147,12 +147,3 @@ static inline uint32_t nst_dropout_threshold(float p) {
   return (uint32_t)t;
 }
 
-// sinusoid timing signal value for (position, channel) -- neurst/layers/common_layers.py:356-413
-__device__ __forceinline__ float sinusoid_value(int pos, int ch, int channels) {
-  int nts = channels >> 1;
-  if (ch >= 2 * nts) return 0.0f;  // odd channel count: zero pad
-  int i = ch < nts ? ch : ch - nts;
-  float inc = 9.210340371976184f / (float)(nts - 1);  // ln(1e4)/(nts-1)
-  float st = (float)pos * expf(-(float)i * inc);
-  return ch < nts ? sinf(st) : cosf(st);
-}

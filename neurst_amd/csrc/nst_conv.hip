@@ -448,6 +448,12 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
   }
 }
 
+int conv_nst() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_NST"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
 bool conv_use_v2() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_GEMM_V1"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -466,7 +472,7 @@ void conv_allow_big_lds(KernelT kernel, int bytes) {
 
 #define NST_CONV_LAUNCH_V2(T_, OutT_, AM, BMO, AL, BL, RM, grid, ktps, ...)                                   \
   do {                                                                                                        \
-    if ((ktps) >= 3) {                                                                                        \
+    if (conv_nst() >= 3 && (ktps) >= 3) {                                                                     \
       auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 3, AL, BL, RM>;                                      \
       conv_allow_big_lds(kfn, 3 * V2_STAGE_BYTES);                                                            \
       kfn<<<grid, THREADS, 3 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                            \

@@ -124,7 +124,10 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_OC, MODE_RC, NS); \
     else NST_GEMM_LAUNCH2(MODE_OC, MODE_OC, NS);                                           \
   } while (0)
-    if (kt_per_split >= 3) NST_GEMM_MODES(3); else NST_GEMM_MODES(2);
+    static int force_nst = -1;
+    if (force_nst < 0) { const char* e = getenv("NST_GEMM_NST"); force_nst = e ? atoi(e) : 0; }
+    const int nst = force_nst ? force_nst : 2;  // 2 stages = 64 KB: two workgroups per CU beat a deeper ring (profiles/)
+    if (nst >= 3 && kt_per_split >= 3) NST_GEMM_MODES(3); else NST_GEMM_MODES(2);
 #undef NST_GEMM_MODES
 #undef NST_GEMM_LAUNCH2
     return 0;

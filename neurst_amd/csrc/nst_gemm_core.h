@@ -509,12 +509,70 @@ __device__ __forceinline__ void dma_tile(const Loader& ld, int o0, int r0, uint3
   }
 }
 
+// Per-thread DMA cursor of one operand tile: the 4 chunk pointers are computed once per tile; every K step only adds a
+// constant byte stride (dense loaders: the generic path above re-derives 64-bit addresses 8 times per step, which on a
+// one-wave-per-SIMD kernel is serialised VALU work next to the MFMAs).
+template <typename T, int MODE>
+struct DenseDma {
+  const char* p[4];
+  int kvalid_base[4];   // reduction index of the chunk at K step 0 (RC: element k; OC: row r)
+  bool ovalid[4];       // the chunk's fixed (non-reduction) coordinate is inside the matrix
+  int64_t step_bytes;
+  int k_limit;
+  __device__ __forceinline__ void init(const DenseLoader<T>& ld, int o0, int r0, int wave, int lane) {
+    constexpr int E = Tile<T>::E;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = (s * 4 + wave) * 64 + lane;
+      if (MODE == MODE_RC) {
+        const int row = c >> 3, slot = c & 7;
+        const int kchunk = slot ^ ((row >> 1) & 7);
+        ovalid[s] = (o0 + row) < ld.outer_limit;
+        kvalid_base[s] = r0 + kchunk * E;
+        p[s] = reinterpret_cast<const char*>(ld.base + (int64_t)(o0 + row) * ld.ld + kvalid_base[s]);
+      } else {
+        constexpr int CPR = Tile<T>::OC_CPR;
+        const int r = c / CPR, c16 = c % CPR;
+        const int g = (r & 3) | (((r >> 3) & 1) << 2);
+        const int col = o0 + (c16 ^ (g << 1)) * E;
+        ovalid[s] = col < ld.contig_limit;
+        kvalid_base[s] = r0 + r;
+        p[s] = reinterpret_cast<const char*>(ld.base + (int64_t)kvalid_base[s] * ld.ld + col);
+      }
+    }
+    step_bytes = MODE == MODE_RC ? (int64_t)Tile<T>::BK * (int64_t)sizeof(T) : (int64_t)Tile<T>::BK * ld.ld * (int64_t)sizeof(T);
+    k_limit = MODE == MODE_RC ? ld.contig_limit : ld.outer_limit;
+  }
+  // issue the DMA of K step `t` (relative to the r0 given to init) into the stage at tile_lds_addr
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = ovalid[s] && (kvalid_base[s] + t * Tile<T>::BK) < k_limit;
+      const void* src = ok ? (const void*)(p[s] + (int64_t)t * step_bytes) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+    }
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
+
+// TileDma: DenseDma for dense loaders, the generic per-step address derivation for the conv gather loaders
+template <typename T, int MODE, typename Loader>
+struct TileDma {
+  const Loader* ld;
+  int o0, r0, lane;
+  __device__ __forceinline__ void init(const Loader& l, int o0_, int r0_, int wave, int lane_) { ld = &l; o0 = o0_; r0 = r0_; lane = lane_; }
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
+    dma_tile<T, MODE, Loader>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
+  }
+};
+template <typename T, int MODE>
+struct TileDma<T, MODE, DenseLoader<T>> : DenseDma<T, MODE> {};
 
 constexpr int V2_STAGE_BYTES = 2 * BM * KBYTES;  // A tile + B tile, 32 KB
 
@@ -538,12 +596,16 @@ __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
+  TileDma<T, AMODE, ALoader> da;
+  TileDma<T, BMODE, BLoader> db;
+  da.init(la, m0, kt_first * BK, wave, lane);
+  db.init(lb, n0, kt_first * BK, wave, lane);
   // prologue: NST-1 tiles in flight
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
     if (s < kt_count) {
-      dma_tile<T, AMODE>(la, m0, (kt_first + s) * BK, smem_addr + s * V2_STAGE_BYTES, wave, lane);
-      dma_tile<T, BMODE>(lb, n0, (kt_first + s) * BK, smem_addr + s * V2_STAGE_BYTES + BM * KBYTES, wave, lane);
+      da.issue(s, smem_addr + s * V2_STAGE_BYTES, wave);
+      db.issue(s, smem_addr + s * V2_STAGE_BYTES + BM * KBYTES, wave);
     }
   }
   int stage = 0;
@@ -559,8 +621,8 @@ __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& 
     if (nxt < kt_count) {
       int st2 = stage + NST - 1;
       if (st2 >= NST) st2 -= NST;
-      dma_tile<T, AMODE>(la, m0, (kt_first + nxt) * BK, smem_addr + st2 * V2_STAGE_BYTES, wave, lane);
-      dma_tile<T, BMODE>(lb, n0, (kt_first + nxt) * BK, smem_addr + st2 * V2_STAGE_BYTES + BM * KBYTES, wave, lane);
+      da.issue(nxt, smem_addr + st2 * V2_STAGE_BYTES, wave);
+      db.issue(nxt, smem_addr + st2 * V2_STAGE_BYTES + BM * KBYTES, wave);
     }
     const char* As = smem + stage * V2_STAGE_BYTES;
     const char* Bs = As + BM * KBYTES;
