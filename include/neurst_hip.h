@@ -56,10 +56,13 @@ int nst_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
                       int64_t rows, int d, float eps, int dtype, void* stream);
 /* dgamma/dbeta [d] f32 are ACCUMULATED into (+=) when accumulate!=0, else overwritten.
  * dres (nullable, [rows,d] dtype) is added to dx: the gradient arriving through the residual branch of
- * PrePostProcessingWrapper (inputs + y, common_layers.py:85), so no separate add pass is needed. */
+ * PrePostProcessingWrapper (inputs + y, common_layers.py:85), so no separate add pass is needed.
+ * workspace (nullable): with at least 512*2*d*4 bytes the per-workgroup partial sums of dgamma/dbeta are written to it
+ * and reduced by a second tiny kernel; without it they are accumulated with float atomics, whose fan-in on 2*d
+ * addresses costs more than the whole data pass. */
 int nst_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
-                      int accumulate, void* stream);
+                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ GEMM with fused epilogue
  * Replaces tf.einsum/tf.matmul/Dense on the path:
@@ -108,8 +111,10 @@ typedef struct {
 
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
 
-/* Column sums: out[N] (f32) (+)= sum_rows x[rows,N] -- bias gradients. */
-int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate, void* stream);
+/* Column sums: out[N] (f32) (+)= sum_rows x[rows,N] -- bias gradients.  workspace (nullable, >= 256*N*4 bytes):
+ * two-stage reduction without atomics, as for nst_layernorm_bwd. */
+int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate, void* workspace,
+               int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ fused scaled-dot-product attention
  * MultiHeadAttention.call / att_fn  neurst/layers/attentions/multi_head_attention.py:124-164, 203-215:
@@ -170,7 +175,7 @@ int nst_layernorm_relu_fwd(const void* x, const float* gamma, const float* beta,
                            int64_t rows, int d, float eps, int dtype, void* stream);
 int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
-                           int accumulate, void* stream);
+                           int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ target embedding
  * WordEmbeddingSharedWeights._bottom + PositionEmbeddingWrapper.call

@@ -56,11 +56,11 @@ SIGNATURES = {
     "nst_abi_version": [],
     "nst_last_error_string": [],
     "nst_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
-    "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
-    "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
-    "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P],
+    "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],
     "nst_attention_fwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "nst_attention_bwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_conv1_ln_relu_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],

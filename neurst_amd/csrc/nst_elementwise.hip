@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) ls_xent_bwd_kernel(const T* __restrict__ 
 // 256 threads cover (256*CPT/ncols_tile) rows per iteration; rows are strided over gridDim.y strips.
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows, int n,
-                                                    int64_t ldx, int64_t rows_per_block, int vec) {
+                                                    int64_t ldx, int64_t rows_per_block, int vec, float* __restrict__ partial) {
   constexpr int CPT = 16 / (int)sizeof(T);  // columns per thread
   constexpr int TPR = 32;                   // threads per row -> a block tile is 8 rows x (32*CPT) columns
   __shared__ float sh[8][TPR * CPT + 1];
@@ -208,9 +208,19 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, fl
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += sh[q][c];
-      atomicAdd(out + col, t);
+      if (partial) partial[(int64_t)blockIdx.y * n + col] = t;
+      else atomicAdd(out + col, t);
     }
   }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int strips, int n,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float t = 0.f;
+  for (int s = 0; s < strips; ++s) t += partial[(int64_t)s * n + c];
+  out[c] = accumulate ? out[c] + t : t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,11 +385,13 @@ extern "C" int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const 
 }
 
 extern "C" int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate,
-                          void* stream) {
+                          void* workspace, int64_t workspace_bytes, void* stream) {
   NST_CHECK_ARG(x && out, "colsum: null pointer");
   NST_CHECK_ARG(n > 0 && ldx >= n, "colsum: bad n=%d ldx=%lld", n, (long long)ldx);
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) NST_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, st));
+  float* partial = (workspace && workspace_bytes >= (int64_t)256 * n * 4 && ((((uintptr_t)workspace) & 3) == 0))
+                       ? (float*)workspace : nullptr;
+  if (!accumulate && (!partial || rows <= 0)) NST_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, st));
   if (rows <= 0) return NST_OK;
   const int esz = dtype == NST_BF16 ? 2 : 4;
   const int cpt = 16 / esz, tile_cols = 32 * cpt;
@@ -388,10 +400,14 @@ extern "C" int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_
   const int64_t rpb = (rows + strips - 1) / strips;
   dim3 grid((n + tile_cols - 1) / tile_cols, (unsigned)((rows + rpb - 1) / rpb));
   const int vec = nst_aligned16(x) && ((ldx * esz) % 16 == 0) && (n % cpt == 0);
-  if (dtype == NST_F32) colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)x, out, rows, n, ldx, rpb, vec);
-  else if (dtype == NST_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, out, rows, n, ldx, rpb, vec);
+  if (dtype == NST_F32) colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)x, out, rows, n, ldx, rpb, vec, partial);
+  else if (dtype == NST_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, out, rows, n, ldx, rpb, vec, partial);
   else { nst_set_error("colsum: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("colsum");
+  if (partial) {
+    colsum_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>(partial, out, (int)grid.y, n, accumulate);
+    NST_CHECK_LAUNCH("colsum(finalize)");
+  }
   return NST_OK;
 }
 

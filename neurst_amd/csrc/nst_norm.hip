@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
                                                               const T* __restrict__ yout, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int64_t rows, int d) {
+                                                              float* __restrict__ dbeta, int64_t rows, int d,
+                                                              float* __restrict__ partial) {
   __shared__ float red[LN_WAVES][256];  // reused twice (dgamma then dbeta) in 4 slices
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_d = 1.0f / (float)d;
@@ -197,12 +198,24 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
           const int e = elem_index<VEC>(lane, base + j);
           if (e < d) {
             float t = red[0][lane * 4 + j] + red[1][lane * 4 + j] + red[2][lane * 4 + j] + red[3][lane * 4 + j];
-            atomicAdd((pass == 0 ? dgamma : dbeta) + e, t);
+            if (partial) partial[((int64_t)blockIdx.x * 2 + pass) * d + e] = t;   // plain store, reduced by ln_bwd_finalize
+            else atomicAdd((pass == 0 ? dgamma : dbeta) + e, t);
           }
         }
       }
     }
   }
+}
+
+// dgamma/dbeta (+)= sum over workgroups of partial[block][2][d]
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       int blocks, int d, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2*d-1
+  if (e >= 2 * d) return;
+  float t = 0.f;
+  for (int b = 0; b < blocks; ++b) t += partial[(int64_t)b * 2 * d + e];
+  float* o = e < d ? dgamma + e : dbeta + (e - d);
+  *o = accumulate ? *o + t : t;
 }
 
 template <typename T>
@@ -229,11 +242,14 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
 
 template <typename T, bool RELU>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
-               const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, hipStream_t st) {
-  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-  if (blocks > 512) blocks = 512;  // one atomic per column per block: keep the fan-in per address small
+               const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
+               hipStream_t st) {
+  int64_t blocks = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
+  const int64_t cap = partial ? 2048 : 512;  // atomics: one per column per block, keep the fan-in per address small
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-#define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d)
+  *nblocks = (int)blocks;
+#define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d, partial)
   if (vec_ok<T>(x, dy, dx, d) && vec_ok<T>(y, dres, nullptr, d)) {
     if (d <= 256) NST_LN_BWD(4, 4); else if (d <= 512) NST_LN_BWD(4, 8); else NST_LN_BWD(4, 16);
   } else {
@@ -263,25 +279,31 @@ int ln_fwd_common(const void* x, const float* gamma, const float* beta, void* y,
 
 int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
-                  int accumulate, void* stream, bool relu) {
+                  int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu) {
   NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
   NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
   NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "layernorm_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) {
+  float* partial = (ws && ws_bytes >= (int64_t)2048 * 2 * d * 4 && ((((uintptr_t)ws) & 3) == 0)) ? (float*)ws : nullptr;
+  if (!accumulate && (!partial || rows <= 0)) {
     NST_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * d, st));
     NST_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * d, st));
   }
   if (rows <= 0) return NST_OK;
+  int nblocks = 0;
   if (dtype == NST_F32) {
-    if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
-    else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+    if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
+    else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
   } else {
-    if (relu) launch_bwd<bf16_t, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
-    else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st);
+    if (relu) launch_bwd<bf16_t, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
+    else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
   }
   NST_CHECK_LAUNCH("layernorm_bwd");
+  if (partial) {
+    ln_bwd_finalize_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(partial, dgamma, dbeta, nblocks, d, accumulate);
+    NST_CHECK_LAUNCH("layernorm_bwd(finalize)");
+  }
   return NST_OK;
 }
 
@@ -297,11 +319,13 @@ extern "C" int nst_layernorm_relu_fwd(const void* x, const float* gamma, const f
 }
 extern "C" int nst_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
-                                 int accumulate, void* stream) {
-  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, stream, false);
+                                 int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, false);
 }
 extern "C" int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d,
-                                      int dtype, int accumulate, void* stream) {
-  return ln_bwd_common(dy, x, y, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, d, dtype, accumulate, stream, true);
+                                      int dtype, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return ln_bwd_common(dy, x, y, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, true);
 }

@@ -12,6 +12,18 @@ from neurst_amd._lib import NST_BF16, NST_F32, NstAttnDesc, NstGemmDesc, check, 
 
 FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
 
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Persistent scratch for two-stage reductions (split-K slabs, LayerNorm / bias-gradient partial sums); grown
+    on demand.  Every launch is ordered on one stream, so consecutive users never overlap."""
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
 
 def _dt(t):
     if t.dtype == torch.float32:
@@ -86,31 +98,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
+    ws = _workspace(64 << 20, x.device)
     if y is not None:
         assert dres is None
         check(lib.nst_layernorm_relu_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
-                                         _p(dbeta), rows, d, _dt(x), int(accumulate), _stream()), "layernorm_relu_bwd")
+                                         _p(dbeta), rows, d, _dt(x), int(accumulate), ws.data_ptr(), ws.numel(),
+                                         _stream()), "layernorm_relu_bwd")
     else:
         if dres is not None:
             assert dres.is_contiguous() and dres.dtype == x.dtype
         check(lib.nst_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma),
-                                    _p(dbeta), rows, d, _dt(x), int(accumulate), _stream()), "layernorm_bwd")
+                                    _p(dbeta), rows, d, _dt(x), int(accumulate), ws.data_ptr(), ws.numel(), _stream()),
+              "layernorm_bwd")
     return dx
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-_WS = {}
-
-
-def _workspace(nbytes, device):
-    """Persistent split-K slab workspace (grown on demand; all launches are ordered on one stream)."""
-    ws = _WS.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = ws
-    return ws
-
-
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
          posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1):
@@ -152,8 +155,9 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
 
 def colsum(x, out, accumulate=False):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
-    check(lib.nst_colsum(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), _dt(x), int(accumulate), _stream()),
-          "colsum")
+    ws = _workspace(64 << 20, x.device)
+    check(lib.nst_colsum(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), _dt(x), int(accumulate), ws.data_ptr(),
+                         ws.numel(), _stream()), "colsum")
     return out
 
 
