@@ -221,6 +221,15 @@ def main():
                 "avg_launch_ms": conv2_ms, "algorithmic_flops_per_launch": fl["conv2"]}
     if roofline["achieved"]:
         roofline["frac"] = roofline["achieved"] / peak
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv2_fwd.json")
+    if args.dtype == "bf16" and B == 128 and T == 900 and os.path.exists(pmc):
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
+        # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in KB); not re-measured by this run.
+        try:
+            roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_conv2_fwd.json"
+        except Exception:
+            pass
     out = {
         "metric": "audio frames/sec, SpeechTransformer-base (speech_transformer_s) training, whole job",
         "value": value, "unit": "frames/s", "value_per_gpu": value / world, "n_gpus": world, "steps": args.steps,

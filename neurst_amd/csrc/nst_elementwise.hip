@@ -214,13 +214,22 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, fl
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int strips, int n,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int strips, int n, int accumulate) {
+  __shared__ float sh[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
   float t = 0.f;
-  for (int s = 0; s < strips; ++s) t += partial[(int64_t)s * n + c];
-  out[c] = accumulate ? out[c] + t : t;
+  if (col < n)
+    for (int s = rg; s < strips; s += 16) t += partial[(int64_t)s * n + col];
+  sh[rg][c] = t;
+  __syncthreads();
+  if (rg == 0 && col < n) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += sh[q][c];
+    out[col] = accumulate ? out[col] + acc : acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,7 +414,7 @@ extern "C" int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_
   else { nst_set_error("colsum: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("colsum");
   if (partial) {
-    colsum_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>(partial, out, (int)grid.y, n, accumulate);
+    colsum_finalize_kernel<<<(n + 15) / 16, 256, 0, st>>>(partial, out, (int)grid.y, n, accumulate);
     NST_CHECK_LAUNCH("colsum(finalize)");
   }
   return NST_OK;

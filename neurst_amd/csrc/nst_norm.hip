@@ -207,15 +207,25 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
   }
 }
 
-// dgamma/dbeta (+)= sum over workgroups of partial[block][2][d]
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       int blocks, int d, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2*d-1
-  if (e >= 2 * d) return;
+// dgamma/dbeta (+)= sum over workgroups of partial[block][2][d].  16 columns x 16 row groups per workgroup: every
+// thread adds rows rg, rg+16, ... (independent loads), then the 16 row groups are combined through LDS.
+__global__ void __launch_bounds__(256) ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int blocks, int d, int accumulate) {
+  __shared__ float sh[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;  // 0 .. 2*d-1
   float t = 0.f;
-  for (int b = 0; b < blocks; ++b) t += partial[(int64_t)b * 2 * d + e];
-  float* o = e < d ? dgamma + e : dbeta + (e - d);
-  *o = accumulate ? *o + t : t;
+  if (e < 2 * d)
+    for (int b = rg; b < blocks; b += 16) t += partial[(int64_t)b * 2 * d + e];
+  sh[rg][c] = t;
+  __syncthreads();
+  if (rg == 0 && e < 2 * d) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += sh[q][c];
+    float* o = e < d ? dgamma + e : dbeta + (e - d);
+    *o = accumulate ? *o + acc : acc;
+  }
 }
 
 template <typename T>
@@ -245,7 +255,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
                hipStream_t st) {
   int64_t blocks = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
-  const int64_t cap = partial ? 2048 : 512;  // atomics: one per column per block, keep the fan-in per address small
+  const int64_t cap = partial ? 1024 : 512;  // atomics: one per column per block, keep the fan-in per address small
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   *nblocks = (int)blocks;
@@ -301,7 +311,7 @@ int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gam
   }
   NST_CHECK_LAUNCH("layernorm_bwd");
   if (partial) {
-    ln_bwd_finalize_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(partial, dgamma, dbeta, nblocks, d, accumulate);
+    ln_bwd_finalize_kernel<<<(2 * d + 15) / 16, 256, 0, st>>>(partial, dgamma, dbeta, nblocks, d, accumulate);
     NST_CHECK_LAUNCH("layernorm_bwd(finalize)");
   }
   return NST_OK;

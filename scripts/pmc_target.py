@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Runs a few launches of one hot kernel at the benchmark shape, for rocprofv3 --pmc passes
+(HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes; MFMA busy).   usage: pmc_target.py conv2_fwd|ffn2_fwd|ffn1_fwd"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neurst_amd import kernels as K  # noqa: E402
+
+DEV = "cuda:0"
+which = sys.argv[1] if len(sys.argv) > 1 else "conv2_fwd"
+dt = torch.bfloat16
+if which == "conv2_fwd":
+    B, C = 128, 256
+    x = (torch.randn(B, 450, 40, C, device=DEV) * 0.5).to(dt)
+    w2 = (torch.randn(3, 3, C, C, device=DEV) * 0.02).to(dt)
+    b2 = torch.zeros(C, device=DEV)
+    fn = lambda: K.conv2_fwd(x, w2, b2)  # noqa: E731
+else:
+    M, d, ffn = 28800, 256, 2048
+    if which == "ffn2_fwd":
+        a, w = (torch.randn(M, ffn, device=DEV) * 0.5).to(dt), (torch.randn(ffn, d, device=DEV) * 0.05).to(dt)
+        fn = lambda: K.gemm(a, w, M, d, ffn)  # noqa: E731
+    else:
+        a, w = (torch.randn(M, d, device=DEV) * 0.5).to(dt), (torch.randn(d, ffn, device=DEV) * 0.05).to(dt)
+        fn = lambda: K.gemm(a, w, M, ffn, d)  # noqa: E731
+for _ in range(4):
+    fn()
+torch.cuda.synchronize()
