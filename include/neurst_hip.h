@@ -133,7 +133,14 @@ typedef struct {
   float float_min;   /* -1e9 (compat.FLOAT_MIN) */
   float dropout_p;
   uint64_t seed, stream_id;
+  /* dropout_p > 0: device buffer of nst_attention_dropout_mask_bytes(desc) bytes, 8-byte aligned.  The forward
+   * call writes one keep bit per probability into it, the backward call of the same step reads it (no RNG in bwd). */
+  void* dropout_mask;
+  int64_t dropout_mask_bytes;
 } NstAttnDesc;
+
+/* B*H*ceil(Tq/16)*ceil(Tk/64)*128 bytes */
+int64_t nst_attention_dropout_mask_bytes(const NstAttnDesc* d);
 
 int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
                       void* out, float* lse, void* stream);

@@ -46,6 +46,7 @@ class NstAttnDesc(C.Structure):
         ("float_min", C.c_float),
         ("dropout_p", C.c_float),
         ("seed", C.c_uint64), ("stream_id", C.c_uint64),
+        ("dropout_mask", C.c_void_p), ("dropout_mask_bytes", C.c_int64),
     ]
 
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],
+    "nst_attention_dropout_mask_bytes": [C.POINTER(NstAttnDesc)],
     "nst_attention_fwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "nst_attention_bwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_conv1_ln_relu_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
@@ -90,7 +92,8 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "nst_last_error_string" else C.c_int
+        fn.restype = (C.c_char_p if name == "nst_last_error_string"
+                      else C.c_int64 if name == "nst_attention_dropout_mask_bytes" else C.c_int)
     ver = lib.nst_abi_version()
     if ver != NST_ABI_VERSION:
         raise ImportError(f"libneurst_hip.so ABI version {ver} != expected {NST_ABI_VERSION}")

@@ -1,15 +1,30 @@
 // Fused scaled-dot-product attention, forward and backward (flash style: the [B,H,Tq,Tk] probability
-// matrix is never written to HBM; only the per-row log-sum-exp is saved).
+// matrix is never written to HBM; only the per-row log-sum-exp and, under dropout, one mask BIT per probability
+// are saved).
 //   replaces q*=dh^-0.5 ; einsum(BTNH,BFNH->BNFT) ; +bias ; softmax ; dropout ; einsum(BNFT,BTNH->BFNH)
 //   of neurst/layers/attentions/multi_head_attention.py:124-164, 203-215 and their TF gradients.
 //
-// One workgroup (4 waves) per (64-row tile, head, batch); each wave owns 16 rows.  K/V (or Q/dO) tiles of
-// 64 rows x 64 head-dim are staged in LDS, row-major with a 16-byte pad; a tile serves both as a
-// reduction-contiguous MFMA operand (ds_read_b128) and as a reduction-major one (ds_read_b64_tr_b16).
-// Softmax statistics live in registers: a 16x16 MFMA C fragment keeps row (lane>>4)*4+reg, column lane&15,
-// so row reductions are shuffles inside 16-lane groups.  P is handed from C layout to A layout through a
-// wave-private LDS tile.  Additive masks follow the reference exactly (bias added in fp32, FLOAT_MIN not -inf),
-// keys beyond Tk are excluded.  Dropout mask = Philox(seed, stream_id, ((b*H+h)*Tq+q)*Tk+k), regenerated in bwd.
+// Register-resident design.  A 16x16 MFMA accumulator keeps, in lane l, column l&15 and rows (l>>4)*4+0..3 of its
+// block -- which is exactly the B-operand layout (column l&15, 4..8 consecutive reduction indices) of the NEXT
+// product as long as the reduction runs over the accumulator's ROW index.  So every kernel computes its score block
+// with the reduction index of the following product on the rows:
+//     forward / dQ :  S^T[key][q] = K.Q^T   -> P^T / dS^T feed  O^T[d][q]  = V^T.P^T   and dQ^T[d][q] = K^T.dS^T
+//     dK,dV        :  S[q][key]   = Q.K^T   -> P / dS feed      dV^T[d][key] = dO^T.P  and dK^T[d][key] = Q^T.dS
+// The probabilities never pass through LDS, the softmax statistics of a query are one scalar per lane (the lane's
+// column), and the transposed A operands (V^T, K^T, dO^T, Q^T) come from the row-major LDS tiles through the LDS
+// transpose read (ds_read_b64_tr_b16).  The 8 reduction slots of a bf16 MFMA step are fed with rows
+// {g*4+0..3, 16+g*4+0..3} of a 32-row step (g = l>>4) on BOTH operands, which is only a permutation of the sum.
+// Each wave owns MI blocks of 16 queries (keys in dK/dV), so one K/V (Q/dO) fragment read serves MI MFMAs.
+//
+// Additive masks follow the reference (bias added in fp32; padding bias stays finite so a fully padded row degrades
+// to the same uniform distribution; causal positions and keys beyond Tk get probability exactly 0, as FLOAT_MIN does
+// in fp32).  exp() is evaluated as exp2 with log2(e) folded into the logit scale.
+//
+// Dropout: the forward kernel draws 16-bit Philox fields (two calls per lane, tile and query block), applies the
+// mask and stores the 16 keep bits of each lane as one u16:
+//     mask[((bh*ceil(Tq/16) + qblk)*ceil(Tk/64) + ktile)*64 + lane]  bit (f*4+r)  <->  query qblk*16 + (lane&15),
+//                                                                      key ktile*64 + f*16 + (lane>>4)*4 + r
+// The backward kernels read the bits back instead of regenerating random numbers.
 #include "nst_gemm_core.h"
 
 #include <stdlib.h>
@@ -19,7 +34,9 @@ using nstgemm::Mma;
 namespace {
 
 constexpr int DH = 64;   // padded head dim (dh <= 64)
-constexpr int TR = 64;   // tile rows (queries or keys)
+constexpr int TR = 64;   // rows of one staged tile (queries or keys)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
 
 template <typename T>
 struct AT {
@@ -27,8 +44,9 @@ struct AT {
   static constexpr int E = 16 / (int)sizeof(T);
   static constexpr int CPR = DH * (int)sizeof(T) / 16;  // 16-byte chunks per row
   static constexpr int KS = Mma<T>::KS;
-  static constexpr int NK = DH / KS;                    // MFMA steps over a 64-long reduction
+  static constexpr int NK = DH / KS;                    // MFMA steps over the head dim
   static constexpr int TILE_BYTES = TR * RS;
+  static constexpr int NCH = TR * CPR / 256;            // chunks per thread per tile
 };
 
 template <typename T>
@@ -38,279 +56,309 @@ struct FragT<bf16_t> { typedef bf16x8_t type; };
 template <>
 struct FragT<float> { typedef float type; };
 
-// reduction-contiguous fragment: rows row0+(l&15), reduction kk + ...
+// head-dim-contiguous fragment (A or B operand of the score products): row row0+(l&15), head dims kk + ...
 template <typename T>
-__device__ __forceinline__ typename FragT<T>::type rc_frag(const char* tile, int row0, int kk, int lane);
-template <>
-__device__ __forceinline__ bf16x8_t rc_frag<bf16_t>(const char* tile, int row0, int kk, int lane) {
-  return *reinterpret_cast<const bf16x8_t*>(tile + (row0 + (lane & 15)) * AT<bf16_t>::RS + (kk + (lane >> 4) * 8) * 2);
-}
-template <>
-__device__ __forceinline__ float rc_frag<float>(const char* tile, int row0, int kk, int lane) {
-  return *reinterpret_cast<const float*>(tile + (row0 + (lane & 15)) * AT<float>::RS + (kk + (lane >> 4)) * 4);
-}
-// reduction-major fragment: tile is [reduction rows][output cols]; output col col0+(l&15)
-template <typename T, bool USE_TR>
-__device__ __forceinline__ typename FragT<T>::type oc_frag(const char* tile, int col0, int kk, int lane);
-template <>
-__device__ __forceinline__ bf16x8_t oc_frag<bf16_t, true>(const char* tile, int col0, int kk, int lane) {
-  const int ii = lane & 15;
-  const char* p = tile + (kk + (lane >> 4) * 8 + (ii >> 2)) * AT<bf16_t>::RS + (col0 + (ii & 3) * 4) * 2;
-  typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
-  short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
-  short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p + 4 * AT<bf16_t>::RS));
-  union { short s[8]; bf16x8_t f; } u;
-  u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
-  u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
-  return u.f;
-}
-template <>
-__device__ __forceinline__ bf16x8_t oc_frag<bf16_t, false>(const char* tile, int col0, int kk, int lane) {
-  const char* p = tile + (kk + (lane >> 4) * 8) * AT<bf16_t>::RS + (col0 + (lane & 15)) * 2;
-  union { short s[8]; bf16x8_t f; } u;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) u.s[j] = *reinterpret_cast<const short*>(p + j * AT<bf16_t>::RS);
-  return u.f;
-}
-template <>
-__device__ __forceinline__ float oc_frag<float, true>(const char* tile, int col0, int kk, int lane) {
-  return *reinterpret_cast<const float*>(tile + (kk + (lane >> 4)) * AT<float>::RS + (col0 + (lane & 15)) * 4);
-}
-template <>
-__device__ __forceinline__ float oc_frag<float, false>(const char* tile, int col0, int kk, int lane) {
-  return oc_frag<float, true>(tile, col0, kk, lane);
+__device__ __forceinline__ typename FragT<T>::type rc_frag(const char* tile, int row0, int kk, int lane) {
+  if constexpr (sizeof(T) == 2)
+    return *reinterpret_cast<const bf16x8_t*>(tile + (row0 + (lane & 15)) * AT<T>::RS + (kk + (lane >> 4) * 8) * 2);
+  else
+    return *reinterpret_cast<const float*>(tile + (row0 + (lane & 15)) * AT<T>::RS + (kk + (lane >> 4)) * 4);
 }
 
-// stage rows [row0, row0+64) x cols [0, DH) of a [nrows, dh] matrix (row stride ld elements) into LDS, zero filled
-template <typename T>
-__device__ __forceinline__ void stage_tile(char* lds, const T* __restrict__ base, int64_t ld, int row0, int nrows, int dh,
-                                           int vec, int tid) {
-  constexpr int CH = TR * AT<T>::CPR;
+// acc[mi][fd] (+)= sum over the 64 rows of `tile` of  tile[row][fd*16 + i] (A operand, output row i)
+//                                                   x  pt[mi][f][r]        (B operand: row f*16 + g*4 + r, column l&15)
+template <typename T, int MI>
+__device__ __forceinline__ void tmul_acc(floatx4_t (&acc)[MI][4], const floatx4_t (&pt)[MI][4], const char* tile, int lane) {
+  const int g = lane >> 4, lc = lane & 15;
+  if constexpr (sizeof(T) == 2) {
+    typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+    // transpose read: lane ii of a 16-lane group addresses row ii>>2, 8-byte chunk ii&3 and receives column ii
+    const char* base = tile + (g * 4 + (lc >> 2)) * AT<T>::RS + (lc & 3) * 8;
 #pragma unroll
-  for (int c = tid; c < CH; c += 256) {
-    const int row = c / AT<T>::CPR, cc = c % AT<T>::CPR;
-    const int col = cc * AT<T>::E;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + row < nrows && col < dh) {
-      const T* p = base + (int64_t)(row0 + row) * ld + col;
-      if (vec) {
-        v = *reinterpret_cast<const uint4*>(p);
-      } else {
-        T tmp[AT<T>::E];
+    for (int st = 0; st < 2; ++st) {
+      bf16x8_t b[MI];
 #pragma unroll
-        for (int e = 0; e < AT<T>::E; ++e) tmp[e] = (col + e < dh) ? p[e] : (T)0;
-        memcpy(&v, tmp, 16);
+      for (int mi = 0; mi < MI; ++mi) {
+        const floatx4_t lo = pt[mi][2 * st], hi = pt[mi][2 * st + 1];
+        union { uint32_t u[4]; bf16x8_t f; } u;
+        u.u[0] = pack_bf16x2(lo[0], lo[1]); u.u[1] = pack_bf16x2(lo[2], lo[3]);
+        u.u[2] = pack_bf16x2(hi[0], hi[1]); u.u[3] = pack_bf16x2(hi[2], hi[3]);
+        b[mi] = u.f;
+      }
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        const char* p = base + st * 32 * AT<T>::RS + fd * 32;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p + 16 * AT<T>::RS));
+        union { short4_t h[2]; bf16x8_t f; } a;
+        a.h[0] = lo; a.h[1] = hi;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][fd] = Mma<T>::run(a.f, b[mi], acc[mi][fd]);
       }
     }
-    *reinterpret_cast<uint4*>(lds + row * AT<T>::RS + cc * 16) = v;
+  } else {
+    const char* base = tile + (g * 4) * AT<T>::RS + lc * 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          const float a = *reinterpret_cast<const float*>(base + (f * 16 + r) * AT<T>::RS + fd * 64);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[mi][fd] = Mma<T>::run(a, pt[mi][f][r], acc[mi][fd]);
+        }
   }
 }
 
-// register-staged variant: issue the global loads of a tile early (tile_load), write them to LDS later (tile_store),
-// so the HBM/L2 latency of tile t+1 hides under the MFMAs of tile t.
+// ---------------------------------------------------------------------------------------------
+// staging: 64 rows x DH of a [nrows, dh] matrix (row stride ld elements) through registers into LDS, zero filled.
+// VEC: 16-byte loads are legal (aligned base, ld and dh multiples of a chunk); the loads are branch-free (a chunk
+// outside the matrix reads the first chunk of the matrix and is zeroed by a select).
+// ---------------------------------------------------------------------------------------------
 template <typename T>
 struct TileRegs {
-  uint4 v[TR * AT<T>::CPR / 256];
+  uint4 v[AT<T>::NCH];
 };
-template <typename T>
+template <typename T, bool VEC>
 __device__ __forceinline__ void tile_load(TileRegs<T>& regs, const T* __restrict__ base, int64_t ld, int row0, int nrows, int dh,
-                                          int vec, int tid) {
-  constexpr int N = TR * AT<T>::CPR / 256;
+                                          int tid) {
 #pragma unroll
-  for (int s = 0; s < N; ++s) {
+  for (int s = 0; s < AT<T>::NCH; ++s) {
     const int c = tid + s * 256;
-    const int row = c / AT<T>::CPR, cc = c % AT<T>::CPR;
-    const int col = cc * AT<T>::E;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + row < nrows && col < dh) {
-      const T* p = base + (int64_t)(row0 + row) * ld + col;
-      if (vec) {
-        v = *reinterpret_cast<const uint4*>(p);
-      } else {
+    const int row = row0 + c / AT<T>::CPR, col = (c % AT<T>::CPR) * AT<T>::E;
+    const bool ok = row < nrows && col < dh;
+    if (VEC) {
+      const T* p = ok ? base + (int64_t)row * ld + col : base;
+      const uint4 v = *reinterpret_cast<const uint4*>(p);
+      regs.v[s] = ok ? v : make_uint4(0, 0, 0, 0);
+    } else {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const T* p = base + (int64_t)row * ld + col;
         T tmp[AT<T>::E];
 #pragma unroll
         for (int e = 0; e < AT<T>::E; ++e) tmp[e] = (col + e < dh) ? p[e] : (T)0;
         memcpy(&v, tmp, 16);
       }
+      regs.v[s] = v;
     }
-    regs.v[s] = v;
   }
 }
 template <typename T>
 __device__ __forceinline__ void tile_store(char* lds, const TileRegs<T>& regs, int tid) {
-  constexpr int N = TR * AT<T>::CPR / 256;
 #pragma unroll
-  for (int s = 0; s < N; ++s) {
+  for (int s = 0; s < AT<T>::NCH; ++s) {
     const int c = tid + s * 256;
-    const int row = c / AT<T>::CPR, cc = c % AT<T>::CPR;
-    *reinterpret_cast<uint4*>(lds + row * AT<T>::RS + cc * 16) = regs.v[s];
+    *reinterpret_cast<uint4*>(lds + (c / AT<T>::CPR) * AT<T>::RS + (c % AT<T>::CPR) * 16) = regs.v[s];
   }
 }
 
-__device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
-  return v;
+// Reductions over the 4 lanes {lc, lc+16, lc+32, lc+48} that share a C-fragment column: two gfx950 lane-row swaps
+// (v_permlane16_swap / v_permlane32_swap, VALU only -- no LDS crossbar).
+//   permlane16_swap(a, b): swaps the odd 16-lane rows of a with the even rows of b;  permlane32_swap: upper half of
+//   a with lower half of b.  With a == b == x the two results hold x and its partner row in every lane.
+typedef __attribute__((ext_vector_type(2))) unsigned uint2_hw_t;
+__device__ __forceinline__ float xgroup_max(float v) {
+  uint2_hw_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
+__device__ __forceinline__ float xgroup_sum(float v) {
+  uint2_hw_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+
+// raw v_exp_f32 (no denormal range fix-up: arguments are <= 0 up to rounding, tiny results may flush to 0)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnParams {
   const void *q, *k, *v, *out, *dout;
   const float* key_bias;
   void *o, *dq, *dk, *dv;
   float *lse, *delta;
+  uint16_t* mask;  // dropout keep bits (see the header comment), NULL without dropout
   int B, H, Tq, Tk, dh;
+  int nqb, nkt;    // ceil(Tq/16), ceil(Tk/64)
   int64_t ldq, ldk, ldv, ldo;
-  float scale, float_min;
+  float scale, scale2;  // dh^-0.5 and dh^-0.5 * log2(e)
   int causal;
-  uint32_t drop_thresh;
+  uint32_t drop_thresh;  // 16-bit threshold, 0 = no dropout
   float drop_inv_keep;
   uint64_t seed, stream_id;
-  int vq, vk, vv, vo;  // 16-byte vector loads legal for q / k / v / (out,dout)
 };
 
-// Dropout mask of attention probabilities.  One Philox call serves the 4 keys {64*kt + 16*f + lc, f = 0..3} of one
-// query row -- exactly the 4 C-fragment columns a lane owns in the forward / dQ kernels -- so those kernels pay one
-// Philox per 4 probabilities.  counter = ((bh*Tq + q) * ceil(Tk/64) + kt) * 16 + lc ; word f.
-__device__ __forceinline__ Philox4 attn_drop4(const AttnParams& p, int64_t bh_row_base, int qg, int kt, int lc) {
-  const int nkt = (p.Tk + TR - 1) / TR;
-  const uint64_t ctr = (uint64_t)(((bh_row_base + qg) * nkt + kt) * 16 + lc);
-  return philox4x32_10(p.seed, p.stream_id, ctr);
-}
-__device__ __forceinline__ float drop_scale(const AttnParams& p, uint32_t word) {
-  return word >= p.drop_thresh ? p.drop_inv_keep : 0.f;
+// additive key term of the logits in the log2 domain; keys beyond Tk are excluded
+__device__ __forceinline__ float key_bias2(const AttnParams& p, int b, int kg) {
+  if (kg >= p.Tk) return -INFINITY;
+  const float v = p.key_bias ? p.key_bias[(int64_t)b * p.Tk + kg] * LOG2E : 0.f;
+  return fmaxf(v, -3.0e38f);
 }
 
-// biased logit of (query qg, key kg) from the raw dot product -- the reference's fp32 order of operations
-__device__ __forceinline__ float biased_logit(const AttnParams& p, float raw, float kbias, int qg, int kg) {
-  float v = raw * p.scale + kbias;
-  if (p.causal && kg > qg) v += p.float_min;
-  return v;
+// write 4 consecutive head dims d..d+3 of one row
+template <typename T, bool VEC>
+__device__ __forceinline__ void store_row4(T* row, int d, int dh, const floatx4_t& v, float mul) {
+  if (VEC) {
+    if (d < dh) {
+      if constexpr (sizeof(T) == 2)
+        *reinterpret_cast<uint2*>(row + d) = make_uint2(pack_bf16x2(v[0] * mul, v[1] * mul), pack_bf16x2(v[2] * mul, v[3] * mul));
+      else
+        *reinterpret_cast<float4*>(row + d) = make_float4(v[0] * mul, v[1] * mul, v[2] * mul, v[3] * mul);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (d + r < dh) row[d + r] = from_f32<T>(v[r] * mul);
+  }
 }
 
 // =============================================================================================
-// forward
+// forward.  One workgroup = 4 waves = 64*MI queries; wave w owns query blocks {mi*4 + w}.
 // =============================================================================================
-template <typename T, bool USE_TR>
+template <typename T, int MI, bool VEC>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   typedef typename FragT<T>::type Frag;
-  __shared__ __attribute__((aligned(16))) char smem[3 * AT<T>::TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES + TR * 4];
   char* Ks = smem;
   char* Vs = smem + AT<T>::TILE_BYTES;
+  float* kbs = reinterpret_cast<float*>(smem + 2 * AT<T>::TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* Ps = smem + 2 * AT<T>::TILE_BYTES + wave * 16 * AT<T>::RS;
-  const int q0 = blockIdx.x * TR, h = blockIdx.y, b = blockIdx.z;
+  const int g = lane >> 4, lc = lane & 15;
+  const int q0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
   const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
   const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
-  const int lq = lane >> 4, lc = lane & 15;
+  const int64_t bh = (int64_t)b * p.H + h;
 
-  stage_tile<T>(Ks, qb, p.ldq, q0, p.Tq, p.dh, p.vq, tid);
-  __syncthreads();
-  Frag qf[AT<T>::NK];
+  Frag qf[MI][AT<T>::NK];
+  {
+    TileRegs<T> qreg;
 #pragma unroll
-  for (int s = 0; s < AT<T>::NK; ++s) qf[s] = rc_frag<T>(Ks, wave * 16, s * AT<T>::KS, lane);
-  __syncthreads();
+    for (int mi = 0; mi < MI; ++mi) {
+      tile_load<T, VEC>(qreg, qb, p.ldq, q0 + mi * TR, p.Tq, p.dh, tid);
+      if (mi) __syncthreads();
+      tile_store<T>(Ks, qreg, tid);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < AT<T>::NK; ++s) qf[mi][s] = rc_frag<T>(Ks, wave * 16, s * AT<T>::KS, lane);
+    }
+    __syncthreads();
+  }
 
-  float m_run[4], l_run[4];
-  floatx4_t o[4];
+  float m_run[MI], l_run[MI];
+  floatx4_t o[MI][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+  for (int mi = 0; mi < MI; ++mi) {
+    m_run[mi] = -INFINITY;
+    l_run[mi] = 0.f;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) o[f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f) o[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
-  int nkt = (p.Tk + TR - 1) / TR;
-  if (p.causal) { const int lim = (q0 + TR - 1) / TR + 1; if (lim < nkt) nkt = lim; }
-  const int64_t drop_row_base = ((int64_t)b * p.H + h) * p.Tq;
+  int nkt = p.nkt;
+  if (p.causal) { const int lim = (q0 + TR * MI - 1) / TR + 1; if (lim < nkt) nkt = lim; }
 
   TileRegs<T> kreg, vreg;
-  tile_load<T>(kreg, kb, p.ldk, 0, p.Tk, p.dh, p.vk, tid);
-  tile_load<T>(vreg, vb, p.ldv, 0, p.Tk, p.dh, p.vv, tid);
+  float kbreg = 0.f;
+  tile_load<T, VEC>(kreg, kb, p.ldk, 0, p.Tk, p.dh, tid);
+  tile_load<T, VEC>(vreg, vb, p.ldv, 0, p.Tk, p.dh, tid);
+  if (tid < TR) kbreg = key_bias2(p, b, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
     tile_store<T>(Ks, kreg, tid);
     tile_store<T>(Vs, vreg, tid);
+    if (tid < TR) kbs[tid] = kbreg;
     __syncthreads();
     if (kt + 1 < nkt) {
-      tile_load<T>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, p.vk, tid);
-      tile_load<T>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, p.vv, tid);
+      tile_load<T, VEC>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, tid);
+      tile_load<T, VEC>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, tid);
+      if (tid < TR) kbreg = key_bias2(p, b, k0 + TR + tid);
     }
-    floatx4_t s[4];
+    floatx4_t kb4[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) s[f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f) kb4[f] = *reinterpret_cast<const floatx4_t*>(kbs + f * 16 + g * 4);
+
+    floatx4_t s[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) s[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < AT<T>::NK; ++st)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) s[f] = Mma<T>::run(qf[st], rc_frag<T>(Ks, f * 16, st * AT<T>::KS, lane), s[f]);
-
-    float rmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int kg = k0 + f * 16 + lc;
-      const bool kvalid = kg < p.Tk;
-      const float kbias = (kvalid && p.key_bias) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qg = q0 + wave * 16 + lq * 4 + r;
-        const float v = kvalid ? biased_logit(p, s[f][r], kbias, qg, kg) : -INFINITY;
-        s[f][r] = v;
-        rmax[r] = fmaxf(rmax[r], v);
-      }
-    }
-    float alpha[4], rsum[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mn = fmaxf(m_run[r], group16_max(rmax[r]));
-      alpha[r] = __expf(m_run[r] - mn);
-      m_run[r] = mn;
-      rsum[r] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qg = q0 + wave * 16 + lq * 4 + r;
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (p.drop_thresh) {
-        const Philox4 w4 = attn_drop4(p, drop_row_base, qg, kt, lc);
-        keep[0] = drop_scale(p, w4.x); keep[1] = drop_scale(p, w4.y); keep[2] = drop_scale(p, w4.z); keep[3] = drop_scale(p, w4.w);
-      }
-#pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const float pv = __expf(s[f][r] - m_run[r]);
-        rsum[r] += pv;
-        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(pv * keep[f]);
+        const Frag a = rc_frag<T>(Ks, f * 16, st * AT<T>::KS, lane);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) s[mi][f] = Mma<T>::run(a, qf[mi][st], s[mi][f]);
       }
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int qblk0 = q0 + mi * TR + wave * 16;  // first query of this block; the lane's query is +lc
+      const int qg = qblk0 + lc;
+      const bool diag = p.causal && (k0 + TR - 1 > qblk0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = fmaf(s[mi][f][r], p.scale2, kb4[f][r]);
+          if (diag && (k0 + f * 16 + g * 4 + r > qg)) x = -INFINITY;
+          s[mi][f][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      mx = xgroup_max(mx);
+      const float mn = fmaxf(m_run[mi], mx);
+      const float alpha = fast_exp2(m_run[mi] - mn);
+      m_run[mi] = mn;
+      float psum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = fast_exp2(s[mi][f][r] - mn);
+          psum += pv;
+          s[mi][f][r] = pv;
+        }
+      l_run[mi] = l_run[mi] * alpha + psum;
+      if (p.drop_thresh) {
+        // 16 fields of 16 bits for the lane's 16 probabilities: two Philox calls
+        const uint64_t ctr = ((uint64_t)((bh * p.Tq + qg) * p.nkt + kt) * 4 + g) * 2;
+        const Philox4 w0 = philox4x32_10(p.seed, p.stream_id, ctr), w1 = philox4x32_10(p.seed, p.stream_id, ctr + 1);
+        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t fld = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+          const bool keep = fld >= p.drop_thresh;
+          bits |= keep ? (1u << e) : 0u;
+          s[mi][e >> 2][e & 3] *= keep ? p.drop_inv_keep : 0.f;
+        }
+        if (qblk0 < p.Tq) p.mask[((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane] = (uint16_t)bits;
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[mi][f][r] *= alpha;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) l_run[r] = l_run[r] * alpha[r] + group16_sum(rsum[r]);
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[f][r] *= alpha[r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int st = 0; st < AT<T>::NK; ++st) {
-      const Frag a = rc_frag<T>(Ps, 0, st * AT<T>::KS, lane);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) o[f] = Mma<T>::run(a, oc_frag<T, USE_TR>(Vs, f * 16, st * AT<T>::KS, lane), o[f]);
-    }
+    tmul_acc<T, MI>(o, s, Vs, lane);
     __syncthreads();
   }
 
   T* ob = (T*)p.o + (int64_t)b * p.Tq * p.ldo + h * p.dh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qg = q0 + wave * 16 + lq * 4 + r;
-    const bool qok = qg < p.Tq;
-    const float inv = 1.f / l_run[r];
+  for (int mi = 0; mi < MI; ++mi) {
+    const int qg = q0 + mi * TR + wave * 16 + lc;
+    const float l = xgroup_sum(l_run[mi]);
+    if (qg < p.Tq) {
+      const float inv = 1.f / l;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int d = f * 16 + lc;
-      if (qok && d < p.dh) ob[(int64_t)qg * p.ldo + d] = from_f32<T>(o[f][r] * inv);
+      for (int fd = 0; fd < 4; ++fd) store_row4<T, VEC>(ob + (int64_t)qg * p.ldo, fd * 16 + g * 4, p.dh, o[mi][fd], inv);
+      if (g == 0) p.lse[bh * p.Tq + qg] = m_run[mi] * LN2 + logf(l);
     }
-    if (qok && lc == 0) p.lse[((int64_t)b * p.H + h) * p.Tq + qg] = m_run[r] + logf(l_run[r]);
   }
 }
 
@@ -333,269 +381,321 @@ __global__ void attn_delta_kernel(AttnParams p) {
     if (lane == 0) p.delta[i] = acc;
   }
 }
+// dh == 64 with 16-byte-legal rows: 16 lanes x 4 elements cover one head, 64/(16*H) (b,q) rows per wave pass
+template <typename T>
+__global__ void attn_delta_vec_kernel(AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpr = p.H * 16, rpw = 64 / lpr;  // lanes per (b,q) row, rows per wave
+  const int sub = lane / lpr, h = (lane % lpr) >> 4, d = (lane & 15) * 4;
+  const int64_t rows = (int64_t)p.B * p.Tq;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rpw; r0 < rows; r0 += (int64_t)gridDim.x * 4 * rpw) {
+    const int64_t row = r0 + sub;
+    float acc = 0.f;
+    if (row < rows) {
+      const T* o = (const T*)p.out + row * p.ldo + h * 64 + d;
+      const T* gp = (const T*)p.dout + row * p.ldo + h * 64 + d;
+      if constexpr (sizeof(T) == 2) {
+        const uint2 a = *reinterpret_cast<const uint2*>(o), c = *reinterpret_cast<const uint2*>(gp);
+        acc = __uint_as_float(a.x << 16) * __uint_as_float(c.x << 16) +
+              __uint_as_float(a.x & 0xffff0000u) * __uint_as_float(c.x & 0xffff0000u) +
+              __uint_as_float(a.y << 16) * __uint_as_float(c.y << 16) +
+              __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(c.y & 0xffff0000u);
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(o), c = *reinterpret_cast<const float4*>(gp);
+        acc = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+      }
+    }
+    acc = dpp_add(acc, 0); acc = dpp_add(acc, 1); acc = dpp_add(acc, 2); acc = dpp_add(acc, 3);
+    if (row < rows && (lane & 15) == 0) {
+      const int64_t b = row / p.Tq, qg = row - b * p.Tq;
+      p.delta[(b * p.H + h) * p.Tq + qg] = acc;
+    }
+  }
+}
+
+// keep-multipliers of the 16 probabilities (f*4+r) of one forward lane from its mask word
+__device__ __forceinline__ float keep_mul(uint32_t bits, int e, float inv_keep) {
+  return (bits >> e) & 1u ? inv_keep : 0.f;
+}
 
 // =============================================================================================
-// backward, step 1: dK, dV.  One workgroup per 64-key tile; loops over query tiles.
-//   S^T[key][q] = K.Q^T ; P^T = exp(S^T*scale + bias - lse[q]) ; dV += Pdrop^T.dO
-//   dP^T[key][q] = V.dO^T ; dS^T = P^T o (keep*dP^T - delta[q]) ; dK += scale * dS^T.Q
+// backward, step 1: dK, dV.  One workgroup = 64*MI keys (wave w owns key blocks {mi*4 + w}); loops over query tiles.
+//   S[q][key] = Q.K^T ; P = exp(S*scale + bias - lse[q]) ; dV^T += dO^T.Pdrop
+//   dP[q][key] = dO.V^T ; dS = P o (keep*dP - delta[q]) ; dK^T += scale * Q^T.dS
 // =============================================================================================
-template <typename T, bool USE_TR>
+template <typename T, int MI, bool VEC>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
   typedef typename FragT<T>::type Frag;
-  __shared__ __attribute__((aligned(16))) char smem[3 * AT<T>::TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES + 2 * TR * 4];
   char* Qs = smem;                       // [q][d]
   char* Gs = smem + AT<T>::TILE_BYTES;   // dO [q][d]
+  float* lss = reinterpret_cast<float*>(smem + 2 * AT<T>::TILE_BYTES);  // lse*log2e of the tile's queries
+  float* dls = lss + TR;                                                // delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* Ps = smem + 2 * AT<T>::TILE_BYTES + wave * 16 * AT<T>::RS;  // [16 keys][64 q], wave private
-  const int k0 = blockIdx.x * TR, h = blockIdx.y, b = blockIdx.z;
+  const int g = lane >> 4, lc = lane & 15;
+  const int k0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
   const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
   const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
   const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
-  const int lq = lane >> 4, lc = lane & 15;
+  const int64_t bh = (int64_t)b * p.H + h;
 
-  // K and V fragments of this wave's 16 keys stay in registers for the whole kernel
-  Frag kf[AT<T>::NK], vf[AT<T>::NK];
-  stage_tile<T>(Qs, kb, p.ldk, k0, p.Tk, p.dh, p.vk, tid);
-  stage_tile<T>(Gs, vb, p.ldv, k0, p.Tk, p.dh, p.vv, tid);
-  __syncthreads();
+  // K and V fragments (B operands: column = key) of this wave's key blocks stay in registers
+  Frag kf[MI][AT<T>::NK], vf[MI][AT<T>::NK];
+  float kb2[MI];
+  {
+    TileRegs<T> r0, r1;
 #pragma unroll
-  for (int s = 0; s < AT<T>::NK; ++s) {
-    kf[s] = rc_frag<T>(Qs, wave * 16, s * AT<T>::KS, lane);
-    vf[s] = rc_frag<T>(Gs, wave * 16, s * AT<T>::KS, lane);
+    for (int mi = 0; mi < MI; ++mi) {
+      tile_load<T, VEC>(r0, kb, p.ldk, k0 + mi * TR, p.Tk, p.dh, tid);
+      tile_load<T, VEC>(r1, vb, p.ldv, k0 + mi * TR, p.Tk, p.dh, tid);
+      if (mi) __syncthreads();
+      tile_store<T>(Qs, r0, tid);
+      tile_store<T>(Gs, r1, tid);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < AT<T>::NK; ++s) {
+        kf[mi][s] = rc_frag<T>(Qs, wave * 16, s * AT<T>::KS, lane);
+        vf[mi][s] = rc_frag<T>(Gs, wave * 16, s * AT<T>::KS, lane);
+      }
+      kb2[mi] = key_bias2(p, b, k0 + mi * TR + wave * 16 + lc);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  floatx4_t dk[4], dv[4];
+  floatx4_t dk[MI][4], dv[MI][4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) { dk[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { dk[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
 
-  // per-lane key data: this lane's rows of the C fragments are keys k0 + wave*16 + lq*4 + r
-  float kbias[4];
-  bool kvalid[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kg = k0 + wave * 16 + lq * 4 + r;
-    kvalid[r] = kg < p.Tk;
-    kbias[r] = (kvalid[r] && p.key_bias) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
-  }
   const int nqt = (p.Tq + TR - 1) / TR;
-  const int qt_first = p.causal ? k0 / TR : 0;  // queries before the key tile never see it
-  const int64_t stat_base = ((int64_t)b * p.H + h) * p.Tq;
+  const int qt_first = p.causal ? k0 / TR : 0;  // queries before the first key of the block never see it
+  // mask words this lane reads: forward lanes (g*4 + r) + 16*(lc>>2), r = 0..3 -> 4 consecutive u16; bit = f_key*4 + (lc&3)
+  const int mlane = g * 4 + 16 * (lc >> 2);
+  const int mbit = wave * 4 + (lc & 3);
 
   TileRegs<T> qreg, greg;
+  float lsreg = 0.f, dlreg = 0.f;
+  auto stat_load = [&](int q) {
+    const bool ok = q < p.Tq;
+    lsreg = ok ? p.lse[bh * p.Tq + q] * LOG2E : INFINITY;
+    dlreg = ok ? p.delta[bh * p.Tq + q] : 0.f;
+  };
   if (qt_first < nqt) {
-    tile_load<T>(qreg, qb, p.ldq, qt_first * TR, p.Tq, p.dh, p.vq, tid);
-    tile_load<T>(greg, gb, p.ldo, qt_first * TR, p.Tq, p.dh, p.vo, tid);
+    tile_load<T, VEC>(qreg, qb, p.ldq, qt_first * TR, p.Tq, p.dh, tid);
+    tile_load<T, VEC>(greg, gb, p.ldo, qt_first * TR, p.Tq, p.dh, tid);
+    if (tid < TR) stat_load(qt_first * TR + tid);
   }
   for (int qt = qt_first; qt < nqt; ++qt) {
     const int q0 = qt * TR;
     tile_store<T>(Qs, qreg, tid);
     tile_store<T>(Gs, greg, tid);
+    if (tid < TR) { lss[tid] = lsreg; dls[tid] = dlreg; }
     __syncthreads();
     if (qt + 1 < nqt) {
-      tile_load<T>(qreg, qb, p.ldq, q0 + TR, p.Tq, p.dh, p.vq, tid);
-      tile_load<T>(greg, gb, p.ldo, q0 + TR, p.Tq, p.dh, p.vo, tid);
+      tile_load<T, VEC>(qreg, qb, p.ldq, q0 + TR, p.Tq, p.dh, tid);
+      tile_load<T, VEC>(greg, gb, p.ldo, q0 + TR, p.Tq, p.dh, tid);
+      if (tid < TR) stat_load(q0 + TR + tid);
     }
-    floatx4_t st[4], dp[4];
+    floatx4_t ls4[4], dl4[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { st[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int f = 0; f < 4; ++f) {
+      ls4[f] = *reinterpret_cast<const floatx4_t*>(lss + f * 16 + g * 4);
+      dl4[f] = *reinterpret_cast<const floatx4_t*>(dls + f * 16 + g * 4);
+    }
+    floatx4_t st[MI][4], dp[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { st[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int s = 0; s < AT<T>::NK; ++s)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        st[f] = Mma<T>::run(kf[s], rc_frag<T>(Qs, f * 16, s * AT<T>::KS, lane), st[f]);
-        dp[f] = Mma<T>::run(vf[s], rc_frag<T>(Gs, f * 16, s * AT<T>::KS, lane), dp[f]);
-      }
-    // P^T (dropped) -> Ps, then dV += P^T . dO
+        const Frag aq = rc_frag<T>(Qs, f * 16, s * AT<T>::KS, lane);
+        const Frag ag = rc_frag<T>(Gs, f * 16, s * AT<T>::KS, lane);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int qg = q0 + f * 16 + lc;
-      const bool qvalid = qg < p.Tq;
-      const float lse = qvalid ? p.lse[stat_base + qg] : 0.f;
-      const float dl = qvalid ? p.delta[stat_base + qg] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kg = k0 + wave * 16 + lq * 4 + r;
-        float pv = 0.f, keep = 1.f;
-        if (qvalid && kvalid[r]) {
-          pv = __expf(biased_logit(p, st[f][r], kbias[r], qg, kg) - lse);
-          if (p.drop_thresh) {
-            const Philox4 w4 = attn_drop4(p, stat_base, qg, blockIdx.x, lq * 4 + r);
-            const uint32_t wsel = wave == 0 ? w4.x : (wave == 1 ? w4.y : (wave == 2 ? w4.z : w4.w));
-            keep = drop_scale(p, wsel);
-          }
+        for (int mi = 0; mi < MI; ++mi) {
+          st[mi][f] = Mma<T>::run(aq, kf[mi][s], st[mi][f]);
+          dp[mi][f] = Mma<T>::run(ag, vf[mi][s], dp[mi][f]);
         }
-        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(pv * keep);
-        st[f][r] = pv * (keep * dp[f][r] - dl) * p.scale;  // dS^T (scaled), kept for the second product
+      }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int kblk0 = k0 + mi * TR + wave * 16;
+      const int kg = kblk0 + lc;
+      const bool diag = p.causal && (kblk0 + 15 > q0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        uint2 mw = make_uint2(0xffffffffu, 0xffffffffu);
+        if (p.drop_thresh && (q0 >> 4) + f < p.nqb)
+          mw = *reinterpret_cast<const uint2*>(
+              p.mask + ((bh * p.nqb + ((q0 >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = fast_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
+          if (diag && (kg > q0 + f * 16 + g * 4 + r)) pv = 0.f;
+          float keep = 1.f;
+          if (p.drop_thresh) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
+          st[mi][f][r] = pv * keep;                                            // dropped P, feeds dV
+          dp[mi][f][r] = pv * (keep * dp[mi][f][r] - dl4[f][r]) * p.scale;      // dS (scaled), feeds dK
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < AT<T>::NK; ++s) {
-      const Frag a = rc_frag<T>(Ps, 0, s * AT<T>::KS, lane);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) dv[f] = Mma<T>::run(a, oc_frag<T, USE_TR>(Gs, f * 16, s * AT<T>::KS, lane), dv[f]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(st[f][r]);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < AT<T>::NK; ++s) {
-      const Frag a = rc_frag<T>(Ps, 0, s * AT<T>::KS, lane);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) dk[f] = Mma<T>::run(a, oc_frag<T, USE_TR>(Qs, f * 16, s * AT<T>::KS, lane), dk[f]);
-    }
+    tmul_acc<T, MI>(dv, st, Gs, lane);
+    tmul_acc<T, MI>(dk, dp, Qs, lane);
     __syncthreads();
   }
 
   T* dkb = (T*)p.dk + (int64_t)b * p.Tk * p.ldk + h * p.dh;
   T* dvb = (T*)p.dv + (int64_t)b * p.Tk * p.ldv + h * p.dh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kg = k0 + wave * 16 + lq * 4 + r;
-    const bool kok = kg < p.Tk;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int kg = k0 + mi * TR + wave * 16 + lc;
+    if (kg < p.Tk) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int d = f * 16 + lc;
-      if (kok && d < p.dh) {
-        dkb[(int64_t)kg * p.ldk + d] = from_f32<T>(dk[f][r]);
-        dvb[(int64_t)kg * p.ldv + d] = from_f32<T>(dv[f][r]);
+      for (int fd = 0; fd < 4; ++fd) {
+        store_row4<T, VEC>(dkb + (int64_t)kg * p.ldk, fd * 16 + g * 4, p.dh, dk[mi][fd], 1.f);
+        store_row4<T, VEC>(dvb + (int64_t)kg * p.ldv, fd * 16 + g * 4, p.dh, dv[mi][fd], 1.f);
       }
     }
   }
 }
 
 // =============================================================================================
-// backward, step 2: dQ.  One workgroup per 64-query tile; loops over key tiles.
-//   S = Q.K^T ; P = exp(S*scale + bias - lse) ; dP = dO.V^T ; dS = P o (keep*dP - delta) ; dQ += scale * dS.K
+// backward, step 2: dQ.  Same blocking as the forward kernel.
+//   S^T = K.Q^T ; P^T = exp(S^T*scale + bias - lse[q]) ; dP^T = V.dO^T ; dS^T = P^T o (keep*dP^T - delta[q])
+//   dQ^T += scale * K^T.dS^T
 // =============================================================================================
-template <typename T, bool USE_TR>
+template <typename T, int MI, bool VEC>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
   typedef typename FragT<T>::type Frag;
-  __shared__ __attribute__((aligned(16))) char smem[3 * AT<T>::TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES + TR * 4];
   char* Ks = smem;
   char* Vs = smem + AT<T>::TILE_BYTES;
+  float* kbs = reinterpret_cast<float*>(smem + 2 * AT<T>::TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* Ps = smem + 2 * AT<T>::TILE_BYTES + wave * 16 * AT<T>::RS;
-  const int q0 = blockIdx.x * TR, h = blockIdx.y, b = blockIdx.z;
+  const int g = lane >> 4, lc = lane & 15;
+  const int q0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
   const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
   const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
   const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
-  const int lq = lane >> 4, lc = lane & 15;
+  const int64_t bh = (int64_t)b * p.H + h;
 
-  Frag qf[AT<T>::NK], gf[AT<T>::NK];
-  stage_tile<T>(Ks, qb, p.ldq, q0, p.Tq, p.dh, p.vq, tid);
-  stage_tile<T>(Vs, gb, p.ldo, q0, p.Tq, p.dh, p.vo, tid);
-  __syncthreads();
+  Frag qf[MI][AT<T>::NK], gf[MI][AT<T>::NK];
+  float ls2[MI], dl[MI];
+  {
+    TileRegs<T> r0, r1;
 #pragma unroll
-  for (int s = 0; s < AT<T>::NK; ++s) {
-    qf[s] = rc_frag<T>(Ks, wave * 16, s * AT<T>::KS, lane);
-    gf[s] = rc_frag<T>(Vs, wave * 16, s * AT<T>::KS, lane);
+    for (int mi = 0; mi < MI; ++mi) {
+      tile_load<T, VEC>(r0, qb, p.ldq, q0 + mi * TR, p.Tq, p.dh, tid);
+      tile_load<T, VEC>(r1, gb, p.ldo, q0 + mi * TR, p.Tq, p.dh, tid);
+      if (mi) __syncthreads();
+      tile_store<T>(Ks, r0, tid);
+      tile_store<T>(Vs, r1, tid);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < AT<T>::NK; ++s) {
+        qf[mi][s] = rc_frag<T>(Ks, wave * 16, s * AT<T>::KS, lane);
+        gf[mi][s] = rc_frag<T>(Vs, wave * 16, s * AT<T>::KS, lane);
+      }
+      const int qg = q0 + mi * TR + wave * 16 + lc;
+      const bool ok = qg < p.Tq;
+      ls2[mi] = ok ? p.lse[bh * p.Tq + qg] * LOG2E : INFINITY;
+      dl[mi] = ok ? p.delta[bh * p.Tq + qg] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-
-  const int64_t stat_base = ((int64_t)b * p.H + h) * p.Tq;
-  float lse[4], dl[4];
-  bool qvalid[4];
+  floatx4_t dq[MI][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qg = q0 + wave * 16 + lq * 4 + r;
-    qvalid[r] = qg < p.Tq;
-    lse[r] = qvalid[r] ? p.lse[stat_base + qg] : 0.f;
-    dl[r] = qvalid[r] ? p.delta[stat_base + qg] : 0.f;
-  }
-  floatx4_t dq[4];
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-  for (int f = 0; f < 4; ++f) dq[f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f) dq[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-  int nkt = (p.Tk + TR - 1) / TR;
-  if (p.causal) { const int lim = (q0 + TR - 1) / TR + 1; if (lim < nkt) nkt = lim; }
+  int nkt = p.nkt;
+  if (p.causal) { const int lim = (q0 + TR * MI - 1) / TR + 1; if (lim < nkt) nkt = lim; }
   TileRegs<T> kreg, vreg;
-  tile_load<T>(kreg, kb, p.ldk, 0, p.Tk, p.dh, p.vk, tid);
-  tile_load<T>(vreg, vb, p.ldv, 0, p.Tk, p.dh, p.vv, tid);
+  float kbreg = 0.f;
+  tile_load<T, VEC>(kreg, kb, p.ldk, 0, p.Tk, p.dh, tid);
+  tile_load<T, VEC>(vreg, vb, p.ldv, 0, p.Tk, p.dh, tid);
+  if (tid < TR) kbreg = key_bias2(p, b, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
     tile_store<T>(Ks, kreg, tid);
     tile_store<T>(Vs, vreg, tid);
+    if (tid < TR) kbs[tid] = kbreg;
     __syncthreads();
     if (kt + 1 < nkt) {
-      tile_load<T>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, p.vk, tid);
-      tile_load<T>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, p.vv, tid);
+      tile_load<T, VEC>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, tid);
+      tile_load<T, VEC>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, tid);
+      if (tid < TR) kbreg = key_bias2(p, b, k0 + TR + tid);
     }
-    floatx4_t s[4], dp[4];
+    floatx4_t kb4[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { s[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int f = 0; f < 4; ++f) kb4[f] = *reinterpret_cast<const floatx4_t*>(kbs + f * 16 + g * 4);
+    floatx4_t s[MI][4], dp[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { s[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int st = 0; st < AT<T>::NK; ++st)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        s[f] = Mma<T>::run(qf[st], rc_frag<T>(Ks, f * 16, st * AT<T>::KS, lane), s[f]);
-        dp[f] = Mma<T>::run(gf[st], rc_frag<T>(Vs, f * 16, st * AT<T>::KS, lane), dp[f]);
-      }
-    float kbias4[4];
-    bool kvalid4[4];
+        const Frag ak = rc_frag<T>(Ks, f * 16, st * AT<T>::KS, lane);
+        const Frag av = rc_frag<T>(Vs, f * 16, st * AT<T>::KS, lane);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int kg = k0 + f * 16 + lc;
-      kvalid4[f] = kg < p.Tk;
-      kbias4[f] = (kvalid4[f] && p.key_bias) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qg = q0 + wave * 16 + lq * 4 + r;
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (p.drop_thresh) {
-        const Philox4 w4 = attn_drop4(p, stat_base, qg, kt, lc);
-        keep[0] = drop_scale(p, w4.x); keep[1] = drop_scale(p, w4.y); keep[2] = drop_scale(p, w4.z); keep[3] = drop_scale(p, w4.w);
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int kg = k0 + f * 16 + lc;
-        float ds = 0.f;
-        if (kvalid4[f] && qvalid[r]) {
-          const float pv = __expf(biased_logit(p, s[f][r], kbias4[f], qg, kg) - lse[r]);
-          ds = pv * (keep[f] * dp[f][r] - dl[r]) * p.scale;
+        for (int mi = 0; mi < MI; ++mi) {
+          s[mi][f] = Mma<T>::run(ak, qf[mi][st], s[mi][f]);
+          dp[mi][f] = Mma<T>::run(av, gf[mi][st], dp[mi][f]);
         }
-        *reinterpret_cast<T*>(Ps + (lq * 4 + r) * AT<T>::RS + (f * 16 + lc) * (int)sizeof(T)) = from_f32<T>(ds);
       }
-    }
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int st = 0; st < AT<T>::NK; ++st) {
-      const Frag a = rc_frag<T>(Ps, 0, st * AT<T>::KS, lane);
+    for (int mi = 0; mi < MI; ++mi) {
+      const int qblk0 = q0 + mi * TR + wave * 16;
+      const int qg = qblk0 + lc;
+      const bool diag = p.causal && (k0 + TR - 1 > qblk0);
+      uint32_t bits = 0xffffu;
+      if (p.drop_thresh && qblk0 < p.Tq) bits = p.mask[((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) dq[f] = Mma<T>::run(a, oc_frag<T, USE_TR>(Ks, f * 16, st * AT<T>::KS, lane), dq[f]);
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = fast_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
+          if (diag && (k0 + f * 16 + g * 4 + r > qg)) pv = 0.f;
+          float keep = 1.f;
+          if (p.drop_thresh) keep = keep_mul(bits, f * 4 + r, p.drop_inv_keep);
+          s[mi][f][r] = pv * (keep * dp[mi][f][r] - dl[mi]) * p.scale;
+        }
     }
+    tmul_acc<T, MI>(dq, s, Ks, lane);
     __syncthreads();
   }
   T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qg = q0 + wave * 16 + lq * 4 + r;
-    const bool qok = qg < p.Tq;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int qg = q0 + mi * TR + wave * 16 + lc;
+    if (qg < p.Tq) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int d = f * 16 + lc;
-      if (qok && d < p.dh) dqb[(int64_t)qg * p.ldq + d] = from_f32<T>(dq[f][r]);
+      for (int fd = 0; fd < 4; ++fd) store_row4<T, VEC>(dqb + (int64_t)qg * p.ldq, fd * 16 + g * 4, p.dh, dq[mi][fd], 1.f);
     }
   }
 }
 
-bool attn_use_tr() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
-
 int vec_legal(const void* base, int64_t ld, int dh, int esz) {
   const int E = 16 / esz;
-  return nst_aligned16(base) && ((ld * esz) % 16 == 0) && (dh % E == 0) && ((dh * esz) % 16 == 0);
+  return nst_aligned16(base) && ((ld * esz) % 16 == 0) && (dh % E == 0);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
+int64_t mask_bytes(const NstAttnDesc* d) {
+  return (int64_t)d->B * d->H * ((d->Tq + 15) / 16) * ((d->Tk + TR - 1) / TR) * 64 * 2;
 }
 
 int fill_params(const NstAttnDesc* d, AttnParams& p) {
@@ -607,15 +707,49 @@ int fill_params(const NstAttnDesc* d, AttnParams& p) {
   NST_CHECK_ARG(d->ldq >= (int64_t)d->H * d->dh && d->ldk >= (int64_t)d->H * d->dh && d->ldv >= (int64_t)d->H * d->dh &&
                     d->ldo >= (int64_t)d->H * d->dh, "attention: row stride smaller than H*dh");
   p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh;
+  p.nqb = (d->Tq + 15) / 16; p.nkt = (d->Tk + TR - 1) / TR;
   p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
-  p.scale = d->scale; p.float_min = d->float_min; p.causal = d->causal;
-  p.drop_thresh = nst_dropout_threshold(d->dropout_p);
-  p.drop_inv_keep = 1.f / (1.f - d->dropout_p);
+  p.scale = d->scale; p.scale2 = d->scale * LOG2E; p.causal = d->causal;
+  nst_dropout_params16(d->dropout_p, &p.drop_thresh, &p.drop_inv_keep);
+  if (p.drop_thresh) {
+    NST_CHECK_ARG(d->dropout_mask, "attention: dropout_p > 0 needs dropout_mask");
+    NST_CHECK_ARG(d->dropout_mask_bytes >= mask_bytes(d) && (((uintptr_t)d->dropout_mask) & 7) == 0,
+                  "attention: dropout_mask needs %lld bytes, 8-byte aligned (got %lld)", (long long)mask_bytes(d),
+                  (long long)d->dropout_mask_bytes);
+    p.mask = reinterpret_cast<uint16_t*>(d->dropout_mask);
+  }
   p.seed = d->seed; p.stream_id = d->stream_id;
   return NST_OK;
 }
 
+// rows per workgroup = 64*MI.  Measured on MI355X (B=128, H=4, dh=64): the forward kernel gains from two 16-query
+// blocks per wave (one K/V fragment read feeds two MFMAs) once there are enough workgroups to fill the chip; the
+// backward kernels hold twice the accumulators and lose more to occupancy than they gain, so they stay at MI=1.
+int pick_mi(const char* env, int rows, int64_t bh, bool prefer2) {
+  const int forced = env_int(env, 0);
+  if (forced == 1 || forced == 2) return forced;
+  if (!prefer2) return 1;
+  return (rows > TR && ((int64_t)((rows + 2 * TR - 1) / (2 * TR)) * bh >= 512)) ? 2 : 1;
+}
+
+#define NST_ATTN_LAUNCH(KERNEL, GRID_ROWS, MI_, VEC_)                                          \
+  do {                                                                                         \
+    dim3 grid_(((GRID_ROWS) + TR * (MI_) - 1) / (TR * (MI_)), d->H, d->B);                      \
+    if (d->dtype == NST_F32) KERNEL<float, MI_, VEC_><<<grid_, 256, 0, st>>>(p);               \
+    else KERNEL<bf16_t, MI_, VEC_><<<grid_, 256, 0, st>>>(p);                                  \
+  } while (0)
+#define NST_ATTN_DISPATCH(KERNEL, GRID_ROWS, mi, vec)                                          \
+  do {                                                                                         \
+    if ((mi) == 2) { if (vec) NST_ATTN_LAUNCH(KERNEL, GRID_ROWS, 2, true); else NST_ATTN_LAUNCH(KERNEL, GRID_ROWS, 2, false); } \
+    else { if (vec) NST_ATTN_LAUNCH(KERNEL, GRID_ROWS, 1, true); else NST_ATTN_LAUNCH(KERNEL, GRID_ROWS, 1, false); }           \
+  } while (0)
+
 }  // namespace
+
+extern "C" int64_t nst_attention_dropout_mask_bytes(const NstAttnDesc* d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->Tq <= 0 || d->Tk <= 0) return 0;
+  return mask_bytes(d);
+}
 
 extern "C" int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
                                  void* out, float* lse, void* stream) {
@@ -626,13 +760,11 @@ extern "C" int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void
   NST_CHECK_ARG(q && k && v && out && lse, "attention_fwd: null pointer");
   const int esz = nst_dtype_size(d->dtype);
   p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse; p.key_bias = key_bias;
-  p.vq = vec_legal(q, d->ldq, d->dh, esz); p.vk = vec_legal(k, d->ldk, d->dh, esz); p.vv = vec_legal(v, d->ldv, d->dh, esz);
-  dim3 grid((d->Tq + TR - 1) / TR, d->H, d->B);
+  const bool vec = vec_legal(q, d->ldq, d->dh, esz) && vec_legal(k, d->ldk, d->dh, esz) && vec_legal(v, d->ldv, d->dh, esz) &&
+                   vec_legal(out, d->ldo, d->dh, esz);
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = attn_use_tr();
-  if (d->dtype == NST_F32) attn_fwd_kernel<float, true><<<grid, 256, 0, st>>>(p);
-  else if (tr) attn_fwd_kernel<bf16_t, true><<<grid, 256, 0, st>>>(p);
-  else attn_fwd_kernel<bf16_t, false><<<grid, 256, 0, st>>>(p);
+  const int mi = pick_mi("NST_ATTN_MI_FWD", d->Tq, (int64_t)d->B * d->H, true);
+  NST_ATTN_DISPATCH(attn_fwd_kernel, d->Tq, mi, vec);
   NST_CHECK_LAUNCH("attention_fwd");
   return NST_OK;
 }
@@ -648,28 +780,27 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
   const int esz = nst_dtype_size(d->dtype);
   p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
   p.key_bias = key_bias; p.dq = dq; p.dk = dk; p.dv = dv;
-  p.vq = vec_legal(q, d->ldq, d->dh, esz); p.vk = vec_legal(k, d->ldk, d->dh, esz); p.vv = vec_legal(v, d->ldv, d->dh, esz);
-  p.vo = vec_legal(dout, d->ldo, d->dh, esz);
+  const bool vo = vec_legal(dout, d->ldo, d->dh, esz) && vec_legal(out, d->ldo, d->dh, esz);
+  const bool vec = vec_legal(q, d->ldq, d->dh, esz) && vec_legal(k, d->ldk, d->dh, esz) && vec_legal(v, d->ldv, d->dh, esz) && vo &&
+                   vec_legal(dq, d->ldq, d->dh, esz) && vec_legal(dk, d->ldk, d->dh, esz) && vec_legal(dv, d->ldv, d->dh, esz);
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = attn_use_tr();
   {
-    int64_t rows = (int64_t)d->B * d->H * d->Tq;
-    int blocks = (int)((rows + 3) / 4 > 4096 ? 4096 : (rows + 3) / 4);
-    if (d->dtype == NST_F32) attn_delta_kernel<float><<<blocks, 256, 0, st>>>(p);
-    else attn_delta_kernel<bf16_t><<<blocks, 256, 0, st>>>(p);
+    const bool fast = vo && d->dh == 64 && (d->H == 1 || d->H == 2 || d->H == 4);
+    const int64_t rows = fast ? ((int64_t)d->B * d->Tq * d->H * 16 + 63) / 64 : (int64_t)d->B * d->H * d->Tq;
+    const int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
+    if (fast) {
+      if (d->dtype == NST_F32) attn_delta_vec_kernel<float><<<blocks, 256, 0, st>>>(p);
+      else attn_delta_vec_kernel<bf16_t><<<blocks, 256, 0, st>>>(p);
+    } else {
+      if (d->dtype == NST_F32) attn_delta_kernel<float><<<blocks, 256, 0, st>>>(p);
+      else attn_delta_kernel<bf16_t><<<blocks, 256, 0, st>>>(p);
+    }
     NST_CHECK_LAUNCH("attention_bwd(delta)");
   }
-  dim3 gk((d->Tk + TR - 1) / TR, d->H, d->B), gq((d->Tq + TR - 1) / TR, d->H, d->B);
-  if (d->dtype == NST_F32) {
-    attn_bwd_dkdv_kernel<float, true><<<gk, 256, 0, st>>>(p);
-    attn_bwd_dq_kernel<float, true><<<gq, 256, 0, st>>>(p);
-  } else if (tr) {
-    attn_bwd_dkdv_kernel<bf16_t, true><<<gk, 256, 0, st>>>(p);
-    attn_bwd_dq_kernel<bf16_t, true><<<gq, 256, 0, st>>>(p);
-  } else {
-    attn_bwd_dkdv_kernel<bf16_t, false><<<gk, 256, 0, st>>>(p);
-    attn_bwd_dq_kernel<bf16_t, false><<<gq, 256, 0, st>>>(p);
-  }
+  const int mik = pick_mi("NST_ATTN_MI_DKDV", d->Tk, (int64_t)d->B * d->H, false);
+  const int miq = pick_mi("NST_ATTN_MI_DQ", d->Tq, (int64_t)d->B * d->H, false);
+  NST_ATTN_DISPATCH(attn_bwd_dkdv_kernel, d->Tk, mik, vec);
+  NST_ATTN_DISPATCH(attn_bwd_dq_kernel, d->Tq, miq, vec);
   NST_CHECK_LAUNCH("attention_bwd");
   return NST_OK;
 }

@@ -53,11 +53,13 @@ static inline bool nst_aligned16(const void* p) { return (((uintptr_t)p) & 15) =
 // bf16 <-> f32 (round to nearest even)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): one instruction per PAIR of values
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+typedef __attribute__((ext_vector_type(2))) float floatx2_hw_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const floatx2_hw_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 
 template <typename T>
@@ -132,14 +134,49 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t stream,
   Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
   return o;
 }
-// keep-multiplier for one element: 0 (dropped) or 1/(1-p)
-__device__ __forceinline__ float dropout_keep_scale(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh,
-                                                    float inv_keep) {
-  Philox4 r = philox4x32_10(seed, stream, idx >> 2);
-  uint32_t sel = (uint32_t)(idx & 3);
-  uint32_t v = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
-  return v >= thresh ? inv_keep : 0.0f;
+// Dropout masks outside attention use 16-bit fields: one Philox call (4 x u32 = 8 x u16) serves the element group
+// idx/8; element idx compares field idx%8 (word (idx%8)/2, low half first) against thresh16 = round(p * 65536).
+// The drop probability is therefore quantised to 1/65536 and inv_keep = 65536/(65536 - thresh16) keeps the mask
+// exactly unbiased.  keep-multiplier: 0 (dropped) or inv_keep.
+__device__ __forceinline__ float drop_field(uint32_t word, int half, uint32_t thresh16, float inv_keep) {
+  const uint32_t f = half ? (word >> 16) : (word & 0xffffu);
+  return f >= thresh16 ? inv_keep : 0.0f;
 }
+__device__ __forceinline__ float dropout_keep_scale(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh16,
+                                                    float inv_keep) {
+  Philox4 r = philox4x32_10(seed, stream, idx >> 3);
+  const uint32_t sel = (uint32_t)(idx & 7), ws = sel >> 1;
+  const uint32_t w = ws == 0 ? r.x : (ws == 1 ? r.y : (ws == 2 ? r.z : r.w));
+  return drop_field(w, sel & 1, thresh16, inv_keep);
+}
+// 8 consecutive elements starting at idx (multiple of 8): one Philox call
+__device__ __forceinline__ void dropout_keep8(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh16,
+                                              float inv_keep, float (&m)[8]) {
+  const Philox4 r = philox4x32_10(seed, stream, idx >> 3);
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = drop_field(w[j >> 1], j & 1, thresh16, inv_keep);
+}
+// 4 consecutive elements starting at idx (multiple of 4): the lower or upper half of one Philox call
+__device__ __forceinline__ void dropout_keep4(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh16,
+                                              float inv_keep, float (&m)[4]) {
+  const Philox4 r = philox4x32_10(seed, stream, idx >> 3);
+  const bool hi = (idx >> 2) & 1;
+  const uint32_t w0 = hi ? r.z : r.x, w1 = hi ? r.w : r.y;
+  m[0] = drop_field(w0, 0, thresh16, inv_keep);
+  m[1] = drop_field(w0, 1, thresh16, inv_keep);
+  m[2] = drop_field(w1, 0, thresh16, inv_keep);
+  m[3] = drop_field(w1, 1, thresh16, inv_keep);
+}
+// host: p -> (thresh16, inv_keep)
+static inline void nst_dropout_params16(float p, uint32_t* thresh16, float* inv_keep) {
+  double t = (double)p * 65536.0 + 0.5;
+  if (t < 0) t = 0;
+  if (t > 65535.0) t = 65535.0;
+  *thresh16 = (uint32_t)t;
+  *inv_keep = (float)(65536.0 / (65536.0 - (double)*thresh16));
+}
+// attention probabilities keep full 32-bit words (one word per probability)
 static inline uint32_t nst_dropout_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t < 0) t = 0;

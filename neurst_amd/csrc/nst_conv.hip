@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(256) conv1_fwd_kernel(const float* __restrict_
             const float v0 = fmaxf(z[k * 4], 0.f), v1 = fmaxf(z[k * 4 + 1], 0.f), v2 = fmaxf(z[k * 4 + 2], 0.f), v3 = fmaxf(z[k * 4 + 3], 0.f);
             if (sizeof(T) == 2) {
               uint2 raw;
-              raw.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-              raw.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+              raw.x = pack_bf16x2(v0, v1);
+              raw.y = pack_bf16x2(v2, v3);
               *reinterpret_cast<uint2*>(o + c) = raw;
             } else {
               *reinterpret_cast<float4*>(o + c) = make_float4(v0, v1, v2, v3);

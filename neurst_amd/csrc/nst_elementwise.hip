@@ -20,8 +20,8 @@ template <typename T>
 __device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
   if (sizeof(T) == 2) {
     uint2 raw;
-    raw.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    raw.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    raw.x = pack_bf16x2(v[0], v[1]);
+    raw.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = raw;
   } else {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -99,13 +99,17 @@ __global__ void scale_posenc_dropout_kernel(const T* __restrict__ x, const float
        i += (int64_t)gridDim.x * blockDim.x * VEC) {
     float v[4];
     if (VEC == 4) load4<T>(x + i, v); else v[0] = to_f32<T>(x[i]);
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (thresh) {
+      if (VEC == 4) dropout_keep4(seed, sid, (uint64_t)i, thresh, inv_keep, m);
+      else m[0] = dropout_keep_scale(seed, sid, (uint64_t)i, thresh, inv_keep);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int64_t idx = i + j;
       float t = v[j] * scale;
       if (posenc) { const int64_t row = idx / d; t += posenc[(row % period) * d + (idx - row * d)]; }
-      if (thresh) t *= dropout_keep_scale(seed, sid, (uint64_t)idx, thresh, inv_keep);
-      v[j] = t;
+      v[j] = t * m[j];
     }
     if (VEC == 4) store4<T>(y + i, v); else y[i] = from_f32<T>(v[0]);
   }
@@ -273,8 +277,8 @@ extern "C" int nst_embedding_fwd(const void* table, const int64_t* ids, const fl
   NST_CHECK_ARG(L > 0 && d > 0 && V > 0, "embedding_fwd: bad dims L=%d d=%d V=%d", L, d, V);
   NST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "embedding_fwd: dropout_p=%f", dropout_p);
   if (rows <= 0) return NST_OK;
-  const uint32_t th = nst_dropout_threshold(dropout_p);
-  const float ik = 1.f / (1.f - dropout_p);
+  uint32_t th; float ik;
+  nst_dropout_params16(dropout_p, &th, &ik);
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(rows, 4, 4096);
   if (dtype == NST_F32)
@@ -292,8 +296,8 @@ extern "C" int nst_embedding_bwd(const void* dout, const int64_t* ids, float* dt
   NST_CHECK_ARG(dout && ids && dtable, "embedding_bwd: null pointer");
   NST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "embedding_bwd: dropout_p=%f", dropout_p);
   if (rows <= 0) return NST_OK;
-  const uint32_t th = nst_dropout_threshold(dropout_p);
-  const float ik = 1.f / (1.f - dropout_p);
+  uint32_t th; float ik;
+  nst_dropout_params16(dropout_p, &th, &ik);
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(rows, 4, 4096);
   if (dtype == NST_F32)
@@ -321,8 +325,8 @@ extern "C" int nst_scale_posenc_dropout_fwd(const void* x, const float* posenc, 
   NST_CHECK_ARG(d > 0 && (posenc == nullptr || period > 0), "scale_posenc_dropout_fwd: bad dims");
   NST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "scale_posenc_dropout_fwd: dropout_p=%f", dropout_p);
   if (rows <= 0) return NST_OK;
-  const uint32_t th = nst_dropout_threshold(dropout_p);
-  const float ik = 1.f / (1.f - dropout_p);
+  uint32_t th; float ik;
+  nst_dropout_params16(dropout_p, &th, &ik);
   hipStream_t st = (hipStream_t)stream;
   if (period <= 0) period = 1;
   if (dtype == NST_F32) launch_spd<float>(x, posenc, y, rows * d, d, period, scale, th, ik, seed, stream_id, st);
@@ -337,8 +341,8 @@ extern "C" int nst_scale_dropout_bwd(const void* dy, void* dx, int64_t n, float 
   NST_CHECK_ARG(dy && dx, "scale_dropout_bwd: null pointer");
   NST_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "scale_dropout_bwd: dropout_p=%f", dropout_p);
   if (n <= 0) return NST_OK;
-  const uint32_t th = nst_dropout_threshold(dropout_p);
-  const float ik = 1.f / (1.f - dropout_p);
+  uint32_t th; float ik;
+  nst_dropout_params16(dropout_p, &th, &ik);
   hipStream_t st = (hipStream_t)stream;
   // d is only used for the posenc lookup (absent here): pass d=4 so the vector path stays eligible
   if (dtype == NST_F32) launch_spd<float>(dy, nullptr, dx, n, 4, 1, scale, th, ik, seed, stream_id, st);

@@ -172,8 +172,7 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   ep.alpha = d->alpha;
   ep.bias = d->bias;
   ep.relu = d->relu;
-  ep.drop_thresh = nst_dropout_threshold(d->dropout_p);
-  ep.drop_inv_keep = 1.f / (1.f - d->dropout_p);
+  nst_dropout_params16(d->dropout_p, &ep.drop_thresh, &ep.drop_inv_keep);
   ep.seed = d->seed;
   ep.stream_id = d->stream_id;
   ep.residual = d->residual;

@@ -248,12 +248,10 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& ep, OutT* __rest
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
   }
   if (ep.drop_thresh) {
-    const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)col;  // multiple of 8 -> two aligned Philox groups
-    const Philox4 r0 = philox4x32_10(ep.seed, ep.stream_id, idx >> 2);
-    const Philox4 r1 = philox4x32_10(ep.seed, ep.stream_id, (idx >> 2) + 1);
-    const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    float m[8];  // (row*N + col) is a multiple of 8: one Philox call covers the 8 columns
+    dropout_keep8(ep.seed, ep.stream_id, (uint64_t)row * (uint64_t)N + (uint64_t)col, ep.drop_thresh, ep.drop_inv_keep, m);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= rr[j] >= ep.drop_thresh ? ep.drop_inv_keep : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] *= m[j];
   }
   OutT tmp[8];
   if (ep.residual) {
@@ -289,10 +287,13 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& ep, OutT* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += to_f32<OutT>(tmp[j]);
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) tmp[j] = from_f32<OutT>(v[j]);
-  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(tmp);
-  if (sizeof(OutT) == 4) *reinterpret_cast<uint4*>(o + 4) = *reinterpret_cast<uint4*>(tmp + 4);
+  if (sizeof(OutT) == 2) {
+    *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                              pack_bf16x2(v[6], v[7]));
+  } else {
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(o) + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
 }
 
 struct IdentityRowMap {

@@ -56,8 +56,8 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, int d, int lane, co
       if (e < d) {
         if (sizeof(T) == 2) {
           uint2 raw;
-          raw.x = (uint32_t)f32_to_bf16(v[k * 4 + 0]) | ((uint32_t)f32_to_bf16(v[k * 4 + 1]) << 16);
-          raw.y = (uint32_t)f32_to_bf16(v[k * 4 + 2]) | ((uint32_t)f32_to_bf16(v[k * 4 + 3]) << 16);
+          raw.x = pack_bf16x2(v[k * 4 + 0], v[k * 4 + 1]);
+          raw.y = pack_bf16x2(v[k * 4 + 2], v[k * 4 + 3]);
           *reinterpret_cast<uint2*>(p + e) = raw;
         } else {
           *reinterpret_cast<float4*>(p + e) = make_float4(v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);

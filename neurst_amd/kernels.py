@@ -15,6 +15,13 @@ FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
 _WS = {}
 
 
+def dropout_inv_keep(p):
+    """Keep-multiplier the kernels apply for rate p outside attention: the mask compares 16-bit Philox fields against
+    round(p*65536), so the multiplier is 65536/(65536 - round(p*65536)) (nst_common.h: nst_dropout_params16)."""
+    t = min(max(int(p * 65536.0 + 0.5), 0), 65535)
+    return 65536.0 / (65536.0 - t)
+
+
 def _workspace(nbytes, device):
     """Persistent scratch for two-stage reductions (split-K slabs, LayerNorm / bias-gradient partial sums); grown
     on demand.  Every launch is ordered on one stream, so consecutive users never overlap."""
@@ -179,22 +186,31 @@ def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id):
 
 
 def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0):
-    """q [B,Tq,H*dh-view], k/v [B,Tk,H*dh-view] (may be column slices of a packed projection)."""
+    """q [B,Tq,H*dh-view], k/v [B,Tk,H*dh-view] (may be column slices of a packed projection).
+    Returns (out, lse, drop_mask); drop_mask (keep bits written by the kernel, None when dropout_p == 0) must be
+    handed to attention_bwd."""
     B, Tq = q.shape[0], q.shape[1]
     out = torch.empty(B, Tq, H * dh, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    mask = None
+    if dropout_p > 0:
+        mask = torch.empty(lib.nst_attention_dropout_mask_bytes(C.byref(d)) // 8, dtype=torch.int64, device=q.device)
+        d.dropout_mask, d.dropout_mask_bytes = mask.data_ptr(), mask.numel() * 8
     check(lib.nst_attention_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(lse), _stream()),
           "attention_fwd")
-    return out, lse
+    return out, lse, mask
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
-                  stream_id=0):
+                  stream_id=0, drop_mask=None):
     assert dout.is_contiguous() and out.is_contiguous()
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
     delta = torch.empty_like(lse)
     d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    if dropout_p > 0:
+        assert drop_mask is not None, "attention_bwd: dropout needs the mask written by attention_fwd"
+        d.dropout_mask, d.dropout_mask_bytes = drop_mask.data_ptr(), drop_mask.numel() * 8
     check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(dout), _p(lse), _p(delta),
                                 _p(dq), _p(dk), _p(dv), _stream()), "attention_bwd")
 

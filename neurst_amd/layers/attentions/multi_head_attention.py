@@ -47,16 +47,16 @@ class MultiHeadAttention(Layer):
         q = self.q_transform.forward(query)
         kv = self.kv_transform.forward(memory)
         q3, kv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d)
-        ctx, lse = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=False,
+        ctx, lse, dmask = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=False,
                                    dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
         out = self.output_transform.forward(ctx.view(B * Tq, d), **(epilogue or {}))
         if is_training:
-            self._saved = (query, memory, q, kv, ctx, lse, memory_bias, B, Tq, Tk, p)
+            self._saved = (query, memory, q, kv, ctx, (lse, dmask), memory_bias, B, Tq, Tk, p)
         return out
 
     def backward(self, dz, dmemory=None, dmemory_accumulate=False):
         """Returns d(query); d(memory) is written (or accumulated) into `dmemory` [B*Tk, d]."""
-        query, memory, q, kv, ctx, lse, bias, B, Tq, Tk, p = self._saved
+        query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
         ctx2 = ctx.view(B * Tq, d)
@@ -67,7 +67,7 @@ class MultiHeadAttention(Layer):
         q3, kv3, dq3, dkv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d), dq.view(B, Tq, d), dkv.view(B, Tk, 2 * d)
         K.attention_bwd(q3, kv3[..., :d], kv3[..., d:], ctx, dctx.view(B, Tq, d), lse, dq3, dkv3[..., :d],
                         dkv3[..., d:], H, dh, key_bias=bias, causal=False, dropout_p=p, seed=self.rt.step_seed,
-                        stream_id=self.site)
+                        stream_id=self.site, drop_mask=dmask)
         self.q_transform.backward_params(query, dq)
         self.kv_transform.backward_params(memory, dkv)
         if dmemory is not None:
@@ -90,15 +90,15 @@ class MultiHeadSelfAttention(MultiHeadAttention):
         p = self.rate if is_training else 0.0
         qkv = self.qkv_transform.forward(x)
         v3 = qkv.view(B, T, 3 * d)
-        ctx, lse = K.attention_fwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], H, dh, key_bias=bias, causal=causal,
+        ctx, lse, dmask = K.attention_fwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], H, dh, key_bias=bias, causal=causal,
                                    dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
         out = self.output_transform.forward(ctx.view(B * T, d), **(epilogue or {}))
         if is_training:
-            self._saved = (x, qkv, ctx, lse, bias, causal, B, T, p)
+            self._saved = (x, qkv, ctx, (lse, dmask), bias, causal, B, T, p)
         return out
 
     def backward(self, dz):
-        x, qkv, ctx, lse, bias, causal, B, T, p = self._saved
+        x, qkv, ctx, (lse, dmask), bias, causal, B, T, p = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
         self.output_transform.backward_params(ctx.view(B * T, d), dz)
@@ -107,6 +107,6 @@ class MultiHeadSelfAttention(MultiHeadAttention):
         v3, g3 = qkv.view(B, T, 3 * d), dqkv.view(B, T, 3 * d)
         K.attention_bwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], ctx, dctx.view(B, T, d), lse, g3[..., :d],
                         g3[..., d:2 * d], g3[..., 2 * d:], H, dh, key_bias=bias, causal=causal, dropout_p=p,
-                        seed=self.rt.step_seed, stream_id=self.site)
+                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask)
         self.qkv_transform.backward_params(x, dqkv)
         return self.qkv_transform.backward_input(dqkv)

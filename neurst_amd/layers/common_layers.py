@@ -137,7 +137,7 @@ class TransformerFFN(Layer):
         x, h, p = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
-        dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=1.0 / (1.0 - p))
+        dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=K.dropout_inv_keep(p))
         self.dense1.backward_params(x, dh)
         return self.dense1.backward_input(dh)
 

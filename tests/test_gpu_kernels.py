@@ -236,9 +236,17 @@ ATTN_CASES = [  # B, H, Tq, Tk, dh, causal, key-padding
     (1, 3, 130, 70, 24, False, True), (1, 2, 64, 64, 64, True, False)]
 
 
+@pytest.fixture(params=[1, 2])
+def attn_mi(request, monkeypatch):
+    """Force the number of 16-row blocks per wave (64*MI rows per workgroup) in all three attention kernels."""
+    for k in ("NST_ATTN_MI_FWD", "NST_ATTN_MI_DKDV", "NST_ATTN_MI_DQ"):
+        monkeypatch.setenv(k, str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,Tq,Tk,dh,causal,pad", ATTN_CASES)
-def test_attention(K, dtype, B, H, Tq, Tk, dh, causal, pad):
+def test_attention(K, dtype, attn_mi, B, H, Tq, Tk, dh, causal, pad):
     d = H * dh
     self_att = Tq == Tk
     bias = None
@@ -261,8 +269,8 @@ def test_attention(K, dtype, B, H, Tq, Tk, dh, causal, pad):
     qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
     ref = _attn_ref(qr, kr, vr, None if bias is None else bias.double(), causal, H, dh)
     ref.backward(dout.double())
-    out, lse = K.attention_fwd(qd, kd, vd, H, dh, key_bias=None if bias is None else bias.to(DEV), causal=causal)
-    tag = f"attn[{dtype},B{B}H{H}q{Tq}k{Tk}d{dh}{'c' if causal else ''}{'p' if pad else ''}]"
+    out, lse, _ = K.attention_fwd(qd, kd, vd, H, dh, key_bias=None if bias is None else bias.to(DEV), causal=causal)
+    tag = f"attn[{dtype},mi{attn_mi},B{B}H{H}q{Tq}k{Tk}d{dh}{'c' if causal else ''}{'p' if pad else ''}]"
     close(tag + ".out", out, ref, dtype)
     if self_att:
         dqkv = torch.zeros_like(qkv_d)
@@ -279,31 +287,78 @@ def test_attention(K, dtype, B, H, Tq, Tk, dh, causal, pad):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_dropout(K, dtype):
-    # V = identity exposes the (dropped) probability matrix as the output, which yields the mask itself.
-    B, H, T, dh, p = 2, 2, 32, 32, 0.3
+@pytest.mark.parametrize("B,H,T,dh,causal", [(2, 2, 32, 32, False), (2, 2, 64, 64, True), (1, 4, 64, 64, False)])
+def test_attention_dropout(K, dtype, attn_mi, B, H, T, dh, causal):
+    # V = identity (T == dh) exposes the dropped probability matrix as the output, which yields the mask itself;
+    # the backward kernels must then reproduce the gradients of exactly that mask from the saved bits.
+    p = 0.3
     d = H * dh
     q, k = rnd(B, T, d, dtype=dtype, seed=1), rnd(B, T, d, dtype=dtype, seed=2)
-    eye = torch.eye(T).reshape(1, T, 1, dh).expand(B, T, H, dh).reshape(B, T, d).to(dtype).contiguous()
-    out, lse = K.attention_fwd(q.to(DEV), k.to(DEV), eye.to(DEV), H, dh, dropout_p=p, seed=77, stream_id=3)
-    P = out.float().cpu().reshape(B, T, H, T).permute(0, 2, 1, 3)  # [B,H,Tq,Tk]
-    keep = (P != 0).double()
-    frac = float(keep.mean())
-    REPORT[f"attn_dropout_keepfrac[{dtype}]"] = frac
-    assert abs(frac - (1 - p)) < 0.03
+    if T == dh:
+        eye = torch.eye(T).reshape(1, T, 1, dh).expand(B, T, H, dh).reshape(B, T, d).to(dtype).contiguous()
+        out, _, _ = K.attention_fwd(q.to(DEV), k.to(DEV), eye.to(DEV), H, dh, causal=causal, dropout_p=p, seed=77,
+                                    stream_id=3)
+        P = out.float().cpu().reshape(B, T, H, T).permute(0, 2, 1, 3)  # [B,H,Tq,Tk]
+        keep = (P != 0).double()
+        visible = torch.tril(torch.ones(T, T)) if causal else torch.ones(T, T)
+        frac = float((keep * visible).sum() / (visible.sum() * B * H))
+        REPORT[f"attn_dropout_keepfrac[{dtype},T{T}{'c' if causal else ''}]"] = frac
+        assert abs(frac - (1 - p)) < 0.03
+        if causal:
+            keep = keep + (1 - visible)  # masked positions carry probability 0 either way
     v = rnd(B, T, d, dtype=dtype, seed=3)
     dout = rnd(B, T, d, dtype=dtype, seed=4)
     qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
-    ref = _attn_ref(qr, kr, vr, None, False, H, dh, keep=keep, p=p)
+    ref = _attn_ref(qr, kr, vr, None, causal, H, dh, keep=keep, p=p)
     ref.backward(dout.double())
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    out, lse = K.attention_fwd(qd, kd, vd, H, dh, dropout_p=p, seed=77, stream_id=3)
-    close(f"attn_dropout[{dtype}].out", out, ref, dtype)
+    out, lse, mask = K.attention_fwd(qd, kd, vd, H, dh, causal=causal, dropout_p=p, seed=77, stream_id=3)
+    tag = f"attn_dropout[{dtype},mi{attn_mi},T{T}{'c' if causal else ''}]"
+    close(tag + ".out", out, ref, dtype)
     dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
-    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dk, dv, H, dh, dropout_p=p, seed=77, stream_id=3)
-    close(f"attn_dropout[{dtype}].dq", dq, qr.grad, dtype, scale=3.0)
-    close(f"attn_dropout[{dtype}].dk", dk, kr.grad, dtype, scale=3.0)
-    close(f"attn_dropout[{dtype}].dv", dv, vr.grad, dtype, scale=3.0)
+    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dk, dv, H, dh, causal=causal, dropout_p=p, seed=77,
+                    stream_id=3, drop_mask=mask)
+    close(tag + ".dq", dq, qr.grad, dtype, scale=3.0)
+    close(tag + ".dk", dk, kr.grad, dtype, scale=3.0)
+    close(tag + ".dv", dv, vr.grad, dtype, scale=3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_dropout_long(K, dtype, attn_mi):
+    """Several key tiles and query blocks (Tq=150, Tk=200, cross attention with padding): the mask is recovered from
+    the bits the forward kernel saved, decoded with the documented layout, and fed to the float64 reference."""
+    B, H, Tq, Tk, dh, p = 2, 2, 150, 200, 64, 0.25
+    d = H * dh
+    q = rnd(B, Tq, d, dtype=dtype, seed=11)
+    kv = rnd(B, Tk, 2 * d, dtype=dtype, seed=12)
+    k, v = kv[..., :d], kv[..., d:]
+    lens = torch.tensor([Tk, Tk - 37])
+    bias = (O.length_to_padding(lens, Tk) * O.FLOAT_MIN).float()
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    kd, vd = kvd[..., :d], kvd[..., d:]
+    out, lse, mask = K.attention_fwd(qd, kd, vd, H, dh, key_bias=bias.to(DEV), dropout_p=p, seed=5, stream_id=9)
+    nqb, nkt = (Tq + 15) // 16, (Tk + 63) // 64
+    words = mask.cpu().view(torch.int16).to(torch.int32).bitwise_and(0xffff).reshape(B, H, nqb, nkt, 64)
+    e = torch.arange(16)
+    bits = (words[..., None] >> e) & 1                                  # [B,H,nqb,nkt,lane,e]
+    bits = bits.reshape(B, H, nqb, nkt, 4, 16, 4, 4)                     # lane = g*16 + lc ; e = f*4 + r
+    # -> [B,H,nqb,lc,nkt,f,g,r] : query = qb*16 + lc ; key = kt*64 + f*16 + g*4 + r
+    keep = bits.permute(0, 1, 2, 5, 3, 6, 4, 7).reshape(B, H, nqb * 16, nkt * 64)[:, :, :Tq, :Tk].double()
+    frac = float(keep.mean())
+    REPORT[f"attn_dropout_long_keepfrac[{dtype}]"] = frac
+    assert abs(frac - (1 - p)) < 0.01
+    dout = rnd(B, Tq, d, dtype=dtype, seed=13)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, bias.double(), False, H, dh, keep=keep, p=p)
+    ref.backward(dout.double())
+    tag = f"attn_dropout_long[{dtype},mi{attn_mi}]"
+    close(tag + ".out", out, ref, dtype)
+    dq, dkv = torch.zeros_like(qd), torch.zeros_like(kvd)
+    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dkv[..., :d], dkv[..., d:], H, dh, key_bias=bias.to(DEV),
+                    dropout_p=p, seed=5, stream_id=9, drop_mask=mask)
+    close(tag + ".dq", dq, qr.grad, dtype, scale=3.0)
+    close(tag + ".dk", dkv[..., :d], kr.grad, dtype, scale=3.0)
+    close(tag + ".dv", dkv[..., d:], vr.grad, dtype, scale=3.0)
 
 
 # ------------------------------------------------------------------------------------------------ conv front end
