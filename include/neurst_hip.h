@@ -107,6 +107,12 @@ typedef struct {
   int split_k;            /* <=1: off */
   void* workspace;        /* split-K slabs (device), or NULL */
   int64_t workspace_bytes;
+  /* colsum != NULL (requires trans_b == 0): colsum[N] f32 (+)= sum_k B[k, :] -- the bias gradient that goes with a
+   * weight gradient dW = X^T.dZ (A = X, trans_a = 1, B = dZ).  Computed inside the MFMA loop (no extra pass over dZ)
+   * when the operands are 16-byte aligned and the output is f32, by a separate column-sum pass otherwise.  With
+   * split_k > 1 the workspace must hold split_k*(M+1)*N floats. */
+  float* colsum;
+  int colsum_accumulate;
 } NstGemmDesc;
 
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
@@ -171,9 +177,10 @@ int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const float* b1, co
 int nst_conv2_fwd(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu,
                   int dtype, void* stream);
 int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, int dtype, void* stream);
-/* workspace (nullable): split-K slabs, see nst_gemm; needs splits*9*C*C*4 bytes (query with workspace==NULL is
+/* workspace (nullable): split-K slabs, see nst_gemm; needs splits*(9*C+1)*C*4 bytes (query with workspace==NULL is
  * not needed: 64 MiB covers every supported shape; smaller workspaces fall back to atomic accumulation). */
-int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
+/* db2 (nullable): [C] f32 (+)= sum over pixels of dy -- the conv bias gradient, produced by the same pass over dy. */
+int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int dtype,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* LayerNorm + ReLU (second conv layer; audio_modalities.py:102-104) -- same contract as nst_layernorm_*,

@@ -33,6 +33,7 @@ class NstGemmDesc(C.Structure):
         ("split_k", C.c_int),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("colsum", C.c_void_p), ("colsum_accumulate", C.c_int),
     ]
 
 
@@ -69,7 +70,7 @@ SIGNATURES = {
     "nst_conv1_ln_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "nst_conv2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nst_conv2_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "nst_conv2_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "nst_conv2_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "nst_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _U64, _U64, _I, _P],
     "nst_embedding_bwd": [_P, _P, _P, _L, _I, _I, _F, _F, _U64, _U64, _I, _P],
     "nst_scale_posenc_dropout_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _U64, _U64, _I, _P],

@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(THREADS) conv_gemm_kernel(AL la, BL lb, OutT* 
                                                         tn * BN, kt_first, kt_count, ep, smem, rm);
 }
 
-template <typename T, typename OutT, int AMODE, int BMODE, int NST, typename AL, typename BL, typename RM>
+template <typename T, typename OutT, int AMODE, int BMODE, int NST, typename AL, typename BL, typename RM, bool CS = false>
 __global__ void __launch_bounds__(THREADS) conv_gemm_kernel_v2(AL la, BL lb, OutT* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                               int tiles_n, int ntiles, int kt_per_split, Epilogue ep, RM rm) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
@@ -426,13 +426,15 @@ __global__ void __launch_bounds__(THREADS) conv_gemm_kernel_v2(AL la, BL lb, Out
   int kt_count = kt_total - kt_first;
   if (kt_count > kt_per_split) kt_count = kt_per_split;
   if (kt_count <= 0) return;
-  gemm_block_v2<T, OutT, AMODE, BMODE, NST, AL, BL, RM>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM,
-                                                        tn * BN, kt_first, kt_count, ep, smem_dyn, rm);
+  gemm_block_v2<T, OutT, AMODE, BMODE, NST, AL, BL, RM, CS>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM,
+                                                            tn * BN, kt_first, kt_count, ep, smem_dyn, rm);
 }
 
-// dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output)
+// dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output);  db2[j] (+)= sum_z cs_parts[z][j] when cs_parts != NULL
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                                int64_t total4, int split, int accumulate) {
+                                                                int64_t total4, int split, int accumulate,
+                                                                const float* __restrict__ cs_parts, float* __restrict__ cs_out,
+                                                                int n, int cs_accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int z = 0; z < split; ++z) {
@@ -445,6 +447,13 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
       acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
     }
     *reinterpret_cast<float4*>(o) = acc;
+  }
+  if (cs_parts) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int z = 0; z < split; ++z) acc += cs_parts[(int64_t)z * n + j];
+      cs_out[j] = cs_accumulate ? cs_out[j] + acc : acc;
+    }
   }
 }
 
@@ -564,8 +573,8 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
 }
 
 template <typename T>
-int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int accumulate, void* ws,
-                  int64_t ws_bytes, hipStream_t st) {
+int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int accumulate, void* ws,
+                  int64_t ws_bytes, hipStream_t st, bool* db2_done) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int P = B * T2 * F2;          // reduction: pixels
   const int M = 9 * C, N = C, K = P;  // dw2[kk][co] = sum_p im2col[p][kk] * dy[p][co]
@@ -587,19 +596,31 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int 
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
-  const bool slab = ws && nst_aligned16(ws) && ws_bytes >= (int64_t)split * M * N * 4 && (N % 8 == 0) && nst_aligned16(dw2);
+  const bool slab = ws && nst_aligned16(ws) && ws_bytes >= (int64_t)split * (M + 1) * N * 4 && (N % 8 == 0) && nst_aligned16(dw2);
+  const bool dma = conv_use_v2() && conv_use_tr() && la.vec && lb.vec;
   float* out = dw2;
+  float* cs_parts = nullptr;
   if (slab) {
     ep.slab_stride = (int64_t)M * N;
     ep.vec = 1;
     out = (float*)ws;
+    if (db2 && dma && conv_nst() < 3) {  // db2 = column sums of dy, accumulated by the same MFMA loop
+      cs_parts = (float*)ws + (int64_t)split * M * N;
+      ep.colsum_dst = cs_parts;
+      ep.colsum_zstride = N;
+    }
   } else {
     ep.atomic = 1;
     if (!accumulate) {
       if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
     }
   }
-  if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
+  if (cs_parts) {
+    auto kfn = conv_gemm_kernel_v2<T, float, MODE_OC, MODE_OC, 2, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>;
+    conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);
+    kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(la, lb, out, (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+    *db2_done = true;
+  } else if (dma)
     NST_CONV_LAUNCH_V2(T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_per_split, la, lb, out,
                        (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
   else if (conv_use_tr())
@@ -609,7 +630,7 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, int B, int T1, int 
   if (slab) {
     const int64_t total4 = (int64_t)M * N / 4;
     int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-    conv_splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)ws, dw2, total4, split, accumulate);
+    conv_splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)ws, dw2, total4, split, accumulate, cs_parts, db2, N, accumulate);
   }
   return 0;
 }
@@ -708,16 +729,21 @@ extern "C" int nst_conv2_dgrad(const void* dy, const void* w2, void* dx, int B, 
   return NST_OK;
 }
 
-extern "C" int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, int B, int T1, int F1, int C, int dtype,
+extern "C" int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int dtype,
                                int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   NST_CHECK_ARG(x && dy && dw2, "conv2_wgrad: null pointer");
   int rc = check_conv_dims("conv2_wgrad", B, T1, F1, C);
   if (rc) return rc;
   int r = 0;
-  if (dtype == NST_F32) r = conv2_wgrad_t<float>(x, dy, dw2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
-  else if (dtype == NST_BF16) r = conv2_wgrad_t<bf16_t>(x, dy, dw2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+  bool db2_done = false;
+  if (dtype == NST_F32) r = conv2_wgrad_t<float>(x, dy, dw2, db2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream, &db2_done);
+  else if (dtype == NST_BF16) r = conv2_wgrad_t<bf16_t>(x, dy, dw2, db2, B, T1, F1, C, accumulate, workspace, workspace_bytes, (hipStream_t)stream, &db2_done);
   else { nst_set_error("conv2_wgrad: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   if (r) { nst_set_error("conv2_wgrad: memset failed"); return NST_ERR_LAUNCH; }
   NST_CHECK_LAUNCH("conv2_wgrad");
+  if (db2 && !db2_done) {  // operands not DMA-legal: separate column-sum pass over dy
+    const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+    return nst_colsum(dy, db2, (int64_t)B * T2 * F2, C, C, dtype, accumulate, nullptr, 0, stream);
+  }
   return NST_OK;
 }

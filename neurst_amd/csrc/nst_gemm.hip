@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, 
                                             kt_first, kt_count, ep, smem);
 }
 
-template <typename T, typename OutT, int AMODE, int BMODE, int NST>
+template <typename T, typename OutT, int AMODE, int BMODE, int NST, bool CS = false>
 __global__ void __launch_bounds__(THREADS) dense_gemm_kernel_v2(DenseLoader<T> la, DenseLoader<T> lb, OutT* __restrict__ C,
                                                                int64_t ldc, int M, int N, int K, int tiles_n, int ntiles,
                                                                int kt_per_split, Epilogue ep) {
@@ -35,8 +35,8 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel_v2(DenseLoader<T> l
   int kt_count = kt_total - kt_first;
   if (kt_count > kt_per_split) kt_count = kt_per_split;
   if (kt_count <= 0) return;
-  gemm_block_v2<T, OutT, AMODE, BMODE, NST>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN,
-                                            kt_first, kt_count, ep, smem_dyn);
+  gemm_block_v2<T, OutT, AMODE, BMODE, NST, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS>(
+      la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem_dyn);
 }
 
 template <typename KernelT>
@@ -56,8 +56,11 @@ bool use_v2() {
 }
 
 // C[i] (+)= sum_z slabs[z][i]   (split-K second stage; slabs are [split][M][N] f32, C has leading dimension ldc)
+// and, when cs_parts != NULL, cs_out[j] (+)= sum_z cs_parts[z][j]  (the fused column sums)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
-                                                           int64_t ldc, int split, int accumulate) {
+                                                           int64_t ldc, int split, int accumulate,
+                                                           const float* __restrict__ cs_parts, float* __restrict__ cs_out,
+                                                           int cs_accumulate) {
   const int64_t total4 = (int64_t)M * N / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -73,6 +76,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
       acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
     }
     *reinterpret_cast<float4*>(o) = acc;
+  }
+  if (cs_parts) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int z = 0; z < split; ++z) acc += cs_parts[(int64_t)z * N + j];
+      cs_out[j] = cs_accumulate ? cs_out[j] + acc : acc;
+    }
   }
 }
 
@@ -124,6 +134,14 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_OC, MODE_RC, NS); \
     else NST_GEMM_LAUNCH2(MODE_OC, MODE_OC, NS);                                           \
   } while (0)
+    if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
+      if constexpr (sizeof(OutT) == 4) {
+        auto kfn = dense_gemm_kernel_v2<T, OutT, MODE_OC, MODE_OC, 2, true>;
+        allow_big_lds(kfn, 2 * V2_STAGE_BYTES);
+        kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, ntiles, kt_per_split, ep);
+        return 0;
+      }
+    }
     static int force_nst = -1;
     if (force_nst < 0) { const char* e = getenv("NST_GEMM_NST"); force_nst = e ? atoi(e) : 0; }
     const int nst = force_nst ? force_nst : 2;  // 2 stages = 64 KB: two workgroups per CU beat a deeper ring (profiles/)
@@ -186,6 +204,18 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   ep.accumulate = d->accumulate;
   ep.atomic = 0;
   ep.slab_stride = 0;
+  ep.colsum_dst = nullptr;
+  ep.colsum_zstride = 0;
+  ep.colsum_acc = 0;
+  // column sums of the B operand (bias gradient): fused into the MFMA loop when the LDS-DMA kernel runs on
+  // OC/OC operands with an f32 output, otherwise a separate nst_colsum pass at the end
+  bool cs_fused = false;
+  if (d->colsum) {
+    NST_CHECK_ARG(!d->trans_b, "gemm: colsum needs trans_b == 0 (B stored [K,N])");
+    const int esz = nst_dtype_size(d->in_dtype), E = 16 / esz;
+    cs_fused = d->trans_a && d->out_dtype == NST_F32 && use_v2() && use_tr() && d->K > 0 && nst_aligned16(A) &&
+               nst_aligned16(B) && (d->lda * esz) % 16 == 0 && (d->ldb * esz) % 16 == 0 && d->M % E == 0 && d->N % E == 0;
+  }
 
   int split = d->split_k > 1 ? d->split_k : 1;
   if (split > 1) {
@@ -196,7 +226,7 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
     if (split > kt_total) split = kt_total;
     const int kps = (kt_total + split - 1) / split;
     split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
-    const int64_t need = (int64_t)split * d->M * d->N * 4;
+    const int64_t need = (int64_t)split * d->M * d->N * 4 + (cs_fused ? (int64_t)split * d->N * 4 : 0);
     const bool slab = split > 1 && d->workspace && d->workspace_bytes >= need && nst_aligned16(d->workspace) &&
                       (d->N % 4 == 0) && ((d->ldc * 4) % 16 == 0) && nst_aligned16(C);
     if (slab) {
@@ -204,6 +234,9 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
       eps.accumulate = 0;
       eps.slab_stride = (int64_t)d->M * d->N;
       eps.vec = (d->N % 8 == 0) ? 1 : 0;
+      float* cs_parts = cs_fused ? (float*)d->workspace + (int64_t)split * d->M * d->N : nullptr;
+      eps.colsum_dst = cs_parts;
+      eps.colsum_zstride = d->N;
       NstGemmDesc ds = *d;
       ds.ldc = d->N;  // slabs are dense [M][N]
       if (d->in_dtype == NST_F32) launch<float, float>(&ds, A, B, d->workspace, eps, split, st);
@@ -212,10 +245,13 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
       const int64_t total4 = (int64_t)d->M * d->N / 4;
       int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
       splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)d->workspace, (float*)C, d->M, d->N, d->ldc, split,
-                                                  d->accumulate);
+                                                  d->accumulate, cs_parts, d->colsum, d->colsum_accumulate);
       NST_CHECK_LAUNCH("gemm(split-K reduce)");
+      if (d->colsum && !cs_fused)
+        return nst_colsum(B, d->colsum, d->K, d->N, d->ldb, d->in_dtype, d->colsum_accumulate, nullptr, 0, stream);
       return NST_OK;
     }
+    cs_fused = false;  // atomic split-K: the column sums take the separate pass
     if (!d->accumulate)
       NST_CHECK_HIP(hipMemset2DAsync(C, d->ldc * sizeof(float), 0, (size_t)d->N * sizeof(float), d->M, st));
     ep.atomic = 1;
@@ -225,9 +261,15 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
     nst_set_error("gemm: K == 0 unsupported");
     return NST_ERR_UNSUPPORTED;
   }
+  if (cs_fused) {
+    ep.colsum_dst = d->colsum;
+    ep.colsum_acc = d->colsum_accumulate;
+  }
   if (d->in_dtype == NST_F32) launch<float, float>(d, A, B, C, ep, split, st);
   else if (d->out_dtype == NST_BF16) launch<bf16_t, bf16_t>(d, A, B, C, ep, split, st);
   else launch<bf16_t, float>(d, A, B, C, ep, split, st);
   NST_CHECK_LAUNCH("gemm");
+  if (d->colsum && !cs_fused)
+    return nst_colsum(B, d->colsum, d->K, d->N, d->ldb, d->in_dtype, d->colsum_accumulate, nullptr, 0, stream);
   return NST_OK;
 }

@@ -77,6 +77,11 @@ struct Epilogue {
   int accumulate;
   int atomic;  // split-K: atomicAdd into an f32 C
   int64_t slab_stride;  // split-K with workspace: split z stores its partial tile at C + z*slab_stride (elements)
+  // fused column sums of the B operand over the reduction (bias gradient next to a weight gradient): split z writes
+  // its partial sum of column j to colsum_dst[z*colsum_zstride + j]; colsum_acc adds the old value (split == 1 only)
+  float* colsum_dst;
+  int64_t colsum_zstride;
+  int colsum_acc;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -577,8 +582,21 @@ struct TileDma<T, MODE, DenseLoader<T>> : DenseDma<T, MODE> {};
 
 constexpr int V2_STAGE_BYTES = 2 * BM * KBYTES;  // A tile + B tile, 32 KB
 
+template <typename T>
+__device__ __forceinline__ typename SwzFrag<T, MODE_RC>::Frag ones_frag() {
+  if constexpr (sizeof(T) == 2) {
+    union { uint32_t u[4]; bf16x8_t f; } o;
+    o.u[0] = o.u[1] = o.u[2] = o.u[3] = 0x3F803F80u;  // bf16 1.0 pairs
+    return o.f;
+  } else {
+    return 1.0f;
+  }
+}
+
+// CS: the first row of tiles (m0 == 0) also accumulates ones^T . Bop -- every row of that accumulator is the column
+// sum of the B operand over this block's reduction range (one extra MFMA per B fragment in 2 of the 4 waves).
 template <typename T, typename OutT, int AMODE, int BMODE, int NST, typename ALoader, typename BLoader,
-          typename RowMap = IdentityRowMap>
+          typename RowMap = IdentityRowMap, bool CS = false>
 __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& lb, OutT* __restrict__ C, int64_t ldc, int M,
                                               int N, int m0, int n0, int kt_first, int kt_count, const Epilogue& ep,
                                               char* smem, const RowMap rowmap = RowMap()) {
@@ -596,6 +614,12 @@ __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  floatx4_t cs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = CS && ep.colsum_dst && m0 == 0 && wm == 0;  // wave-uniform
+  const typename RA::Frag ones = ones_frag<T>();
 
   TileDma<T, AMODE, ALoader> da;
   TileDma<T, BMODE, BLoader> db;
@@ -639,8 +663,22 @@ __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+      if (CS && do_cs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b[j], cs[j]);
+      }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
+  }
+  if (CS && do_cs && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn + j * 16 + lane;
+      if (col < N) {
+        float* dst = ep.colsum_dst + (int64_t)blockIdx.z * ep.colsum_zstride + col;
+        *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
+      }
+    }
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the epilogue reuses the LDS

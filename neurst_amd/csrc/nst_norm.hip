@@ -207,6 +207,224 @@ __global__ void __launch_bounds__(LN_WAVES * 64) ln_bwd_kernel(const T* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide path (d % 8 == 0, 16-byte aligned rows): every lane moves 8 consecutive elements per access (16 bytes of bf16,
+// 2 x 16 bytes of f32), LPR lanes cover one row, so a wave pass covers 64/LPR consecutive rows and U passes are in
+// flight before the first reduction -- the kernels are HBM-latency bound otherwise (one 512-byte row per wave).
+// Row reductions: 4 DPP steps inside a 16-lane row, then gfx950 lane-row swaps (v_permlane16/32_swap).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) unsigned ln_uint2_t;
+__device__ __forceinline__ float swap16_add(float v) {
+  const ln_uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap32_add(float v) {
+  const ln_uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+  if (LPR >= 32) v = swap16_add(v);
+  if (LPR >= 64) v = swap32_add(v);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void load8(const T* __restrict__ p, float (&v)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* __restrict__ p, const float (&v)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                              pack_bf16x2(v[6], v[7]));
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+}
+
+template <typename T, int LPR, int S, bool RELU, int U>
+__global__ void __launch_bounds__(256) ln_fwd_wide_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         int64_t rows, int d, float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, li = lane % LPR;
+  float gm[S][8], bt[S][8];
+  bool cok[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) {
+    const int col = (li + c * LPR) * 8;
+    cok[c] = col < d;
+    if (cok[c]) { load8<float>(gamma + col, gm[c]); load8<float>(beta + col, bt[c]); }
+    else { zero8(gm[c]); zero8(bt[c]); }
+  }
+  const float inv_d = 1.0f / (float)d;
+  const int64_t step = (int64_t)gridDim.x * 4 * RPW * U;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW * U; base < rows; base += step) {
+    float v[U][S][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * RPW + sub;
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        if (row < rows && cok[c]) load8<T>(x + row * d + (li + c * LPR) * 8, v[u][c]);
+        else zero8(v[u][c]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * RPW + sub;
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < S; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[u][c][j];
+      const float mean = group_sum<LPR>(sum) * inv_d;
+      float sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < S; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = cok[c] ? v[u][c][j] - mean : 0.f;
+          sq += t * t;
+        }
+      const float rstd = rsqrtf(group_sum<LPR>(sq) * inv_d + eps);
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float o = (v[u][c][j] - mean) * rstd * gm[c][j] + bt[c][j];
+          if (RELU) o = fmaxf(o, 0.f);
+          v[u][c][j] = o;
+        }
+        if (row < rows && cok[c]) store8<T>(y + row * d + (li + c * LPR) * 8, v[u][c]);
+      }
+      if (li == 0 && row < rows) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+      }
+    }
+  }
+}
+
+template <typename T, int LPR, int S, bool RELU, int U>
+__global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ yout, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const T* __restrict__ dres, T* __restrict__ dx, int64_t rows, int d,
+                                                         float* __restrict__ partial) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int W = LPR * S * 8;  // padded row width
+  __shared__ float red[4][2][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, li = lane % LPR;
+  float gm[S][8], g_acc[S][8], b_acc[S][8];
+  bool cok[S];
+#pragma unroll
+  for (int c = 0; c < S; ++c) {
+    const int col = (li + c * LPR) * 8;
+    cok[c] = col < d;
+    if (cok[c]) load8<float>(gamma + col, gm[c]); else zero8(gm[c]);
+    zero8(g_acc[c]); zero8(b_acc[c]);
+  }
+  const float inv_d = 1.0f / (float)d;
+  const int64_t step = (int64_t)gridDim.x * 4 * RPW * U;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW * U; base < rows; base += step) {
+    float xv[U][S][8], gv[U][S][8], rv[U][S][8];
+    float mu[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * RPW + sub;
+      const bool rok = row < rows;
+      mu[u] = rok ? mean_in[row] : 0.f;
+      rs[u] = rok ? rstd_in[row] : 0.f;
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+        const int64_t off = row * d + (li + c * LPR) * 8;
+        if (rok && cok[c]) {
+          load8<T>(x + off, xv[u][c]);
+          load8<T>(dy + off, gv[u][c]);
+          if (RELU) load8<T>(yout + off, rv[u][c]);
+          else if (dres) load8<T>(dres + off, rv[u][c]);
+          else zero8(rv[u][c]);
+        } else {
+          zero8(xv[u][c]); zero8(gv[u][c]); zero8(rv[u][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = base + u * RPW + sub;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < S; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float g = gv[u][c][j];
+          if (RELU) g = rv[u][c][j] > 0.f ? g : 0.f;
+          const float xhat = cok[c] ? (xv[u][c][j] - mu[u]) * rs[u] : 0.f;
+          const float dxh = g * gm[c][j];
+          g_acc[c][j] += g * xhat;
+          b_acc[c][j] += g;
+          s1 += dxh;
+          s2 += dxh * xhat;
+          xv[u][c][j] = xhat;
+          gv[u][c][j] = dxh;
+        }
+      const float c1 = group_sum<LPR>(s1) * inv_d, c2m = group_sum<LPR>(s2) * inv_d;
+#pragma unroll
+      for (int c = 0; c < S; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float o = rs[u] * (gv[u][c][j] - c1 - xv[u][c][j] * c2m);
+          if (!RELU) o += rv[u][c][j];
+          xv[u][c][j] = o;
+        }
+        if (row < rows && cok[c]) store8<T>(dx + row * d + (li + c * LPR) * 8, xv[u][c]);
+      }
+    }
+  }
+  // lanes with the same li (different rows of a pass) hold partial sums of the same columns
+#pragma unroll
+  for (int c = 0; c < S; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (LPR <= 16) { g_acc[c][j] = swap16_add(g_acc[c][j]); b_acc[c][j] = swap16_add(b_acc[c][j]); }
+      if (LPR <= 32) { g_acc[c][j] = swap32_add(g_acc[c][j]); b_acc[c][j] = swap32_add(b_acc[c][j]); }
+    }
+  if (sub == 0) {
+#pragma unroll
+    for (int c = 0; c < S; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[wave][0][(li + c * LPR) * 8 + j] = g_acc[c][j];
+        red[wave][1][(li + c * LPR) * 8 + j] = b_acc[c][j];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * W; i += 256) {
+    const int pass = i / W, e = i % W;
+    if (e < d)
+      partial[((int64_t)blockIdx.x * 2 + pass) * d + e] = (red[0][pass][e] + red[1][pass][e]) + (red[2][pass][e] + red[3][pass][e]);
+  }
+}
+
 // dgamma/dbeta (+)= sum over workgroups of partial[block][2][d].  16 columns x 16 row groups per workgroup: every
 // thread adds rows rg, rg+16, ... (independent loads), then the 16 row groups are combined through LDS.
 __global__ void __launch_bounds__(256) ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
@@ -215,8 +433,18 @@ __global__ void __launch_bounds__(256) ln_bwd_finalize_kernel(const float* __res
   const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int e = blockIdx.x * 16 + c;  // 0 .. 2*d-1
   float t = 0.f;
-  if (e < 2 * d)
-    for (int b = rg; b < blocks; b += 16) t += partial[(int64_t)b * 2 * d + e];
+  if (e < 2 * d) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;  // independent chains: the loads of one thread overlap
+    int b = rg;
+    for (; b + 48 < blocks; b += 64) {
+      t0 += partial[(int64_t)b * 2 * d + e];
+      t1 += partial[(int64_t)(b + 16) * 2 * d + e];
+      t2 += partial[(int64_t)(b + 32) * 2 * d + e];
+      t3 += partial[(int64_t)(b + 48) * 2 * d + e];
+    }
+    for (; b < blocks; b += 16) t0 += partial[(int64_t)b * 2 * d + e];
+    t = (t0 + t1) + (t2 + t3);
+  }
   sh[rg][c] = t;
   __syncthreads();
   if (rg == 0 && e < 2 * d) {
@@ -234,9 +462,25 @@ bool vec_ok(const void* a, const void* b, const void* c, int d) {
   return d % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & al) == 0;
 }
 
+// 8 elements per lane access: d multiple of 8 (rows then stay 16-byte aligned for bf16, 32 for f32), aligned bases
+template <typename T>
+bool wide_ok(int d, const void* a, const void* b, const void* c, const void* e) {
+  return d % 8 == 0 && d <= 1024 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)e) & 15) == 0);
+}
+
 template <typename T, bool RELU>
 int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
                int d, float eps, hipStream_t st) {
+  if (wide_ok<T>(d, x, y, gamma, beta)) {
+    const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
+    constexpr int U = 4;
+    int64_t wb = (rows + 4 * (64 / lpr) * U - 1) / (4 * (64 / lpr) * U);
+    if (wb > 65535) wb = 65535;
+#define NST_LN_FWDW(L, S) ln_fwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)x, gamma, beta, (T*)y, mean, rstd, rows, d, eps)
+    if (lpr == 16) NST_LN_FWDW(16, 1); else if (lpr == 32) NST_LN_FWDW(32, 1); else if (d <= 512) NST_LN_FWDW(64, 1); else NST_LN_FWDW(64, 2);
+#undef NST_LN_FWDW
+    return 0;
+  }
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
@@ -254,6 +498,17 @@ template <typename T, bool RELU>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
                hipStream_t st) {
+  if (partial && wide_ok<T>(d, x, dy, dx, RELU ? y : dres) && wide_ok<T>(d, gamma, nullptr, nullptr, nullptr)) {
+    const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
+    constexpr int U = 2;
+    int64_t wb = (rows + 4 * (64 / lpr) * U - 1) / (4 * (64 / lpr) * U);
+    if (wb > 512) wb = 512;
+    *nblocks = (int)wb;
+#define NST_LN_BWDW(L, S) ln_bwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial)
+    if (lpr == 16) NST_LN_BWDW(16, 1); else if (lpr == 32) NST_LN_BWDW(32, 1); else if (d <= 512) NST_LN_BWDW(64, 1); else NST_LN_BWDW(64, 2);
+#undef NST_LN_BWDW
+    return 0;
+  }
   int64_t blocks = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
   const int64_t cap = partial ? 1024 : 512;  // atomics: one per column per block, keep the fan-in per address small
   if (blocks > cap) blocks = cap;

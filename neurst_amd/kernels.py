@@ -123,8 +123,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
-         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1):
-    """C[M,N] = epilogue(alpha * op(A) @ op(B)); A/B are 2-D views with unit inner stride (see neurst_hip.h)."""
+         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False):
+    """C[M,N] = epilogue(alpha * op(A) @ op(B)); A/B are 2-D views with unit inner stride (see neurst_hip.h).
+    colsum_out [N] f32 (+)= column sums of B over the reduction (the bias gradient of a weight-gradient GEMM)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if out is None:
@@ -154,8 +155,11 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     d.accumulate = int(accumulate)
     d.split_k = split_k
     if split_k > 1:
-        ws = _workspace(split_k * M * N * 4, A.device)
+        ws = _workspace(split_k * (M + 1) * N * 4, A.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if colsum_out is not None:
+        assert colsum_out.dtype == torch.float32 and colsum_out.numel() == N and colsum_out.is_contiguous()
+        d.colsum, d.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
     check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
     return out
 
@@ -257,12 +261,14 @@ def conv2_dgrad(dy, w2, T1, F1):
     return dx
 
 
-def conv2_wgrad(x, dy, dw2, accumulate=False):
+def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
+    """dw2 (+)= x (*) dy ; db2 [C] (+)= sum over pixels of dy (same pass over dy)."""
     B, T1, F1, Cc = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
+    assert db2 is None or (db2.dtype == torch.float32 and db2.numel() == Cc and db2.is_contiguous())
     ws = _workspace(64 << 20, x.device)
-    check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), B, T1, F1, Cc, _dt(x), int(accumulate), ws.data_ptr(), ws.numel(),
-                              _stream()), "conv2_wgrad")
+    check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), _p(db2), B, T1, F1, Cc, _dt(x), int(accumulate), ws.data_ptr(),
+                              ws.numel(), _stream()), "conv2_wgrad")
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise

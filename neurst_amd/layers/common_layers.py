@@ -92,10 +92,12 @@ class Dense(Layer):
         """dkernel (+)= x^T dz ; dbias (+)= colsum(dz)."""
         st = self.rt.store
         rows = x.shape[0]
-        K.gemm(x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad,
-               accumulate=st.acc_flag(self.kernel), split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype))
-        if self.bias is not None:
-            K.colsum(dz, self.bias.grad, accumulate=st.acc_flag(self.bias))
+        acc_k = st.acc_flag(self.kernel)
+        bias_kw = {}
+        if self.bias is not None:  # dbias rides on the same pass over dz (ones^T.dz inside the MFMA loop)
+            bias_kw = dict(colsum_out=self.bias.grad, colsum_accumulate=st.acc_flag(self.bias))
+        K.gemm(x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad, accumulate=acc_k,
+               split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), **bias_kw)
 
     def backward_input(self, dz, **epi):
         """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""

@@ -88,7 +88,8 @@ def test_lds_transpose_read_map(K):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,d", [(7, 4), (37, 8), (300, 256), (100, 512), (33, 1024), (5, 250)])
+@pytest.mark.parametrize("rows,d", [(7, 4), (37, 8), (300, 256), (100, 512), (33, 1024), (5, 250), (1000, 128), (131, 64),
+                                    (20001, 256), (77, 768)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_layernorm(K, dtype, rows, d, relu):
     x = rnd(rows, d, dtype=dtype, seed=1)
@@ -183,6 +184,26 @@ def test_gemm_splitk_wgrad(K, dtype):
     out = torch.full((Kin, N), 3.0, dtype=torch.float32, device=DEV)
     K.gemm(X.to(DEV), dY.to(DEV), Kin, N, rows, trans_a=True, out=out, split_k=16, accumulate=True)
     close(f"gemm_wgrad_acc[{dtype}]", out, ref + 3.0, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,Kin,N", [(3000, 136, 264), (28800 // 8, 256, 768), (517, 2048, 256), (300, 130, 132)])
+def test_gemm_wgrad_fused_colsum(K, dtype, rows, Kin, N):
+    """dW = X^T.dZ with db = colsum(dZ) produced by the same kernel (MFMA ones-row), all split factors, accumulate;
+    the last shape is not 8-element granular and takes the separate column-sum pass behind the same interface."""
+    X, dZ = rnd(rows, Kin, dtype=dtype, seed=1), rnd(rows, N, dtype=dtype, seed=2)
+    ref_w, ref_b = X.double().t() @ dZ.double(), dZ.double().sum(0)
+    for split in (1, 5, 32):
+        dw = torch.full((Kin, N), 3.0, dtype=torch.float32, device=DEV)
+        db = torch.full((N,), 5.0, dtype=torch.float32, device=DEV)
+        K.gemm(X.to(DEV), dZ.to(DEV), Kin, N, rows, trans_a=True, out=dw, split_k=split, colsum_out=db)
+        tag = f"gemm_wgrad_colsum[{dtype},{rows}x{Kin}x{N},split{split}]"
+        close(tag + ".dw", dw, ref_w, dtype)
+        close(tag + ".db", db, ref_b, torch.float32)   # sums of the (already rounded) inputs: f32 accuracy either way
+        K.gemm(X.to(DEV), dZ.to(DEV), Kin, N, rows, trans_a=True, out=dw, split_k=split, accumulate=True, colsum_out=db,
+               colsum_accumulate=True)
+        close(tag + ".dw_acc", dw, 2 * ref_w, dtype)
+        close(tag + ".db_acc", db, 2 * ref_b, torch.float32)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -415,10 +436,17 @@ def test_conv2(K, dtype, B, T1, F1, C):
     dx = K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1)
     close(tag + ".dx", dx, xr.grad, dtype, scale=2.0)
     dw2 = torch.full((3, 3, C, C), 2.0, device=DEV)
-    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2)
+    db2 = torch.full((C,), 2.0, device=DEV)
+    db_ref = dy.double().sum((0, 1, 2))
+    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, db2=db2)
     close(tag + ".dw2", dw2, wr.grad, dtype, scale=2.0)
-    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, accumulate=True)
+    close(tag + ".db2", db2, db_ref, torch.float32)
+    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, db2=db2, accumulate=True)
     close(tag + ".dw2_acc", dw2, 2 * wr.grad, dtype, scale=2.0)
+    close(tag + ".db2_acc", db2, 2 * db_ref, torch.float32)
+    dw3 = torch.full((3, 3, C, C), 2.0, device=DEV)
+    K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw3)   # without the bias gradient
+    close(tag + ".dw2_nobias", dw3, wr.grad, dtype, scale=2.0)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise
