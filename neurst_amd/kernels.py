@@ -24,11 +24,13 @@ def dropout_inv_keep(p):
 
 def _workspace(nbytes, device):
     """Persistent scratch for two-stage reductions (split-K slabs, LayerNorm / bias-gradient partial sums); grown
-    on demand.  Every launch is ordered on one stream, so consecutive users never overlap."""
-    ws = _WS.get(device)
+    on demand.  One buffer per (device, stream): launches on one stream are ordered, so consecutive users never
+    overlap, and concurrent streams never share a buffer."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 

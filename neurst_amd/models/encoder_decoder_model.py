@@ -106,7 +106,12 @@ class EncoderDecoderModel(BaseModel):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
         self.rt.store.begin_backward(accumulate)
-        hook = self.grad_ready_hook or (lambda prefixes: None)
+        user_hook = self.grad_ready_hook or (lambda prefixes: None)
+
+        def hook(prefixes):  # a component's gradients are complete once its weight-gradient stream work is joined
+            self.rt.join_wgrad_stream()
+            user_hook(prefixes)
+
         shared = self._src_modality is self._trg_modality
         ddec = self._trg_modality.backward(dlogits, mode="linear")
         ddec_in, dmemory = self._decoder.backward(ddec)

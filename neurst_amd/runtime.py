@@ -7,7 +7,9 @@ forward registration order, so the data-parallel reducer can all-reduce contiguo
 backward pass has finished the layers they cover (neurst_amd/training/distributed.py).
 """
 import collections
+import contextlib
 import math
+import os
 
 import torch
 
@@ -128,6 +130,30 @@ class Runtime(object):
         self.step = 0
         self._sites = 0
         self._posenc_cache = {}
+        # Weight-gradient GEMMs do not feed the backward chain: they run on a second HIP stream so that their
+        # workgroups fill the ramp-up / tail gaps of the dgrad-path kernels (NST_WGRAD_STREAM=0 keeps one stream).
+        self.wgrad_stream = None
+        if self.device.type == "cuda" and os.environ.get("NST_WGRAD_STREAM", "1") != "0":
+            self.wgrad_stream = torch.cuda.Stream(self.device)
+
+    @contextlib.contextmanager
+    def on_wgrad_stream(self, *tensors):
+        """Runs the body on the weight-gradient stream, ordered after everything queued so far on the current
+        stream; `tensors` are the operands it reads (kept alive for that stream by the caching allocator)."""
+        s = self.wgrad_stream
+        if s is None:
+            yield
+            return
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            yield
+        for t in tensors:
+            t.record_stream(s)
+
+    def join_wgrad_stream(self):
+        """The current stream waits for every weight gradient queued so far."""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
 
     def new_dropout_site(self):
         self._sites += 1
