@@ -39,6 +39,36 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel_v2(DenseLoader<T> l
       la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem_dyn);
 }
 
+template <typename T, typename OutT, int AMODE, int BMODE, bool CS>
+__global__ void __launch_bounds__(THREADS, 2)
+dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;  // read through the kernarg segment, see gemm_stream_v3
+  gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS>(smem_dyn);
+}
+
+// workgroups of the persistent kernels: two per CU are resident (64 KB of LDS each); every workgroup gets the same
+// number of units, and the count is a multiple of 8 so that a workgroup keeps its XCD across units
+int v3_grid(int units) {
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    resident = 2 * (cus > 0 ? cus : 256);
+  }
+  if (units <= resident) return units;
+  const int rounds = (units + resident - 1) / resident;
+  int g = (units + rounds - 1) / rounds;
+  g = (g + 7) & ~7;
+  return g > units ? units : g;
+}
+
+int gemm_version() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_VERSION"); v = e ? atoi(e) : 3; }
+  return v;
+}
+
 template <typename KernelT>
 void allow_big_lds(KernelT kernel, int bytes) {
   static thread_local const void* done[64];
@@ -134,6 +164,28 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_OC, MODE_RC, NS); \
     else NST_GEMM_LAUNCH2(MODE_OC, MODE_OC, NS);                                           \
   } while (0)
+    if (gemm_version() >= 3) {
+      const int units = ntiles * split;
+      dim3 g3(v3_grid(units), 1, 1);
+      GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
+      ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
+      ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
+#define NST_GEMM_LAUNCH3(AM, BMO, CS_)                                                                                \
+  do {                                                                                                               \
+    auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_>;                                                           \
+    allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
+    kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
+  } while (0)
+      if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
+        if constexpr (sizeof(OutT) == 4) { NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, true); return 0; }
+      }
+      if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_RC, MODE_RC, false);
+      else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH3(MODE_RC, MODE_OC, false);
+      else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_OC, MODE_RC, false);
+      else NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, false);
+#undef NST_GEMM_LAUNCH3
+      return 0;
+    }
     if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
       if constexpr (sizeof(OutT) == 4) {
         auto kfn = dense_gemm_kernel_v2<T, OutT, MODE_OC, MODE_OC, 2, true>;

@@ -302,6 +302,7 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& ep, OutT* __rest
 }
 
 struct IdentityRowMap {
+  int unused = 0;  // keeps the struct a dword multiple (kernarg-resident arguments are copied dword-wise)
   __device__ __forceinline__ int64_t operator()(int row) const { return row; }
 };
 
@@ -549,6 +550,61 @@ struct DenseDma {
     step_bytes = MODE == MODE_RC ? (int64_t)Tile<T>::BK * (int64_t)sizeof(T) : (int64_t)Tile<T>::BK * ld.ld * (int64_t)sizeof(T);
     k_limit = MODE == MODE_RC ? ld.contig_limit : ld.outer_limit;
   }
+  // v3 streaming interface.  begin(): after init(), decides (wave-uniformly) whether every chunk of every K step of the
+  // unit lies inside the matrix; the cursors then only advance by a constant and the 4 DMA pieces go out back to back
+  // from one asm block (m0 = LDS base of the piece, +4 KB per piece).  Otherwise next() falls back to issue().
+  int n_fast;  // the first n_fast K steps of the unit are entirely inside the matrix (wave-uniform)
+  int t_next;
+  __device__ __forceinline__ void begin(int kt_count) {
+    bool ok = true;
+    int kmax = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ok = ok && ovalid[s];
+      kmax = kvalid_base[s] > kmax ? kvalid_base[s] : kmax;
+    }
+    // step t is inside iff kmax + t*BK < k_limit for the largest kmax of the wave
+    int nf = (k_limit - 1 - kmax) >= 0 ? (k_limit - 1 - kmax) / Tile<T>::BK + 1 : 0;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) nf = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(nf, o, 64); nf = other < nf ? other : nf; }
+    n_fast = __builtin_amdgcn_readfirstlane(nf < kt_count ? nf : kt_count);
+    t_next = 0;
+  }
+  __device__ __forceinline__ void next(uint32_t piece0_lds_addr_uniform, uint32_t tile_lds_addr, int wave) {
+    if (t_next < n_fast) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_add_u32 m0, m0, 0x1000\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off\n\t"
+          "s_add_u32 m0, m0, 0x1000\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %3, off\n\t"
+          "s_add_u32 m0, m0, 0x1000\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %4, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "s"(piece0_lds_addr_uniform)
+          : "memory", "scc");
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p[s] += step_bytes;
+    } else {  // edge steps: per-chunk bounds, out-of-range chunks read the zero block
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = ovalid[s] && (kvalid_base[s] + t_next * Tile<T>::BK) < k_limit;
+        const void* src = ok ? (const void*)p[s] : (const void*)g_nst_zero16;
+        glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+        p[s] += step_bytes;
+      }
+    }
+    ++t_next;
+  }
   // issue the DMA of K step `t` (relative to the r0 given to init) into the stage at tile_lds_addr
   __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
 #pragma unroll
@@ -576,6 +632,9 @@ struct TileDma {
   __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
     dma_tile<T, MODE, Loader>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
   }
+  int t_next;
+  __device__ __forceinline__ void begin(int) { t_next = 0; }
+  __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
 };
 template <typename T, int MODE>
 struct TileDma<T, MODE, DenseLoader<T>> : DenseDma<T, MODE> {};
@@ -692,6 +751,377 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + idx;
+}
+
+
+// =============================================================================================
+// v3: persistent stream of (output tile, K step) work over the same LDS-DMA stage ring.
+//
+//  * accumulators are kept TRANSPOSED: acc[i][j] = Bfrag[j] (MFMA A operand, rows = n) x Afrag[i] (MFMA B operand,
+//    columns = m), so lane l owns row m = i*16 + (l&15) and the 4 CONSECUTIVE columns n = j*16 + (l>>4)*4 + 0..3 of
+//    every 16x16 block.  The epilogue is then written straight from registers with 8-byte (bf16) / 16-byte (f32)
+//    stores -- no LDS transposition, no barrier, and the LDS stays free for the DMA ring;
+//  * a workgroup walks units u = blockIdx.x, +gridDim.x, ... (unit = output tile x split-K slice); the DMA of the
+//    first K step of unit u+1 is issued before the last K step of unit u is multiplied, so the global-load latency of
+//    a new tile and the stores of the finished one overlap (short-K GEMMs are otherwise dominated by both);
+//  * grid = units / ceil(units / resident workgroups): every workgroup gets the same number of units.
+// =============================================================================================
+// out-of-line copy of the per-element mask (keeps the rarely taken unaligned paths from bloating the kernels)
+__device__ __attribute__((noinline)) float dropout_keep_scale_call(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t thresh16,
+                                                                   float inv_keep) {
+  return dropout_keep_scale(seed, stream, idx, thresh16, inv_keep);
+}
+
+// register select acc[i][j][r] by a runtime index (compare/select chain; only the unaligned scalar epilogue uses it)
+__device__ __forceinline__ float acc_pick(const floatx4_t (&acc)[4][4], int q) {
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v = (q == (i * 4 + j) * 4 + r) ? acc[i][j][r] : v;
+  return v;
+}
+
+// v3 epilogue.  The accumulators of a wave (64x64 outputs, lane l: column j*16 + (l&15), rows i*16 + (l>>4)*4 + r) are
+// turned into row-major pieces through a 4 KB wave-private LDS buffer, 16 rows x 64 f32 at a time: afterwards lane l
+// owns the 16 consecutive columns (l&3)*16.. of row l>>2, i.e. 4 adjacent lanes cover one 128-byte (bf16) row segment
+// and the stores coalesce.  The buffer lives behind the DMA stages (it is never a DMA target), so the prefetch of
+// the next unit keeps running underneath.  16-byte chunk index ^= row & 3 keeps the b128 reads conflict free.
+constexpr int V3_EPI_BYTES_PER_WAVE = 16 * 64 * 4;
+constexpr int V3_LDS_BYTES = 2 * V2_STAGE_BYTES + 4 * V3_EPI_BYTES_PER_WAVE;  // 80 KB: two workgroups fill the 160 KB of a CU
+
+template <typename OutT>
+__device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict__ C, int64_t ldc, int row, int64_t out_row, int n, int N,
+                                               const Epilogue& ep) {
+  // v: outputs (row, n .. n+15) with alpha and bias already applied
+  if (ep.relu) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+  }
+  if (ep.drop_thresh) {
+    float m0[8], m1[8];
+    const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)n;  // multiple of 8 (N % 8 == 0, n % 16 == 0)
+    dropout_keep8(ep.seed, ep.stream_id, idx, ep.drop_thresh, ep.drop_inv_keep, m0);
+    dropout_keep8(ep.seed, ep.stream_id, idx + 8, ep.drop_thresh, ep.drop_inv_keep, m1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { v[r] *= m0[r]; v[8 + r] *= m1[r]; }
+  }
+  constexpr int NV = (int)sizeof(OutT);  // 16-byte vectors per 16 outputs: 2 (bf16) or 4 (f32)
+  const int nv = (n + 16 <= N) ? NV : NV / 2;  // N % 8 == 0: the last piece of a row may hold only 8 outputs
+  OutT tmp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tmp[r] = (OutT)0;
+  if (ep.residual) {
+    const OutT* p = reinterpret_cast<const OutT*>(ep.residual) + (int64_t)row * ep.ldr + n;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (q < nv) reinterpret_cast<uint4*>(tmp)[q] = reinterpret_cast<const uint4*>(p)[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += to_f32<OutT>(tmp[r]);
+  }
+  if (ep.gate_src) {
+    const OutT* p = reinterpret_cast<const OutT*>(ep.gate_src) + (int64_t)row * ep.ldg + n;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (q < nv) reinterpret_cast<uint4*>(tmp)[q] = reinterpret_cast<const uint4*>(p)[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] *= to_f32<OutT>(tmp[r]) > 0.f ? ep.gate_scale : 0.f;
+  }
+  if (ep.posenc) {
+    const float* p = ep.posenc + (int64_t)(row % ep.posenc_period) * N + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (n + q * 4 < N) {
+        const float4 pe = reinterpret_cast<const float4*>(p)[q];
+        v[q * 4 + 0] = v[q * 4 + 0] * ep.emb_scale + pe.x; v[q * 4 + 1] = v[q * 4 + 1] * ep.emb_scale + pe.y;
+        v[q * 4 + 2] = v[q * 4 + 2] * ep.emb_scale + pe.z; v[q * 4 + 3] = v[q * 4 + 3] * ep.emb_scale + pe.w;
+      }
+    }
+  }
+  OutT* o = C + out_row * ldc + n;
+  if (ep.atomic) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (n + r < N) atomicAdd(reinterpret_cast<float*>(o) + r, v[r]);
+    return;
+  }
+  if (ep.accumulate) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (q < nv) reinterpret_cast<uint4*>(tmp)[q] = reinterpret_cast<const uint4*>(o)[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += to_f32<OutT>(tmp[r]);
+  }
+  if (sizeof(OutT) == 2) {
+    reinterpret_cast<uint4*>(o)[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    if (nv == NV)
+      reinterpret_cast<uint4*>(o)[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nv) reinterpret_cast<float4*>(o)[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+  }
+}
+
+// one 16-row block i of the wave tile: acc_i[j][r] = output (row g*4 + r, column j*16 + lc) of the block
+template <typename OutT, typename RowMap>
+__device__ __forceinline__ void epi_block_v3(const floatx4_t (&a)[4], float* __restrict__ epi, OutT* __restrict__ C, int64_t ldc, int M,
+                                             int N, int row0, int nw, const float (&bias16)[16], const Epilogue& ep,
+                                             const RowMap& rowmap, int lane) {
+  const int g = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = g * 4 + r, chunk = (j * 4 + (lc >> 2)) ^ r;  // row & 3 == r
+      epi[row * 64 + chunk * 4 + (lc & 3)] = a[j][r];
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+  __builtin_amdgcn_wave_barrier();
+  const int rr = lane >> 2, c16 = lane & 3;  // this lane: row rr, columns c16*16 .. +15
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 x = *reinterpret_cast<const float4*>(epi + rr * 64 + (((c16 * 4 + q) ^ (rr & 3)) << 2));
+    v[q * 4 + 0] = x.x * ep.alpha + bias16[q * 4 + 0]; v[q * 4 + 1] = x.y * ep.alpha + bias16[q * 4 + 1];
+    v[q * 4 + 2] = x.z * ep.alpha + bias16[q * 4 + 2]; v[q * 4 + 3] = x.w * ep.alpha + bias16[q * 4 + 3];
+  }
+  __builtin_amdgcn_wave_barrier();  // every lane has read before the next block overwrites the buffer
+  const int row = row0 + rr, n = nw + c16 * 16;
+  if (row < M && n < N) epi_piece16_v3<OutT>(v, C, ldc, row, rowmap(row), n, N, ep);
+}
+
+template <typename OutT, typename RowMap>
+__device__ __forceinline__ void epilogue_v3(floatx4_t (&acc)[4][4], float* __restrict__ epi, OutT* __restrict__ C, int64_t ldc, int M,
+                                            int N, int mw, int nw, const Epilogue& ep, const RowMap& rowmap, int lane) {
+  if (ep.vec) {  // N % 8 == 0, 16-byte aligned rows; a 16-column piece may be cut to 8 at the right edge
+    const int c16 = lane & 3;
+    float bias16[16];
+    {
+      const int n = nw + c16 * 16;
+      // unconditional loads (zero block without a bias) consumed unconditionally: a load left pending on some path
+      // makes the compiler drain vmcnt(0) -- and with it the LDS-DMA prefetch -- inside the K loop
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* bp = (ep.bias && n + q * 4 < N) ? ep.bias + n + q * 4 : reinterpret_cast<const float*>(g_nst_zero16);
+        const float4 x = *reinterpret_cast<const float4*>(bp);
+        bias16[q * 4] = x.x; bias16[q * 4 + 1] = x.y; bias16[q * 4 + 2] = x.z; bias16[q * 4 + 3] = x.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(bias16[q]));
+    }
+    epi_block_v3<OutT, RowMap>(acc[0], epi, C, ldc, M, N, mw, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap>(acc[1], epi, C, ldc, M, N, mw + 16, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap>(acc[2], epi, C, ldc, M, N, mw + 32, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap>(acc[3], epi, C, ldc, M, N, mw + 48, nw, bias16, ep, rowmap, lane);
+  } else {  // unaligned / odd-N outputs: one element at a time in a rolled loop
+    const int g = lane >> 4, lc = lane & 15;
+#pragma unroll 1
+    for (int q = 0; q < 64; ++q) {
+      const int i = q >> 4, j = (q >> 2) & 3, r = q & 3;
+      const int row = mw + i * 16 + g * 4 + r, n = nw + j * 16 + lc;
+      const float v = acc_pick(acc, q);
+      if (row < M && n < N) epilogue_store<OutT>(ep, C, ldc, row, n, N, v, rowmap(row));
+    }
+  }
+}
+
+
+// Kernel arguments of the v3 kernels travel as ONE by-value struct, i.e. they sit at offset 0 of the kernarg segment.
+// The K loop keeps only its own bookkeeping in SGPRs; everything that is needed once per unit (loaders for the DMA
+// cursors, the whole Epilogue) is re-read from the kernarg segment through a laundered pointer at the point of use.
+// Left to itself the compiler keeps all ~100 scalars live across the loop and spills SGPRs to VGPR lanes inside it.
+#define NST_AS4 __attribute__((address_space(4)))
+template <typename OutT, typename ALoader, typename BLoader, typename RowMap>
+struct GemmArgs {
+  ALoader la;
+  BLoader lb;
+  OutT* C;
+  int64_t ldc;
+  int M, N, K, tiles_n, ntiles, split, kt_per_split;
+  Epilogue ep;
+  RowMap rowmap;
+};
+template <typename F>
+__device__ __forceinline__ F kload(const NST_AS4 F* p) {  // dword-wise copy: stays in the constant address space (s_load)
+  static_assert(sizeof(F) % 4 == 0, "kernarg structs are dword multiples");
+  uint32_t w[sizeof(F) / 4];
+  const NST_AS4 uint32_t* src = reinterpret_cast<const NST_AS4 uint32_t*>(p);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(F) / 4; ++i) w[i] = src[i];
+  return __builtin_bit_cast(F, w);
+}
+template <typename A>
+__device__ __forceinline__ const NST_AS4 A* launder(const NST_AS4 A* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap, bool CS>
+__device__ __forceinline__ void gemm_stream_v3(char* smem) {
+  typedef GemmArgs<OutT, ALoader, BLoader, RowMap> Args;
+  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  typedef SwzFrag<T, AMODE> RA;
+  typedef SwzFrag<T, BMODE> RB;
+  constexpr int BK = Tile<T>::BK;
+  constexpr int KS = Mma<T>::KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int ntiles = ka->ntiles, tiles_n = ka->tiles_n, kt_per_split = ka->kt_per_split;
+  const int kt_total = (ka->K + BK - 1) / BK;
+  const int units = ntiles * ka->split;
+  const bool has_cs = CS && ka->ep.colsum_dst != nullptr;
+
+  // unit -> tile origin and K range
+  struct Unit { int m0, n0, z, kt_first, kt_count; };
+  auto unit_of = [&](int u) {
+    Unit q;
+    q.z = u / ntiles;
+    const int tile = xcd_remap(u - q.z * ntiles, ntiles);
+    const int tm = tile / tiles_n;
+    q.m0 = tm * BM;
+    q.n0 = (tile - tm * tiles_n) * BN;
+    q.kt_first = q.z * kt_per_split;
+    q.kt_count = kt_total - q.kt_first;
+    if (q.kt_count > kt_per_split) q.kt_count = kt_per_split;
+    return q;
+  };
+
+  floatx4_t acc[4][4], cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  const typename RA::Frag ones = ones_frag<T>();
+
+  int iu = blockIdx.x;           // unit whose K steps are being issued
+  if (iu >= units) return;
+  int ikt = 0, ikt_count;        // next K step of iu to issue
+  TileDma<T, AMODE, ALoader> da;
+  TileDma<T, BMODE, BLoader> db;
+  ALoader la_cur;                // loader copies the cursors point at (generic TileDma keeps a pointer to its loader)
+  BLoader lb_cur;
+  auto cursor_init = [&](int u) {
+    const NST_AS4 Args* k2 = launder(ka);
+    la_cur = kload(&k2->la);
+    lb_cur = kload(&k2->lb);
+    const Unit q = unit_of(u);
+    ikt_count = q.kt_count;
+    da.init(la_cur, q.m0, q.kt_first * BK, wave, lane);
+    db.init(lb_cur, q.n0, q.kt_first * BK, wave, lane);
+    da.begin(q.kt_count);
+    db.begin(q.kt_count);
+  };
+  cursor_init(iu);
+  int cu = iu;                   // unit being multiplied
+  Unit cq = unit_of(cu);
+  int ckt = 0;
+
+  auto issue_next = [&](int stage) {
+    const uint32_t sa = smem_addr + stage * V2_STAGE_BYTES;
+    da.next(sa + wave * 1024, sa, wave);
+    db.next(sa + BM * KBYTES + wave * 1024, sa + BM * KBYTES, wave);
+    if (++ikt == ikt_count) {
+      iu += gridDim.x;
+      ikt = 0;
+      if (iu < units) cursor_init(iu);
+    }
+  };
+
+  issue_next(0);
+  int stage = 0;
+  while (true) {
+    wait_vmcnt<0>();                 // the K step about to be multiplied has landed (and older stores have retired)
+    __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is also done reading the other stage
+    asm volatile("" ::: "memory");
+    if (iu < units) issue_next(stage ^ 1);
+    const char* As = smem + stage * V2_STAGE_BYTES;
+    const char* Bs = As + BM * KBYTES;
+    const bool do_cs = has_cs && cq.m0 == 0 && wm == 0;  // wave-uniform
+    if constexpr (BK / KS == 2) {
+      // both halves of the K step are requested up front: the second set of fragments lands under the first 16 MFMAs
+      typename RA::Frag a0[4], a1[4];
+      typename RB::Frag b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wn + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = RA::read(As, wm + i * 16, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wn + j * 16, KS, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[i] = RA::read(As, wm + i * 16, KS, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a0[i], b0[j], acc[i][j]);
+      if (CS && do_cs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b0[j], cs[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a1[i], b1[j], acc[i][j]);
+      if (CS && do_cs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b1[j], cs[j]);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += KS) {
+        typename RA::Frag a[4];
+        typename RB::Frag b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = RB::read(Bs, wn + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = RA::read(As, wm + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        if (CS && do_cs) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b[j], cs[j]);
+        }
+      }
+    }
+    stage ^= 1;
+    if (++ckt == cq.kt_count) {
+      const NST_AS4 Args* k2 = launder(ka);
+      const Epilogue ep = kload(&k2->ep);
+      const RowMap rowmap = kload(&k2->rowmap);
+      const int M = k2->M, N = k2->N;
+      if (CS && do_cs && lane < 16) {  // every row of cs holds the column sums; lane = column within the 16-block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = cq.n0 + wn + j * 16 + lane;
+          if (col < N) {
+            float* dst = ep.colsum_dst + (int64_t)cq.z * ep.colsum_zstride + col;
+            *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
+          }
+        }
+      }
+      epilogue_v3<OutT, RowMap>(acc, reinterpret_cast<float*>(smem + 2 * V2_STAGE_BYTES + wave * V3_EPI_BYTES_PER_WAVE),
+                                k2->C + (int64_t)cq.z * ep.slab_stride, k2->ldc, M, N, cq.m0 + wm, cq.n0 + wn, ep, rowmap, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+      cu += gridDim.x;
+      if (cu >= units) break;
+      cq = unit_of(cu);
+      ckt = 0;
+    }
+  }
 }
 
 }  // namespace nstgemm
