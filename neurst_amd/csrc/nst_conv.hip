@@ -151,78 +151,110 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const float* __restrict_
   }
   const int nrows = B * T1;
   const float inv_c = 1.f / (float)C;
+  // dout row of output pixel (row, fo): 512 bytes per wave -- far too little per request to cover the HBM latency if
+  // loaded when needed, so the rows of the next GRP pixels are requested before the current GRP are processed
+  constexpr int GRP = 4;
+  auto load_gy = [&](const T* go, float (&gy)[S]) {
+    if (VEC) {
+#pragma unroll
+      for (int k = 0; k < S / 4; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c < C) {
+          if (sizeof(T) == 2) {
+            uint2 raw = *reinterpret_cast<const uint2*>(go + c);
+            gy[k * 4 + 0] = bf16_to_f32((bf16_t)(raw.x & 0xffff)); gy[k * 4 + 1] = bf16_to_f32((bf16_t)(raw.x >> 16));
+            gy[k * 4 + 2] = bf16_to_f32((bf16_t)(raw.y & 0xffff)); gy[k * 4 + 3] = bf16_to_f32((bf16_t)(raw.y >> 16));
+          } else {
+            float4 raw = *reinterpret_cast<const float4*>(go + c);
+            gy[k * 4 + 0] = raw.x; gy[k * 4 + 1] = raw.y; gy[k * 4 + 2] = raw.z; gy[k * 4 + 3] = raw.w;
+          }
+        } else {
+          gy[k * 4 + 0] = 0.f; gy[k * 4 + 1] = 0.f; gy[k * 4 + 2] = 0.f; gy[k * 4 + 3] = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int c = lane + s * 64;
+        gy[s] = c < C ? to_f32<T>(go[c]) : 0.f;
+      }
+    }
+  };
   for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
     const int b = row / T1, to = row - b * T1;
     c1_stage_rows(xs, src, b, to, T_, F, lane);
+    // LayerNorm statistics of the whole output row: lane f keeps pixels f and f+64, broadcast later by a lane read
+    float mean_lo = 0.f, mean_hi = 0.f, rstd_lo = 1.f, rstd_hi = 1.f;
+    if (layer_norm) {
+      const int64_t p0 = (int64_t)row * F1;
+      if (lane < F1) { mean_lo = mean_in[p0 + lane]; rstd_lo = rstd_in[p0 + lane]; }
+      if (lane + 64 < F1) { mean_hi = mean_in[p0 + lane + 64]; rstd_hi = rstd_in[p0 + lane + 64]; }
+    }
     __builtin_amdgcn_wave_barrier();
-    for (int fo = 0; fo < F1; ++fo) {
-      float x[9];
+    float gyn[GRP][S];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int u = 0; u < GRP; ++u) {
+      if (u < F1) load_gy(dout + ((int64_t)row * F1 + u) * C, gyn[u]);
+      else {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = xs[kh][2 * fo + kw];
-      const int64_t pix = (int64_t)row * F1 + fo;
-      const float mean = layer_norm ? mean_in[pix] : 0.f;
-      const float rstd = layer_norm ? rstd_in[pix] : 1.f;
-      const T* go = dout + pix * C;
-      float gy[S];
-      if (VEC) {
+        for (int s = 0; s < S; ++s) gyn[u][s] = 0.f;
+      }
+    }
+    for (int f0 = 0; f0 < F1; f0 += GRP) {
+      float gyc[GRP][S];
 #pragma unroll
-        for (int k = 0; k < S / 4; ++k) {
-          const int c = lane * 4 + k * 256;
-          if (c < C) {
-            if (sizeof(T) == 2) {
-              uint2 raw = *reinterpret_cast<const uint2*>(go + c);
-              gy[k * 4 + 0] = bf16_to_f32((bf16_t)(raw.x & 0xffff)); gy[k * 4 + 1] = bf16_to_f32((bf16_t)(raw.x >> 16));
-              gy[k * 4 + 2] = bf16_to_f32((bf16_t)(raw.y & 0xffff)); gy[k * 4 + 3] = bf16_to_f32((bf16_t)(raw.y >> 16));
+      for (int u = 0; u < GRP; ++u)
+#pragma unroll
+        for (int s = 0; s < S; ++s) gyc[u][s] = gyn[u][s];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u)
+        if (f0 + GRP + u < F1) load_gy(dout + ((int64_t)row * F1 + f0 + GRP + u) * C, gyn[u]);
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int fo = f0 + u;
+        if (fo < F1) {
+          float x[9];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = xs[kh][2 * fo + kw];
+          const float mean = __shfl(fo < 64 ? mean_lo : mean_hi, fo & 63, 64);
+          const float rstd = __shfl(fo < 64 ? rstd_lo : rstd_hi, fo & 63, 64);
+          float xh[S], dxh[S];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            float a = bias[s];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
+            float gv = gyc[u][s];
+            if (layer_norm) {
+              const float xhat = (a - mean) * rstd;
+              const float y = xhat * g[s] + be[s];
+              gv = y > 0.f ? gv : 0.f;
+              ag[s] += gv * xhat;
+              abe[s] += gv;
+              const float d = gv * g[s];
+              xh[s] = xhat;
+              dxh[s] = d;
+              s1 += d;
+              s2 += d * xhat;
             } else {
-              float4 raw = *reinterpret_cast<const float4*>(go + c);
-              gy[k * 4 + 0] = raw.x; gy[k * 4 + 1] = raw.y; gy[k * 4 + 2] = raw.z; gy[k * 4 + 3] = raw.w;
+              dxh[s] = a > 0.f ? gv : 0.f;
+              xh[s] = 0.f;
             }
-          } else {
-            gy[k * 4 + 0] = 0.f; gy[k * 4 + 1] = 0.f; gy[k * 4 + 2] = 0.f; gy[k * 4 + 3] = 0.f;
+          }
+          float c1 = 0.f, c2 = 0.f;
+          if (layer_norm) { c1 = wave_sum_fast(s1) * inv_c; c2 = wave_sum_fast(s2) * inv_c; }
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const float dz = layer_norm ? rstd * (dxh[s] - c1 - xh[s] * c2) : dxh[s];
+            const float dzc = c1_channel(lane, s, VEC) < C ? dz : 0.f;
+            ab[s] += dzc;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) aw[s][t] = fmaf(dzc, x[t], aw[s][t]);
           }
         }
-      } else {
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const int c = lane + s * 64;
-          gy[s] = c < C ? to_f32<T>(go[c]) : 0.f;
-        }
-      }
-      float xh[S], dxh[S];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        float a = bias[s];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a = fmaf(w[s][t], x[t], a);
-        float gv = gy[s];
-        if (layer_norm) {
-          const float xhat = (a - mean) * rstd;
-          const float y = xhat * g[s] + be[s];
-          gv = y > 0.f ? gv : 0.f;
-          ag[s] += gv * xhat;
-          abe[s] += gv;
-          const float d = gv * g[s];
-          xh[s] = xhat;
-          dxh[s] = d;
-          s1 += d;
-          s2 += d * xhat;
-        } else {
-          dxh[s] = a > 0.f ? gv : 0.f;
-          xh[s] = 0.f;
-        }
-      }
-      float c1 = 0.f, c2 = 0.f;
-      if (layer_norm) { c1 = wave_sum_fast(s1) * inv_c; c2 = wave_sum_fast(s2) * inv_c; }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const float dz = layer_norm ? rstd * (dxh[s] - c1 - xh[s] * c2) : dxh[s];
-        const float dzc = c1_channel(lane, s, VEC) < C ? dz : 0.f;
-        ab[s] += dzc;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) aw[s][t] = fmaf(dzc, x[t], aw[s][t]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -303,6 +335,73 @@ struct Im2colLoader {
     return r;
   }
 };
+
+}  // namespace
+
+// DMA cursor of the im2col operand when it is the row (RC) operand of the implicit GEMM (conv2 forward): the pixel of
+// every chunk is fixed for the whole tile, so its (b, t, f) decomposition and the 9 tap-validity bits are computed
+// once; a K step then only adds a wave-uniform tap/channel offset (the generic path re-derives three integer
+// divisions and a bounds check per 16-byte chunk per K step, which made the kernel VALU-bound on address math).
+namespace nstgemm {
+template <typename T>
+struct TileDma<T, MODE_RC, Im2colLoader<T>> {
+  const Im2colLoader<T>* ld;
+  int o0, r0, lane;
+  bool fastc;            // a K step never straddles a tap (C % BK == 0, aligned start)
+  const char* base[4];   // &x[b][2*to-1][2*fo-1][kchunk*E] of the chunk's pixel; only dereferenced under a valid tap
+  uint32_t tapmask[4];   // bit kh*3+kw: that tap of the pixel lies inside the image
+  __device__ __forceinline__ void init(const Im2colLoader<T>& l, int o0_, int r0_, int wave, int lane_) {
+    ld = &l; o0 = o0_; r0 = r0_; lane = lane_;
+    fastc = l.vec && (l.C % Tile<T>::BK) == 0 && (r0_ % Tile<T>::BK) == 0;
+    if (!fastc) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = (s * 4 + wave) * 64 + lane;
+      const int row = c >> 3, slot = c & 7;
+      const int kchunk = slot ^ ((row >> 1) & 7);
+      const int pixel = o0 + row;
+      uint32_t q, fo, b, to;
+      l.dF2.divmod((uint32_t)pixel, q, fo);
+      l.dT2.divmod(q, b, to);
+      uint32_t mask = 0;
+      if (pixel < l.outer_limit) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ti = 2 * (int)to + kh - 1, fi = 2 * (int)fo + kw - 1;
+            if (ti >= 0 && ti < l.T1 && fi >= 0 && fi < l.F1) mask |= 1u << (kh * 3 + kw);
+          }
+      }
+      tapmask[s] = mask;
+      base[s] = reinterpret_cast<const char*>(l.x + (((int64_t)b * l.T1 + (2 * (int)to - 1)) * l.F1 + (2 * (int)fo - 1)) * l.C +
+                                              kchunk * Tile<T>::E);
+    }
+  }
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
+    if (!fastc) {
+      dma_tile<T, MODE_RC, Im2colLoader<T>>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
+      return;
+    }
+    const int kk0 = r0 + t * Tile<T>::BK;  // wave-uniform
+    const int tap = (int)ld->dC.div((uint32_t)kk0), c0 = kk0 - tap * ld->C;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int64_t off = (((int64_t)kh * ld->F1 + kw) * ld->C + c0) * (int64_t)sizeof(T);
+    const bool kin = kk0 < ld->contig_limit;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = kin && ((tapmask[s] >> tap) & 1u);
+      const void* src = ok ? (const void*)(base[s] + off) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+    }
+  }
+  int t_next;
+  __device__ __forceinline__ void begin(int) { t_next = 0; }
+  __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
+};
+}  // namespace nstgemm
+
+namespace {
 
 // dgrad, one stride parity class (pt, pf): logical row = (b, th, fh) with ti = 2*th+pt, fi = 2*fh+pf.
 // Reduction index r = tapidx*C + co over the class's valid taps: kh in {1} (pt=0) or {0,2} (pt=1), same for kw.
@@ -388,6 +487,114 @@ struct DgradBLoader {  // RC: outer = ci, contig = r ; element = w2[tap][ci][co]
     return r;
   }
 };
+}  // namespace
+
+// Same idea for the two operands of the dgrad implicit GEMM (see the im2col cursor above): per chunk the class row
+// (or the input channel) is fixed, a K step adds a wave-uniform (tap, channel) offset.
+namespace nstgemm {
+template <typename T>
+struct TileDma<T, MODE_RC, DgradALoader<T>> {
+  const DgradALoader<T>* ld;
+  int o0, r0, lane;
+  bool fastc;
+  const char* base[4];   // &dy[b][th][fh][kchunk*E]
+  uint32_t tapmask[4];   // bit tapidx: (to, fo) of that tap lies inside dy
+  __device__ __forceinline__ void init(const DgradALoader<T>& l, int o0_, int r0_, int wave, int lane_) {
+    ld = &l; o0 = o0_; r0 = r0_; lane = lane_;
+    fastc = l.vec && (l.C % Tile<T>::BK) == 0 && (r0_ % Tile<T>::BK) == 0;
+    if (!fastc) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = (s * 4 + wave) * 64 + lane;
+      const int row = c >> 3, slot = c & 7;
+      const int kchunk = slot ^ ((row >> 1) & 7);
+      const int orow = o0 + row;
+      uint32_t q, fh, b, th;
+      l.dcf.divmod((uint32_t)orow, q, fh);
+      l.dct.divmod(q, b, th);
+      uint32_t mask = 0;
+      if (orow < l.outer_limit) {
+#pragma unroll
+        for (int tapidx = 0; tapidx < 4; ++tapidx) {
+          const int ih = l.nkw == 2 ? (tapidx >> 1) : tapidx, iw = l.nkw == 2 ? (tapidx & 1) : 0;
+          const int to = l.pt ? (ih == 0 ? (int)th + 1 : (int)th) : (int)th;
+          const int fo = l.pf ? (iw == 0 ? (int)fh + 1 : (int)fh) : (int)fh;
+          if (to < l.T2 && fo < l.F2) mask |= 1u << tapidx;
+        }
+      }
+      tapmask[s] = mask;
+      base[s] = reinterpret_cast<const char*>(l.dy + (((int64_t)b * l.T2 + (int)th) * l.F2 + (int)fh) * l.C + kchunk * Tile<T>::E);
+    }
+  }
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
+    if (!fastc) {
+      dma_tile<T, MODE_RC, DgradALoader<T>>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
+      return;
+    }
+    const int kk0 = r0 + t * Tile<T>::BK;  // wave-uniform
+    const int tapidx = (int)ld->dC.div((uint32_t)kk0), c0 = kk0 - tapidx * ld->C;
+    const int ih = ld->nkw == 2 ? (tapidx >> 1) : tapidx, iw = ld->nkw == 2 ? (tapidx & 1) : 0;
+    const int dto = (ld->pt && ih == 0) ? 1 : 0, dfo = (ld->pf && iw == 0) ? 1 : 0;
+    const int64_t off = (((int64_t)dto * ld->F2 + dfo) * ld->C + c0) * (int64_t)sizeof(T);
+    const bool kin = kk0 < ld->contig_limit;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = kin && ((tapmask[s] >> tapidx) & 1u);
+      const void* src = ok ? (const void*)(base[s] + off) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+    }
+  }
+  int t_next;
+  __device__ __forceinline__ void begin(int) { t_next = 0; }
+  __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
+};
+
+template <typename T>
+struct TileDma<T, MODE_RC, DgradBLoader<T>> {
+  const DgradBLoader<T>* ld;
+  int o0, r0, lane;
+  bool fastc;
+  const char* base[4];   // &w2[0][ci][kchunk*E]
+  bool ovalid[4];
+  __device__ __forceinline__ void init(const DgradBLoader<T>& l, int o0_, int r0_, int wave, int lane_) {
+    ld = &l; o0 = o0_; r0 = r0_; lane = lane_;
+    fastc = l.vec && (l.C % Tile<T>::BK) == 0 && (r0_ % Tile<T>::BK) == 0;
+    if (!fastc) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = (s * 4 + wave) * 64 + lane;
+      const int row = c >> 3, slot = c & 7;
+      const int kchunk = slot ^ ((row >> 1) & 7);
+      const int ci = o0 + row;
+      ovalid[s] = ci < l.outer_limit;
+      base[s] = reinterpret_cast<const char*>(l.w2 + (int64_t)ci * l.C + kchunk * Tile<T>::E);
+    }
+  }
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
+    if (!fastc) {
+      dma_tile<T, MODE_RC, DgradBLoader<T>>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
+      return;
+    }
+    const int kk0 = r0 + t * Tile<T>::BK;
+    const int tapidx = (int)ld->dC.div((uint32_t)kk0), c0 = kk0 - tapidx * ld->C;
+    const int ih = ld->nkw == 2 ? (tapidx >> 1) : tapidx, iw = ld->nkw == 2 ? (tapidx & 1) : 0;
+    const int kh = ld->pt ? (ih == 0 ? 0 : 2) : 1, kw = ld->pf ? (iw == 0 ? 0 : 2) : 1;
+    const int64_t off = ((int64_t)(kh * 3 + kw) * ld->C * ld->C + c0) * (int64_t)sizeof(T);
+    const bool kin = kk0 < ld->contig_limit;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = kin && ovalid[s];
+      const void* src = ok ? (const void*)(base[s] + off) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+    }
+  }
+  int t_next;
+  __device__ __forceinline__ void begin(int) { t_next = 0; }
+  __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
+};
+}  // namespace nstgemm
+
+namespace {
 struct DgradRowMap {  // class row -> pixel row of dx [B*T1*F1]
   int T1, F1, ct, cf, pt, pf;
   FastDiv dcf, dct;
