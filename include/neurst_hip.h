@@ -187,6 +187,13 @@ int nst_conv2_wgrad(const void* x, const void* dy, float* dw2, float* db2, int B
  * y = relu(LN(x)); backward takes dy w.r.t. the ReLU output and the saved y (gate y>0). */
 int nst_layernorm_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                            int64_t rows, int d, float eps, int dtype, void* stream);
+/* nst_layernorm_bwd that also emits dz = dropout_backward(dx) with the mask Philox(seed, stream_id, element index) of
+ * the sublayer that consumes dx next (PrePostProcessingWrapper, common_layers.py:80-84): the pre-norm residual chain
+ * feeds every dx through exactly that dropout mask, so the extra pass over dx is folded into this kernel. */
+int nst_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                              const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed, uint64_t stream_id,
+                              float* dgamma, float* dbeta, int64_t rows, int d, int dtype, int accumulate,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream);

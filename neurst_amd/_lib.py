@@ -60,6 +60,7 @@ SIGNATURES = {
     "nst_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "nst_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],

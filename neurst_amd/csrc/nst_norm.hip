@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
                                                          const T* __restrict__ yout, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const T* __restrict__ dres, T* __restrict__ dx, int64_t rows, int d,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, T* __restrict__ dz, uint32_t dz_thresh,
+                                                         float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid) {
   constexpr int RPW = 64 / LPR;
   constexpr int W = LPR * S * 8;  // padded row width
   __shared__ float red[4][2][W];
@@ -396,7 +397,17 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
           if (!RELU) o += rv[u][c][j];
           xv[u][c][j] = o;
         }
-        if (row < rows && cok[c]) store8<T>(dx + row * d + (li + c * LPR) * 8, xv[u][c]);
+        if (row < rows && cok[c]) {
+          const int64_t off = row * d + (li + c * LPR) * 8;
+          store8<T>(dx + off, xv[u][c]);
+          if (dz) {  // second output: the dropout backward of dx for the sublayer that consumes it next
+            float m[8];
+            dropout_keep8(dz_seed, dz_sid, (uint64_t)off, dz_thresh, dz_inv_keep, m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[u][c][j] *= m[j];
+            store8<T>(dz + off, xv[u][c]);
+          }
+        }
       }
     }
   }
@@ -497,14 +508,15 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
 template <typename T, bool RELU>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
-               hipStream_t st) {
+               hipStream_t st, void* dz, uint32_t dz_thresh, float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid, bool* dz_done) {
   if (partial && wide_ok<T>(d, x, dy, dx, RELU ? y : dres) && wide_ok<T>(d, gamma, nullptr, nullptr, nullptr)) {
     const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
     constexpr int U = 2;
     int64_t wb = (rows + 4 * (64 / lpr) * U - 1) / (4 * (64 / lpr) * U);
     if (wb > 512) wb = 512;
     *nblocks = (int)wb;
-#define NST_LN_BWDW(L, S) ln_bwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial)
+#define NST_LN_BWDW(L, S) ln_bwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid)
+    *dz_done = true;
     if (lpr == 16) NST_LN_BWDW(16, 1); else if (lpr == 32) NST_LN_BWDW(32, 1); else if (d <= 512) NST_LN_BWDW(64, 1); else NST_LN_BWDW(64, 2);
 #undef NST_LN_BWDW
     return 0;
@@ -544,12 +556,18 @@ int ln_fwd_common(const void* x, const float* gamma, const float* beta, void* y,
 
 int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
-                  int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu) {
+                  int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu, void* dz = nullptr, float dz_p = 0.f,
+                  uint64_t dz_seed = 0, uint64_t dz_sid = 0) {
   NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
   NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
   NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "layernorm_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
+  NST_CHECK_ARG(dz_p >= 0.f && dz_p < 1.f, "layernorm_bwd: dropout_p=%f", dz_p);
+  uint32_t dz_thresh = 0;
+  float dz_inv_keep = 1.f;
+  nst_dropout_params16(dz_p, &dz_thresh, &dz_inv_keep);
+  bool dz_done = false;
   float* partial = (ws && ws_bytes >= (int64_t)2048 * 2 * d * 4 && ((((uintptr_t)ws) & 3) == 0)) ? (float*)ws : nullptr;
   if (!accumulate && (!partial || rows <= 0)) {
     NST_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * d, st));
@@ -558,17 +576,19 @@ int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gam
   if (rows <= 0) return NST_OK;
   int nblocks = 0;
   if (dtype == NST_F32) {
-    if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
-    else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
+    if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
+    else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
   } else {
-    if (relu) launch_bwd<bf16_t, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
-    else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st);
+    if (relu) launch_bwd<bf16_t, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
+    else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
   }
   NST_CHECK_LAUNCH("layernorm_bwd");
   if (partial) {
     ln_bwd_finalize_kernel<<<(2 * d + 15) / 16, 256, 0, st>>>(partial, dgamma, dbeta, nblocks, d, accumulate);
     NST_CHECK_LAUNCH("layernorm_bwd(finalize)");
   }
+  if (dz && !dz_done)  // narrow / unaligned rows: separate element-wise pass
+    return nst_scale_dropout_bwd(dx, dz, rows * d, 1.0f, dz_p, dz_seed, dz_sid, dtype, stream);
   return NST_OK;
 }
 
@@ -587,6 +607,14 @@ extern "C" int nst_layernorm_bwd(const void* dy, const void* x, const float* gam
                                  int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
                        workspace_bytes, stream, false);
+}
+extern "C" int nst_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                         const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed,
+                                         uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                                         int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  NST_CHECK_ARG(dz, "layernorm_bwd_dropout: null dz");
+  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, false, dz, dropout_p, seed, stream_id);
 }
 extern "C" int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d,

@@ -101,13 +101,24 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None):
-    """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x))."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None):
+    """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x)).
+    emit_dropout=(p, seed, site): also returns dz = dropout_backward(dx) under that mask -> (dx, dz)."""
     assert dy.is_contiguous() and x.is_contiguous()
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
     ws = _workspace(64 << 20, x.device)
+    if emit_dropout is not None:
+        assert y is None
+        p, seed, site = emit_dropout
+        dz = torch.empty_like(x)
+        if dres is not None:
+            assert dres.is_contiguous() and dres.dtype == x.dtype
+        check(lib.nst_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dz), p, seed,
+                                            site, _p(dgamma), _p(dbeta), rows, d, _dt(x), int(accumulate), ws.data_ptr(),
+                                            ws.numel(), _stream()), "layernorm_bwd_dropout")
+        return dx, dz
     if y is not None:
         assert dres is None
         check(lib.nst_layernorm_relu_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),

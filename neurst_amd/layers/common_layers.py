@@ -64,14 +64,33 @@ class LayerNorm(Layer):
             self._saved = (x, mean, rstd)
         return y
 
-    def backward(self, dy, dres=None):
+    def backward(self, dy, dres=None, consumer=None):
+        """consumer: the dropout site (object with .site and .drop_rate()) that receives dx next; its dropout backward
+        is then produced by the same kernel and attached to dx (see dropped_grad)."""
         x, mean, rstd = self._saved
         self._saved = None
         st = self.rt.store
         acc = st.acc_flag(self.gamma)
         st.acc_flag(self.beta)
+        p = consumer.drop_rate() if consumer is not None else 0.0
+        if p > 0:
+            dx, dz = K.layernorm_bwd(dy, x, self.gamma.data, mean, rstd, self.gamma.grad, self.beta.grad, accumulate=acc,
+                                     dres=dres, emit_dropout=(p, self.rt.step_seed, consumer.site))
+            dx._nst_dropped = (consumer.site, dz)
+            return dx
         return K.layernorm_bwd(dy, x, self.gamma.data, mean, rstd, self.gamma.grad, self.beta.grad, accumulate=acc,
                                dres=dres)
+
+
+def dropped_grad(rt, dy, p, site):
+    """dropout backward of dy under mask (step seed, site): taken from the tensor if the producing LayerNorm backward
+    already emitted it, computed by the element-wise kernel otherwise."""
+    if p <= 0:
+        return dy
+    tag = getattr(dy, "_nst_dropped", None)
+    if tag is not None and tag[0] == site:
+        return tag[1]
+    return K.scale_dropout_bwd(dy, 1.0, p, rt.step_seed, site)
 
 
 class Dense(Layer):
@@ -164,11 +183,13 @@ class PrePostProcessingWrapper(Layer):
         self._p = p
         return self.layer.forward(y, is_training=is_training, epilogue=epi, **kwargs)
 
-    def backward(self, dy):
-        p = self._p
-        dz = K.scale_dropout_bwd(dy, 1.0, p, self.rt.step_seed, self.site) if p > 0 else dy
+    def drop_rate(self):
+        return self._p
+
+    def backward(self, dy, consumer=None):
+        dz = dropped_grad(self.rt, dy, self._p, self.site)
         dn = self.layer.backward(dz)
-        return self.norm.backward(dn, dres=dy)
+        return self.norm.backward(dn, dres=dy, consumer=consumer)
 
 
 class PositionEmbeddingWrapper(Layer):

@@ -4,7 +4,7 @@ import torch
 
 from neurst_amd import kernels as K
 from neurst_amd.layers import layer_utils
-from neurst_amd.layers.common_layers import LayerNorm
+from neurst_amd.layers.common_layers import LayerNorm, dropped_grad
 from neurst_amd.layers.decoders.decoder import Decoder, register_decoder
 from neurst_amd.layers.transformer_layers import TransformerDecoderLayer
 
@@ -78,14 +78,24 @@ class TransformerDecoder(Decoder):
         """Returns (d decoder_inputs [B,L,d], d memory [B,Tm,d])."""
         B, L, d, Tm = self._shapes
         dmemory = torch.empty(B * Tm, d, dtype=dout.dtype, device=dout.device) if Tm else None
-        dx = self._output_norm_layer.backward(dout.reshape(B * L, d))
+        layers = self._stacking_layers
+        dx = self._output_norm_layer.backward(dout.reshape(B * L, d),
+                                              consumer=layers[-1].first_backward_site if layers else self)
         first = True
-        for layer in reversed(self._stacking_layers):
-            dx = layer.backward(dx, dmemory, dmemory_accumulate=not first)
-            if layer._with_cross_attention:
+        for i in range(len(layers) - 1, -1, -1):
+            dx = layers[i].backward(dx, dmemory, dmemory_accumulate=not first,
+                                    consumer=layers[i - 1].first_backward_site if i > 0 else self)
+            if layers[i]._with_cross_attention:
                 first = False
-        if self._p > 0:
-            dx = K.scale_dropout_bwd(dx, 1.0, self._p, self.rt.step_seed, self._site)
+        dx = dropped_grad(self.rt, dx, self._p, self._site)
         if dmemory is not None and first:
             dmemory.zero_()
         return dx.view(B, L, d), (dmemory.view(B, Tm, d) if dmemory is not None else None)
+
+    # the decoder's input dropout as a dropout site (see LayerNorm.backward)
+    @property
+    def site(self):
+        return self._site
+
+    def drop_rate(self):
+        return self._p

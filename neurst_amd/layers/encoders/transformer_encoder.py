@@ -3,7 +3,7 @@ import torch
 
 from neurst_amd import kernels as K
 from neurst_amd.layers import layer_utils
-from neurst_amd.layers.common_layers import LayerNorm
+from neurst_amd.layers.common_layers import dropped_grad, LayerNorm
 from neurst_amd.layers.encoders.encoder import Encoder, register_encoder
 from neurst_amd.layers.transformer_layers import TransformerEncoderLayer
 
@@ -60,9 +60,20 @@ class TransformerEncoder(Encoder):
 
     def backward(self, dout):
         B, T, d = dout.shape
-        dx = self._output_norm_layer.backward(dout.reshape(B * T, d))
-        for layer in reversed(self._stacking_layers):
-            dx = layer.backward(dx)
-        if self._p > 0:
-            dx = K.scale_dropout_bwd(dx, 1.0, self._p, self.rt.step_seed, self._site)
+        layers = self._stacking_layers
+        # every gradient on the residual chain next meets a dropout mask: the LayerNorm backward that produces it also
+        # emits the masked copy (consumer = that dropout site), saving one element-wise pass per sublayer
+        dx = self._output_norm_layer.backward(dout.reshape(B * T, d),
+                                              consumer=layers[-1].first_backward_site if layers else self)
+        for i in range(len(layers) - 1, -1, -1):
+            dx = layers[i].backward(dx, consumer=layers[i - 1].first_backward_site if i > 0 else self)
+        dx = dropped_grad(self.rt, dx, self._p, self._site)
         return dx.view(B, T, d)
+
+    # the encoder's input dropout as a dropout site (see LayerNorm.backward)
+    @property
+    def site(self):
+        return self._site
+
+    def drop_rate(self):
+        return self._p

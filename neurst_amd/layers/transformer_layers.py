@@ -26,8 +26,14 @@ class TransformerEncoderLayer(Layer):
         y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=False)
         return self._ffn_layer.forward(y, is_training)
 
-    def backward(self, dy):
-        return self._selfatt_layer.backward(self._ffn_layer.backward(dy))
+    @property
+    def first_backward_site(self):
+        """The dropout site that receives this layer's incoming gradient first (the FFN wrapper)."""
+        return self._ffn_layer
+
+    def backward(self, dy, consumer=None):
+        """consumer: dropout site that receives the returned gradient next (see LayerNorm.backward)."""
+        return self._selfatt_layer.backward(self._ffn_layer.backward(dy, consumer=self._selfatt_layer), consumer=consumer)
 
 
 class _CrossAttentionAdapter(object):
@@ -79,9 +85,15 @@ class TransformerDecoderLayer(Layer):
             y = self._crossatt_layer.forward(y, is_training, memory=memory, B=B, Tq=L, Tk=Tm, memory_bias=memory_bias)
         return self._ffn_layer.forward(y, is_training)
 
-    def backward(self, dy, dmemory, dmemory_accumulate):
-        d = self._ffn_layer.backward(dy)
+    @property
+    def first_backward_site(self):
+        return self._ffn_layer
+
+    def backward(self, dy, dmemory, dmemory_accumulate, consumer=None):
         if self._with_cross_attention:
+            d = self._ffn_layer.backward(dy, consumer=self._crossatt_layer)
             self._cross.dmemory, self._cross.dmemory_accumulate = dmemory, dmemory_accumulate
-            d = self._crossatt_layer.backward(d)
-        return self._selfatt_layer.backward(d)
+            d = self._crossatt_layer.backward(d, consumer=self._selfatt_layer)
+        else:
+            d = self._ffn_layer.backward(dy, consumer=self._selfatt_layer)
+        return self._selfatt_layer.backward(d, consumer=consumer)

@@ -117,6 +117,19 @@ def test_layernorm(K, dtype, rows, d, relu):
     if not relu or dtype == torch.float32:  # relu gate on a bf16-rounded y can flip near zero
         close(tag + ".dgamma", dgamma, gr.grad, dtype, scale=2.0)
         close(tag + ".dbeta", dbeta, br.grad, dtype, scale=2.0)
+    if not relu:  # second output: dropout backward of dx under the consumer's mask, bit-identical to the stand-alone kernel
+        dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        dx2, dz2 = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dg2, db2, dres=dres.to(DEV),
+                                   emit_dropout=(0.3, 11, 5))
+        assert torch.equal(dx2, dx)
+        dz_ref = K.scale_dropout_bwd(dx2, 1.0, 0.3, 11, 5)
+        if dtype == torch.float32:
+            assert torch.equal(dz2, dz_ref)
+        else:  # the fused output is rounded once from the f32 gradient, the stand-alone kernel re-rounds the bf16 dx
+            assert torch.equal(dz2 == 0, dz_ref == 0)
+            close(tag + ".dz_emit", dz2, dz_ref.float().cpu().double(), dtype)
+        kept = float((dz2 != 0).float().mean())
+        assert rows * d < 2000 or abs(kept - 0.7) < 0.05
     # accumulate
     before = dgamma.clone()
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, accumulate=True,
