@@ -11,6 +11,7 @@ Activations are 2-D ``[B*T, d]`` row-major tensors.
   PositionEmbeddingWrapper   neurst/layers/common_layers.py:298-446
 """
 import math
+import os
 
 import torch
 
@@ -31,12 +32,15 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
     return (torch.rand(*shape, generator=gen, dtype=torch.float64) * 2 - 1).mul_(lim).float()
 
 
+_WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
+
+
 def _wgrad_split(rows, k_in, n_out, dtype):
-    """split-K factor for dW[k_in, n_out] = X^T dY reduced over `rows`."""
+    """split-K factor for dW[k_in, n_out] = X^T dY reduced over `rows`: tiles*split ~ _WGRAD_UNITS workgroups."""
     tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
     bk = 64 if dtype == torch.bfloat16 else 32
     kt = (rows + bk - 1) // bk
-    return max(1, min(512 // max(tiles, 1), kt // 8))
+    return max(1, min(_WGRAD_UNITS // max(tiles, 1), kt // 8))
 
 
 class Layer(object):
