@@ -336,6 +336,320 @@ struct Im2colLoader {
   }
 };
 
+
+// =============================================================================================
+// layer 1 backward on the matrix cores (bf16 activations, C a multiple of 16, C <= 256).
+//
+// The VALU kernel above spends 9 + 9 fp32 FMAs per output element (recomputed conv + tap gradient); both are tiny
+// GEMMs, so a wave takes 32 consecutive output pixels and runs, per block of 16 channels,
+//   (1)  Z[pix, c]   = P[pix, :] . W[:, c]          one v_mfma_f32_16x16x32_bf16 per 16 pixels: the 32 K slots hold
+//        x_hi*w_hi + x_hi*w_lo + x_lo*w_hi for the 9 taps plus 1*b_hi + 1*b_lo (bf16 hi/lo splits of the fp32 inputs:
+//        the recomputed pre-norm activation agrees with the fp32 forward to ~2^-16 relative);
+//   (2)  dW[t, c]   += P^T[t, pix] . dZ[pix, c]      one MFMA per 32 pixels; row 9 of P^T is all ones, so the same
+//        instruction accumulates db1.  dZ reaches the B operand straight from the registers that computed it: a
+//        16x16 accumulator holds rows (l>>4)*4+r of column l&15, i.e. 4 (per tile) x 2 tiles = the 8 reduction slots
+//        of lane l -- the A operand simply enumerates the pixels in the same order.
+// The LayerNorm backward needs two per-pixel channel means first, hence two passes over the channel blocks (Z is
+// recomputed in the second: two MFMAs).  dgamma / dbeta are accumulated per lane and reduced at the end.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(2))) unsigned c1_uint2_t;
+__device__ __forceinline__ float c1_swap16_add(float v) {
+  const c1_uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float c1_swap32_add(float v) {
+  const c1_uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lanes that share l>>4
+  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+  return v;
+}
+__device__ __forceinline__ void c1_split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16(x);
+  lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+constexpr int C1M_PT = 12;  // floats per pixel in the wave's patch table: 9 taps, -mean*rstd, rstd, pixel mask
+constexpr int C1M_WAVES = 4;  // one wave per SIMD: the kernel needs ~300 registers (64 MFMA accumulators + per-pixel state)
+
+template <int NCB>
+struct C1mLds {
+  uint4 w[NCB][64];                    // B operand of product (1) per channel block
+  float2 gb[NCB * 16];                 // (gamma, beta)
+  float pt[C1M_WAVES][32][C1M_PT];     // per-wave patch table
+  char dst[C1M_WAVES][32 * NCB * 32];  // per-wave dout tile: 32 pixels x C bf16, 32-byte units XOR-swizzled by (pix>>2)&3
+};
+
+template <int NCB, bool LN>
+__global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
+    const float* __restrict__ src, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const bf16_t* __restrict__ dout, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int T_, int F, int T1, int F1, int64_t npix, FastDiv dF1, FastDiv dT1) {
+  constexpr int C = NCB * 16;
+  constexpr int ROWB = C * 2;  // bytes per pixel row of dout
+  extern __shared__ __attribute__((aligned(16))) char c1m_smem[];
+  C1mLds<NCB>& L = *reinterpret_cast<C1mLds<NCB>*>(c1m_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lc = lane & 15;
+
+  // ---- weights -> MFMA B fragments (once per workgroup).  K slot (g, j) carries, for channel c:
+  //   g=0: w_hi[tap j]   g=1: w_lo[tap j]   g=2: w_hi[tap j]   (taps 0..7; the A side holds x_hi, x_hi, x_lo)
+  //   g=3: j=0 w_hi[8], j=1 w_lo[8], j=2 w_hi[8], j=3 b_hi, j=4 b_lo, j=5..7 zero
+  for (int i = tid; i < NCB * 64; i += C1M_WAVES * 64) {
+    const int cb = i >> 6, l = i & 63, gg = l >> 4, c = cb * 16 + (l & 15);
+    bf16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16_t hi, lo;
+      float x = 0.f;
+      bool want_lo = false;
+      if (gg < 3) { x = w1[j * C + c]; want_lo = (gg == 1); }
+      else if (j < 3) { x = w1[8 * C + c]; want_lo = (j == 1); }
+      else if (j < 5) { x = b1[c]; want_lo = (j == 4); }
+      c1_split_bf16(x, hi, lo);
+      v[j] = want_lo ? lo : hi;
+    }
+    uint4 pk;
+    pk.x = v[0] | ((uint32_t)v[1] << 16); pk.y = v[2] | ((uint32_t)v[3] << 16);
+    pk.z = v[4] | ((uint32_t)v[5] << 16); pk.w = v[6] | ((uint32_t)v[7] << 16);
+    L.w[cb][l] = pk;
+  }
+  for (int c = tid; c < C; c += C1M_WAVES * 64) L.gb[c] = LN ? make_float2(gamma[c], beta[c]) : make_float2(1.f, 0.f);
+  __syncthreads();
+
+  floatx4_t accw[NCB];
+  float ag[NCB], abe[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) { accw[cb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; ag[cb] = 0.f; abe[cb] = 0.f; }
+  const float inv_c = 1.f / (float)C;
+  float(*pt)[C1M_PT] = L.pt[wave];
+  char* dst = L.dst[wave];
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t dst_addr = (uint32_t)(uintptr_t)((lds_char_ptr)dst);
+  const int64_t ngroups = (npix + 31) / 32;
+
+  for (int64_t grp = (int64_t)blockIdx.x * C1M_WAVES + wave; grp < ngroups; grp += (int64_t)gridDim.x * C1M_WAVES) {
+    const int64_t p0 = grp * 32;
+    __builtin_amdgcn_wave_barrier();  // every lane is done with the previous group's tables
+    // ---- dout tile -> LDS by LDS-DMA (1 KB = 2 pixel rows per instruction)
+    {
+      constexpr int NI = 32 * ROWB / 1024;  // instructions per tile
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int byte = i * 1024 + lane * 16;
+        const int pix = byte / ROWB, chunk = (byte % ROWB) >> 4;
+        const int64_t p = p0 + pix;
+        const int schunk = chunk ^ (((pix >> 2) & 3) << 1);  // source chunk that lands at this LDS position
+        const void* srcp = p < npix ? (const void*)(reinterpret_cast<const char*>(dout) + p * ROWB + schunk * 16)
+                                    : (const void*)g_nst_zero16;  // pixels past the end stage zeros
+        glds16(srcp, dst_addr + i * 1024);
+      }
+    }
+    // ---- patch table: lane l < 32 gathers the 9 taps (zero padded) and the LN statistics of pixel p0 + l
+    if (lane < 32) {
+      const int64_t p = p0 + lane;
+      float x[9];
+      float nmr = 0.f, rs = 0.f, msk = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[t] = 0.f;
+      if (p < npix) {
+        uint32_t row, fo, b, to;
+        dF1.divmod((uint32_t)p, row, fo);
+        dT1.divmod(row, b, to);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ti = 2 * (int)to + kh - 1;
+          if (ti >= 0 && ti < T_) {
+            const float* sp = src + ((int64_t)b * T_ + ti) * F;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int fi = 2 * (int)fo + kw - 1;
+              if (fi >= 0 && fi < F) x[kh * 3 + kw] = sp[fi];
+            }
+          }
+        }
+        msk = 1.f;
+        if (LN) { rs = rstd_in[p]; nmr = -mean_in[p] * rs; } else { rs = 1.f; }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) pt[lane][t] = x[t];
+      pt[lane][9] = nmr;
+      pt[lane][10] = rs;
+      pt[lane][11] = msk;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // DMA landed, table written
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- A operands of product (1): pixel u*16 + lc, K slots by g (see the weight layout above)
+    bf16x8_t a1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float* xp = pt[u * 16 + lc];
+      bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16_t hi, lo;
+        c1_split_bf16(xp[j], hi, lo);
+        v[j] = g == 2 ? lo : hi;
+      }
+      if (g == 3) {
+        bf16_t hi, lo;
+        c1_split_bf16(xp[8], hi, lo);
+        v[0] = hi; v[1] = hi; v[2] = lo; v[3] = 0x3F80; v[4] = 0x3F80; v[5] = 0; v[6] = 0; v[7] = 0;
+      }
+      union { uint32_t w[4]; bf16x8_t f; } pk;
+      pk.w[0] = v[0] | ((uint32_t)v[1] << 16); pk.w[1] = v[2] | ((uint32_t)v[3] << 16);
+      pk.w[2] = v[4] | ((uint32_t)v[5] << 16); pk.w[3] = v[6] | ((uint32_t)v[7] << 16);
+      a1[u] = pk.f;
+    }
+    // ---- A operand of product (2): row t = lc (taps 0..8, row 9 = ones), K slot j = pixel (j>>2)*16 + g*4 + (j&3)
+    bf16x8_t a2;
+    {
+      bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pix = (j >> 2) * 16 + g * 4 + (j & 3);
+        const float x = (lc < 9 ? pt[pix][lc < 9 ? lc : 0] : (lc == 9 ? 1.f : 0.f)) * pt[pix][11];
+        v[j] = f32_to_bf16(x);
+      }
+      union { uint32_t w[4]; bf16x8_t f; } pk;
+      pk.w[0] = v[0] | ((uint32_t)v[1] << 16); pk.w[1] = v[2] | ((uint32_t)v[3] << 16);
+      pk.w[2] = v[4] | ((uint32_t)v[5] << 16); pk.w[3] = v[6] | ((uint32_t)v[7] << 16);
+      a2 = pk.f;
+    }
+    // ---- per-pixel scalars of this lane's accumulator rows: pixel u*16 + g*4 + r
+    float nmr[2][4], rs[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pix = u * 16 + g * 4 + r;
+        nmr[u][r] = pt[pix][9];
+        rs[u][r] = pt[pix][10];
+      }
+    // dout of channel block cb for the lane's 8 pixels from the staged tile: row (u*16+g*4+r)*ROWB, 32-byte unit cb ^ g
+    int wofs = lane, gofs = lc;  // laundered per group: keeps the table reads below from being hoisted out of the loop
+    int dofs = g * 4 * ROWB + lc * 2;
+    asm volatile("" : "+v"(wofs), "+v"(gofs), "+v"(dofs));
+    const int xg0 = (0 ^ g) << 5, xg1 = (1 ^ g) << 5, xg2 = (2 ^ g) << 5, xg3 = (3 ^ g) << 5;
+    auto load_go = [&](int cb, float (&go)[2][4]) {
+      const int k = cb & 3;
+      const int unit = ((cb & ~3) << 5) + (k == 0 ? xg0 : (k == 1 ? xg1 : (k == 2 ? xg2 : xg3)));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16_t raw = *reinterpret_cast<const bf16_t*>(dst + dofs + (u * 16 + r) * ROWB + unit);
+          go[u][r] = bf16_to_f32(raw);
+        }
+    };
+
+    float c1[2][4], c2[2][4];
+    if (LN) {
+      float s1[2][4], s2[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[u][r] = 0.f; s2[u][r] = 0.f; }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        float go[2][4];
+        load_go(cb, go);
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, L.w[cb][wofs]);
+        const float2 gbv = L.gb[cb * 16 + gofs];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const floatx4_t z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf, floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xhat = fmaf(z[r], rs[u][r], nmr[u][r]);
+            const float y = fmaf(xhat, gbv.x, gbv.y);
+            const float d = (y > 0.f ? go[u][r] : 0.f) * gbv.x;
+            s1[u][r] += d;
+            s2[u][r] = fmaf(d, xhat, s2[u][r]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // bounds how far LDS reads are hoisted (register pressure)
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c1[u][r] = c1_row16_sum(s1[u][r]) * inv_c;
+          c2[u][r] = c1_row16_sum(s2[u][r]) * inv_c;
+        }
+      // second pass re-reads the tables: without this the compiler keeps all first-pass values (14 VGPRs per block) live
+      asm volatile("" : "+v"(wofs), "+v"(gofs), "+v"(dofs));
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      float go[2][4];
+      load_go(cb, go);
+      const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, L.w[cb][wofs]);
+      const float2 gbv = L.gb[cb * 16 + gofs];
+      float dz[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const floatx4_t z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf, floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (LN) {
+            const float xhat = fmaf(z[r], rs[u][r], nmr[u][r]);
+            const float y = fmaf(xhat, gbv.x, gbv.y);
+            const float gv = y > 0.f ? go[u][r] : 0.f;
+            const float d = gv * gbv.x;
+            ag[cb] = fmaf(gv, xhat, ag[cb]);
+            abe[cb] += gv;
+            dz[u][r] = rs[u][r] * (d - c1[u][r] - xhat * c2[u][r]);
+          } else {
+            dz[u][r] = z[r] > 0.f ? go[u][r] : 0.f;
+          }
+        }
+      }
+      union { uint32_t w[4]; bf16x8_t f; } b2;
+      b2.w[0] = pack_bf16x2(dz[0][0], dz[0][1]); b2.w[1] = pack_bf16x2(dz[0][2], dz[0][3]);
+      b2.w[2] = pack_bf16x2(dz[1][0], dz[1][1]); b2.w[3] = pack_bf16x2(dz[1][2], dz[1][3]);
+      accw[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2.f, accw[cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- reductions: accw[cb][r] = gradient of (tap g*4+r | db1 at 9, channel cb*16+lc); ag/abe per (cb, lc) summed over g.
+  // The dout staging area is free now and doubles as the cross-wave reduction buffer [wave][C].
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(L.dst[0]);
+  for (int q = 0; q < 12; ++q) {  // q = 0..8 taps, 9 db1, 10 dgamma, 11 dbeta
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (q < 10) {
+        if ((q >> 2) == g) {
+          const int r = q & 3;
+          const float v = r == 0 ? accw[cb][0] : (r == 1 ? accw[cb][1] : (r == 2 ? accw[cb][2] : accw[cb][3]));
+          red[wave * C + cb * 16 + lc] = v;
+        }
+      } else if (LN) {
+        float v = q == 10 ? ag[cb] : abe[cb];
+        v = c1_swap32_add(c1_swap16_add(v));  // over the 4 lanes that share lc
+        if (g == 0) red[wave * C + cb * 16 + lc] = v;
+      }
+    }
+    __syncthreads();
+    if (q < 10 || LN) {
+      for (int c = tid; c < C; c += C1M_WAVES * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < C1M_WAVES; ++w) t += red[w * C + c];
+        if (q < 9) atomicAdd(dw1 + q * C + c, t);
+        else if (q == 9) atomicAdd(db1 + c, t);
+        else atomicAdd((q == 10 ? dgamma : dbeta) + c, t);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // DMA cursor of the im2col operand when it is the row (RC) operand of the implicit GEMM (conv2 forward): the pixel of
@@ -900,6 +1214,34 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
   const int64_t nrows = (int64_t)B * T1;
   int blocks = (int)((nrows + 3) / 4 > 1024 ? 1024 : (nrows + 3) / 4);
   const bool vec = (C % 4 == 0) && ((((uintptr_t)dout) & 15) == 0);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("NST_CONV1_BWD_VALU"); use_mfma = (e && e[0] == '1') ? 0 : 1; }
+  if (use_mfma && dtype == NST_BF16 && (C == 64 || C == 128 || C == 256) && (int64_t)B * T1 * F1 < ((int64_t)1 << 31)) {
+    const int64_t npix = (int64_t)B * T1 * F1;
+    FastDiv dF1, dT1;
+    dF1.init((uint32_t)F1);
+    dT1.init((uint32_t)T1);
+    const int64_t ngroups = (npix + 31) / 32;
+    int cus = 256;
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (cus <= 0) cus = 256;
+    }
+    int mb = (int)((ngroups + C1M_WAVES - 1) / C1M_WAVES > cus ? cus : (ngroups + C1M_WAVES - 1) / C1M_WAVES);
+#define NST_C1M(NCB, LN_)                                                                                              \
+  do {                                                                                                                 \
+    auto kfn = conv1_bwd_mfma_kernel<NCB, LN_>;                                                                         \
+    conv_allow_big_lds(kfn, (int)sizeof(C1mLds<NCB>));                                                                  \
+    kfn<<<mb, C1M_WAVES * 64, sizeof(C1mLds<NCB>), st>>>(src, w1, b1, gamma, beta, mean, rstd, (const bf16_t*)dout, dw1, \
+                                                        db1, dgamma, dbeta, T, F, T1, F1, npix, dF1, dT1);             \
+  } while (0)
+    if (layer_norm) { if (C == 256) NST_C1M(16, true); else if (C == 128) NST_C1M(8, true); else NST_C1M(4, true); }
+    else { if (C == 256) NST_C1M(16, false); else if (C == 128) NST_C1M(8, false); else NST_C1M(4, false); }
+#undef NST_C1M
+    NST_CHECK_LAUNCH("conv1_bwd(mfma)");
+    return NST_OK;
+  }
 #define NST_C1B(TT, S, V) conv1_bwd_kernel<TT, S, V><<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, mean, rstd, (const TT*)dout, dw1, db1, dgamma, dbeta, B, T, F, C, T1, F1, layer_norm)
   if (dtype == NST_F32) {
     if (vec) { if (C <= 256) NST_C1B(float, 4, true); else NST_C1B(float, 8, true); }

@@ -18,6 +18,15 @@ if which == "conv2_fwd":
     w2 = (torch.randn(3, 3, C, C, device=DEV) * 0.02).to(dt)
     b2 = torch.zeros(C, device=DEV)
     fn = lambda: K.conv2_fwd(x, w2, b2)  # noqa: E731
+elif which == "conv1_bwd":
+    B, C, T, F = 128, 256, 900, 80
+    src = torch.randn(B, T, F, device=DEV)
+    w1 = torch.randn(3, 3, 1, C, device=DEV) * 0.3
+    b1, g1, be1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    a1, mean1, rstd1 = K.conv1_ln_relu_fwd(src, w1, b1, g1, be1, True, 1e-6, dt)
+    dout = (torch.randn_like(a1.float()) * 0.1).to(dt)
+    dw1, db1, dg1, dbe1 = torch.zeros_like(w1), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    fn = lambda: K.conv1_ln_relu_bwd(src, w1, b1, g1, be1, mean1, rstd1, dout, dw1, db1, dg1, dbe1, True, 1e-6, accumulate=True)  # noqa: E731
 else:
     M, d, ffn = 28800, 256, 2048
     if which == "ffn2_fwd":
