@@ -378,7 +378,7 @@ struct C1mLds {
   uint4 w[NCB][64];                    // B operand of product (1) per channel block
   float2 gb[NCB * 16];                 // (gamma, beta)
   float pt[C1M_WAVES][32][C1M_PT];     // per-wave patch table
-  char dst[C1M_WAVES][32 * NCB * 32];  // per-wave dout tile: 32 pixels x C bf16, 32-byte units XOR-swizzled by (pix>>2)&3
+  char dst[C1M_WAVES][2][32 * NCB * 32];  // per-wave dout tiles (double buffered): 32 pixels x C bf16, 32-byte units XOR-swizzled by (pix>>2)&3
 };
 
 template <int NCB, bool LN>
@@ -425,61 +425,74 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
   for (int cb = 0; cb < NCB; ++cb) { accw[cb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; ag[cb] = 0.f; abe[cb] = 0.f; }
   const float inv_c = 1.f / (float)C;
   float(*pt)[C1M_PT] = L.pt[wave];
-  char* dst = L.dst[wave];
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t dst_addr = (uint32_t)(uintptr_t)((lds_char_ptr)dst);
+  const uint32_t dst_addr0 = (uint32_t)(uintptr_t)((lds_char_ptr)L.dst[wave][0]);
   const int64_t ngroups = (npix + 31) / 32;
+  const int64_t gstride = (int64_t)gridDim.x * C1M_WAVES;
 
-  for (int64_t grp = (int64_t)blockIdx.x * C1M_WAVES + wave; grp < ngroups; grp += (int64_t)gridDim.x * C1M_WAVES) {
-    const int64_t p0 = grp * 32;
-    __builtin_amdgcn_wave_barrier();  // every lane is done with the previous group's tables
-    // ---- dout tile -> LDS by LDS-DMA (1 KB = 2 pixel rows per instruction)
-    {
-      constexpr int NI = 32 * ROWB / 1024;  // instructions per tile
+  // dout tile of a group -> LDS by LDS-DMA (1 KB = 2 pixel rows per instruction); pixels past the end stage zeros
+  auto stage_tile = [&](int64_t p0, int buf) {
+    constexpr int NI = 32 * ROWB / 1024;  // instructions per tile
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int byte = i * 1024 + lane * 16;
-        const int pix = byte / ROWB, chunk = (byte % ROWB) >> 4;
-        const int64_t p = p0 + pix;
-        const int schunk = chunk ^ (((pix >> 2) & 3) << 1);  // source chunk that lands at this LDS position
-        const void* srcp = p < npix ? (const void*)(reinterpret_cast<const char*>(dout) + p * ROWB + schunk * 16)
-                                    : (const void*)g_nst_zero16;  // pixels past the end stage zeros
-        glds16(srcp, dst_addr + i * 1024);
-      }
+    for (int i = 0; i < NI; ++i) {
+      const int byte = i * 1024 + lane * 16;
+      const int pix = byte / ROWB, chunk = (byte % ROWB) >> 4;
+      const int64_t p = p0 + pix;
+      const int schunk = chunk ^ (((pix >> 2) & 3) << 1);  // source chunk that lands at this LDS position
+      const void* srcp = p < npix ? (const void*)(reinterpret_cast<const char*>(dout) + p * ROWB + schunk * 16)
+                                  : (const void*)g_nst_zero16;
+      glds16(srcp, dst_addr0 + buf * (32 * ROWB) + i * 1024);
     }
-    // ---- patch table: lane l < 32 gathers the 9 taps (zero padded) and the LN statistics of pixel p0 + l
-    if (lane < 32) {
-      const int64_t p = p0 + lane;
-      float x[9];
-      float nmr = 0.f, rs = 0.f, msk = 0.f;
+  };
+  // patch-table row of pixel p0 + lane (lanes < 32): 9 zero-padded taps, -mean*rstd, rstd, pixel mask
+  struct PixRow { float x[9], nmr, rs, msk; };
+  auto gather_row = [&](int64_t p0) {
+    PixRow q;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) x[t] = 0.f;
-      if (p < npix) {
-        uint32_t row, fo, b, to;
-        dF1.divmod((uint32_t)p, row, fo);
-        dT1.divmod(row, b, to);
+    for (int t = 0; t < 9; ++t) q.x[t] = 0.f;
+    q.nmr = 0.f; q.rs = 0.f; q.msk = 0.f;
+    const int64_t p = p0 + lane;
+    if (lane < 32 && p < npix) {
+      uint32_t row, fo, b, to;
+      dF1.divmod((uint32_t)p, row, fo);
+      dT1.divmod(row, b, to);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int ti = 2 * (int)to + kh - 1;
-          if (ti >= 0 && ti < T_) {
-            const float* sp = src + ((int64_t)b * T_ + ti) * F;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ti = 2 * (int)to + kh - 1;
+        if (ti >= 0 && ti < T_) {
+          const float* sp = src + ((int64_t)b * T_ + ti) * F;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const int fi = 2 * (int)fo + kw - 1;
-              if (fi >= 0 && fi < F) x[kh * 3 + kw] = sp[fi];
-            }
+          for (int kw = 0; kw < 3; ++kw) {
+            const int fi = 2 * (int)fo + kw - 1;
+            if (fi >= 0 && fi < F) q.x[kh * 3 + kw] = sp[fi];
           }
         }
-        msk = 1.f;
-        if (LN) { rs = rstd_in[p]; nmr = -mean_in[p] * rs; } else { rs = 1.f; }
       }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) pt[lane][t] = x[t];
-      pt[lane][9] = nmr;
-      pt[lane][10] = rs;
-      pt[lane][11] = msk;
+      q.msk = 1.f;
+      if (LN) { q.rs = rstd_in[p]; q.nmr = -mean_in[p] * q.rs; } else { q.rs = 1.f; }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // DMA landed, table written
+    return q;
+  };
+  auto write_row = [&](const PixRow& q) {
+    if (lane < 32) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) pt[lane][t] = q.x[t];
+      pt[lane][9] = q.nmr;
+      pt[lane][10] = q.rs;
+      pt[lane][11] = q.msk;
+    }
+  };
+
+  int64_t grp = (int64_t)blockIdx.x * C1M_WAVES + wave;
+  int buf = 0;
+  if (grp < ngroups) {
+    stage_tile(grp * 32, 0);
+    write_row(gather_row(grp * 32));
+  }
+  for (; grp < ngroups; grp += gstride) {
+    const int64_t p0 = grp * 32;
+    const char* dst = L.dst[wave][buf];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this group's tile has landed, its table is written
     __builtin_amdgcn_wave_barrier();
 
     // ---- A operands of product (1): pixel u*16 + lc, K slots by g (see the weight layout above)
@@ -529,6 +542,15 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
         nmr[u][r] = pt[pix][9];
         rs[u][r] = pt[pix][10];
       }
+    // ---- the table is consumed: start the next group (tile by DMA into the other buffer, table row into registers)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int64_t nxt = grp + gstride;
+    PixRow nrow;
+    if (nxt < ngroups) {
+      stage_tile(nxt * 32, buf ^ 1);
+      nrow = gather_row(nxt * 32);
+    }
     // dout of channel block cb for the lane's 8 pixels from the staged tile: row (u*16+g*4+r)*ROWB, 32-byte unit cb ^ g
     int wofs = lane, gofs = lc;  // laundered per group: keeps the table reads below from being hoisted out of the loop
     int dofs = g * 4 * ROWB + lc * 2;
@@ -614,12 +636,14 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
       accw[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2.f, accw[cb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (nxt < ngroups) write_row(nrow);
+    buf ^= 1;
   }
 
   // ---- reductions: accw[cb][r] = gradient of (tap g*4+r | db1 at 9, channel cb*16+lc); ag/abe per (cb, lc) summed over g.
   // The dout staging area is free now and doubles as the cross-wave reduction buffer [wave][C].
   __syncthreads();
-  float* red = reinterpret_cast<float*>(L.dst[0]);
+  float* red = reinterpret_cast<float*>(&L.dst[0][0][0]);
   for (int q = 0; q < 12; ++q) {  // q = 0..8 taps, 9 db1, 10 dgamma, 11 dbeta
     __syncthreads();
 #pragma unroll
