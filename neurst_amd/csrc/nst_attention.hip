@@ -29,6 +29,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 using nstgemm::Mma;
 
 namespace {
@@ -526,22 +528,26 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
       const int kblk0 = k0 + mi * TR + wave * 16;
       const int kg = kblk0 + lc;
       const bool diag = p.causal && (kblk0 + 15 > q0);
+      auto elems = [&](auto DIAG, auto DROP) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        uint2 mw = make_uint2(0xffffffffu, 0xffffffffu);
-        if (p.drop_thresh && (q0 >> 4) + f < p.nqb)
-          mw = *reinterpret_cast<const uint2*>(
-              p.mask + ((bh * p.nqb + ((q0 >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
+        for (int f = 0; f < 4; ++f) {
+          uint2 mw = make_uint2(0xffffffffu, 0xffffffffu);
+          if (decltype(DROP)::value && (q0 >> 4) + f < p.nqb)
+            mw = *reinterpret_cast<const uint2*>(
+                p.mask + ((bh * p.nqb + ((q0 >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pv = fast_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
-          if (diag && (kg > q0 + f * 16 + g * 4 + r)) pv = 0.f;
-          float keep = 1.f;
-          if (p.drop_thresh) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
-          st[mi][f][r] = pv * keep;                                            // dropped P, feeds dV
-          dp[mi][f][r] = pv * (keep * dp[mi][f][r] - dl4[f][r]) * p.scale;      // dS (scaled), feeds dK
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
+            if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r)) pv = 0.f;
+            float keep = 1.f;
+            if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
+            st[mi][f][r] = pv * keep;                                            // dropped P, feeds dV
+            dp[mi][f][r] = pv * (keep * dp[mi][f][r] - dl4[f][r]) * p.scale;      // dS (scaled), feeds dK
+          }
         }
-      }
+      };
+      if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
+      else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
     }
     tmul_acc<T, MI>(dv, st, Gs, lane);
     tmul_acc<T, MI>(dk, dp, Qs, lane);
@@ -659,16 +665,20 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
       const bool diag = p.causal && (k0 + TR - 1 > qblk0);
       uint32_t bits = 0xffffu;
       if (p.drop_thresh && qblk0 < p.Tq) bits = p.mask[((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane];
+      auto elems = [&](auto DIAG, auto DROP) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pv = fast_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
-          if (diag && (k0 + f * 16 + g * 4 + r > qg)) pv = 0.f;
-          float keep = 1.f;
-          if (p.drop_thresh) keep = keep_mul(bits, f * 4 + r, p.drop_inv_keep);
-          s[mi][f][r] = pv * (keep * dp[mi][f][r] - dl[mi]) * p.scale;
-        }
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
+            if (decltype(DIAG)::value && (k0 + f * 16 + g * 4 + r > qg)) pv = 0.f;
+            float keep = 1.f;
+            if (decltype(DROP)::value) keep = keep_mul(bits, f * 4 + r, p.drop_inv_keep);
+            s[mi][f][r] = pv * (keep * dp[mi][f][r] - dl[mi]) * p.scale;
+          }
+      };
+      if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
+      else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
     }
     tmul_acc<T, MI>(dq, s, Ks, lane);
     __syncthreads();

@@ -94,6 +94,22 @@ def main():
         dE = torch.zeros(V, d, device=DEV)
         rec("gemm.logits.wgrad", timeit(lambda: K.gemm(dl, x, V, d, Md, trans_a=True, out=dE, accumulate=True, split_k=4), a.iters), fl)
 
+    # ------------------------------------------------------------------ vendor-library reference (measurement only)
+    if want("blas"):
+        # torch.mm = hipBLASLt / rocBLAS on the same shapes: not part of the product path, only a yardstick for the
+        # hand-written kernel (plain GEMM, no epilogue fusion).
+        shapes = [("qkv", Me, 3 * d, d), ("attn_out", Me, d, d), ("ffn1", Me, ffn, d), ("ffn2", Me, d, ffn),
+                  ("front_dense", Me, d, 20 * C), ("conv2_as_gemm", B * 225 * 20, C, 9 * C)]
+        for name, M, N, Kd in shapes:
+            x, w, dy = rnd(M, Kd), rnd(Kd, N), rnd(M, N)
+            fl = 2.0 * M * N * Kd
+            out = torch.empty(M, N, dtype=dt, device=DEV)
+            rec(f"blas.{name}.fwd[{M}x{N}x{Kd}]", timeit(lambda: torch.mm(x, w, out=out), a.iters), fl)
+            dxo = torch.empty(M, Kd, dtype=dt, device=DEV)
+            rec(f"blas.{name}.dgrad", timeit(lambda: torch.mm(dy, w.t(), out=dxo), a.iters), fl)
+            dwo = torch.empty(Kd, N, dtype=dt, device=DEV)
+            rec(f"blas.{name}.wgrad", timeit(lambda: torch.mm(x.t(), dy, out=dwo), a.iters), fl)
+
     # ------------------------------------------------------------------ conv front end
     if want("conv"):
         src = torch.randn(B, 900, 80, device=DEV)
