@@ -23,22 +23,6 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, 
                                             kt_first, kt_count, ep, smem);
 }
 
-template <typename T, typename OutT, int AMODE, int BMODE, int NST, bool CS = false>
-__global__ void __launch_bounds__(THREADS) dense_gemm_kernel_v2(DenseLoader<T> la, DenseLoader<T> lb, OutT* __restrict__ C,
-                                                               int64_t ldc, int M, int N, int K, int tiles_n, int ntiles,
-                                                               int kt_per_split, Epilogue ep) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
-  const int kt_first = blockIdx.z * kt_per_split;
-  int kt_count = kt_total - kt_first;
-  if (kt_count > kt_per_split) kt_count = kt_per_split;
-  if (kt_count <= 0) return;
-  gemm_block_v2<T, OutT, AMODE, BMODE, NST, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS>(
-      la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN, kt_first, kt_count, ep, smem_dyn);
-}
-
 template <typename T, typename OutT, int AMODE, int BMODE, bool CS>
 __global__ void __launch_bounds__(THREADS, 2)
 dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> args) {
@@ -61,12 +45,6 @@ int v3_grid(int units) {
   int g = (units + rounds - 1) / rounds;
   g = (g + 7) & ~7;
   return g > units ? units : g;
-}
-
-int gemm_version() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_VERSION"); v = e ? atoi(e) : 3; }
-  return v;
 }
 
 template <typename KernelT>
@@ -149,57 +127,26 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
   const bool tr = use_tr();
-  if (use_v2() && tr && la.vec && lb.vec) {  // LDS-DMA pipeline: needs 16-byte aligned, 8-element granular operands
-#define NST_GEMM_LAUNCH2(AM, BMO, NS)                                                                                  \
-  do {                                                                                                               \
-    auto kfn = dense_gemm_kernel_v2<T, OutT, AM, BMO, NS>;                                                            \
-    allow_big_lds(kfn, NS * V2_STAGE_BYTES);                                                                          \
-    kfn<<<grid, THREADS, NS * V2_STAGE_BYTES, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, ntiles,      \
-                                                    kt_per_split, ep);                                                \
-  } while (0)
-#define NST_GEMM_MODES(NS)                                                                 \
-  do {                                                                                     \
-    if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_RC, MODE_RC, NS);      \
-    else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH2(MODE_RC, MODE_OC, NS); \
-    else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH2(MODE_OC, MODE_RC, NS); \
-    else NST_GEMM_LAUNCH2(MODE_OC, MODE_OC, NS);                                           \
-  } while (0)
-    if (gemm_version() >= 3) {
-      const int units = ntiles * split;
-      dim3 g3(v3_grid(units), 1, 1);
-      GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
-      ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
-      ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
+  if (use_v2() && tr && la.vec && lb.vec) {  // LDS-DMA stream kernel: needs 16-byte aligned, 8-element granular operands
+    const int units = ntiles * split;
+    dim3 g3(v3_grid(units), 1, 1);
+    GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
+    ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
+    ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
 #define NST_GEMM_LAUNCH3(AM, BMO, CS_)                                                                                \
   do {                                                                                                               \
     auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_>;                                                           \
     allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
     kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
   } while (0)
-      if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
-        if constexpr (sizeof(OutT) == 4) { NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, true); return 0; }
-      }
-      if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_RC, MODE_RC, false);
-      else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH3(MODE_RC, MODE_OC, false);
-      else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_OC, MODE_RC, false);
-      else NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, false);
-#undef NST_GEMM_LAUNCH3
-      return 0;
-    }
     if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
-      if constexpr (sizeof(OutT) == 4) {
-        auto kfn = dense_gemm_kernel_v2<T, OutT, MODE_OC, MODE_OC, 2, true>;
-        allow_big_lds(kfn, 2 * V2_STAGE_BYTES);
-        kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, ntiles, kt_per_split, ep);
-        return 0;
-      }
+      if constexpr (sizeof(OutT) == 4) { NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, true); return 0; }
     }
-    static int force_nst = -1;
-    if (force_nst < 0) { const char* e = getenv("NST_GEMM_NST"); force_nst = e ? atoi(e) : 0; }
-    const int nst = force_nst ? force_nst : 2;  // 2 stages = 64 KB: two workgroups per CU beat a deeper ring (profiles/)
-    if (nst >= 3 && kt_per_split >= 3) NST_GEMM_MODES(3); else NST_GEMM_MODES(2);
-#undef NST_GEMM_MODES
-#undef NST_GEMM_LAUNCH2
+    if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_RC, MODE_RC, false);
+    else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH3(MODE_RC, MODE_OC, false);
+    else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_OC, MODE_RC, false);
+    else NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, false);
+#undef NST_GEMM_LAUNCH3
     return 0;
   }
 #define NST_GEMM_LAUNCH(AM, BMO, TR)                                                                                   \
