@@ -975,6 +975,29 @@ __global__ void __launch_bounds__(THREADS) conv_gemm_kernel_v2(AL la, BL lb, Out
                                                             tn * BN, kt_first, kt_count, ep, smem_dyn, rm);
 }
 
+// 128 x 256 tiles (8 waves) for outputs wider than 128 columns: the im2col / dy operand is read once per row panel
+template <typename T, typename OutT, int AMODE, int BMODE, typename AL, typename BL, typename RM>
+__global__ void __launch_bounds__(V2W_THREADS) conv_gemm_kernel_v2w(AL la, BL lb, OutT* __restrict__ C, int64_t ldc, int M, int N,
+                                                                    int K, int tiles_n, int ntiles, Epilogue ep, RM rm) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  gemm_block_v2w<T, OutT, AMODE, BMODE, AL, BL, RM>(la, lb, C, ldc, M, N, tm * BM, tn * 2 * BN, kt_total, ep, smem_dyn, rm);
+}
+
+bool conv_wide_dgrad() {  // measured slower than two 128-column tiles for the dgrad classes (short K): off unless asked for
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV_WIDE_DGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+bool conv_use_wide() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 // dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output);  db2[j] (+)= sum_z cs_parts[z][j] when cs_parts != NULL
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int64_t total4, int split, int accumulate,
@@ -1073,7 +1096,12 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   dim3 grid(ntiles, 1, 1);
-  if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
+  if (conv_use_v2() && conv_use_wide() && conv_use_tr() && la.vec && lb.vec && N > BN) {
+    const int tiles_nw = (N + 2 * BN - 1) / (2 * BN), ntw = tiles_m * tiles_nw;
+    auto kfn = conv_gemm_kernel_v2w<T, T, MODE_RC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap>;
+    conv_allow_big_lds(kfn, V2W_LDS_BYTES);
+    kfn<<<ntw, V2W_THREADS, V2W_LDS_BYTES, st>>>(la, lb, (T*)y, (int64_t)C, M, N, K, tiles_nw, ntw, ep, IdentityRowMap());
+  } else if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
     NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_total, la, lb, (T*)y,
                        (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
   else if (conv_use_tr())
@@ -1108,7 +1136,12 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
       const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
       const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
       dim3 grid(ntiles, 1, 1);
-      if (conv_use_v2() && la.vec && lb.vec)
+      if (conv_use_v2() && conv_wide_dgrad() && la.vec && lb.vec && N > BN) {
+        const int tiles_nw = (N + 2 * BN - 1) / (2 * BN), ntw = tiles_m * tiles_nw;
+        auto kfn = conv_gemm_kernel_v2w<T, T, MODE_RC, MODE_RC, DgradALoader<T>, DgradBLoader<T>, DgradRowMap>;
+        conv_allow_big_lds(kfn, V2W_LDS_BYTES);
+        kfn<<<ntw, V2W_THREADS, V2W_LDS_BYTES, st>>>(la, lb, (T*)dx, (int64_t)C, M, N, K, tiles_nw, ntw, ep, rm);
+      } else if (conv_use_v2() && la.vec && lb.vec)
         NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_RC, DgradALoader<T>, DgradBLoader<T>, DgradRowMap, grid, kt_total, la, lb, (T*)dx,
                            (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
       else

@@ -307,18 +307,18 @@ struct IdentityRowMap {
 };
 
 // Shared epilogue of both main loops (see gemm_block).
-template <typename OutT, typename RowMap>
+template <typename OutT, typename RowMap, int NWN = 2>
 __device__ __forceinline__ void gemm_epilogue(floatx4_t (&acc)[4][4], OutT* __restrict__ C, int64_t ldc, int M, int N, int m0,
                                               int n0, const Epilogue& ep, char* smem, const RowMap& rowmap) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave / NWN) * 64, wn = (wave % NWN) * 64;  // NWN waves side by side over a tile of NWN*64 columns
   // Epilogue through LDS: each wave transposes its 64x64 accumulator tile in two 32-row halves so that global
   // accesses are row-contiguous.  Fast path (interior tile, aligned): a lane finishes 8 consecutive columns with
   // 16-byte accesses; edge tiles fall back to one element per lane.
   constexpr int EPI_LD = 68;  // floats; multiple of 4 keeps the float4 reads 16-byte aligned
   float* epi = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
   const int lr = (lane >> 4) * 4, lc = lane & 15;
-  const bool fast = ep.vec && (m0 + BM <= M) && (n0 + BN <= N);
+  const bool fast = ep.vec && (m0 + BM <= M) && (n0 + NWN * 64 <= N);
   const int vrow = lane >> 3, vcol = (lane & 7) * 8;
   float bias8[8];
 #pragma unroll
@@ -743,6 +743,102 @@ __device__ __forceinline__ void gemm_block_v2(const ALoader& la, const BLoader& 
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the epilogue reuses the LDS
   asm volatile("" ::: "memory");
   gemm_epilogue<OutT, RowMap>(acc, C, ldc, M, N, m0, n0, ep, smem, rowmap);
+}
+
+// Wide variant of the v2 block for outputs with more than 128 columns (conv2: N = C = 256): one workgroup of 8 waves
+// owns a 128 x 256 tile, i.e. the (large, streamed) A operand is read ONCE per row panel instead of once per 128-column
+// tile -- the two column tiles of a row panel otherwise fetch the same im2col rows twice from HBM (measured 2.0x the
+// algorithmic traffic, which made the conv2 kernels HBM-bound).  Stage = [A | B0 | B1] = 48 KB, two stages; the B
+// operand is kept as two independent 128-column tile images so the fragment readers are unchanged.  Waves 0-3 issue
+// the DMA of A and B0, waves 4-7 that of B1.
+constexpr int V2W_THREADS = 512;
+constexpr int V2W_STAGE_BYTES = 3 * BM * KBYTES;
+constexpr int V2W_LDS_BYTES = 2 * V2W_STAGE_BYTES;
+
+template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap>
+__device__ __forceinline__ void gemm_block_v2w(const ALoader& la, const BLoader& lb, OutT* __restrict__ C, int64_t ldc, int M, int N,
+                                               int m0, int n0, int kt_count, const Epilogue& ep, char* smem, const RowMap rowmap) {
+  typedef SwzFrag<T, AMODE> RA;
+  typedef SwzFrag<T, BMODE> RB;
+  constexpr int BK = Tile<T>::BK;
+  constexpr int KS = Mma<T>::KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave >> 2, wq = wave & 3;
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+
+  floatx4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  TileDma<T, AMODE, ALoader> da;
+  TileDma<T, BMODE, BLoader> db;
+  if (quad == 0) da.init(la, m0, 0, wq, lane);
+  db.init(lb, n0 + quad * BN, 0, wq, lane);
+  auto issue = [&](int kt, int stage) {
+    const uint32_t sa = smem_addr + stage * V2W_STAGE_BYTES;
+    if (quad == 0) {
+      da.issue(kt, sa, wq);
+      db.issue(kt, sa + BM * KBYTES, wq);
+    } else {
+      db.issue(kt, sa + 2 * BM * KBYTES, wq);
+    }
+  };
+  if (kt_count > 0) issue(0, 0);
+  int stage = 0;
+  for (int kt = 0; kt < kt_count; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < kt_count) issue(kt + 1, stage ^ 1);
+    const char* As = smem + stage * V2W_STAGE_BYTES;
+    const char* Bs = As + BM * KBYTES * (1 + (wn >> 7));
+    const int wnl = wn & 127;
+    if constexpr (BK / KS == 2) {
+      // both halves of the K step are requested up front: the second set of fragments lands under the first 16 MFMAs
+      typename RA::Frag a0[4], a1[4];
+      typename RB::Frag b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wnl + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = RA::read(As, wm + i * 16, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, KS, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[i] = RA::read(As, wm + i * 16, KS, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a1[i], b1[j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += KS) {
+        typename RA::Frag a[4];
+        typename RB::Frag b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = RA::read(As, wm + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = RB::read(Bs, wnl + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+      }
+    }
+    stage ^= 1;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the epilogue reuses the LDS
+  asm volatile("" ::: "memory");
+  gemm_epilogue<OutT, RowMap, 4>(acc, C, ldc, M, N, m0, n0, ep, smem, rowmap);
 }
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (id % 8); give each XCD a contiguous
