@@ -500,3 +500,27 @@ def train_step_reference(W, inputs, cfg, label_smoothing, is_training=False):
     grads = torch.autograd.grad(loss, [Wg[n] for n in names], allow_unused=True)
     return loss.detach(), logits.detach(), {n: (g if g is not None else torch.zeros_like(W[n]))
                                             for n, g in zip(names, grads)}
+
+
+def text_train_step_reference(W, inputs, cfg, label_smoothing, is_training=False):
+    """train_step_reference for the text Transformer (transformer_logits): inputs carry src ids, src_length,
+    trg, trg_length, trg_input; the source padding follows EncoderDecoderModel.get_symbols_to_logits_fn /
+    call (encoder_decoder_model.py:211-224: padding = 1 - sequence_mask(src_length))."""
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    inp = dict(inputs)
+    inp["src_padding"] = length_to_padding(inputs["src_length"], inputs["src"].shape[1]).to(next(iter(W.values())).dtype)
+    if "input_symbol_modality/emb/weights" not in Wg:  # shared source/target embedding
+        Wg2 = dict(Wg)
+        Wg2["input_symbol_modality/emb/weights"] = Wg["shared_symbol_modality/shared/weights"]
+        Wg2["target_symbol_modality/shared/weights"] = Wg["shared_symbol_modality/shared/weights"]
+        if "shared_symbol_modality/shared/bias" in Wg:
+            Wg2["target_symbol_modality/shared/bias"] = Wg["shared_symbol_modality/shared/bias"]
+    else:
+        Wg2 = Wg
+    logits = transformer_logits(inp, Wg2, cfg, is_training=is_training)
+    nll, _, ntok = label_smoothed_cross_entropy(logits, inputs["trg"], inputs["trg_length"], label_smoothing)
+    loss = reduce_loss(nll, ntok)
+    names = list(Wg.keys())
+    grads = torch.autograd.grad(loss, [Wg[n] for n in names], allow_unused=True)
+    return loss.detach(), logits.detach(), {n: (g if g is not None else torch.zeros_like(W[n]))
+                                            for n, g in zip(names, grads)}

@@ -248,6 +248,84 @@ def test_speech_transformer_forward_backward(case, dtype):
     assert glob <= (1e-3 if dtype == "float32" else 3e-2), f"{tag}: global gradient rel-L2 error {glob:.3e}"
 
 
+# ------------------------------------------------------------------------------------------------ text Transformer (§8(f) rank 1)
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("case", ["toy", "small_shared", "mid"])
+def test_text_transformer_forward_backward(case, dtype):
+    """Transformer (embedding source side, optional shared source/target embedding) through the Seq2Seq task inputs:
+    logits, loss and every gradient against the oracle's transformer_logits + criterion + autograd."""
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.models import build_model
+    from neurst_amd.models.transformer import Transformer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils import compat
+    cases = {  # d, H, enc, dec, ffn, B, S, L, Vs, Vt, share
+        "toy": (8, 2, 2, 2, 10, 2, 5, 4, 11, 13, False),
+        "small_shared": (64, 2, 2, 2, 128, 3, 17, 9, 40, 40, True),
+        "mid": (256, 4, 2, 1, 512, 4, 33, 21, 300, 200, False),
+    }
+    d, H, ne, nd, ffn, B, S, L, Vs, Vt, share = cases[case]
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    p.update({"modality.dim": d, "modality.share_source_target_embedding": share, "encoder.num_layers": ne,
+              "decoder.num_layers": nd, "encoder.hidden_size": d, "decoder.hidden_size": d,
+              "encoder.num_attention_heads": H, "decoder.num_attention_heads": H, "encoder.filter_size": ffn,
+              "decoder.filter_size": ffn})
+    for k in list(p):
+        if k.endswith("dropout_rate"):
+            p[k] = 0.0
+    task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": Vs, "trg_vocab_size": Vt}})
+    model = task.build_model({"model.class": "Transformer", "model.params": p}, device=DEV, dtype=dtype, init_seed=5)
+    g = torch.Generator().manual_seed(21)
+    sd = {}
+    for n, prm in model.store.params.items():
+        if n.endswith("/bias") or n.endswith("/beta"):
+            sd[n] = torch.randn(prm.shape, generator=g) * 0.05
+        elif n.endswith("/gamma"):
+            sd[n] = 1.0 + torch.randn(prm.shape, generator=g) * 0.1
+    model.store.load_state_dict(sd, strict=False)
+
+    def side(Lx, V, lens):
+        ids = torch.randint(0, V - 3, (B, Lx), generator=g)
+        return torch.where(torch.arange(Lx)[None] >= (lens[:, None] - 1), torch.full_like(ids, V - 1), ids)
+    src_len = torch.tensor([S - (i * S) // (2 * B) for i in range(B)])
+    trg_len = torch.tensor([max(1, L - i) for i in range(B)])
+    batch = {"feature": side(S, Vs, src_len), "label": side(L, Vt, trg_len)}
+    inputs = task.example_to_input(batch, compat.ModeKeys.TRAIN)
+    assert inputs["src_length"].tolist() == src_len.tolist() and inputs["trg_length"].tolist() == trg_len.tolist()
+
+    W = {n: prm.data.detach().cpu().clone() for n, prm in model.store.params.items()}
+    if dtype == "bfloat16":
+        for n, prm in model.store.params.items():
+            if n.endswith("/kernel") or n.endswith("/weights"):
+                W[n] = prm.compute.detach().float().cpu()
+    cfg = {"num_enc": ne, "num_dec": nd, "num_heads": H}
+    loss_ref, logits_ref, grads_ref = O.text_train_step_reference({k: v.double() for k, v in W.items()}, inputs, cfg, 0.1)
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    loss = crit.reduce_loss(dinp, logits)
+    model.backward(crit.backward())
+    tol = TOL[dtype]
+    tag = f"text[{case},{dtype}]"
+    check(tag + ".logits", logits, logits_ref, tol * (3 if dtype == "bfloat16" else 1))
+    REPORT[tag + ".loss_abs_err"] = abs(float(loss) - float(loss_ref))
+    assert abs(float(loss) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
+    num = den = 0.0
+    bad = []
+    for n, prm in model.store.params.items():
+        gg, r = prm.grad.detach().float().cpu().double(), grads_ref[n].double()
+        e = rel_err(prm.grad, grads_ref[n]) if dtype == "float32" else float((gg - r).norm() / max(float(r.norm()), 1e-12))
+        REPORT[f"{tag}.grad.{n}"] = e
+        num += float(((gg - r) ** 2).sum())
+        den += float((r ** 2).sum())
+        if not (e <= (2e-3 if dtype == "float32" else 0.25)):
+            bad.append((n, e))
+    glob = math.sqrt(num / max(den, 1e-30))
+    REPORT[tag + ".grad_global_rel_l2"] = glob
+    assert not bad, f"{tag}: gradients out of tolerance: {bad[:8]}"
+    assert glob <= (1e-3 if dtype == "float32" else 3e-2), f"{tag}: global gradient rel-L2 error {glob:.3e}"
+
+
 def test_gradient_accumulation_and_tied_embedding():
     from neurst_amd.criterions import build_criterion
     model, inputs, cfg = _speech_case("small", "float32")

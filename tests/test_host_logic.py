@@ -213,3 +213,37 @@ def test_length_masks():
 def test_graft_entry_build_runs():
     import __graft_entry__ as g
     g.build()
+
+
+def test_seq2seq_example_to_input_follows_reference():
+    """neurst/tasks/seq2seq.py:110-136: src_length / trg_length from EOS-as-padding, trg_input = [BOS, trg[:-1]]."""
+    import torch
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils import compat
+    task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": 13, "trg_vocab_size": 23}})
+    eos_s, eos_t, bos_t = 12, 22, 21
+    batch = {"feature": torch.tensor([[1, 2, 3, eos_s, eos_s], [4, 5, 6, 7, eos_s]]),
+             "label": torch.tensor([[9, 8, eos_t, eos_t], [1, 2, 3, eos_t]])}
+    out = task.example_to_input(batch, compat.ModeKeys.TRAIN)
+    assert out["src_length"].tolist() == [4, 5] and out["trg_length"].tolist() == [3, 4]
+    assert out["trg_input"].tolist() == [[bos_t, 9, 8, eos_t], [bos_t, 1, 2, 3]]
+    assert torch.equal(out["trg"], batch["label"]) and torch.equal(out["src"], batch["feature"])
+    inf = task.example_to_input(batch, compat.ModeKeys.INFER)
+    assert inf["trg_input"].tolist() == [bos_t, bos_t] and "trg" not in inf
+    eos_task = build_task({"task.class": "seq2seq", "task.params": {"src_vocab_size": 13, "trg_vocab_size": 23,
+                                                                     "target_begin_of_sentence": "eos"}})
+    assert eos_task.example_to_input(batch, compat.ModeKeys.TRAIN)["trg_input"][:, 0].tolist() == [eos_t, eos_t]
+
+
+def test_synthetic_text_dataset_shapes_and_eos_padding():
+    import torch
+    from neurst_amd.data.datasets import build_dataset
+    ds = build_dataset({"dataset.class": "synthetic_text", "dataset.params": {"batch_per_gpu": 4, "src_len": 9, "trg_len": 7,
+                                                                            "src_vocab_size": 50, "trg_vocab_size": 60,
+                                                                            "ragged": True, "num_batches": 2}})
+    batches = list(ds.build_iterator())
+    assert len(batches) == 2
+    b = batches[0]
+    assert b["feature"].shape == (4, 9) and b["label"].shape == (4, 7)
+    assert (b["feature"][:, -1] == 49).all() and (b["label"][:, -1] == 59).all()
+    assert int(b["feature"].max()) <= 49 and int(b["label"][:, :-1].min()) >= 0
