@@ -215,19 +215,19 @@ def main():
     value = frames / elapsed
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     conv2_ms = sum(probe_ms) / max(len(probe_ms), 1) if probe_ms else None
-    roofline = {"kernel": "conv_gemm_kernel (conv2 implicit-GEMM forward, M=B*T2*F2, N=C, K=9C)", "bound": "mfma",
+    roofline = {"kernel": "conv2_fwd_patch_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C; LDS-resident input patch)", "bound": "mfma",
                 "achieved": (fl["conv2"] / (conv2_ms * 1e-3) / 1e12) if conv2_ms else None, "peak": peak,
                 "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_timed": len(probe_ms),
                 "avg_launch_ms": conv2_ms, "algorithmic_flops_per_launch": fl["conv2"]}
     if roofline["achieved"]:
         roofline["frac"] = roofline["achieved"] / peak
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv2_fwd.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv2_fwd_patch.json")
     if args.dtype == "bf16" and B == 128 and T == 900 and os.path.exists(pmc):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
         # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in KB); not re-measured by this run.
         try:
             roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_conv2_fwd.json"
+            roofline["traffic_source"] = "profiles/r01_pmc_conv2_fwd_patch.json"
         except Exception:
             pass
     out = {

@@ -1077,10 +1077,208 @@ Epilogue plain_epilogue() {
   return ep;
 }
 
+
+// =============================================================================================
+// conv2 forward with an LDS-RESIDENT input patch (bf16, C == 256, even T1).
+//
+// The implicit-GEMM kernels above gather the A operand tap by tap, so every input pixel crosses the L2 / HBM interface
+// up to 2.25 times (measured 2.7 GB against 1.5 GB of algorithmic traffic).  Here a workgroup owns 128 consecutive
+// output pixels x all 256 output channels and, per 64-channel slice of the input, stages the BAND of input rows those
+// pixels touch ONCE (<= 17 rows x (F1+2) columns x 128 B, zero columns left and right stand for the padding); the nine
+// taps then read their A fragments from that patch at per-lane addresses (position = patch row (2*dr+kh), column
+// (2*fo+kw)), and only the 32 KB weight tile of each (tap, slice) streams through a double buffer.
+//   * with T1 == 2*T2 the band is contiguous in memory across images: input row of output row `orow` (global, over
+//     all images) and tap kh is 2*orow + kh - 1; only the top padding row (to == 0, kh == 0) needs a mask, which is a
+//     per-lane select of a zero block in LDS;
+//   * patch layout: pixel position `pos` lives at 128-byte slot pos ^ ((pos>>4)&1) with its eight 16-byte chunks
+//     XOR-ed by (pos>>1)&7 -- the 16 lanes of a fragment read walk positions two apart (same involution on the DMA
+//     source side); a ds_read_b128 of this layout costs 8-12 LDS cycles instead of 4, which the loop does not feel.
+// Variants measured and dropped (same shape, 983 us for this kernel): 32-channel slices with two workgroups per CU
+// (1070 us), a double-buffered 32-channel patch (1086 us), even/odd row regions reloaded under the multiply steps
+// (1008 us) -- the K loop, not the patch reload, is the limit: ~2100 cycles per K step for 1024 MFMA cycles per SIMD.
+// =============================================================================================
+struct PatchArgs {
+  const bf16_t* x;
+  const bf16_t* w2;
+  bf16_t* y;
+  int T2, F1, F2, C, M, PW, in_rows, ntiles;
+  FastDiv dF2, dT2, dPW;
+  Epilogue ep;
+};
+constexpr int CP_THREADS = 512;
+constexpr int CP_BBUF = 2 * BM * KBYTES;                      // one (tap, slice) weight tile: two 128-column images
+constexpr int CP_LDS_BYTES = 160 * 1024;
+constexpr int CP_ZERO_OFF = CP_LDS_BYTES - 2 * CP_BBUF - 1024;  // 128-byte zero block (1 KB slot) behind the patch
+constexpr int CP_PATCH_MAX = CP_ZERO_OFF;                      // 97280 B = 760 pixel positions
+constexpr int CP_B_OFF = CP_ZERO_OFF + 1024;
+constexpr int CP_NIT = (CP_PATCH_MAX / 1024 + 7) / 8;         // patch pieces (1 KB) per wave
+
+__global__ void __launch_bounds__(CP_THREADS) conv2_fwd_patch_kernel(PatchArgs a) {
+  typedef SwzFrag<bf16_t, MODE_OC> RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave >> 2, wq = wave & 3;
+  const int wm = quad * 64, wn = wq * 64;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int m0 = tile * BM;
+  const int last_p = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
+  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
+  const int band_row0 = 2 * orow_first - 1;
+  const int npos = (2 * (orow_last - orow_first) + 3) * a.PW;
+  const int npieces = (npos + 7) >> 3;
+  if (tid < 32) reinterpret_cast<uint32_t*>(smem + CP_ZERO_OFF)[tid] = 0u;
+
+  // DMA sources of this wave's patch pieces (byte offsets into x for channel slice 0; ~0u = zero block)
+  uint32_t poff[CP_NIT];
+#pragma unroll
+  for (int it = 0; it < CP_NIT; ++it) {
+    const int P = (it * 8 + wave) * 8 + (lane >> 3);
+    const int pos = P ^ ((P >> 4) & 1);
+    const int prow = (int)a.dPW.div((uint32_t)pos), pc = pos - prow * a.PW;
+    const int grow = band_row0 + prow;
+    const bool ok = pos < npos && pc >= 1 && pc <= a.F1 && grow >= 0 && grow < a.in_rows;
+    const uint32_t chunk = (uint32_t)((lane & 7) ^ ((pos >> 1) & 7));
+    poff[it] = ok ? ((uint32_t)(grow * a.F1 + pc - 1) * (uint32_t)(a.C * 2) + chunk * 16u) : ~0u;
+  }
+  auto stage_patch = [&](int cc) {
+#pragma unroll
+    for (int it = 0; it < CP_NIT; ++it) {
+      const int piece = it * 8 + wave;
+      if (piece < npieces) {
+        const char* src = poff[it] != ~0u ? reinterpret_cast<const char*>(a.x) + poff[it] + cc * KBYTES
+                                          : reinterpret_cast<const char*>(g_nst_zero16);
+        glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
+      }
+    }
+  };
+  // weight tile (rows k0..k0+63 of w2 viewed as [9C, C], this wave's quarter of image `quad`)
+  uint32_t boff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = (s * 4 + wq) * 64 + lane;
+    const int r = c >> 4, c16 = c & 15;
+    const int g = (r & 3) | (((r >> 3) & 1) << 2);
+    boff[s] = (uint32_t)((r * a.C + quad * BM + (c16 ^ (g << 1)) * 8) * 2);
+  }
+  auto issue_b = [&](int k0, int buf) {
+    const char* wb = reinterpret_cast<const char*>(a.w2) + (int64_t)k0 * a.C * 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      glds16(wb + boff[s], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(CP_B_OFF + buf * CP_BBUF + quad * (BM * KBYTES) +
+                                                                               (s * 4 + wq) * 1024)));
+  };
+
+  // this lane's four A rows: patch position of tap (0, 0) and the top-padding flag
+  int pb[4];
+  bool top[4];
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = m0 + wm + i * 16 + (lane & 15);
+    const bool ok = p < a.M;
+    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
+    const int fo = (ok ? p : m0) - orow * a.F2;
+    const int to = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
+    pb[i] = ok ? 2 * (orow - orow_first) * a.PW + 2 * fo : 0;
+    top[i] = ok && to == 0;
+  }
+
+  floatx4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int ncc = a.C / 64;
+  stage_patch(0);
+  issue_b(0, 0);
+  int buf = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tap < 8) issue_b((tap + 1) * a.C + cc * 64, buf ^ 1);
+      else if (cc + 1 < ncc) issue_b((cc + 1) * 64, buf ^ 1);
+      const char* Bs = smem + CP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
+      const int wnl = wn & 127;
+      const int toff = kh * a.PW + kw;
+      bf16x8_t a0[4], a1[4];
+      typename RB::Frag b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wnl + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pos = pb[i] + toff;
+        int ad = ((pos ^ ((pos >> 4) & 1)) << 7) + ((g ^ ((pos >> 1) & 7)) << 4);
+        if (kh == 0) ad = top[i] ? CP_ZERO_OFF + (g << 4) : ad;
+        a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
+        a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + (ad ^ 64));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a1[i], b1[j], acc[i][j]);
+      buf ^= 1;
+    }
+    if (cc + 1 < ncc) {
+      __builtin_amdgcn_s_barrier();  // every wave has read its last fragment of this slice's patch
+      asm volatile("" ::: "memory");
+      stage_patch(cc + 1);
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  gemm_epilogue<bf16_t, IdentityRowMap, 4>(acc, a.y, (int64_t)a.C, a.M, a.C, m0, 0, a.ep, smem, IdentityRowMap());
+}
+
+bool conv2_use_patch() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV2_PATCH"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+// returns true when the patch kernel handled the call
+bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  if (!conv2_use_patch() || C != 256 || (T1 & 1) || !nst_aligned16(x) || !nst_aligned16(w2) || !nst_aligned16(y)) return false;
+  const int64_t M = (int64_t)B * T2 * F2;
+  if ((int64_t)B * T1 * F1 * C * 2 >= (int64_t)0xFFFFFFFFll || M >= (1ll << 30)) return false;
+  const int PW = F1 + 2;
+  const int rows_out = (F2 - 1 + BM - 1) / F2 + 1;  // output rows a 128-pixel run can touch
+  const int npos_max = (2 * (rows_out - 1) + 3) * PW;
+  if (((npos_max + 15) & ~15) * 128 > CP_PATCH_MAX) return false;
+  PatchArgs a;
+  a.x = (const bf16_t*)x; a.w2 = (const bf16_t*)w2; a.y = (bf16_t*)y;
+  a.T2 = T2; a.F1 = F1; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.in_rows = B * T1;
+  a.ntiles = (int)((M + BM - 1) / BM);
+  a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
+  a.ep = plain_epilogue();
+  a.ep.bias = b2; a.ep.relu = relu; a.ep.vec = 1;
+  conv_allow_big_lds(conv2_fwd_patch_kernel, CP_LDS_BYTES);
+  conv2_fwd_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
+  return true;
+}
+
 template <typename T>
 int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int M = B * T2 * F2, N = C, K = 9 * C;
+  if constexpr (sizeof(T) == 2)
+    if (conv2_fwd_patch(x, w2, b2, y, B, T1, F1, C, relu, st)) return 0;
   Im2colLoader<T> la;
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
   la.outer_limit = M; la.contig_limit = K;

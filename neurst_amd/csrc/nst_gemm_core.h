@@ -618,9 +618,8 @@ struct DenseDma {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // TileDma: DenseDma for dense loaders, the generic per-step address derivation for the conv gather loaders

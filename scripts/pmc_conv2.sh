@@ -5,11 +5,13 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 REPO=$PWD
 TARGET=${1:-conv2_fwd}
-FILT=${2:-conv_gemm_kernel}
+FILT=${2:-conv2_fwd_patch_kernel}
 export PMC_TARGET=$TARGET PMC_FILT=$FILT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY; do
+COUNTERS=${PMC_COUNTERS:-"FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"}
+export COUNTERS
+for c in $COUNTERS; do
   rm -rf /tmp/pmc_$c
   (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $REPO/scripts/pmc_target.py $TARGET > /tmp/pmc_$c.log 2>&1)
 done
@@ -17,7 +19,7 @@ python - <<'PY'
 import csv, glob, json, os
 FILT = os.environ['PMC_FILT']; TARGET = os.environ['PMC_TARGET']
 out = {}
-for c in ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"]:
+for c in os.environ["COUNTERS"].split():
     vals, durs = [], {}
     for f in glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):

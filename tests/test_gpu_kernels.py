@@ -462,6 +462,25 @@ def test_conv2(K, dtype, B, T1, F1, C):
     close(tag + ".dw2_nobias", dw3, wr.grad, dtype, scale=2.0)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("B,T1,F1", [(2, 8, 6), (3, 50, 40), (5, 34, 7), (2, 128, 41), (4, 2, 2), (1, 450, 40), (9, 450, 40)])
+def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
+    """bf16, C == 256, even T1: the LDS-resident input-patch kernel (nst_conv.hip conv2_fwd_patch_kernel) -- images that
+    share a tile, ragged last tiles, odd / even widths, the top padding row of every image, > 256 tiles."""
+    C, dtype = 256, torch.bfloat16
+    x = rnd(B, T1, F1, C, dtype=dtype, seed=11)
+    w2 = (rnd(3, 3, C, C, seed=12) * (1.0 / math.sqrt(9 * C))).to(dtype)
+    b2 = rnd(C, seed=13) * 0.1
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w2.double().permute(3, 2, 0, 1), b2.double(), stride=2,
+                                     padding=1).permute(0, 2, 3, 1)
+    if relu:
+        ref = ref.relu()
+    y = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV), relu=relu)
+    close(f"conv2_patch[B{B}T{T1}F{F1}relu{int(relu)}].y", y, ref, dtype)
+    y2 = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV), relu=relu)
+    assert torch.equal(y, y2), "conv2 forward is not deterministic"
+
+
 # ------------------------------------------------------------------------------------------------ embedding / elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_embedding(K, dtype):
