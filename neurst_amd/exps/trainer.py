@@ -78,9 +78,19 @@ class Trainer(BaseExperiment):
             ModelConfigs.dump({"model.class": model.__class__.__name__, "model.params": model.args,
                                "task.class": self.task.__class__.__name__, "task.params": self.task.get_config()},
                               self.model_dir)
-        it = self.custom_dataset.build_iterator(
-            map_func=lambda b: self.task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
-            total_shards=world, device=rt.device)
+        if getattr(self.custom_dataset, "batched", True):
+            it = self.custom_dataset.build_iterator(
+                map_func=lambda b: self.task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
+                total_shards=world, device=rt.device)
+        else:  # single examples (TFRecords): the task buckets and pads them (tasks/*.create_and_batch).  One process per
+            # GPU is the reference's Horovod arrangement: every worker batches its own file shard with
+            # num_replicas_in_sync = 1 (training_utils.py:146-151), i.e. `batch_size` is per worker.
+            def _feed():
+                for b in self.task.create_and_batch(self.custom_dataset, compat.ModeKeys.TRAIN, num_replicas_in_sync=1,
+                                                    shard_id=rank, total_shards=world, seed=self._args.get("seed", None) or 1234):
+                    yield self.task.example_to_input({k: torch.from_numpy(v).to(rt.device, non_blocking=True)
+                                                      for k, v in b.items()}, compat.ModeKeys.TRAIN)
+            it = _feed()
         t0, frames, last_loss = time.time(), 0.0, None
         for step in range(1, self._train_steps + 1):
             try:

@@ -1,0 +1,327 @@
+"""Data-feed row: TFRecord / tf.train.Example codec, vocabulary ids, SpecAugment, frame-bucketed
+batching -- against records TensorFlow wrote, the reference's own functions (tests/golden/make_golden_data.py) and
+google.protobuf.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pb_example import example_message_class  # noqa: E402
+
+from neurst_amd.data import batching, tfrecord  # noqa: E402
+from neurst_amd.data.datasets import build_dataset  # noqa: E402
+from neurst_amd.data.text_pipeline import TextDataPipeline  # noqa: E402
+from neurst_amd.tasks import build_task  # noqa: E402
+from neurst_amd.utils import compat  # noqa: E402
+from neurst_amd.utils.audio_lib import SpecAugment  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ------------------------------------------------------------------------------------------------ CRC-32C / framing
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors + the classic check value
+    assert tfrecord.crc32c(b"\x00" * 32) == 0x8A9136AA
+    assert tfrecord.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tfrecord.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tfrecord.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283
+    assert tfrecord.crc32c(b"") == 0
+
+
+def _pipeline(gold, side):
+    """TextDataPipeline whose vocabulary holds the fixture's tokens at their real ids (the rest are placeholders)."""
+    n = int(gold[f"vocab_size_{side}"])
+    tokens = [f"<tok{i}>" for i in range(n)]
+    for i, t in zip(gold[f"{side}_ids"], gold[f"{side}_tokens"]):
+        tokens[int(i)] = str(t)
+    return TextDataPipeline(vocab_path=tokens)
+
+
+def test_tensorflow_written_records():
+    """tests/golden/tfrecord_seq2seq_head.bin = the first 12 records of the reference's tests/examples/train.tfrecords-00000-of-00004,
+    bytes TensorFlow wrote: both CRCs of every record verify, the Example decodes, and the int64 lists are exactly the
+    vocabulary ids (+ EOS) of the text lines the records were made from."""
+    gold = np.load(os.path.join(GOLD, "tfrecord_seq2seq_head.npz"))
+    recs = list(tfrecord.read_records(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"), check_crc=True))
+    assert len(recs) == int(gold["nrec"]) == 12
+    src_pipe, trg_pipe = _pipeline(gold, "src"), _pipeline(gold, "trg")
+    assert trg_pipe.meta["vocab_size"] == int(gold["vocab_size_trg"]) + 3
+    assert trg_pipe.meta["eos_id"] == trg_pipe.meta["pad_id"] == trg_pipe.meta["vocab_size"] - 1
+    assert trg_pipe.meta["padding_mode"] == compat.PaddingMode.EOS_AS_PADDING
+    Example = example_message_class()
+    for rec, src_line, trg_line in zip(recs, gold["src_lines"], gold["trg_lines"]):
+        ex = tfrecord.parse_example(rec)
+        assert sorted(ex) == ["feature", "label"]
+        assert ex["feature"][0] == ex["label"][0] == "int64"
+        assert ex["feature"][1].tolist() == src_pipe.encode(str(src_line), is_processed=True)
+        assert ex["label"][1].tolist() == trg_pipe.encode(str(trg_line), is_processed=True)
+        assert trg_pipe.decode(ex["label"][1]) == str(trg_line)
+        msg = Example()
+        msg.ParseFromString(rec)  # the independent decoder agrees
+        assert list(msg.features.feature["label"].int64_list.value) == ex["label"][1].tolist()
+        # and re-encoding the parsed values reproduces TensorFlow's bytes exactly
+        assert tfrecord.encode_example({"feature": ex["feature"][1], "label": ex["label"][1]}) == rec
+    # re-framing reproduces the file byte for byte
+    assert b"".join(tfrecord.frame_record(r) for r in recs) == open(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"), "rb").read()
+
+
+def test_corruption_is_detected(tmp_path):
+    raw = bytearray(open(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"), "rb").read())
+    raw[40] ^= 0x01
+    p = tmp_path / "bad.tfrecords"
+    p.write_bytes(bytes(raw))
+    with pytest.raises(tfrecord.TFRecordError):
+        list(tfrecord.read_records(str(p)))
+    assert len(list(tfrecord.read_records(str(p), check_crc=False))) == 12
+    p.write_bytes(bytes(raw[:100]))
+    with pytest.raises(tfrecord.TFRecordError):
+        list(tfrecord.read_records(str(p), check_crc=False))
+
+
+def test_example_codec_against_protobuf():
+    Example = example_message_class()
+    rng = np.random.RandomState(0)
+    for trial in range(20):
+        audio = rng.randn(rng.randint(0, 300)).astype(np.float32)
+        ids = rng.randint(-5, 1 << 40, size=rng.randint(0, 40)).astype(np.int64)
+        texts = [("utt-%d" % trial).encode(), "übung ✓".encode("utf-8")][:rng.randint(1, 3)]
+        msg = Example()
+        msg.features.feature["audio"].float_list.value.extend(audio.tolist())
+        msg.features.feature["transcript"].int64_list.value.extend(ids.tolist())
+        msg.features.feature["uuid"].bytes_list.value.extend(texts)
+        got = tfrecord.parse_example(msg.SerializeToString())
+        assert got["audio"][0] == "float" and np.array_equal(got["audio"][1], audio)
+        assert got["transcript"][0] == "int64" and np.array_equal(got["transcript"][1], ids)
+        assert got["uuid"] == ("bytes", texts)
+        back = Example()
+        back.ParseFromString(tfrecord.encode_example({"audio": audio, "transcript": ids, "uuid": texts}))
+        assert np.array_equal(np.asarray(back.features.feature["audio"].float_list.value, np.float32), audio)
+        assert list(back.features.feature["transcript"].int64_list.value) == ids.tolist()
+        assert list(back.features.feature["uuid"].bytes_list.value) == texts
+    # unpacked repeated scalars (legal protobuf, older writers) are accepted too
+    ld = tfrecord._ld
+    unpacked = ld(1, ld(1, ld(1, b"a") + ld(2, ld(3, b"\x08\x01\x08\x02\x08\xff\xff\xff\xff\x0f"))))
+    assert tfrecord.parse_example(unpacked)["a"][1].tolist() == [1, 2, 0xFFFFFFFF]
+
+
+def test_file_set_and_interleave(tmp_path):
+    d = tmp_path / "data"
+    d.mkdir()
+    counts = {}
+    for i in range(13):
+        n = 3 + (i % 4)
+        counts[i] = n
+        tfrecord.write_records(str(d / f"train.tfrecords-{i:05d}-of-00013"),
+                               [tfrecord.encode_example({"k": [i * 100 + j]}) for j in range(n)])
+    tfrecord.write_records(str(d / "dev.tfrecords"), [tfrecord.encode_example({"k": [-1]})])
+    files = tfrecord.list_record_files(str(d))                       # a directory means dir/*train*
+    assert [os.path.basename(f) for f in files] == [f"train.tfrecords-{i:05d}-of-00013" for i in range(13)]
+    assert tfrecord.list_record_files(str(d / "train.tfrecords-0000")) == files[:10]      # a prefix means prefix*
+    assert tfrecord.list_record_files(str(d / "dev.tfrecords")) == [str(d / "dev.tfrecords")]
+    assert tfrecord.list_record_files(f"{d}/dev.tfrecords, {d}/train.tfrecords-00012") == [str(d / "dev.tfrecords"), files[12]]
+    got = [int(tfrecord.parse_example(r)["k"][1][0]) for r in tfrecord.interleave_records(files)]
+    # model of Dataset.interleave(cycle_length=10, block_length=1)
+    its = [iter([i * 100 + j for j in range(counts[i])]) for i in range(13)]
+    slots, nxt, want, i = its[:10], 10, [], 0
+    while slots:
+        if i >= len(slots):
+            i = 0
+        try:
+            want.append(next(slots[i]))
+            i += 1
+        except StopIteration:
+            if nxt < 13:
+                slots[i] = its[nxt]
+                nxt += 1
+            else:
+                slots.pop(i)
+    assert got == want and sorted(got) == sorted(i * 100 + j for i in range(13) for j in range(counts[i]))
+    assert got[:11] == [0, 100, 200, 300, 400, 500, 600, 700, 800, 900, 1]
+
+
+# ------------------------------------------------------------------------------------------------ SpecAugment
+@pytest.mark.parametrize("tag", ["LB", "LD", "SM", "SS", "LB_short", "custom"])
+def test_specaugment_matches_reference(tag):
+    """Outputs of the reference's SpecAugment class under the same numpy seed (masked cells + the fill value)."""
+    g = np.load(os.path.join(GOLD, f"specaug_{tag}.npz"))
+    shape = tuple(int(v) for v in g["shape"])
+    x = np.random.RandomState(int(g["x_seed"])).randn(*shape).astype(np.float32)
+    if tag == "custom":
+        aug = SpecAugment.build("{time_wrap_w: 0, freq_mask_n: 3, freq_mask_f: 10, time_mask_n: 4, time_mask_t: 30, "
+                                "time_mask_p: 0.5, mask_value: 0.25}")
+    else:
+        aug = SpecAugment.build(tag.split("_")[0])
+    np.random.seed(int(g["seed"]))
+    y = aug(x.copy())
+    mask = np.unpackbits(g["mask"])[:x.size].reshape(shape).astype(bool)
+    assert int(mask.sum()) == int(g["n_masked"])
+    want = np.where(mask, g["mask_value"], x)
+    assert np.array_equal(y, want)
+    if tag == "LB_short":
+        assert mask.sum() == 0 or mask.any(axis=0).sum() <= 27   # 60 frames < time_mask_t = 100: no time mask at all
+    assert SpecAugment.build(None) is None and SpecAugment.build("nonsense") is None
+
+
+# ------------------------------------------------------------------------------------------------ bucket arithmetic
+def test_bucket_boundaries_match_reference():
+    g = np.load(os.path.join(GOLD, "bucket_boundaries.npz"))
+    for k in g.files:
+        if not k.startswith("case"):
+            continue
+        mx, mn = int(g[k][0]), int(g[k][1])
+        assert batching.create_audio_bucket_boundaries(mx, None if mn < 0 else mn) == g[k][2:].tolist()
+    for v, f, want in g["minimal_multiple"]:
+        assert batching.minimal_multiple(int(v), int(f)) == int(want)
+
+
+def test_bucket_plan_of_the_mustc_recipe():
+    """examples/speech_transformer/must-c/st_training_args.yml: batch_size 80000 frames, max_src_len 3000, max_trg_len 150,
+    experimental_frame_transcript_ratio 12 (speech2text.py:293-336 evaluated by hand)."""
+    plan = batching.speech_bucket_plan(3000, 150, 128, 80000, None, 1, False, 12)
+    b, s, t = plan["audio_bounds"], plan["batch_sizes"], plan["trans_bounds"]
+    assert b[0] == 128 and b[-1] == 3008 and b == sorted(b) and len(b) == len(s) == len(t)
+    assert s[0] == 632 and s[-1] == 32            # ceil8(80000 // 128), ceil8(80000 // 3008)
+    assert all(x % 8 == 0 for x in s)
+    assert t[0][0] == 16                          # ceil8(min(int(128 / 12), 152))
+    assert t[-1] == [152, 152] and all(p[1] >= p[0] for p in t)
+    plain = batching.speech_bucket_plan(3000, 150, 128, None, 20000, 4, True, None)
+    assert plain["trans_bounds"] is None and plain["batch_sizes"][0] == (20000 // 128) * 4
+    with pytest.raises(AssertionError):
+        batching.speech_bucket_plan(3000, 150, 128, 2000, None, 1)   # per-GPU batch must exceed max_src_len
+    with pytest.raises(RuntimeError):
+        batching.speech_bucket_plan(None, 150, 128, 80000, None, 1)
+
+
+def test_clean_shuffle_window():
+    exs = [{"audio": np.zeros(n * 4, np.float32), "audio_length": np.int64(n), "transcript": np.arange(t)}
+           for n, t in [(5, 3), (50, 3), (5, 1), (5, 9), (0, 3), (7, 2)]]
+    kept = list(batching.clean_by_length(iter(exs), {"audio": 40, "audio_length": -1, "transcript": 8}))
+    assert [int(e["audio_length"]) for e in kept] == [5, 7]    # too long / 1-token transcript / too long transcript / empty audio
+    rng = np.random.RandomState(0)
+    out = list(batching.shuffle_buffer(iter(range(100)), 16, rng))
+    assert sorted(out) == list(range(100)) and out != list(range(100))
+    assert all(abs(v - i) <= 100 for i, v in enumerate(out)) and max(out[:10]) < 26   # only the buffer's reach is mixed
+    assert list(batching.shuffle_buffer(iter(range(5)), 0, rng)) == list(range(5))
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+def _write_speech_shards(d, n_files=4, per_file=40, fdim=8, seed=0, projected=True):
+    rng = np.random.RandomState(seed)
+    uid = 0
+    total = {}
+    for i in range(n_files):
+        recs = []
+        for _ in range(per_file):
+            frames = int(rng.randint(20, 400))
+            tr = rng.randint(0, 50, size=max(2, frames // 12)).astype(np.int64)
+            tr[-1] = 52  # EOS of a 50 + 3 vocabulary
+            feats = {"audio": (rng.randn(frames * fdim) + uid).astype(np.float32), "uuid": [f"utt{uid}"], "src_lang": ["en"],
+                     "translation": tr if projected else [" ".join(f"w{t}" for t in tr[:-1])]}
+            total[f"utt{uid}"] = (frames, tr)
+            recs.append(tfrecord.encode_example(feats))
+            uid += 1
+        tfrecord.write_records(os.path.join(d, f"train.tfrecords-{i:05d}-of-{n_files:05d}"), recs)
+    return total
+
+
+def _task_and_dataset(d, **task_params):
+    params = {"audio_feature_dim": 8, "audio_feature_channels": 1, "vocab_size": 53, "max_src_len": 300, "max_trg_len": 30,
+              "batch_size": 2000, "min_src_bucket_boundary": 64, "truncate_src": False}
+    params.update(task_params)
+    task = build_task({"task.class": "SpeechToText", "task.params": params})
+    ds = build_dataset({"dataset.class": "AudioTFRecordDataset",
+                        "dataset.params": {"data_path": d, "shuffle_dataset": True, "feature_key": "audio", "transcript_key": "translation"}})
+    return task, ds
+
+
+def test_audio_tfrecord_dataset_and_bucketed_batches(tmp_path):
+    d = str(tmp_path)
+    total = _write_speech_shards(d)
+    task, ds = _task_and_dataset(d)
+    assert ds.status == {"audio": compat.DataStatus.PROJECTED, "transcript": compat.DataStatus.PROJECTED}
+    # file-level sharding: disjoint, complete
+    seen = []
+    for r in range(2):
+        ids = [e["uuid"] for e in ds.build_iterator(shard_id=r, total_shards=2)()]
+        assert len(ids) == 80
+        seen += ids
+    assert sorted(seen) == sorted(total)
+    first = next(ds.build_iterator()())
+    assert first["uuid"] == "utt0" and first["src_lang"] == "en" and first["audio"].dtype == np.float32
+    assert first["audio"].shape[0] == total["utt0"][0] * 8 and np.array_equal(first["transcript"], total["utt0"][1])
+
+    plan = batching.speech_bucket_plan(300, 30, 64, 2000, None, 1)
+    bounds, sizes = plan["audio_bounds"], plan["batch_sizes"]
+    it = task.create_and_batch(ds, compat.ModeKeys.TRAIN, seed=3)
+    n_utts = 0
+    for _ in range(12):
+        b = next(it)
+        B = b["audio"].shape[0]
+        bucket = bounds.index(b["audio"].shape[1] // 8)
+        assert B == sizes[bucket] and b["audio"].shape[1] == bounds[bucket] * 8      # padded to the bucket bound
+        lo = bounds[bucket - 1] if bucket else 0
+        assert (b["audio_length"] <= bounds[bucket]).all() and (b["audio_length"] > lo).all() and (b["audio_length"] <= 300).all()
+        assert b["transcript"].shape[1] == max(int((row != 52).sum()) + 1 for row in b["transcript"])  # longest of the batch
+        for row, n in zip(b["audio"], b["audio_length"]):
+            assert (row[int(n) * 8:] == 0).all() and row[:int(n) * 8].any()
+        for row in b["transcript"]:
+            k = int((row != 52).sum())
+            assert row[k] == 52 and (row[k:] == 52).all()                             # EOS, then EOS as padding
+        n_utts += B
+        x = task.example_to_input({k: torch.from_numpy(v) for k, v in b.items()}, compat.ModeKeys.TRAIN)
+        assert x["src"].shape == (B, bounds[bucket], 8, 1) and x["trg_input"][:, 0].eq(51).all()
+        assert torch.equal(x["trg_length"], torch.from_numpy((b["transcript"] != 52).sum(1) + 1))
+    assert n_utts > 160 * 0.5                                                         # runs over epochs, drops little
+
+    # evaluation: ordered, fixed utterance count, last batch partial, padded to the longest
+    ev = list(task.create_and_batch(ds, compat.ModeKeys.EVAL, args={"batch_size": 64}))
+    assert [b["audio"].shape[0] for b in ev] == [64, 64, 32]
+    assert ev[0]["audio"].shape[1] == int(ev[0]["audio_length"].max()) * 8
+
+
+def test_truncation_specaug_and_fixed_transcript_buckets(tmp_path):
+    d = str(tmp_path)
+    _write_speech_shards(d, n_files=2, per_file=60, seed=5)
+    task, ds = _task_and_dataset(d, max_src_len=200, truncate_src=True, truncate_trg=True, max_trg_len=10, specaug="LB",
+                                 experimental_frame_transcript_ratio=12, batch_size=1200, min_src_bucket_boundary=64)
+    np.random.seed(0)
+    it = task.create_and_batch(ds, compat.ModeKeys.TRAIN, seed=1)
+    plan = batching.speech_bucket_plan(200, 10, 64, 1200, None, 1, False, 12)
+    for _ in range(6):
+        b = next(it)
+        bucket = plan["audio_bounds"].index(b["audio"].shape[1] // 8)
+        assert b["transcript"].shape[1] in plan["trans_bounds"][bucket]               # fixed transcript length of the bucket
+        assert (b["audio_length"] <= 200).all()                                      # truncated, not dropped
+        real = (b["transcript"] != 52).sum(1) + 1
+        assert (real <= 10).all()                                                    # head + EOS kept
+    task2, _ = _task_and_dataset(d, specaug="{time_wrap_w: 0, freq_mask_n: 1, freq_mask_f: 4, time_mask_n: 1, time_mask_t: 10, time_mask_p: 1.0}")
+    prep = task2.get_data_preprocess_fn(compat.ModeKeys.TRAIN, ds.status)
+    ex = next(ds.build_iterator()())
+    np.random.seed(4)
+    out = prep(dict(ex))
+    changed = out["audio"].reshape(-1, 8) != ex["audio"].reshape(-1, 8)
+    assert changed.any() and np.unique(out["audio"].reshape(-1, 8)[changed]).size == 1
+    evalp = task2.get_data_preprocess_fn(compat.ModeKeys.EVAL, ds.status)
+    assert np.array_equal(evalp(dict(ex))["audio"], ex["audio"])                   # no augmentation outside training
+
+
+def test_raw_transcripts_need_a_pipeline(tmp_path):
+    d = str(tmp_path)
+    _write_speech_shards(d, n_files=1, per_file=5, projected=False)
+    task, ds = _task_and_dataset(d)
+    assert ds.status["transcript"] == compat.DataStatus.RAW
+    with pytest.raises(RuntimeError):
+        next(task.create_and_batch(ds, compat.ModeKeys.TRAIN))
+    vocab = [f"w{i}" for i in range(50)]
+    task, ds = _task_and_dataset(d, **{"transcript_data_pipeline.params": {"vocab_path": vocab}, "batch_size": 400,
+                                       "max_src_len": 399, "min_src_bucket_boundary": 512})
+    assert task.trg_meta["vocab_size"] == 53 and task.trg_meta["eos_id"] == 52
+    prep = task.get_data_preprocess_fn(compat.ModeKeys.TRAIN, ds.status)
+    ex = next(ds.build_iterator()())
+    ids = prep(dict(ex))["transcript"]
+    assert ids[-1] == 52 and [f"w{i}" for i in ids[:-1]] == ex["transcript"].split()
+    assert ds.targets[0] == ex["transcript"]

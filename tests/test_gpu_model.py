@@ -408,3 +408,49 @@ def test_dropout_training_step_runs_and_is_reproducible():
         eval_logits = model(inputs, is_training=False)
         assert torch.isfinite(eval_logits.float()).all()
     assert losses[0] == losses[1]  # same seed, same step -> identical Philox masks
+
+
+def test_cli_training_from_tfrecord_shards(tmp_path):
+    """The reference's recipe layout end to end (examples/speech_transformer/must-c/st_training_args.yml): a yaml with
+    dataset.class AudioTFRecordDataset + task.class SpeechToText (frame-bucketed batches, SpecAugment) drives the trainer
+    from TFRecord shards; the loss of the toy model must fall, and model_configs.yml + a checkpoint must be written."""
+    import yaml
+    import neurst_amd.cli.run_exp as run_exp
+    from neurst_amd.data import tfrecord
+    rng = np.random.RandomState(0)
+    data = tmp_path / "train"
+    data.mkdir()
+    V, fdim = 23, 16
+    for i in range(2):
+        recs = []
+        for _ in range(64):
+            frames = int(rng.randint(24, 120))
+            tr = rng.randint(0, 4, size=max(2, frames // 12)).astype(np.int64)   # tiny vocabulary: learnable in a few steps
+            tr[-1] = V - 1
+            recs.append(tfrecord.encode_example({"audio": rng.randn(frames * fdim).astype(np.float32), "translation": tr,
+                                                 "uuid": ["u"], "src_lang": ["en"]}))
+        tfrecord.write_records(str(data / f"train.tfrecords-{i:05d}-of-00002"), recs)
+    cfg = {
+        "entry.class": "trainer",
+        "entry.params": {"train_steps": 30, "summary_steps": 10, "save_checkpoint_steps": 30,
+                         "criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1},
+                         "optimizer.class": "adam", "optimizer.params": {"epsilon": 1.e-9, "beta_1": 0.9, "beta_2": 0.98},
+                         "lr_schedule.class": "noam", "lr_schedule.params": {"initial_factor": 3.5, "dmodel": 32, "warmup_steps": 10}},
+        "dataset.class": "AudioTFRecordDataset",
+        "dataset.params": {"data_path": str(data), "shuffle_dataset": True, "feature_key": "audio", "transcript_key": "translation"},
+        "task.class": "SpeechToText",
+        "task.params": {"audio_feature_dim": fdim, "vocab_size": V, "batch_size": 1200, "max_src_len": 100, "max_trg_len": 12,
+                        "min_src_bucket_boundary": 32, "truncate_src": True, "specaug": "SS", "shuffle_buffer": 16},
+    }
+    cfg_path = tmp_path / "train.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    model_dir = tmp_path / "model"
+    first = run_exp._main(["--config_paths", str(cfg_path), "--hparams_set", "speech_transformer_toy", "--model_dir", str(model_dir),
+                           "--dtype", "float32", "--distribution_strategy", "none", "--train_steps", "1"])
+    last = run_exp._main(["--config_paths", str(cfg_path), "--hparams_set", "speech_transformer_toy", "--model_dir", str(model_dir),
+                          "--dtype", "float32", "--distribution_strategy", "none"])
+    REPORT["cli_tfrecord.first_loss"], REPORT["cli_tfrecord.last_loss"] = float(first), float(last)
+    assert math.isfinite(float(last)) and float(last) < float(first)
+    assert (model_dir / "model_configs.yml").exists() and (model_dir / "ckpt-30.pt").exists()
+    saved = yaml.safe_load((model_dir / "model_configs.yml").read_text())
+    assert saved["task.class"] == "SpeechToText" and saved["task.params"]["audio_feature_dim"] == fdim
