@@ -16,6 +16,7 @@ from neurst_amd.optimizers import build_lr_schedule, build_optimizer
 from neurst_amd.training.distributed import GradientReducer
 from neurst_amd.training.train_step import TrainStep
 from neurst_amd.utils import compat
+from neurst_amd.utils.checkpoints import NameBasedCheckpointManager, restore_checkpoint_if_possible
 from neurst_amd.utils.configurable import ModelConfigs
 from neurst_amd.utils.flags_core import Flag, ModuleFlag
 
@@ -33,6 +34,9 @@ class Trainer(BaseExperiment):
         self._optimizer_args = {"optimizer.class": args["optimizer.class"], "optimizer.params": args["optimizer.params"]}
         self._lr_args = {"lr_schedule.class": args["lr_schedule.class"], "lr_schedule.params": args["lr_schedule.params"]}
         self._bucket_mb = args.get("allreduce_bucket_mb", 32) or 32
+        self._max_to_keep = args.get("checkpoints_max_to_keep", 8) or 8
+        self._pretrain_model = args.get("pretrain_model", None)
+        self._ckpt_manager = None
 
     @staticmethod
     def class_or_method_args():
@@ -45,19 +49,17 @@ class Trainer(BaseExperiment):
             Flag("save_checkpoint_steps", dtype=Flag.TYPE.INTEGER, default=1000, help="Saving checkpoints every N steps."),
             Flag("checkpoints_max_to_keep", dtype=Flag.TYPE.INTEGER, default=8, help="Number of checkpoints to keep."),
             Flag("update_cycle", dtype=Flag.TYPE.INTEGER, default=1, help="Gradient accumulation micro steps."),
+            Flag("pretrain_model", dtype=Flag.TYPE.STRING, default=None,
+                 help="A checkpoint (directory or prefix, TensorFlow bundle format) to initialise the weights from."),
             Flag("allreduce_bucket_mb", dtype=Flag.TYPE.INTEGER, default=32,
                  help="Size of one RCCL all-reduce message of the flat gradient buffer."),
         ]
 
     def _save(self, step):
-        if not self.model_dir:
+        if self._ckpt_manager is None:
             return
-        os.makedirs(self.model_dir, exist_ok=True)
-        path = os.path.join(self.model_dir, f"ckpt-{step}.pt")
         try:
-            torch.save({"step": step, "variables": self.model.store.state_dict()}, path)
-            with open(os.path.join(self.model_dir, "checkpoint"), "w") as fp:
-                fp.write(f'model_checkpoint_path: "ckpt-{step}.pt"\n')
+            self._ckpt_manager.save(step)
         except Exception as e:  # the reference also only warns (callbacks.py:88-92)
             logging.warning("fail to save checkpoint: %s", e)
 
@@ -71,8 +73,25 @@ class Trainer(BaseExperiment):
         optimizer.bind(model.store)
         if lr is not None:
             optimizer.learning_rate = lr
+        # weights: --pretrain_model first, then the latest checkpoint of model_dir (trainer.py:207-236); rank 0 reads,
+        # everyone receives the broadcast
+        start_step = 0
+        if rank == 0:
+            if self._pretrain_model:
+                got = restore_checkpoint_if_possible(model, self._pretrain_model)
+                logging.info("pretrain_model %s: %s", self._pretrain_model, "restored" if got else "nothing restored")
+            if self.model_dir:
+                self._ckpt_manager = NameBasedCheckpointManager(model, self.model_dir, self._max_to_keep, optimizer=optimizer)
+                if self._ckpt_manager.restore() is not None:
+                    start_step = optimizer.iterations
+                    logging.info("resuming %s at step %d", self.model_dir, start_step)
         reducer = GradientReducer(model.store, bucket_bytes=self._bucket_mb << 20)
         reducer.broadcast_parameters(0)
+        if world > 1:
+            start_step = int(reducer.reduce_metrics({"start_step": float(start_step)})["start_step"])
+            if start_step:
+                optimizer.iterations = start_step
+                reducer.broadcast_tensors([optimizer.m, optimizer.v], 0)
         step_fn = TrainStep(model, self._criterion, optimizer, reducer, self._update_cycle)
         if rank == 0 and self.model_dir:
             ModelConfigs.dump({"model.class": model.__class__.__name__, "model.params": model.args,
@@ -92,7 +111,7 @@ class Trainer(BaseExperiment):
                                                       for k, v in b.items()}, compat.ModeKeys.TRAIN)
             it = _feed()
         t0, frames, last_loss = time.time(), 0.0, None
-        for step in range(1, self._train_steps + 1):
+        for step in range(start_step + 1, self._train_steps + 1):
             try:
                 batches = [next(it) for _ in range(self._update_cycle)]
             except StopIteration:

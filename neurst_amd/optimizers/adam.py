@@ -41,5 +41,16 @@ class Adam(object):
                       grad_scale)
         self.iterations = t
 
+    def state(self):
+        """Resume state (checkpoints.py keeps it next to the weights): step count and both moment buffers."""
+        return {"step": self.iterations, "m": self.m, "v": self.v}
+
+    def load_state(self, st):
+        if st["m"].numel() != self.m.numel():
+            raise ValueError("optimizer state does not match this parameter layout")
+        self.iterations = int(st["step"])
+        self.m.copy_(st["m"].to(self.m.device))
+        self.v.copy_(st["v"].to(self.v.device))
+
     def get_config(self):
         return {"beta_1": self.beta_1, "beta_2": self.beta_2, "epsilon": self.epsilon}

@@ -117,6 +117,12 @@ class GradientReducer(object):
             dist.broadcast(self.store.master, src=src, group=self.group)
             self.store.refresh_shadow()
 
+    def broadcast_tensors(self, tensors, src=0):
+        """Other replicated state that must start identical on every rank (optimizer moments after a resume)."""
+        if self.world > 1:
+            for t in tensors:
+                dist.broadcast(t, src=src, group=self.group)
+
     def reduce_metrics(self, values):
         """One packed all-reduce for the logged scalars (MetricReductionCallback, callbacks.py:149-207).
         values: dict name -> float (summed over ranks)."""
