@@ -325,3 +325,47 @@ def test_raw_transcripts_need_a_pipeline(tmp_path):
     ids = prep(dict(ex))["transcript"]
     assert ids[-1] == 52 and [f"w{i}" for i in ids[:-1]] == ex["transcript"].split()
     assert ds.targets[0] == ex["transcript"]
+
+
+def test_reference_recipe_yaml_layout_builds_task_and_dataset(tmp_path):
+    """The argument layout of examples/speech_transformer/must-c/st_training_args.yml goes through the CLI flag parser:
+    entry / dataset / task classes by their reference names, nested *.params, the Noam schedule with a decaying factor."""
+    import yaml
+    import neurst_amd.cli.run_exp as run_exp
+    import neurst_amd.utils.flags_core as fc
+    from neurst_amd.optimizers import build_lr_schedule
+    train = tmp_path / "asr_st" / "de" / "train"
+    train.mkdir(parents=True)
+    tfrecord.write_records(str(train / "train.tfrecords-00000-of-00001"),
+                           [tfrecord.encode_example({"audio": np.zeros(80 * 50, np.float32), "translation": np.array([1, 2, 5], np.int64)})])
+    (tmp_path / "vocab.de").write_text("a\nb\nc\n")
+    cfg = {
+        "entry.class": "trainer",
+        "entry.params": {"train_steps": 200000, "summary_steps": 200, "save_checkpoint_steps": 2000,
+                         "criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1},
+                         "optimizer.class": "adam", "optimizer.params": {"epsilon": 1.e-9, "beta_1": 0.9, "beta_2": 0.98},
+                         "lr_schedule.class": "noam",
+                         "lr_schedule.params": {"initial_factor": 3.5, "end_factor": 1.5, "dmodel": 256, "warmup_steps": 25000,
+                                                "start_decay_at": 50000, "decay_steps": 50000}},
+        "dataset.class": "AudioTFRecordDataset",
+        "dataset.params": {"data_path": str(train), "shuffle_dataset": True, "feature_key": "audio", "transcript_key": "translation"},
+        "task.class": "SpeechToText",
+        "task.params": {"audio_feature_dim": 80, "transcript_data_pipeline.class": "TranscriptDataPipeline",
+                        "transcript_data_pipeline.params": {"language": "de", "vocab_path": str(tmp_path / "vocab.de")},
+                        "batch_by_frames": True, "batch_size": 80000, "max_src_len": 3000, "max_trg_len": 150, "truncate_src": True,
+                        "experimental_frame_transcript_ratio": 12},
+    }
+    path = tmp_path / "st_training_args.yml"
+    path.write_text(yaml.safe_dump(cfg))
+    argv = ["--config_paths", str(path), "--hparams_set", "speech_transformer_s"]
+    parser = fc.define_flags(run_exp.FLAG_LIST, argv=argv)
+    args, _ = fc.intelligent_parse_flags(run_exp.FLAG_LIST, parser, run_exp._pre_load_args, argv=argv)
+    assert (args["entry.class"], args["dataset.class"], args["task.class"]) == ("trainer", "AudioTFRecordDataset", "SpeechToText")
+    task, ds = build_task(args), build_dataset(args)
+    assert task.trg_meta["vocab_size"] == 6 and task.trg_meta["eos_id"] == 5
+    assert ds.status == {"audio": compat.DataStatus.PROJECTED, "transcript": compat.DataStatus.PROJECTED}
+    assert task.get_config()["transcript_data_pipeline.params"]["language"] == "de"
+    lr = build_lr_schedule({"lr_schedule.class": args["entry.params"]["lr_schedule.class"],
+                            "lr_schedule.params": args["entry.params"]["lr_schedule.params"]})
+    assert abs(lr(24999) - 3.5 * 256 ** -0.5 * 25000 ** -0.5) < 1e-12
+    assert abs(lr(99999) - 1.5 * 256 ** -0.5 * 100000 ** -0.5) < 1e-12
