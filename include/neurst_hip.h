@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 1
+#define NST_ABI_VERSION 2
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -143,6 +143,10 @@ typedef struct {
    * call writes one keep bit per probability into it, the backward call of the same step reads it (no RNG in bwd). */
   void* dropout_mask;
   int64_t dropout_mask_bytes;
+  /* batch strides (elements) of k and v (and of dk, dv); 0 = Tk * ldk / Tk * ldv (dense [B,Tk,*]).  A larger stride
+   * lets incremental decoding attend over the filled prefix of a preallocated [B, Tmax, *] key / value cache
+   * (multi_head_attention.py:254-290 concatenates instead). */
+  int64_t bsk, bsv;
 } NstAttnDesc;
 
 /* B*H*ceil(Tq/16)*ceil(Tk/64)*128 bytes */

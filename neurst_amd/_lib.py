@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 1
+NST_ABI_VERSION = 2
 
 
 class NstGemmDesc(C.Structure):
@@ -48,6 +48,7 @@ class NstAttnDesc(C.Structure):
         ("dropout_p", C.c_float),
         ("seed", C.c_uint64), ("stream_id", C.c_uint64),
         ("dropout_mask", C.c_void_p), ("dropout_mask_bytes", C.c_int64),
+        ("bsk", C.c_int64), ("bsv", C.c_int64),
     ]
 
 

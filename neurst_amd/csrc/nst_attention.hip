@@ -186,6 +186,7 @@ struct AttnParams {
   int B, H, Tq, Tk, dh;
   int nqb, nkt;    // ceil(Tq/16), ceil(Tk/64)
   int64_t ldq, ldk, ldv, ldo;
+  int64_t bsk, bsv;  // batch strides of k / v (and dk / dv), elements
   float scale, scale2;  // dh^-0.5 and dh^-0.5 * log2(e)
   int causal;
   uint32_t drop_thresh;  // 16-bit threshold, 0 = no dropout
@@ -231,8 +232,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   const int g = lane >> 4, lc = lane & 15;
   const int q0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
-  const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
-  const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
+  const T* kb = (const T*)p.k + (int64_t)b * p.bsk + h * p.dh;
+  const T* vb = (const T*)p.v + (int64_t)b * p.bsv + h * p.dh;
   const int64_t bh = (int64_t)b * p.H + h;
 
   Frag qf[MI][AT<T>::NK];
@@ -437,8 +438,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
   const int g = lane >> 4, lc = lane & 15;
   const int k0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
-  const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
-  const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
+  const T* kb = (const T*)p.k + (int64_t)b * p.bsk + h * p.dh;
+  const T* vb = (const T*)p.v + (int64_t)b * p.bsv + h * p.dh;
   const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
   const int64_t bh = (int64_t)b * p.H + h;
 
@@ -554,8 +555,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
     __syncthreads();
   }
 
-  T* dkb = (T*)p.dk + (int64_t)b * p.Tk * p.ldk + h * p.dh;
-  T* dvb = (T*)p.dv + (int64_t)b * p.Tk * p.ldv + h * p.dh;
+  T* dkb = (T*)p.dk + (int64_t)b * p.bsk + h * p.dh;
+  T* dvb = (T*)p.dv + (int64_t)b * p.bsv + h * p.dh;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int kg = k0 + mi * TR + wave * 16 + lc;
@@ -585,8 +586,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
   const int g = lane >> 4, lc = lane & 15;
   const int q0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
   const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
-  const T* kb = (const T*)p.k + (int64_t)b * p.Tk * p.ldk + h * p.dh;
-  const T* vb = (const T*)p.v + (int64_t)b * p.Tk * p.ldv + h * p.dh;
+  const T* kb = (const T*)p.k + (int64_t)b * p.bsk + h * p.dh;
+  const T* vb = (const T*)p.v + (int64_t)b * p.bsv + h * p.dh;
   const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
   const int64_t bh = (int64_t)b * p.H + h;
 
@@ -719,6 +720,9 @@ int fill_params(const NstAttnDesc* d, AttnParams& p) {
   p.B = d->B; p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.dh = d->dh;
   p.nqb = (d->Tq + 15) / 16; p.nkt = (d->Tk + TR - 1) / TR;
   p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
+  p.bsk = d->bsk ? d->bsk : (int64_t)d->Tk * d->ldk;
+  p.bsv = d->bsv ? d->bsv : (int64_t)d->Tk * d->ldv;
+  NST_CHECK_ARG(p.bsk >= (int64_t)d->Tk * d->ldk && p.bsv >= (int64_t)d->Tk * d->ldv, "attention: k/v batch stride smaller than Tk rows");
   p.scale = d->scale; p.scale2 = d->scale * LOG2E; p.causal = d->causal;
   nst_dropout_params16(d->dropout_p, &p.drop_thresh, &p.drop_inv_keep);
   if (p.drop_thresh) {

@@ -190,9 +190,12 @@ def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id):
     # q [B,Tq,*] k,v [B,Tk,*] views whose last dim starts at this tensor's head 0 (row stride = stride(1))
     d = NstAttnDesc()
     d.B, d.Tq, d.Tk, d.H, d.dh = q.shape[0], q.shape[1], k.shape[1], H, dh
-    for t in (q, k, v, out):
+    for t in (q, out):
         assert t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "batch stride must be T*row stride"
+    for t in (k, v):  # k / v may be the filled prefix of a longer cache: any batch stride >= Tk rows
+        assert t.stride(-1) == 1 and t.stride(0) >= t.shape[1] * t.stride(1), "k/v batch stride smaller than Tk rows"
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    d.bsk, d.bsv = k.stride(0), v.stride(0)
     d.dtype = _dt(q)
     d.scale = float(dh) ** -0.5
     d.causal = int(causal)

@@ -1,5 +1,9 @@
-"""MultiHeadAttention / MultiHeadSelfAttention (neurst/layers/attentions/multi_head_attention.py:21-290),
-training path (no decode cache).
+"""MultiHeadAttention / MultiHeadSelfAttention (neurst/layers/attentions/multi_head_attention.py:21-290): the training
+path, and the incremental decoding path with a cache (`compute_qkv` cache branches, :151-174 and :254-290).
+
+decode : `cache` is a dict owned by the decoder.  Cross attention projects the memory ONCE (cache["kv"]); self
+         attention appends the new position's k|v to preallocated [B', Tmax, d] buffers (the reference concatenates)
+         and attends over the filled prefix -- the same fused attention kernel with Tq = 1.
 
 forward : packed projection GEMM (bias fused) -> fused flash attention kernel reading q|k|v as strided column
           views of the projection output (no split / transpose copies) -> output projection GEMM whose epilogue
@@ -40,12 +44,18 @@ class MultiHeadAttention(Layer):
         self.q_transform = MultiHeadDenseLayer(self.rt, self.name + "/q_transform", self.input_depth, d, H, gen)
         self.kv_transform = MultiHeadDenseLayer(self.rt, self.name + "/kv_transform", self.memory_depth, [d, d], H, gen)
 
-    def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None):
-        """query [B*Tq, d], memory [B*Tk, d]; memory_bias [B,Tk] f32 (padding*FLOAT_MIN) or None."""
+    def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None, cache=None):
+        """query [B*Tq, d], memory [B*Tk, d]; memory_bias [B,Tk] f32 (padding*FLOAT_MIN) or None.
+        cache (decoding only): the projected memory is computed at the first step and reused."""
         d, H, dh = self.num_units, self.num_heads, self.dh
         p = self.rate if is_training else 0.0
         q = self.q_transform.forward(query)
-        kv = self.kv_transform.forward(memory)
+        if cache is not None:
+            if "kv" not in cache:
+                cache["kv"] = self.kv_transform.forward(memory)
+            kv = cache["kv"]
+        else:
+            kv = self.kv_transform.forward(memory)
         q3, kv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d)
         ctx, lse, dmask = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=False,
                                    dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
@@ -84,11 +94,23 @@ class MultiHeadSelfAttention(MultiHeadAttention):
                                                     is_output_transform=True)
         self.qkv_transform = MultiHeadDenseLayer(self.rt, self.name + "/qkv_transform", self.input_depth, [d, d, d], H, gen)
 
-    def forward(self, x, B, T, bias=None, causal=False, is_training=True, epilogue=None):
-        """x [B*T, d]; bias [B,T] f32 key-padding bias or None; causal=True is the decoder's lower-triangle bias."""
+    def forward(self, x, B, T, bias=None, causal=False, is_training=True, epilogue=None, cache=None):
+        """x [B*T, d]; bias [B,T] f32 key-padding bias or None; causal=True is the decoder's lower-triangle bias.
+        cache (decoding only, T == 1): {"keys", "values": [B, Tmax, d] buffers, "len": filled positions}."""
         d, H, dh = self.num_units, self.num_heads, self.dh
         p = self.rate if is_training else 0.0
         qkv = self.qkv_transform.forward(x)
+        if cache is not None:
+            assert T == 1 and not is_training
+            t = cache["len"]
+            if t >= cache["keys"].shape[1]:
+                raise RuntimeError(f"decoding cache of {cache['keys'].shape[1]} positions is full")
+            cache["keys"][:, t] = qkv[:, d:2 * d]
+            cache["values"][:, t] = qkv[:, 2 * d:]
+            cache["len"] = t + 1
+            ctx, _, _ = K.attention_fwd(qkv.view(B, 1, 3 * d)[..., :d], cache["keys"][:, :t + 1], cache["values"][:, :t + 1],
+                                        H, dh, key_bias=None, causal=False)
+            return self.output_transform.forward(ctx.view(B, d), **(epilogue or {}))
         v3 = qkv.view(B, T, 3 * d)
         ctx, lse, dmask = K.attention_fwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], H, dh, key_bias=bias, causal=causal,
                                    dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)

@@ -1,5 +1,5 @@
-"""TransformerDecoder (neurst/layers/decoders/transformer_decoder.py:23-228), training branch
-(cache["decoding_states"] is None; wait-k lagging and incremental decoding are off the hot path)."""
+"""TransformerDecoder (neurst/layers/decoders/transformer_decoder.py:23-228): the training branch
+(cache["decoding_states"] is None) and incremental decoding with per-layer caches (wait-k lagging is not built)."""
 import torch
 
 from neurst_amd import kernels as K
@@ -43,19 +43,57 @@ class TransformerDecoder(Decoder):
 
     def create_decoding_internal_cache(self, encoder_outputs, encoder_inputs_padding, is_inference=False,
                                        decode_padded_length=None):
-        """transformer_decoder.py:105-147, training branch: {"decoding_states": None, "memory", "memory_bias"}."""
-        if is_inference:
-            raise NotImplementedError("incremental decoding cache is not on the training hot path")
+        """transformer_decoder.py:105-147.  Training: {"decoding_states": None, "memory", "memory_bias"}.  Inference adds
+        per-layer decoding states: self-attention key / value buffers of `decode_padded_length` positions (filled one
+        position per step) and the cross attention's projected memory (filled at the first step)."""
         cache = dict(decoding_states=None)
         if encoder_inputs_padding is not None:
             cache["memory"] = encoder_outputs
             cache["memory_bias"] = layer_utils.input_padding_to_bias(encoder_inputs_padding)
+        if is_inference:
+            if decode_padded_length is None:
+                raise ValueError("inference needs decode_padded_length (the maximum number of decoding steps)")
+            B, d = encoder_outputs.shape[0], self._params["hidden_size"]
+            states = {}
+            for i in range(self._params["num_layers"]):
+                states[f"layer_{i}"] = {
+                    "self_attention": {"keys": torch.zeros(B, decode_padded_length, d, dtype=encoder_outputs.dtype, device=encoder_outputs.device),
+                                       "values": torch.zeros(B, decode_padded_length, d, dtype=encoder_outputs.dtype, device=encoder_outputs.device),
+                                       "len": 0},
+                    "encdec_attention": {}}
+            cache["decoding_states"] = states
         return cache
+
+    @staticmethod
+    def reorder_cache(cache, beam_ids):
+        """tf.gather(cache, beam_ids) of the beam search (beam_search.py:409-410): only the self-attention buffers depend on
+        the hypothesis; memory, memory_bias and the projected memory are identical for all beams of a sample (beam_ids
+        never leave the sample's block), so they stay in place."""
+        for st in cache["decoding_states"].values():
+            sa = st["self_attention"]
+            n = sa["len"]
+            sa["keys"][:, :n] = sa["keys"][:, :n].index_select(0, beam_ids)
+            sa["values"][:, :n] = sa["values"][:, :n].index_select(0, beam_ids)
+        return cache
+
+    def decode_step(self, decoder_inputs, cache):
+        """One incremental step: decoder_inputs [B', d] (embedding of the last generated symbols) -> [B', d]."""
+        assert cache.get("decoding_states", None) is not None, "create_decoding_internal_cache(is_inference=True) first"
+        Bp, d = decoder_inputs.shape
+        memory, memory_bias = cache.get("memory", None), cache.get("memory_bias", None)
+        Tm = memory.shape[1] if memory is not None else 0
+        mem2 = memory.reshape(Bp * Tm, d) if memory is not None else None
+        x = decoder_inputs
+        for i, layer in enumerate(self._stacking_layers):
+            x = layer.forward(x, Bp, 1, mem2, Tm, memory_bias, is_training=False, cache=cache["decoding_states"][f"layer_{i}"])
+        return self._output_norm_layer.forward(x, save=False)
 
     def forward(self, decoder_inputs, cache, decode_lagging=None, is_training=True, decode_loop_step=None):
         """decoder_inputs [B,L,d]; cache from create_decoding_internal_cache -> [B,L,d]."""
         if decode_lagging is not None or decode_loop_step is not None:
             raise NotImplementedError("wait-k / static-shape decoding are off the hot path")
+        if cache.get("decoding_states", None) is not None:
+            return self.decode_step(decoder_inputs.reshape(-1, decoder_inputs.shape[-1]), cache).view(decoder_inputs.shape)
         B, L, d = decoder_inputs.shape
         memory = cache.get("memory", None)
         memory_bias = cache.get("memory_bias", None)

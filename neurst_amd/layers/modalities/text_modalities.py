@@ -27,8 +27,15 @@ class WordEmbeddingSharedWeights(Layer):
     embedding_dim = property(lambda self: self._embedding_dim)
     vocab_size = property(lambda self: self._vocab_size)
 
-    def forward(self, inputs, mode="embedding", timing=None, is_training=True, **kw):
+    def forward(self, inputs, mode="embedding", timing=None, is_training=True, time=None, **kw):
         d, V = self._embedding_dim, self._vocab_size
+        if mode == "embedding" and time is not None:
+            # incremental decoding (common_layers.py:415-434 with `time`): ids [B'] of ONE position, signal row `time`
+            ids = inputs.long().reshape(-1, 1)
+            scale = float(d) ** 0.5 if timing == "sinusoids" else 1.0
+            table_len = max(512, 1 << int(time).bit_length())  # rows do not depend on the table length
+            pos = self.rt.posenc(table_len, d)[int(time):int(time) + 1].contiguous() if timing == "sinusoids" else None
+            return K.embedding_fwd(self._shared_weights.compute, ids, pos, 1, scale).view(-1, d)
         if mode == "embedding":
             ids = inputs.long()
             L = ids.shape[-1]

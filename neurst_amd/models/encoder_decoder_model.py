@@ -102,6 +102,32 @@ class EncoderDecoderModel(BaseModel):
 
     __call__ = forward
 
+    # ------------------------------------------------------------------ inference
+    def get_symbols_to_logits_fn(self, inputs, beam_size=1, decode_padded_length=256):
+        """encoder_decoder_model.py:187-260 for inference: runs the encoder once, builds the decoder's incremental cache for
+        batch * beam rows and returns (symbols_to_logits_fn, generation_initializer, reorder_cache_fn) for
+        neurst_amd.layers.search.sequence_beam_search."""
+        from neurst_amd.layers.search.beam_search import stack_beam_size
+        embedded_inputs = self._src_modality.forward(inputs["src"], is_training=False)
+        src_padding = self._src_padding(inputs, embedded_inputs)
+        encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=False)
+        cache = self._decoder.create_decoding_internal_cache(
+            stack_beam_size(encoder_outputs, beam_size).contiguous(), stack_beam_size(src_padding, beam_size).contiguous(),
+            is_inference=True, decode_padded_length=decode_padded_length)
+
+        def symbols_to_logits_fn(ids, cache, time):
+            dec_in = self._trg_modality.forward(ids, is_training=False, time=time)
+            return self.output_logits_layer(self._decoder.decode_step(dec_in, cache), is_training=False)
+
+        batch = encoder_outputs.shape[0]
+        first = inputs.get("trg_input", None)
+        if first is None:
+            first = torch.full((batch,), self._trg_meta["bos_id"], dtype=torch.int64, device=encoder_outputs.device)
+        init = {"decoder_input": first.reshape(batch), "decoder_internal_cache": cache,
+                "encoder_inputs_maxlen": int(encoder_outputs.shape[1]), "eos_id": self._trg_meta["eos_id"],
+                "unk_id": self._trg_meta.get("unk_id", None)}
+        return symbols_to_logits_fn, init, self._decoder.reorder_cache
+
     def backward(self, dlogits, accumulate=False):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""

@@ -395,6 +395,23 @@ def test_attention_dropout_long(K, dtype, attn_mi):
     close(tag + ".dv", dkv[..., d:], vr.grad, dtype, scale=3.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_over_cache_prefix(K, dtype):
+    """k / v given as the filled prefix [:, :t] of a longer [B, Tmax, d] cache (NstAttnDesc.bsk / bsv): the decoding step's
+    view must give what a dense copy of the prefix gives, bit for bit."""
+    B, H, dh, Tmax = 3, 4, 16, 40
+    d = H * dh
+    kc, vc = rnd(B, Tmax, d, dtype=dtype, seed=1).to(DEV), rnd(B, Tmax, d, dtype=dtype, seed=2).to(DEV)
+    for t in (1, 7, 16, 33):
+        q = rnd(B, 1, d, dtype=dtype, seed=10 + t).to(DEV)
+        got, _, _ = K.attention_fwd(q, kc[:, :t], vc[:, :t], H, dh)
+        want, _, _ = K.attention_fwd(q, kc[:, :t].contiguous(), vc[:, :t].contiguous(), H, dh)
+        assert torch.equal(got, want)
+        qf, kf, vf = q.double().view(B, 1, H, dh), kc[:, :t].double().view(B, t, H, dh), vc[:, :t].double().view(B, t, H, dh)
+        p = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qf, kf) * dh ** -0.5, -1)
+        close(f"attn_cache[{dtype},t{t}]", got, torch.einsum("bhqk,bkhd->bqhd", p, vf).reshape(B, 1, d).cpu(), dtype)
+
+
 # ------------------------------------------------------------------------------------------------ conv front end
 def _conv1_ref(src, w1, b1, gamma, beta, ln):
     x = torch.nn.functional.conv2d(src[:, None], w1.permute(3, 2, 0, 1), b1, stride=2, padding=1)  # [B,C,T1,F1]

@@ -463,3 +463,73 @@ def test_cli_training_from_tfrecord_shards(tmp_path):
     assert float(resumed) < float(first) and (model_dir / "ckpt-33.index").exists()
     saved = yaml.safe_load((model_dir / "model_configs.yml").read_text())
     assert saved["task.class"] == "SpeechToText" and saved["task.params"]["audio_feature_dim"] == fdim
+
+
+# ------------------------------------------------------------------------------------------------ inference (rank 3)
+def _toy_speech_model(dtype, V=20, seed=5):
+    from neurst_amd.models import build_model
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    hp = get_hyper_parameters("speech_transformer_toy")
+    return build_model(hp, {"audio_feature_dim": 16, "audio_feature_channels": 1},
+                       {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=DEV, dtype=dtype, seed=seed)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_incremental_decoding_matches_full_forward(dtype):
+    """Step t of the cached decoder (multi_head_attention.py:254-290 cache branch, transformer_decoder.py:105-147) must give
+    the logits the full teacher-forced forward gives at position t."""
+    V, B, L = 20, 3, 7
+    model = _toy_speech_model(dtype)
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(B, 40, 16, 1, generator=g).to(DEV)
+    src_length = torch.tensor([40, 33, 21]).to(DEV)
+    trg = torch.randint(0, V - 3, (B, L), generator=g).to(DEV)
+    trg_input = torch.cat([torch.full((B, 1), V - 2, device=DEV), trg[:, :-1]], 1)
+    full = model({"src": src, "src_length": src_length, "trg_input": trg_input}, is_training=False).float()
+    fn, init, _ = model.get_symbols_to_logits_fn({"src": src, "src_length": src_length}, beam_size=1, decode_padded_length=L)
+    assert init["decoder_input"].tolist() == [V - 2] * B and init["eos_id"] == V - 1
+    cache = init["decoder_internal_cache"]
+    for t in range(L):
+        step = fn(trg_input[:, t], cache, t).float()
+        check(f"decode.step{t}[{dtype}]", step, full[:, t].cpu(), 5 * TOL[dtype])
+    assert all(st["self_attention"]["len"] == L for st in cache["decoding_states"].values())
+    with pytest.raises(RuntimeError):
+        fn(trg_input[:, 0], cache, L)           # the cache holds exactly decode_padded_length positions
+
+
+def test_beam_search_on_the_model_matches_oracle_search():
+    """The real cache (K/V buffers re-ordered with the beams) against the oracle search that scores every hypothesis with a
+    fresh full forward of the same model -- a wrong gather of the cache changes the hypotheses."""
+    from neurst_amd.layers.search import BeamSearch
+    from oracle import beam_search_oracle as BO
+    V, B = 20, 2
+    model = _toy_speech_model("float32", seed=11)
+    g = torch.Generator().manual_seed(8)
+    src = torch.randn(B, 36, 16, 1, generator=g).to(DEV)
+    src_length = torch.tensor([36, 25]).to(DEV)
+    inputs = {"src": src, "src_length": src_length}
+
+    def prefix_logits(sample, prefix):
+        ti = torch.tensor([prefix], device=DEV)
+        out = model({"src": src[sample:sample + 1], "src_length": src_length[sample:sample + 1], "trg_input": ti}, is_training=False)
+        return out[0, -1].float().cpu().numpy()
+    for beam, top_k, alpha in ((1, 1, 0.6), (3, 2, 0.6), (4, 1, 1.0)):
+        search = BeamSearch(beam_size=beam, top_k=top_k, length_penalty=alpha, maximum_decode_length=8, extra_decode_length=50)
+        hyp, scores = search(model, inputs)
+        want_h, want_s = BO.beam_search(prefix_logits, B, V - 2, V - 1, V - 3, V, beam_size=beam, top_k=top_k, length_penalty=alpha,
+                                        extra_decode_length=50, maximum_decode_length=8, encoder_len=9)
+        assert hyp.shape == (B * top_k, 8)
+        assert hyp.cpu().tolist() == want_h.tolist(), (beam, top_k, alpha)
+        assert np.allclose(scores.cpu().numpy(), want_s, rtol=2e-3, atol=2e-3)
+        REPORT[f"search.beam{beam}.score0"] = float(scores[0])
+    # greedy == argmax roll-out of the full forward
+    hyp, _ = BeamSearch(beam_size=1, maximum_decode_length=6)(model, inputs)
+    prefix = torch.full((B, 1), V - 2, device=DEV)
+    for t in range(6):
+        nxt = model({"src": src, "src_length": src_length, "trg_input": prefix}, is_training=False)[:, -1].float()
+        nxt[:, V - 3] = -1e9                    # UNK is masked by the search
+        tok = nxt.argmax(-1)
+        done = (prefix[:, 1:] == V - 1).any(1)
+        tok = torch.where(done, torch.full_like(tok, V - 1), tok)
+        assert hyp[:, t].tolist() == tok.tolist()
+        prefix = torch.cat([prefix, tok[:, None]], 1)
