@@ -54,14 +54,15 @@ class TransformerDecoder(Decoder):
             if decode_padded_length is None:
                 raise ValueError("inference needs decode_padded_length (the maximum number of decoding steps)")
             B, d = encoder_outputs.shape[0], self._params["hidden_size"]
+            # one buffer for the keys and values of all layers: a beam re-ordering is ONE gather over it
+            kv_all = torch.zeros(self._params["num_layers"], 2, B, decode_padded_length, d, dtype=encoder_outputs.dtype,
+                                 device=encoder_outputs.device)
             states = {}
             for i in range(self._params["num_layers"]):
-                states[f"layer_{i}"] = {
-                    "self_attention": {"keys": torch.zeros(B, decode_padded_length, d, dtype=encoder_outputs.dtype, device=encoder_outputs.device),
-                                       "values": torch.zeros(B, decode_padded_length, d, dtype=encoder_outputs.dtype, device=encoder_outputs.device),
-                                       "len": 0},
-                    "encdec_attention": {}}
+                states[f"layer_{i}"] = {"self_attention": {"keys": kv_all[i, 0], "values": kv_all[i, 1], "len": 0},
+                                        "encdec_attention": {}}
             cache["decoding_states"] = states
+            cache["self_attention_kv"] = kv_all
         return cache
 
     @staticmethod
@@ -69,11 +70,9 @@ class TransformerDecoder(Decoder):
         """tf.gather(cache, beam_ids) of the beam search (beam_search.py:409-410): only the self-attention buffers depend on
         the hypothesis; memory, memory_bias and the projected memory are identical for all beams of a sample (beam_ids
         never leave the sample's block), so they stay in place."""
-        for st in cache["decoding_states"].values():
-            sa = st["self_attention"]
-            n = sa["len"]
-            sa["keys"][:, :n] = sa["keys"][:, :n].index_select(0, beam_ids)
-            sa["values"][:, :n] = sa["values"][:, :n].index_select(0, beam_ids)
+        n = next(iter(cache["decoding_states"].values()))["self_attention"]["len"]
+        kv = cache["self_attention_kv"]
+        kv[:, :, :, :n] = kv[:, :, :, :n].index_select(2, beam_ids)
         return cache
 
     def decode_step(self, decoder_inputs, cache):

@@ -59,7 +59,9 @@ def sequence_beam_search(symbols_to_logits_fn, generation_initializer, top_k=1, 
     max_steps = max(max_steps, minimum_decode_length)
     beam_base = (torch.arange(batch, device=dev) * beam_size).repeat_interleave(beam_size)
     time = 0
-    while time < max_steps and not bool(finished.all()):
+    # the all-finished test costs a device sync: it is made every 4th step -- extra steps on finished beams only append
+    # EOS at zero cost (log-prob, length and ranking unchanged), the returned hypotheses are the same
+    while time < max_steps and not (time % 4 == 0 and time > 0 and bool(finished.all())):
         logits = symbols_to_logits_fn(input_ids, cache, time)
         vocab = logits.shape[-1]
         step_lp = torch.log_softmax(logits.float(), dim=-1)
@@ -104,7 +106,8 @@ class BeamSearch(object):
     """SequenceSearch "beam_search" (beam_search.py:443-551): binds the search hyper-parameters, drives a model."""
 
     def __init__(self, beam_size=4, length_penalty=0.6, top_k=1, maximum_decode_length=None, minimum_decode_length=0,
-                 extra_decode_length=50, enable_unk=False):
+                 extra_decode_length=50, enable_unk=False, use_graphs=False):
+        self.use_graphs = use_graphs
         self.beam_size, self.length_penalty, self.top_k = beam_size, length_penalty, top_k
         self.maximum_decode_length, self.minimum_decode_length = maximum_decode_length, minimum_decode_length
         self.extra_decode_length, self.enable_unk = extra_decode_length, enable_unk
@@ -112,7 +115,8 @@ class BeamSearch(object):
 
     def __call__(self, model, inputs):
         max_len = self.maximum_decode_length or 256
-        fn, init, reorder = model.get_symbols_to_logits_fn(inputs, beam_size=self.beam_size, decode_padded_length=max_len)
+        fn, init, reorder = model.get_symbols_to_logits_fn(inputs, beam_size=self.beam_size, decode_padded_length=max_len,
+                                                           use_graphs=self.use_graphs)
         return sequence_beam_search(fn, init, top_k=self.top_k, beam_size=self.beam_size, length_penalty=self.length_penalty,
                                     extra_decode_length=self.extra_decode_length, maximum_decode_length=max_len,
                                     minimum_decode_length=self.minimum_decode_length, enable_unk=self.enable_unk,

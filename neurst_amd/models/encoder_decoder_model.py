@@ -18,6 +18,54 @@ def _timing_name(timing):
     return timing
 
 
+class _DecodeSession(object):
+    """Static buffers + one captured HIP graph per decoding time index for one (batch * beam, memory length, dtype,
+    maximum length) shape.  begin() copies a new batch's encoder memory into the static buffers and resets the cache
+    lengths; step(ids, cache, t) replays graph t (capturing it the first time: an eager warm-up run, then the capture of
+    the same step -- writing position t twice is idempotent)."""
+
+    def __init__(self, decoder, eager_step, memory, padding, max_len):
+        self.decoder, self.eager_step, self.max_len = decoder, eager_step, max_len
+        self.memory, self.padding = memory.clone(), padding.clone()
+        self.cache = decoder.create_decoding_internal_cache(self.memory, self.padding, is_inference=True, decode_padded_length=max_len)
+        self.graphs, self.pool = {}, None
+
+    def _set_len(self, n):
+        for st in self.cache["decoding_states"].values():
+            st["self_attention"]["len"] = n
+
+    def begin(self, memory, padding):
+        from neurst_amd.layers import layer_utils
+        self.memory.copy_(memory)
+        self.cache["memory_bias"].copy_(layer_utils.input_padding_to_bias(padding))
+        self._set_len(0)
+        return self.cache, self.step
+
+    def step(self, ids, cache, time):
+        assert cache is self.cache
+        entry = self.graphs.get(time)
+        if entry is None:
+            static_ids = ids.clone()
+            self._set_len(time)
+            self.eager_step(static_ids, cache, time)          # warm-up: allocations, lazy state (projected memory at t = 0)
+            self._set_len(time)
+            if time == 0:  # the projection of the memory belongs INSIDE graph 0: every new batch must recompute it
+                for st in cache["decoding_states"].values():
+                    st["encdec_attention"].pop("kv", None)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, pool=self.pool):
+                static_logits = self.eager_step(static_ids, cache, time)
+            if self.pool is None:
+                self.pool = graph.pool()
+            entry = self.graphs[time] = (graph, static_ids, static_logits)
+        graph, static_ids, static_logits = entry
+        static_ids.copy_(ids)
+        graph.replay()
+        self._set_len(time + 1)
+        return static_logits
+
+
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
 class EncoderDecoderModel(BaseModel):
     def __init__(self, args, src_meta, trg_meta, src_modality, trg_modality, encoder, decoder, name=None, rt=None):
@@ -103,22 +151,35 @@ class EncoderDecoderModel(BaseModel):
     __call__ = forward
 
     # ------------------------------------------------------------------ inference
-    def get_symbols_to_logits_fn(self, inputs, beam_size=1, decode_padded_length=256):
+    def get_symbols_to_logits_fn(self, inputs, beam_size=1, decode_padded_length=256, use_graphs=False):
         """encoder_decoder_model.py:187-260 for inference: runs the encoder once, builds the decoder's incremental cache for
         batch * beam rows and returns (symbols_to_logits_fn, generation_initializer, reorder_cache_fn) for
-        neurst_amd.layers.search.sequence_beam_search."""
+        neurst_amd.layers.search.sequence_beam_search.
+
+        use_graphs: a decoding step is ~100 small launches and host-launch bound; with use_graphs the step of every time
+        index is captured ONCE into a HIP graph over static buffers (ids in, logits out, the K/V caches and the encoder
+        memory in place) and replayed for every later batch of the same shape (see _DecodeSession)."""
         from neurst_amd.layers.search.beam_search import stack_beam_size
         embedded_inputs = self._src_modality.forward(inputs["src"], is_training=False)
         src_padding = self._src_padding(inputs, embedded_inputs)
         encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=False)
-        cache = self._decoder.create_decoding_internal_cache(
-            stack_beam_size(encoder_outputs, beam_size).contiguous(), stack_beam_size(src_padding, beam_size).contiguous(),
-            is_inference=True, decode_padded_length=decode_padded_length)
+        memory = stack_beam_size(encoder_outputs, beam_size).contiguous()
+        padding = stack_beam_size(src_padding, beam_size).contiguous()
 
-        def symbols_to_logits_fn(ids, cache, time):
+        def eager_step(ids, cache, time):
             dec_in = self._trg_modality.forward(ids, is_training=False, time=time)
             return self.output_logits_layer(self._decoder.decode_step(dec_in, cache), is_training=False)
 
+        if use_graphs:
+            key = (tuple(memory.shape), memory.dtype, decode_padded_length)
+            sessions = self.__dict__.setdefault("_decode_sessions", {})
+            if key not in sessions:
+                sessions[key] = _DecodeSession(self._decoder, eager_step, memory, padding, decode_padded_length)
+            cache, step_fn = sessions[key].begin(memory, padding)
+        else:
+            cache = self._decoder.create_decoding_internal_cache(memory, padding, is_inference=True,
+                                                                 decode_padded_length=decode_padded_length)
+            step_fn = eager_step
         batch = encoder_outputs.shape[0]
         first = inputs.get("trg_input", None)
         if first is None:
@@ -126,7 +187,7 @@ class EncoderDecoderModel(BaseModel):
         init = {"decoder_input": first.reshape(batch), "decoder_internal_cache": cache,
                 "encoder_inputs_maxlen": int(encoder_outputs.shape[1]), "eos_id": self._trg_meta["eos_id"],
                 "unk_id": self._trg_meta.get("unk_id", None)}
-        return symbols_to_logits_fn, init, self._decoder.reorder_cache
+        return step_fn, init, self._decoder.reorder_cache
 
     def backward(self, dlogits, accumulate=False):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat

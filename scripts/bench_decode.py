@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--beam", type=int, default=4)
     ap.add_argument("--max-len", type=int, default=75)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--graphs", action="store_true", help="replay one captured HIP graph per decoding step")
     a = ap.parse_args()
     from neurst_amd.layers.search import BeamSearch
     from neurst_amd.models import build_model
@@ -35,7 +36,7 @@ def main():
     inputs = {"src": torch.randn(a.batch, a.frames, 80, 1, generator=g).to(dev),
               "src_length": torch.full((a.batch,), a.frames, dtype=torch.int64, device=dev)}
     search = BeamSearch(beam_size=a.beam, length_penalty=0.6, maximum_decode_length=a.max_len, extra_decode_length=0,
-                        minimum_decode_length=a.max_len)   # EOS masked until the last step: fixed amount of work
+                        minimum_decode_length=a.max_len, use_graphs=a.graphs)   # EOS masked until the last step: fixed amount of work
     hyp, _ = search(model, inputs)                          # warm-up
     torch.cuda.synchronize()
     t0 = time.time()
@@ -46,12 +47,12 @@ def main():
     # encoder alone
     t0 = time.time()
     for _ in range(a.reps):
-        model.get_symbols_to_logits_fn(inputs, beam_size=a.beam, decode_padded_length=a.max_len)
+        model.get_symbols_to_logits_fn(inputs, beam_size=a.beam, decode_padded_length=a.max_len, use_graphs=a.graphs)
     torch.cuda.synchronize()
     enc = (time.time() - t0) / a.reps
     steps = int(hyp.shape[1])
     out = {"metric": "beam-search decoding, SpeechTransformer (synthetic, random weights)", "model": a.model, "dtype": a.dtype,
-           "batch": a.batch, "frames": a.frames, "beam_size": a.beam, "decode_steps": steps,
+           "batch": a.batch, "frames": a.frames, "beam_size": a.beam, "decode_steps": steps, "hip_graphs": bool(a.graphs),
            "ms_per_batch": total * 1e3, "ms_encoder_and_cache": enc * 1e3, "ms_per_decode_step": (total - enc) / steps * 1e3,
            "utterances_per_s": a.batch / total, "generated_tokens_per_s": a.batch * steps / total,
            "beam_tokens_per_s": a.batch * a.beam * steps / total}

@@ -533,3 +533,20 @@ def test_beam_search_on_the_model_matches_oracle_search():
         tok = torch.where(done, torch.full_like(tok, V - 1), tok)
         assert hyp[:, t].tolist() == tok.tolist()
         prefix = torch.cat([prefix, tok[:, None]], 1)
+
+
+def test_graph_replayed_decoding_equals_eager_decoding():
+    """HIP-graph capture of the decoding steps (one graph per time index over static buffers) must not change a single
+    hypothesis, also for a SECOND batch that replays the graphs captured for the first one."""
+    from neurst_amd.layers.search import BeamSearch
+    V, B = 20, 3
+    model = _toy_speech_model("bfloat16", seed=21)
+    eager = BeamSearch(beam_size=3, top_k=2, maximum_decode_length=9)
+    graphed = BeamSearch(beam_size=3, top_k=2, maximum_decode_length=9, use_graphs=True)
+    for seed in (1, 2, 3):
+        g = torch.Generator().manual_seed(seed)
+        inputs = {"src": torch.randn(B, 44, 16, 1, generator=g).to(DEV), "src_length": torch.tensor([44, 30, 37]).to(DEV)}
+        h0, s0 = eager(model, inputs)
+        h1, s1 = graphed(model, inputs)
+        assert torch.equal(h0, h1) and torch.equal(s0, s1), seed
+    assert len(model._decode_sessions) == 1 and len(next(iter(model._decode_sessions.values())).graphs) >= 1
