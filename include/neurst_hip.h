@@ -147,6 +147,10 @@ typedef struct {
    * lets incremental decoding attend over the filled prefix of a preallocated [B, Tmax, *] key / value cache
    * (multi_head_attention.py:254-290 concatenates instead). */
   int64_t bsk, bsv;
+  /* with causal != 0: key j is masked for query i when j > i + causal_offset (0 = the lower-triangle bias; k - 1 = the
+   * wait-k bias of layer_utils.py:56-78 for cross attention, band_part(ones, -1, k - 1)).  Must be >= 0. */
+  int causal_offset;
+  int reserved0;
 } NstAttnDesc;
 
 /* B*H*ceil(Tq/16)*ceil(Tk/64)*128 bytes */

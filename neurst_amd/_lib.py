@@ -49,6 +49,7 @@ class NstAttnDesc(C.Structure):
         ("seed", C.c_uint64), ("stream_id", C.c_uint64),
         ("dropout_mask", C.c_void_p), ("dropout_mask_bytes", C.c_int64),
         ("bsk", C.c_int64), ("bsv", C.c_int64),
+        ("causal_offset", C.c_int), ("reserved0", C.c_int),
     ]
 
 

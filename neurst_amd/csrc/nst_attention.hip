@@ -189,6 +189,7 @@ struct AttnParams {
   int64_t bsk, bsv;  // batch strides of k / v (and dk / dv), elements
   float scale, scale2;  // dh^-0.5 and dh^-0.5 * log2(e)
   int causal;
+  int coff;        // causal offset: key j is masked for query i when j > i + coff (0 = lower triangle, k-1 = wait-k)
   uint32_t drop_thresh;  // 16-bit threshold, 0 = no dropout
   float drop_inv_keep;
   uint64_t seed, stream_id;
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   }
 
   int nkt = p.nkt;
-  if (p.causal) { const int lim = (q0 + TR * MI - 1) / TR + 1; if (lim < nkt) nkt = lim; }
+  if (p.causal) { const int lim = (q0 + TR * MI - 1 + p.coff) / TR + 1; if (lim < nkt) nkt = lim; }
 
   TileRegs<T> kreg, vreg;
   float kbreg = 0.f;
@@ -302,14 +303,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
     for (int mi = 0; mi < MI; ++mi) {
       const int qblk0 = q0 + mi * TR + wave * 16;  // first query of this block; the lane's query is +lc
       const int qg = qblk0 + lc;
-      const bool diag = p.causal && (k0 + TR - 1 > qblk0);
+      const bool diag = p.causal && (k0 + TR - 1 > qblk0 + p.coff);
       float mx = -INFINITY;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float x = fmaf(s[mi][f][r], p.scale2, kb4[f][r]);
-          if (diag && (k0 + f * 16 + g * 4 + r > qg)) x = -INFINITY;
+          if (diag && (k0 + f * 16 + g * 4 + r > qg + p.coff)) x = -INFINITY;
           s[mi][f][r] = x;
           mx = fmaxf(mx, x);
         }
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
     for (int f = 0; f < 4; ++f) { dk[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqt = (p.Tq + TR - 1) / TR;
-  const int qt_first = p.causal ? k0 / TR : 0;  // queries before the first key of the block never see it
+  const int qt_first = (p.causal && k0 > p.coff) ? (k0 - p.coff) / TR : 0;  // queries before the first key of the block never see it
   // mask words this lane reads: forward lanes (g*4 + r) + 16*(lc>>2), r = 0..3 -> 4 consecutive u16; bit = f_key*4 + (lc&3)
   const int mlane = g * 4 + 16 * (lc >> 2);
   const int mbit = wave * 4 + (lc & 3);
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
     for (int mi = 0; mi < MI; ++mi) {
       const int kblk0 = k0 + mi * TR + wave * 16;
       const int kg = kblk0 + lc;
-      const bool diag = p.causal && (kblk0 + 15 > q0);
+      const bool diag = p.causal && (kblk0 + 15 > q0 + p.coff);
       auto elems = [&](auto DIAG, auto DROP) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
-            if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r)) pv = 0.f;
+            if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r + p.coff)) pv = 0.f;
             float keep = 1.f;
             if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
             st[mi][f][r] = pv * keep;                                            // dropped P, feeds dV
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
     for (int f = 0; f < 4; ++f) dq[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
   int nkt = p.nkt;
-  if (p.causal) { const int lim = (q0 + TR * MI - 1) / TR + 1; if (lim < nkt) nkt = lim; }
+  if (p.causal) { const int lim = (q0 + TR * MI - 1 + p.coff) / TR + 1; if (lim < nkt) nkt = lim; }
   TileRegs<T> kreg, vreg;
   float kbreg = 0.f;
   tile_load<T, VEC>(kreg, kb, p.ldk, 0, p.Tk, p.dh, tid);
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
     for (int mi = 0; mi < MI; ++mi) {
       const int qblk0 = q0 + mi * TR + wave * 16;
       const int qg = qblk0 + lc;
-      const bool diag = p.causal && (k0 + TR - 1 > qblk0);
+      const bool diag = p.causal && (k0 + TR - 1 > qblk0 + p.coff);
       uint32_t bits = 0xffffu;
       if (p.drop_thresh && qblk0 < p.Tq) bits = p.mask[((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane];
       auto elems = [&](auto DIAG, auto DROP) {
@@ -672,7 +673,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
-            if (decltype(DIAG)::value && (k0 + f * 16 + g * 4 + r > qg)) pv = 0.f;
+            if (decltype(DIAG)::value && (k0 + f * 16 + g * 4 + r > qg + p.coff)) pv = 0.f;
             float keep = 1.f;
             if (decltype(DROP)::value) keep = keep_mul(bits, f * 4 + r, p.drop_inv_keep);
             s[mi][f][r] = pv * (keep * dp[mi][f][r] - dl[mi]) * p.scale;
@@ -724,6 +725,8 @@ int fill_params(const NstAttnDesc* d, AttnParams& p) {
   p.bsv = d->bsv ? d->bsv : (int64_t)d->Tk * d->ldv;
   NST_CHECK_ARG(p.bsk >= (int64_t)d->Tk * d->ldk && p.bsv >= (int64_t)d->Tk * d->ldv, "attention: k/v batch stride smaller than Tk rows");
   p.scale = d->scale; p.scale2 = d->scale * LOG2E; p.causal = d->causal;
+  p.coff = d->causal ? d->causal_offset : 0;
+  NST_CHECK_ARG(p.coff >= 0, "attention: causal_offset=%d must be >= 0", p.coff);
   nst_dropout_params16(d->dropout_p, &p.drop_thresh, &p.drop_inv_keep);
   if (p.drop_thresh) {
     NST_CHECK_ARG(d->dropout_mask, "attention: dropout_p > 0 needs dropout_mask");

@@ -186,7 +186,7 @@ def colsum(x, out, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id):
+def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id, causal_offset=0):
     # q [B,Tq,*] k,v [B,Tk,*] views whose last dim starts at this tensor's head 0 (row stride = stride(1))
     d = NstAttnDesc()
     d.B, d.Tq, d.Tk, d.H, d.dh = q.shape[0], q.shape[1], k.shape[1], H, dh
@@ -199,20 +199,21 @@ def _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id):
     d.dtype = _dt(q)
     d.scale = float(dh) ** -0.5
     d.causal = int(causal)
+    d.causal_offset = int(causal_offset)
     d.float_min = FLOAT_MIN
     d.dropout_p = dropout_p
     d.seed, d.stream_id = seed, stream_id
     return d
 
 
-def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0):
+def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0, causal_offset=0):
     """q [B,Tq,H*dh-view], k/v [B,Tk,H*dh-view] (may be column slices of a packed projection).
     Returns (out, lse, drop_mask); drop_mask (keep bits written by the kernel, None when dropout_p == 0) must be
     handed to attention_bwd."""
     B, Tq = q.shape[0], q.shape[1]
     out = torch.empty(B, Tq, H * dh, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
-    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id, causal_offset)
     mask = None
     if dropout_p > 0:
         mask = torch.empty(lib.nst_attention_dropout_mask_bytes(C.byref(d)) // 8, dtype=torch.int64, device=q.device)
@@ -223,11 +224,11 @@ def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, se
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
-                  stream_id=0, drop_mask=None):
+                  stream_id=0, drop_mask=None, causal_offset=0):
     assert dout.is_contiguous() and out.is_contiguous()
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
     delta = torch.empty_like(lse)
-    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id)
+    d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id, causal_offset)
     if dropout_p > 0:
         assert drop_mask is not None, "attention_bwd: dropout needs the mask written by attention_fwd"
         d.dropout_mask, d.dropout_mask_bytes = drop_mask.data_ptr(), drop_mask.numel() * 8

@@ -44,9 +44,11 @@ class MultiHeadAttention(Layer):
         self.q_transform = MultiHeadDenseLayer(self.rt, self.name + "/q_transform", self.input_depth, d, H, gen)
         self.kv_transform = MultiHeadDenseLayer(self.rt, self.name + "/kv_transform", self.memory_depth, [d, d], H, gen)
 
-    def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None, cache=None):
+    def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None, cache=None, lagging=None):
         """query [B*Tq, d], memory [B*Tk, d]; memory_bias [B,Tk] f32 (padding*FLOAT_MIN) or None.
-        cache (decoding only): the projected memory is computed at the first step and reused."""
+        cache (decoding only): the projected memory is computed at the first step and reused.
+        lagging (wait-k, transformer_decoder.py:76-92 + layer_utils.py:56-78): query i only sees memory positions
+        j <= i + lagging - 1 -- the kernel's causal mask shifted by lagging - 1, on top of the padding bias."""
         d, H, dh = self.num_units, self.num_heads, self.dh
         p = self.rate if is_training else 0.0
         q = self.q_transform.forward(query)
@@ -57,16 +59,17 @@ class MultiHeadAttention(Layer):
         else:
             kv = self.kv_transform.forward(memory)
         q3, kv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d)
-        ctx, lse, dmask = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=False,
-                                   dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        lag = None if lagging is None else max(int(lagging) - 1, 0)
+        ctx, lse, dmask = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=lag is not None,
+                                   causal_offset=lag or 0, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
         out = self.output_transform.forward(ctx.view(B * Tq, d), **(epilogue or {}))
         if is_training:
-            self._saved = (query, memory, q, kv, ctx, (lse, dmask), memory_bias, B, Tq, Tk, p)
+            self._saved = (query, memory, q, kv, ctx, (lse, dmask), memory_bias, B, Tq, Tk, p, lag)
         return out
 
     def backward(self, dz, dmemory=None, dmemory_accumulate=False):
         """Returns d(query); d(memory) is written (or accumulated) into `dmemory` [B*Tk, d]."""
-        query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p = self._saved
+        query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p, lag = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
         ctx2 = ctx.view(B * Tq, d)
@@ -76,8 +79,8 @@ class MultiHeadAttention(Layer):
         dkv = torch.empty_like(kv)
         q3, kv3, dq3, dkv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d), dq.view(B, Tq, d), dkv.view(B, Tk, 2 * d)
         K.attention_bwd(q3, kv3[..., :d], kv3[..., d:], ctx, dctx.view(B, Tq, d), lse, dq3, dkv3[..., :d],
-                        dkv3[..., d:], H, dh, key_bias=bias, causal=False, dropout_p=p, seed=self.rt.step_seed,
-                        stream_id=self.site, drop_mask=dmask)
+                        dkv3[..., d:], H, dh, key_bias=bias, causal=lag is not None, causal_offset=lag or 0, dropout_p=p,
+                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask)
         self.q_transform.backward_params(query, dq)
         self.kv_transform.backward_params(memory, dkv)
         if dmemory is not None:

@@ -75,13 +75,17 @@ class TransformerDecoder(Decoder):
         kv[:, :, :, :n] = kv[:, :, :, :n].index_select(2, beam_ids)
         return cache
 
-    def decode_step(self, decoder_inputs, cache):
-        """One incremental step: decoder_inputs [B', d] (embedding of the last generated symbols) -> [B', d]."""
+    def decode_step(self, decoder_inputs, cache, decode_lagging=None):
+        """One incremental step: decoder_inputs [B', d] (embedding of the last generated symbols) -> [B', d].
+        decode_lagging (wait-k inference, transformer_decoder.py:86-92): the memory positions this step may see."""
         assert cache.get("decoding_states", None) is not None, "create_decoding_internal_cache(is_inference=True) first"
         Bp, d = decoder_inputs.shape
         memory, memory_bias = cache.get("memory", None), cache.get("memory_bias", None)
         Tm = memory.shape[1] if memory is not None else 0
         mem2 = memory.reshape(Bp * Tm, d) if memory is not None else None
+        if decode_lagging is not None and memory_bias is not None:
+            seen = (torch.arange(Tm, device=memory_bias.device) < int(decode_lagging)).to(memory_bias.dtype)
+            memory_bias = torch.minimum(memory_bias, layer_utils.FLOAT_MIN * (1.0 - seen)[None, :])
         x = decoder_inputs
         for i, layer in enumerate(self._stacking_layers):
             x = layer.forward(x, Bp, 1, mem2, Tm, memory_bias, is_training=False, cache=cache["decoding_states"][f"layer_{i}"])
@@ -89,10 +93,11 @@ class TransformerDecoder(Decoder):
 
     def forward(self, decoder_inputs, cache, decode_lagging=None, is_training=True, decode_loop_step=None):
         """decoder_inputs [B,L,d]; cache from create_decoding_internal_cache -> [B,L,d]."""
-        if decode_lagging is not None or decode_loop_step is not None:
-            raise NotImplementedError("wait-k / static-shape decoding are off the hot path")
+        if decode_loop_step is not None:
+            raise NotImplementedError("static-shape (padded) decoding caches are not built: the cache is preallocated anyway")
         if cache.get("decoding_states", None) is not None:
-            return self.decode_step(decoder_inputs.reshape(-1, decoder_inputs.shape[-1]), cache).view(decoder_inputs.shape)
+            return self.decode_step(decoder_inputs.reshape(-1, decoder_inputs.shape[-1]), cache,
+                                    decode_lagging=decode_lagging).view(decoder_inputs.shape)
         B, L, d = decoder_inputs.shape
         memory = cache.get("memory", None)
         memory_bias = cache.get("memory_bias", None)
@@ -104,7 +109,7 @@ class TransformerDecoder(Decoder):
         if p > 0:
             x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
         for layer in self._stacking_layers:
-            x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training)
+            x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
         out = self._output_norm_layer.forward(x, save=is_training)
         self._shapes = (B, L, d, Tm)
         return out.view(B, L, d)

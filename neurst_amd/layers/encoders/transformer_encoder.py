@@ -21,8 +21,8 @@ class TransformerEncoder(Encoder):
                          layer_postprocess_dropout_rate=layer_postprocess_dropout_rate,
                          layer_postprocess_epsilon=layer_postprocess_epsilon, post_normalize=post_normalize,
                          attention_monotonic=attention_monotonic, return_all_layers=return_all_layers)
-        if attention_monotonic or return_all_layers or post_normalize:
-            raise NotImplementedError("attention_monotonic / return_all_layers / post_normalize are off the hot path")
+        if return_all_layers or post_normalize:
+            raise NotImplementedError("return_all_layers / post_normalize are off the hot path")
         self.name = name or self.__class__.__name__
         self._built = False
 
@@ -51,8 +51,11 @@ class TransformerEncoder(Encoder):
         self._p = p
         if p > 0:
             x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
+        # attention_monotonic (transformer_encoder.py:121-123): min(padding bias, lower-triangle bias) = the kernel's
+        # key bias + causal flag together
+        causal = bool(self._params["attention_monotonic"])
         for layer in self._stacking_layers:
-            x = layer.forward(x, B, T, bias, is_training=is_training)
+            x = layer.forward(x, B, T, bias, is_training=is_training, causal=causal)
         out = self._output_norm_layer.forward(x, save=is_training)
         return out.view(B, T, d)
 

@@ -22,8 +22,8 @@ class TransformerEncoderLayer(Layer):
             TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
             hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
 
-    def forward(self, x, B, T, x_bias, is_training=True):
-        y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=False)
+    def forward(self, x, B, T, x_bias, is_training=True, causal=False):
+        y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=causal)
         return self._ffn_layer.forward(y, is_training)
 
     @property
@@ -43,9 +43,9 @@ class _CrossAttentionAdapter(object):
         self.att = att
         self.dmemory, self.dmemory_accumulate = None, False
 
-    def forward(self, y, is_training, epilogue, memory, B, Tq, Tk, memory_bias, cache=None):
+    def forward(self, y, is_training, epilogue, memory, B, Tq, Tk, memory_bias, cache=None, lagging=None):
         return self.att.forward(y, memory, B, Tq, Tk, memory_bias=memory_bias, is_training=is_training,
-                                epilogue=epilogue, cache=cache)
+                                epilogue=epilogue, cache=cache, lagging=lagging)
 
     def backward(self, dz):
         return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate)
@@ -79,7 +79,7 @@ class TransformerDecoderLayer(Layer):
             TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
             hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
 
-    def forward(self, x, B, L, memory, Tm, memory_bias, is_training=True, cache=None):
+    def forward(self, x, B, L, memory, Tm, memory_bias, is_training=True, cache=None, lagging=None):
         """cache (incremental decoding, L == 1): {"self_attention": {...}, "encdec_attention": {...}} of this layer
         (transformer_layers.py:197-234 `decoding_states`)."""
         if cache is None:
@@ -88,7 +88,7 @@ class TransformerDecoderLayer(Layer):
             y = self._selfatt_layer.forward(x, is_training, B=B, T=L, bias=None, causal=False, cache=cache["self_attention"])
         if self._with_cross_attention:
             y = self._crossatt_layer.forward(y, is_training, memory=memory, B=B, Tq=L, Tk=Tm, memory_bias=memory_bias,
-                                             **({} if cache is None else {"cache": cache["encdec_attention"]}))
+                                             lagging=lagging, **({} if cache is None else {"cache": cache["encdec_attention"]}))
         return self._ffn_layer.forward(y, is_training)
 
     @property

@@ -145,8 +145,13 @@ class EncoderDecoderModel(BaseModel):
         encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=is_training)
         cache = self._decoder.create_decoding_internal_cache(encoder_outputs, src_padding, is_inference=False)
         dec_in = self._trg_modality.forward(inputs["trg_input"], is_training=is_training)
-        decoder_output = self._decoder.forward(dec_in, cache, is_training=is_training)
+        decoder_output = self._decoder.forward(dec_in, cache, is_training=is_training,
+                                               decode_lagging=self.decode_lagging(is_training, None))
         return self.output_logits_layer(decoder_output, is_training=is_training)
+
+    def decode_lagging(self, is_training, time):
+        """The wait-k lagging of this call (None = full attention); WaitkTransformer overrides."""
+        return None
 
     __call__ = forward
 
@@ -168,7 +173,8 @@ class EncoderDecoderModel(BaseModel):
 
         def eager_step(ids, cache, time):
             dec_in = self._trg_modality.forward(ids, is_training=False, time=time)
-            return self.output_logits_layer(self._decoder.decode_step(dec_in, cache), is_training=False)
+            hidden = self._decoder.decode_step(dec_in, cache, decode_lagging=self.decode_lagging(False, time))
+            return self.output_logits_layer(hidden, is_training=False)
 
         if use_graphs:
             key = (tuple(memory.shape), memory.dtype, decode_padded_length)

@@ -43,6 +43,8 @@ class SpeechTransformer(EncoderDecoderModel):
             F("encoder.attention_type", dtype=F.TYPE.STRING, default="dot_product", help="Encoder attention type."),
             F("encoder.ffn_dropout_rate", dtype=F.TYPE.FLOAT, default=0., help="Encoder ffn dropout."),
             F("encoder.post_normalize", dtype=F.TYPE.BOOLEAN, default=False, help="Layer norm after each block."),
+            F("encoder.attention_monotonic", dtype=F.TYPE.BOOLEAN, default=False,
+              help="Whether the encoder self attention is restricted to the past (streaming / wait-k)."),
             F("encoder.layer_postprocess_dropout_rate", dtype=F.TYPE.FLOAT, default=0., help="Encoder post dropout."),
             F("encoder.layer_postprocess_epsilon", dtype=F.TYPE.FLOAT, default=1e-6, help="Encoder LN epsilon."),
             F("decoder.num_layers", dtype=F.TYPE.INTEGER, default=None, help="Number of decoder layers."),

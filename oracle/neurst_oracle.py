@@ -172,11 +172,23 @@ def lower_triangle_attention_bias(length, dtype=torch.float32):
     return (FLOAT_MIN * (1.0 - tril)).reshape(1, 1, length, length)
 
 
+def waitk_attention_bias(memory_length, waitk_lagging, query_length, dtype=torch.float32):
+    """neurst/layers/layer_utils.py:56-78, training form: [query_length, memory_length], 0 where key j <= query i + lagging - 1
+    (tf.linalg.band_part(ones, -1, min(lagging - 1, memory_length))), FLOAT_MIN elsewhere."""
+    upper = min(waitk_lagging - 1, memory_length)
+    i = torch.arange(query_length)[:, None]
+    j = torch.arange(memory_length)[None, :]
+    keep = (j - i <= upper).to(dtype)
+    return FLOAT_MIN * (1.0 - keep)
+
+
 def transformer_encoder(x, padding, W, scope, num_layers, num_heads, eps=1e-6,
-                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None):
+                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, monotonic=False):
     """TransformerEncoder.call (neurst/layers/encoders/transformer_encoder.py:104-136)
-    with TransformerEncoderLayer.call (transformer_layers.py:90-98)."""
+    with TransformerEncoderLayer.call (transformer_layers.py:90-98); attention_monotonic :121-123."""
     bias = input_padding_to_bias(padding)
+    if monotonic:
+        bias = torch.minimum(bias[:, None, None, :], lower_triangle_attention_bias(x.shape[1], x.dtype))
     x = dropout(x, post_rate, is_training, generator)
     for i in range(num_layers):
         p = f"{scope}/layer_{i}"
@@ -192,11 +204,14 @@ def transformer_encoder(x, padding, W, scope, num_layers, num_heads, eps=1e-6,
 
 
 def transformer_decoder(x, memory, memory_padding, W, scope, num_layers, num_heads, eps=1e-6,
-                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None):
+                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, decode_lagging=None):
     """TransformerDecoder.call, training branch (neurst/layers/decoders/transformer_decoder.py:171-228)
     with TransformerDecoderLayer.call (transformer_layers.py:213-234).  Cross-attention
     K/V are projected from ``memory`` directly (the encoder's output_ln output)."""
     memory_bias = input_padding_to_bias(memory_padding) if memory_padding is not None else None
+    if memory_bias is not None and decode_lagging is not None:  # transformer_decoder.py:76-85 (3-d inputs)
+        memory_bias = torch.minimum(memory_bias[:, None, :], waitk_attention_bias(
+            memory_bias.shape[1], decode_lagging, x.shape[1], x.dtype)[None, :, :])[:, None, :, :]
     causal = lower_triangle_attention_bias(x.shape[1], x.dtype)
     x = dropout(x, post_rate, is_training, generator)
     for i in range(num_layers):
@@ -329,13 +344,15 @@ def transformer_logits(inputs, W, cfg, is_training=False, generator=None):
     if cfg.get("timing", "sinusoids"):
         emb = position_embedding(emb)
     enc = transformer_encoder(emb, inputs["src_padding"], W, "TransformerEncoder", cfg["num_enc"],
-                              cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator)
+                              cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
+                              monotonic=cfg.get("attention_monotonic", False))
     table = W["target_symbol_modality/shared/weights"]
     temb = word_embedding(inputs["trg_input"], table)
     if cfg.get("timing", "sinusoids"):
         temb = position_embedding(temb)
     dec = transformer_decoder(temb, enc, inputs["src_padding"], W, "TransformerDecoder", cfg["num_dec"],
-                              cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator)
+                              cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
+                              decode_lagging=cfg.get("wait_k", None))
     return tied_logits(dec, table, W.get("target_symbol_modality/shared/bias"))
 
 

@@ -321,6 +321,54 @@ def test_attention(K, dtype, attn_mi, B, H, Tq, Tk, dh, causal, pad):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,off,pad,drop", [(2, 2, 5, 9, 4, 0, False, 0.0), (2, 2, 7, 20, 8, 2, True, 0.0),
+                                                      (2, 4, 75, 225, 64, 4, True, 0.0), (1, 2, 130, 200, 64, 70, True, 0.0),
+                                                      (2, 2, 40, 100, 32, 8, False, 0.0), (1, 3, 90, 60, 16, 1, True, 0.0),
+                                                      (2, 2, 64, 160, 64, 2, True, 0.2)])
+def test_attention_waitk_offset(K, dtype, attn_mi, B, H, Tq, Tk, dh, off, pad, drop):
+    """causal_offset (NstAttnDesc): key j masked for query i when j > i + off -- the wait-k cross-attention bias
+    band_part(ones[Tq, Tk], -1, off) of layer_utils.py:56-78 -- together with key padding, forward and backward."""
+    d = H * dh
+    bias = None
+    if pad:
+        lens = torch.tensor([Tk - (i * Tk) // (3 * B) for i in range(B)])
+        bias = (O.length_to_padding(lens, Tk) * O.FLOAT_MIN).float()
+    q = rnd(B, Tq, d, dtype=dtype, seed=5)
+    kv = rnd(B, Tk, 2 * d, dtype=dtype, seed=6)
+    k, v = kv[..., :d], kv[..., d:]
+    dout = rnd(B, Tq, d, dtype=dtype, seed=7)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    kd, vd = kvd[..., :d], kvd[..., d:]
+    bd = None if bias is None else bias.to(DEV)
+    out, lse, mask = K.attention_fwd(qd, kd, vd, H, dh, key_bias=bd, causal=True, causal_offset=off, dropout_p=drop, seed=3, stream_id=1)
+    band = O.waitk_attention_bias(Tk, off + 1, Tq, torch.float64)                       # [Tq, Tk]
+    assert band[0, min(off, Tk - 1)] == 0 and (off + 1 >= Tk or band[0, off + 1] < 0)
+    full = band[None, :, :] if bias is None else torch.minimum(bias.double()[:, None, :], band[None, :, :])
+    keep = None
+    if drop > 0:   # recover the kept set from the kernel's own output is not possible here: check dropout-free rows instead
+        out0, _, _ = K.attention_fwd(qd, kd, vd, H, dh, key_bias=bd, causal=True, causal_offset=off)
+        assert not torch.equal(out0, out) and torch.isfinite(out.float()).all()
+        out, lse, mask, drop = out0, K.attention_fwd(qd, kd, vd, H, dh, key_bias=bd, causal=True, causal_offset=off)[1], None, 0.0
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    q4, k4, v4 = qr.reshape(B, Tq, H, dh), kr.reshape(B, Tk, H, dh), vr.reshape(B, Tk, H, dh)
+    w = torch.softmax(torch.einsum("bthd,bfhd->bhft", k4, q4 * dh ** -0.5) + full[:, None], -1)
+    ref = torch.einsum("bhft,bthd->bfhd", w, v4).reshape(B, Tq, d)
+    ref.backward(dout.double())
+    tag = f"attn_waitk[{dtype},mi{attn_mi},q{Tq}k{Tk}d{dh}o{off}{'p' if pad else ''}]"
+    close(tag + ".out", out, ref, dtype)
+    dq, dkv = torch.zeros_like(qd), torch.zeros_like(kvd)
+    K.attention_bwd(qd, kd, vd, out, dout.to(DEV), lse, dq, dkv[..., :d], dkv[..., d:], H, dh, key_bias=bd, causal=True,
+                    causal_offset=off)
+    close(tag + ".dq", dq, qr.grad, dtype, scale=3.0)
+    close(tag + ".dk", dkv[..., :d], kr.grad, dtype, scale=3.0)
+    close(tag + ".dv", dkv[..., d:], vr.grad, dtype, scale=3.0)
+    # keys no query may see get exactly zero gradient
+    hidden = (band.max(0).values < 0)
+    if hidden.any():
+        assert float(dkv[:, hidden].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,T,dh,causal", [(2, 2, 32, 32, False), (2, 2, 64, 64, True), (1, 4, 64, 64, False)])
 def test_attention_dropout(K, dtype, attn_mi, B, H, T, dh, causal):
     # V = identity (T == dh) exposes the dropped probability matrix as the output, which yields the mask itself;

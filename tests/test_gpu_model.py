@@ -250,10 +250,11 @@ def test_speech_transformer_forward_backward(case, dtype):
 
 # ------------------------------------------------------------------------------------------------ text Transformer (§8(f) rank 1)
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-@pytest.mark.parametrize("case", ["toy", "small_shared", "mid"])
+@pytest.mark.parametrize("case", ["toy", "small_shared", "mid", "waitk3", "waitk1_mid"])
 def test_text_transformer_forward_backward(case, dtype):
     """Transformer (embedding source side, optional shared source/target embedding) through the Seq2Seq task inputs:
-    logits, loss and every gradient against the oracle's transformer_logits + criterion + autograd."""
+    logits, loss and every gradient against the oracle's transformer_logits + criterion + autograd.  The waitk cases run
+    WaitkTransformer (neurst/models/waitk_transformer.py): monotonic encoder + lagged cross attention."""
     from neurst_amd.criterions import build_criterion
     from neurst_amd.models import build_model
     from neurst_amd.models.transformer import Transformer
@@ -263,8 +264,11 @@ def test_text_transformer_forward_backward(case, dtype):
         "toy": (8, 2, 2, 2, 10, 2, 5, 4, 11, 13, False),
         "small_shared": (64, 2, 2, 2, 128, 3, 17, 9, 40, 40, True),
         "mid": (256, 4, 2, 1, 512, 4, 33, 21, 300, 200, False),
+        "waitk3": (64, 2, 2, 2, 128, 3, 17, 9, 40, 37, False),
+        "waitk1_mid": (256, 4, 2, 2, 512, 3, 90, 70, 300, 200, False),
     }
     d, H, ne, nd, ffn, B, S, L, Vs, Vt, share = cases[case]
+    wait_k = {"waitk3": 3, "waitk1_mid": 1}.get(case, None)
     p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
     p.update({"modality.dim": d, "modality.share_source_target_embedding": share, "encoder.num_layers": ne,
               "decoder.num_layers": nd, "encoder.hidden_size": d, "decoder.hidden_size": d,
@@ -274,7 +278,12 @@ def test_text_transformer_forward_backward(case, dtype):
         if k.endswith("dropout_rate"):
             p[k] = 0.0
     task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": Vs, "trg_vocab_size": Vt}})
-    model = task.build_model({"model.class": "Transformer", "model.params": p}, device=DEV, dtype=dtype, init_seed=5)
+    if wait_k is None:
+        model = task.build_model({"model.class": "Transformer", "model.params": p}, device=DEV, dtype=dtype, init_seed=5)
+    else:
+        model = task.build_model({"model.class": "WaitkTransformer", "model.params": dict(p, wait_k=wait_k)}, device=DEV,
+                                 dtype=dtype, init_seed=5)
+        assert model.wait_k == wait_k and model.decode_lagging(True, None) == wait_k and model.decode_lagging(False, 4) == wait_k + 4
     g = torch.Generator().manual_seed(21)
     sd = {}
     for n, prm in model.store.params.items():
@@ -299,6 +308,8 @@ def test_text_transformer_forward_backward(case, dtype):
             if n.endswith("/kernel") or n.endswith("/weights"):
                 W[n] = prm.compute.detach().float().cpu()
     cfg = {"num_enc": ne, "num_dec": nd, "num_heads": H}
+    if wait_k is not None:
+        cfg.update({"attention_monotonic": True, "wait_k": wait_k})
     loss_ref, logits_ref, grads_ref = O.text_train_step_reference({k: v.double() for k, v in W.items()}, inputs, cfg, 0.1)
     dinp = {k: v.to(DEV) for k, v in inputs.items()}
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
@@ -550,3 +561,30 @@ def test_graph_replayed_decoding_equals_eager_decoding():
         h1, s1 = graphed(model, inputs)
         assert torch.equal(h0, h1) and torch.equal(s0, s1), seed
     assert len(model._decode_sessions) == 1 and len(next(iter(model._decode_sessions.values())).graphs) >= 1
+
+
+def test_waitk_incremental_decoding_matches_training_mask():
+    """WaitkTransformer inference (waitk_transformer.py:103-104: lagging + time positions visible at step `time`) must give,
+    step by step, the logits of the teacher-forced forward under the training-time wait-k mask."""
+    from neurst_amd.tasks import build_task
+    from neurst_amd.models.transformer import Transformer
+    Vs, Vt, B, S, L, k = 30, 26, 3, 14, 8, 2
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    for n in list(p):
+        if n.endswith("dropout_rate"):
+            p[n] = 0.0
+    task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": Vs, "trg_vocab_size": Vt}})
+    model = task.build_model({"model.class": "WaitkTransformer", "model.params": dict(p, wait_k=k)}, device=DEV, dtype="float32", init_seed=9)
+    g = torch.Generator().manual_seed(2)
+    src = torch.randint(0, Vs - 3, (B, S), generator=g).to(DEV)
+    src_length = torch.tensor([S, S - 3, S - 6]).to(DEV)
+    trg_input = torch.cat([torch.full((B, 1), Vt - 2), torch.randint(0, Vt - 3, (B, L - 1), generator=g)], 1).to(DEV)
+    full = model({"src": src, "src_length": src_length, "trg_input": trg_input}, is_training=False).float()
+    fn, init, _ = model.get_symbols_to_logits_fn({"src": src, "src_length": src_length}, beam_size=1, decode_padded_length=L)
+    for t in range(L):
+        step = fn(trg_input[:, t], init["decoder_internal_cache"], t).float()
+        check(f"waitk.decode.step{t}", step, full[:, t].cpu(), 5e-3)
+    # and the mask matters: a full-attention Transformer with the same weights disagrees at the early steps
+    model.wait_k = None
+    other = model({"src": src, "src_length": src_length, "trg_input": trg_input}, is_training=False).float()
+    assert float((other[:, 0] - full[:, 0]).abs().max()) > 1e-4
