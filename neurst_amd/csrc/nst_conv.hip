@@ -1309,9 +1309,228 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   return 0;
 }
 
+// =============================================================================================
+// conv2 data gradient with an LDS-RESIDENT dy patch (bf16, C == 256, even T1 and F1).
+//
+// dx[b, ti, fi, :] = sum over the taps (kh, kw) that reach it:  dy[b, (ti+1-kh)/2, (fi+1-kw)/2, :] . w2[kh, kw]^T.
+// With even T1 / F1 each of the four parity classes (ti & 1, fi & 1) of dx has exactly the T2 x F2 grid of dy, and class
+// pixel (u, v) needs dy at (u + du, v + dv), du / dv in {0, 1} (1, 2, 2 and 4 taps).  The per-class implicit GEMMs
+// above run four launches with K = 256 ... 1024 (a handful of K steps per tile, 280 TFLOP/s on the benchmark shape).
+// Here a workgroup owns 128 consecutive dy pixels and produces ALL FOUR classes of their 2 x 2 dx pixels:
+//   * the dy patch -- those pixels plus one halo row, rows of F2 + 1 positions whose last column is the zero right
+//     border -- is staged ONCE with all 256 channels (<= 190 positions x 512 B); the bottom border of an image
+//     (u == T2 - 1, du == 1) is a per-lane select of the zero block;
+//   * the classes run one after the other over that patch: 9 (class, tap) groups x 4 channel slices = 36 K steps,
+//     the same MFMA work as the forward tile; only the 32 KB w2^T tile of each step streams through a double buffer
+//     (rows = input channel ci, contiguous along co: the RC layout);
+//   * every class ends with its own store epilogue (the patch has to survive, so the transposition scratch is the weight
+//     double buffer: no weight prefetch across a class boundary);
+//   * patch layout: position pos at byte pos * 512, its 128-byte channel slice cc at slot cc ^ ((pos>>3)&1) and the
+//     16-byte chunks of a slice XOR-ed with pos & 7 (consecutive class pixels are consecutive positions).
+// =============================================================================================
+struct DgradPatchArgs {
+  const bf16_t* dy;
+  const bf16_t* w2;
+  bf16_t* dx;
+  int T1, F1, T2, F2, C, M, PW, dy_rows, ntiles;
+  FastDiv dF2, dT2, dPW;
+};
+constexpr int DP_ZERO_OFF = CP_LDS_BYTES - 2 * CP_BBUF - 1024;   // patch bytes available: 97280 = 190 positions
+constexpr int DP_B_OFF = DP_ZERO_OFF + 1024;
+constexpr int DP_MAX_POS = DP_ZERO_OFF / 512;
+constexpr int DP_NIT = (DP_MAX_POS / 2 + 7) / 8;                // 1 KB pieces (2 positions) per wave
+constexpr int DP_EPI_LD = 68;
+
+// the nine (class, tap) groups: class = (pt << 1) | pf, shift (du, dv) into the patch, tap index kh * 3 + kw
+__device__ constexpr int DP_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+__device__ constexpr int DP_DU[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0};
+__device__ constexpr int DP_DV[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0};
+__device__ constexpr int DP_TAP[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+
+__global__ void __launch_bounds__(CP_THREADS) conv2_dgrad_patch_kernel(DgradPatchArgs a) {
+  typedef SwzFrag<bf16_t, MODE_RC> RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave >> 2, wq = wave & 3;
+  const int wm = quad * 64, wn = wq * 64;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int m0 = tile * BM;
+  const int last_p = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
+  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
+  const int npos = (orow_last - orow_first + 2) * a.PW;   // the tile's rows + one halo row
+  const int npieces = (npos + 1) >> 1;
+  if (tid < 32) reinterpret_cast<uint32_t*>(smem + DP_ZERO_OFF)[tid] = 0u;
+
+  // the whole patch, all channels: piece = two positions of 512 bytes
+#pragma unroll
+  for (int it = 0; it < DP_NIT; ++it) {
+    const int piece = it * 8 + wave;
+    if (piece < npieces) {
+      const int pos = piece * 2 + (lane >> 5);
+      const int r = (int)a.dPW.div((uint32_t)pos), c = pos - r * a.PW;
+      const int grow = orow_first + r;
+      const bool ok = pos < npos && c < a.F2 && grow < a.dy_rows;
+      const int slice = ((lane & 31) >> 3) ^ ((pos >> 3) & 1), chunk = (lane & 7) ^ (pos & 7);
+      const char* src = ok ? reinterpret_cast<const char*>(a.dy) + ((int64_t)grow * a.F2 + c) * (a.C * 2) + slice * KBYTES + chunk * 16
+                           : reinterpret_cast<const char*>(g_nst_zero16);
+      glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
+    }
+  }
+  // weight tile of (tap, slice): w2[tap][ci][co-slice] -- image `quad` holds input channels quad*128 .. +127
+  uint32_t boff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = (s * 4 + wq) * 64 + lane;
+    const int row = c >> 3, slot = c & 7;
+    const int kchunk = slot ^ ((row >> 1) & 7);
+    boff[s] = (uint32_t)(((quad * BM + row) * a.C + kchunk * 8) * 2);
+  }
+  auto issue_b = [&](int tap, int cc, int buf) {
+    const char* wb = reinterpret_cast<const char*>(a.w2) + ((int64_t)tap * a.C * a.C + cc * 64) * 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      glds16(wb + boff[s], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(DP_B_OFF + buf * CP_BBUF + quad * (BM * KBYTES) +
+                                                                               (s * 4 + wq) * 1024)));
+  };
+
+  // this lane's four A rows: patch position of (du, dv) = (0, 0) and the bottom-border flag
+  int pb[4];
+  bool bot[4];
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = m0 + wm + i * 16 + (lane & 15);
+    const bool ok = p < a.M;
+    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
+    const int v = (ok ? p : m0) - orow * a.F2;
+    const int u = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
+    pb[i] = ok ? (orow - orow_first) * a.PW + v : 0;
+    bot[i] = ok && u == a.T2 - 1;
+  }
+
+  floatx4_t acc[4][4];
+  issue_b(DP_TAP[0], 0, 0);
+  int buf = 0;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const bool first = e == 0 || DP_CLS[e] != DP_CLS[e - 1], last = e == 8 || DP_CLS[e] != DP_CLS[e + 1];
+    if (first) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const int toff = DP_DU[e] * a.PW + DP_DV[e];
+    for (int cc = 0; cc < 4; ++cc) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (cc < 3) issue_b(DP_TAP[e], cc + 1, buf ^ 1);
+      else if (!last) issue_b(DP_TAP[e + 1], 0, buf ^ 1);
+      const char* Bs = smem + DP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
+      const int wnl = wn & 127;
+      bf16x8_t a0[4], a1[4];
+      typename RB::Frag b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wnl + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pos = pb[i] + toff;
+        int ad = (pos << 9) + ((cc ^ ((pos >> 3) & 1)) << 7) + ((g ^ (pos & 7)) << 4);
+        if (DP_DU[e]) ad = bot[i] ? DP_ZERO_OFF + (g << 4) : ad;
+        a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
+        a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + (ad ^ 64));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a1[i], b1[j], acc[i][j]);
+      buf ^= 1;
+    }
+    if (last) {
+      // class epilogue: 16-row quarters of the wave's 64 x 64 tile through the (now idle) weight buffers
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int pt = DP_CLS[e] >> 1, pf = DP_CLS[e] & 1;
+      float* epi = reinterpret_cast<float*>(smem + DP_B_OFF) + wave * (16 * DP_EPI_LD);
+      const int lr = (lane >> 4) * 4, lc = lane & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const floatx4_t v4 = acc[q][j];
+          epi[(lr + 0) * DP_EPI_LD + j * 16 + lc] = v4[0];
+          epi[(lr + 1) * DP_EPI_LD + j * 16 + lc] = v4[1];
+          epi[(lr + 2) * DP_EPI_LD + j * 16 + lc] = v4[2];
+          epi[(lr + 3) * DP_EPI_LD + j * 16 + lc] = v4[3];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int rl = lane >> 2, cseg = (lane & 3) * 16;
+        const int p = m0 + wm + q * 16 + rl;
+        if (p < a.M) {
+          const int orow = (int)a.dF2.div((uint32_t)p), v = p - orow * a.F2;
+          const int b = (int)a.dT2.div((uint32_t)orow), u = orow - b * a.T2;
+          const int64_t pix = ((int64_t)b * a.T1 + 2 * u + pt) * a.F1 + 2 * v + pf;
+          const float* srow = epi + rl * DP_EPI_LD + cseg;
+          uint32_t w[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 x = *reinterpret_cast<const float4*>(srow + k * 4);
+            w[k * 2] = pack_bf16x2(x.x, x.y);
+            w[k * 2 + 1] = pack_bf16x2(x.z, x.w);
+          }
+          uint4* dst = reinterpret_cast<uint4*>(a.dx + pix * a.C + wn + cseg);
+          dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+          dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (e < 8) {
+        __builtin_amdgcn_s_barrier();  // every wave is done with the scratch before the next class's first weight tile lands
+        asm volatile("" ::: "memory");
+        issue_b(DP_TAP[e + 1], 0, buf);
+      }
+    }
+  }
+}
+
+bool conv2_dgrad_patch(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("NST_CONV2_DGRAD_PATCH"); enabled = (e && e[0] == '0') ? 0 : 1; }
+  const int T2 = T1 / 2, F2 = F1 / 2;
+  if (!enabled || C != 256 || (T1 & 1) || (F1 & 1) || T1 < 2 || F1 < 2 || !nst_aligned16(dy) || !nst_aligned16(w2) || !nst_aligned16(dx))
+    return false;
+  const int64_t M = (int64_t)B * T2 * F2;
+  if (M >= (1ll << 30)) return false;
+  const int PW = F2 + 1;
+  const int rows_out = (F2 - 1 + BM - 1) / F2 + 1;
+  if ((rows_out + 1) * PW > DP_MAX_POS) return false;
+  DgradPatchArgs a;
+  a.dy = (const bf16_t*)dy; a.w2 = (const bf16_t*)w2; a.dx = (bf16_t*)dx;
+  a.T1 = T1; a.F1 = F1; a.T2 = T2; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.dy_rows = B * T2;
+  a.ntiles = (int)((M + BM - 1) / BM);
+  a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
+  conv_allow_big_lds(conv2_dgrad_patch_kernel, CP_LDS_BYTES);
+  conv2_dgrad_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
+  return true;
+}
+
 template <typename T>
 int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  if constexpr (sizeof(T) == 2)
+    if (conv2_dgrad_patch(dy, w2, dx, B, T1, F1, C, st)) return 0;
   for (int pt = 0; pt < 2; ++pt)
     for (int pf = 0; pf < 2; ++pf) {
       const int ct = (T1 - pt + 1) / 2, cf = (F1 - pf + 1) / 2;  // rows / cols of this parity

@@ -35,3 +35,11 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 fl = 2.0 * B * 225 * 20 * 256 * 2304
 print("conv2 fwd patch=%s: %.1f us  %.1f TF/s" % (os.environ.get("NST_CONV2_PATCH", "1"), us, fl / us / 1e6))
+dy = torch.randn(B, 225, 20, C, device=dev).to(torch.bfloat16)
+for _ in range(3): K.conv2_dgrad(dy, w2, T1, F1)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20): K.conv2_dgrad(dy, w2, T1, F1)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print("conv2 dgrad patch=%s: %.1f us  %.1f TF/s" % (os.environ.get("NST_CONV2_DGRAD_PATCH", "1"), us, fl / us / 1e6))

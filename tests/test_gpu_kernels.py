@@ -544,6 +544,17 @@ def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
     close(f"conv2_patch[B{B}T{T1}F{F1}relu{int(relu)}].y", y, ref, dtype)
     y2 = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV), relu=relu)
     assert torch.equal(y, y2), "conv2 forward is not deterministic"
+    if not relu:
+        # data gradient: even T1 and F1 take conv2_dgrad_patch_kernel (all four parity classes from one dy patch), the
+        # odd width falls back to the per-class implicit GEMMs -- both against autograd of the same convolution
+        T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+        dy = rnd(B, T2, F2, C, dtype=dtype, seed=14)
+        xr = x.double().requires_grad_(True)
+        torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), w2.double().permute(3, 2, 0, 1), None, stride=2,
+                                   padding=1).permute(0, 2, 3, 1).backward(dy.double())
+        dx = K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1)
+        close(f"conv2_patch[B{B}T{T1}F{F1}].dx", dx, xr.grad, dtype, scale=2.0)
+        assert torch.equal(dx, K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1))
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise
