@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--vocab", type=int, default=8008)
     ap.add_argument("--dropout", type=float, default=None, help="override the hparams set's dropout (0.1)")
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL batch, split over the ranks (default: per-GPU batch, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -168,6 +170,10 @@ def main():
             if k.endswith("dropout_rate"):
                 hp["model.params"][k] = args.dropout
     B, T, F, V = args.batch, args.frames, 80, args.vocab
+    if args.strong:
+        if B % world:
+            raise SystemExit(f"--strong: global batch {B} is not divisible by {world} ranks")
+        B //= world
     L = max(1, T // 12)
     task = build_task({"task.class": "speech2text", "task.params": {"audio_feature_dim": F, "vocab_size": V}})
     model = task.build_model(hp, device=dev, dtype=dtype, seed=1234 + rank, init_seed=42)
@@ -233,7 +239,7 @@ def main():
     out = {
         "metric": "audio frames/sec, SpeechTransformer-base (speech_transformer_s) training, whole job",
         "value": value, "unit": "frames/s", "value_per_gpu": value / world, "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} train step: B={B}/GPU x T={T} frames x F={F} mel, L={L}, V={V}, "
                                f"dropout {hp['model.params']['encoder.ffn_dropout_rate']}, label smoothing 0.1, "
