@@ -251,6 +251,16 @@ int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weig
 int nst_adam_update(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n, float lr_t,
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Gradient clipping of the flat gradient buffer after the data-parallel average (GradAccumKerasModel.train_step,
+ * neurst/training/gradaccum_keras_model.py:228-233):  g *= pre_scale (the 1/world_size average), then
+ *   clip_value > 0: g = clamp(g, -clip_value, +clip_value)                     (tf.clip_by_value)
+ *   clip_norm  > 0: g = g * clip_norm / max(||g||_2, clip_norm)  PER TENSOR   (tf.clip_by_norm on each gradient)
+ * exactly one of the two must be positive.  table (device, nentries x 16 bytes): {int64 off; int32 n (<= 4096); int32 seg}
+ * -- entries of one tensor (segment) are consecutive; seg_first (device, int32[nseg + 1]): first entry of every
+ * segment; workspace: nentries + nseg floats (clip_norm only).  Deterministic (no atomics). */
+int nst_grad_clip(float* grad, const void* table, int nentries, const int32_t* seg_first, int nseg, float* workspace,
+                  int64_t workspace_floats, float pre_scale, float clip_value, float clip_norm, void* stream);
+
 /* f32 -> bf16 cast (weight shadow refresh), bf16 -> f32, and fill. */
 int nst_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 int nst_cast_bf16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream);

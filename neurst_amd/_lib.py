@@ -59,6 +59,7 @@ _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "nst_abi_version": [],
     "nst_last_error_string": [],
+    "nst_grad_clip": [_P, _P, _I, _P, _I, _P, _L, _F, _F, _F, _P],
     "nst_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],

@@ -447,3 +447,88 @@ extern "C" int nst_cast_bf16_to_f32(const uint16_t* in, float* out, int64_t n, v
   NST_CHECK_LAUNCH("cast_bf16_to_f32");
   return NST_OK;
 }
+
+// =============================================================================================
+// Gradient clipping on the flat gradient buffer (GradAccumKerasModel.train_step,
+// neurst/training/gradaccum_keras_model.py:228-233): after the data-parallel average,
+//   clip_value:  g = clamp(g, -c, +c)                      (tf.clip_by_value, every element)
+//   clip_norm :  g = g * c / max(||g||_2, c)  PER TENSOR   (tf.clip_by_norm of each gradient, not the global norm)
+// One table entry (<= 4096 consecutive elements of one tensor) per workgroup; the norms take two deterministic
+// stages (per-entry partial sums of squares, then one workgroup per tensor).
+// =============================================================================================
+struct ClipEntry {
+  int64_t off;
+  int32_t n;
+  int32_t seg;
+};
+
+__global__ void __launch_bounds__(256) clip_value_kernel(float* __restrict__ g, const ClipEntry* __restrict__ table, float pre_scale,
+                                                         float clip) {
+  const ClipEntry e = table[blockIdx.x];
+  float* p = g + e.off;
+  for (int i = threadIdx.x; i < e.n; i += 256) {
+    const float v = p[i] * pre_scale;
+    p[i] = fminf(fmaxf(v, -clip), clip);
+  }
+}
+
+__global__ void __launch_bounds__(256) clip_sumsq_kernel(const float* __restrict__ g, const ClipEntry* __restrict__ table,
+                                                         float* __restrict__ partial) {
+  const ClipEntry e = table[blockIdx.x];
+  const float* p = g + e.off;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < e.n; i += 256) acc = fmaf(p[i], p[i], acc);
+  __shared__ float red[4];
+  acc = wave_sum_fast(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// factor[seg] = pre_scale * c / max(pre_scale * sqrt(sum of the segment's partials), c)
+__global__ void __launch_bounds__(256) clip_factor_kernel(const float* __restrict__ partial, const int32_t* __restrict__ seg_first,
+                                                          float* __restrict__ factor, float pre_scale, float clip) {
+  const int s = blockIdx.x;
+  float acc = 0.f;
+  for (int i = seg_first[s] + threadIdx.x; i < seg_first[s + 1]; i += 256) acc += partial[i];
+  __shared__ float red[4];
+  acc = wave_sum_fast(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = pre_scale * sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    factor[s] = pre_scale * clip / fmaxf(norm, clip);
+  }
+}
+
+__global__ void __launch_bounds__(256) clip_scale_kernel(float* __restrict__ g, const ClipEntry* __restrict__ table,
+                                                         const float* __restrict__ factor) {
+  const ClipEntry e = table[blockIdx.x];
+  const float f = factor[e.seg];
+  float* p = g + e.off;
+  for (int i = threadIdx.x; i < e.n; i += 256) p[i] *= f;
+}
+
+extern "C" int nst_grad_clip(float* grad, const void* table, int nentries, const int32_t* seg_first, int nseg, float* workspace,
+                             int64_t workspace_floats, float pre_scale, float clip_value, float clip_norm, void* stream) {
+  NST_CHECK_ARG(grad && table && nentries >= 0, "grad_clip: null pointer");
+  NST_CHECK_ARG((clip_value > 0.f) != (clip_norm > 0.f), "grad_clip: exactly one of clip_value / clip_norm must be positive");
+  if (nentries == 0) return NST_OK;
+  static_assert(sizeof(ClipEntry) == 16, "table entry layout");
+  hipStream_t st = (hipStream_t)stream;
+  const ClipEntry* t = (const ClipEntry*)table;
+  if (clip_value > 0.f) {
+    clip_value_kernel<<<nentries, 256, 0, st>>>(grad, t, pre_scale, clip_value);
+    NST_CHECK_LAUNCH("grad_clip(value)");
+    return NST_OK;
+  }
+  NST_CHECK_ARG(seg_first && nseg > 0 && workspace && workspace_floats >= (int64_t)nentries + nseg,
+                "grad_clip: clip_norm needs the segment table and a workspace of nentries + nseg floats");
+  float* partial = workspace;
+  float* factor = workspace + nentries;
+  clip_sumsq_kernel<<<nentries, 256, 0, st>>>(grad, t, partial);
+  clip_factor_kernel<<<nseg, 256, 0, st>>>(partial, seg_first, factor, pre_scale, clip_norm);
+  clip_scale_kernel<<<nentries, 256, 0, st>>>(grad, t, factor);
+  NST_CHECK_LAUNCH("grad_clip(norm)");
+  return NST_OK;
+}

@@ -34,6 +34,7 @@ class Trainer(BaseExperiment):
         self._optimizer_args = {"optimizer.class": args["optimizer.class"], "optimizer.params": args["optimizer.params"]}
         self._lr_args = {"lr_schedule.class": args["lr_schedule.class"], "lr_schedule.params": args["lr_schedule.params"]}
         self._bucket_mb = args.get("allreduce_bucket_mb", 32) or 32
+        self._clip_value, self._clip_norm = args.get("clip_value", None), args.get("clip_norm", None)
         self._max_to_keep = args.get("checkpoints_max_to_keep", 8) or 8
         self._pretrain_model = args.get("pretrain_model", None)
         self._ckpt_manager = None
@@ -49,6 +50,8 @@ class Trainer(BaseExperiment):
             Flag("save_checkpoint_steps", dtype=Flag.TYPE.INTEGER, default=1000, help="Saving checkpoints every N steps."),
             Flag("checkpoints_max_to_keep", dtype=Flag.TYPE.INTEGER, default=8, help="Number of checkpoints to keep."),
             Flag("update_cycle", dtype=Flag.TYPE.INTEGER, default=1, help="Gradient accumulation micro steps."),
+            Flag("clip_value", dtype=Flag.TYPE.FLOAT, default=None, help="Gradient clipping by value."),
+            Flag("clip_norm", dtype=Flag.TYPE.FLOAT, default=None, help="Gradient clipping by norm."),
             Flag("pretrain_model", dtype=Flag.TYPE.STRING, default=None,
                  help="A checkpoint (directory or prefix, TensorFlow bundle format) to initialise the weights from."),
             Flag("allreduce_bucket_mb", dtype=Flag.TYPE.INTEGER, default=32,
@@ -92,7 +95,8 @@ class Trainer(BaseExperiment):
             if start_step:
                 optimizer.iterations = start_step
                 reducer.broadcast_tensors([optimizer.m, optimizer.v], 0)
-        step_fn = TrainStep(model, self._criterion, optimizer, reducer, self._update_cycle)
+        step_fn = TrainStep(model, self._criterion, optimizer, reducer, self._update_cycle, clip_value=self._clip_value,
+                            clip_norm=self._clip_norm)
         if rank == 0 and self.model_dir:
             ModelConfigs.dump({"model.class": model.__class__.__name__, "model.params": model.args,
                                "task.class": self.task.__class__.__name__, "task.params": self.task.get_config()},

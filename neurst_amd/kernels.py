@@ -177,6 +177,15 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     return out
 
 
+def grad_clip(grad, table, nentries, seg_first, nseg, pre_scale=1.0, clip_value=None, clip_norm=None):
+    """In place on the flat gradient buffer: g *= pre_scale, then clamp to +-clip_value or scale every tensor to an L2 norm
+    of at most clip_norm (neurst_hip.h nst_grad_clip; gradaccum_keras_model.py:228-233)."""
+    assert grad.dtype == torch.float32 and grad.is_contiguous()
+    ws = torch.empty(nentries + nseg, dtype=torch.float32, device=grad.device)
+    check(lib.nst_grad_clip(_p(grad), _p(table), nentries, _p(seg_first), nseg, _p(ws), ws.numel(), float(pre_scale),
+                            float(clip_value or 0.0), float(clip_norm or 0.0), _stream()), "grad_clip")
+
+
 def colsum(x, out, accumulate=False):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
     ws = _workspace(64 << 20, x.device)

@@ -100,6 +100,22 @@ class ParamStore(object):
     def zero_grad(self):
         self.grad.zero_()
 
+    def clip_tables(self, entry_elems=4096):
+        """Device tables of nst_grad_clip: one entry per <= 4096 consecutive elements of one parameter, one segment per
+        parameter (tf.clip_by_norm clips every gradient tensor by ITS norm)."""
+        if getattr(self, "_clip_tables", None) is None:
+            import numpy as np
+            rows, first = [], []
+            for seg, p in enumerate(self.params.values()):
+                first.append(len(rows))
+                for c in range(0, p.numel, entry_elems):
+                    rows.append((p.offset + c, min(entry_elems, p.numel - c), seg))
+            first.append(len(rows))
+            arr = np.array(rows, dtype=np.dtype([("off", "<i8"), ("n", "<i4"), ("seg", "<i4")]))
+            self._clip_tables = (torch.from_numpy(arr.view(np.uint8).copy()).to(self.device), len(rows),
+                                 torch.tensor(first, dtype=torch.int32, device=self.device), len(first) - 1)
+        return self._clip_tables
+
     def state_dict(self):
         return {n: p.data.detach().cpu().clone() for n, p in self.params.items()}
 

@@ -2,7 +2,7 @@
 neurst/training/gradaccum_keras_model.py:162-260, 437-477; hvd optimizer hook hvd_utils.py:85-91):
 
     forward -> label-smoothed CE -> backward (bucketed RCCL all-reduce overlapped on a side stream)
-            -> [update_cycle-1 more micro batches accumulated] -> average -> fused Adam
+            -> [update_cycle-1 more micro batches accumulated] -> average [-> clip by value / per-tensor norm] -> fused Adam
 
 No host<->device synchronisation happens inside a step; the loss is returned as a device scalar.
 """
@@ -10,8 +10,11 @@ import torch
 
 
 class TrainStep(object):
-    def __init__(self, model, criterion, optimizer, reducer=None, update_cycle=1):
+    def __init__(self, model, criterion, optimizer, reducer=None, update_cycle=1, clip_value=None, clip_norm=None):
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
+        # gradaccum_keras_model.py:228-233: clip_value takes precedence over clip_norm; both act on the averaged gradients
+        self.clip_value = clip_value if clip_value else None
+        self.clip_norm = None if self.clip_value else (clip_norm if clip_norm else None)
         self.update_cycle = max(1, int(update_cycle))
         if reducer is not None:
             model.grad_ready_hook = self._hook
@@ -37,6 +40,12 @@ class TrainStep(object):
             self.model.backward(dlogits, accumulate=(i > 0))
             loss_sum = loss if loss_sum is None else loss_sum + loss
         scale = self.reducer.finish() if self.reducer is not None else 1.0
+        if self.clip_value or self.clip_norm:
+            from neurst_amd import kernels as K
+            table, nentries, seg_first, nseg = self.model.store.clip_tables()
+            K.grad_clip(self.model.store.grad, table, nentries, seg_first, nseg, pre_scale=scale,
+                        clip_value=self.clip_value, clip_norm=self.clip_norm)
+            scale = 1.0   # the average is already applied
         self.optimizer.apply_gradients(grad_scale=scale)
         self.model.rt.step += 1
         return loss_sum / n

@@ -436,6 +436,20 @@ def keras_adam_step(p, g, m, v, t, lr, beta1=0.9, beta2=0.98, eps=1e-9):
     return p, m, v
 
 
+def clip_gradients(grads, clip_value=None, clip_norm=None):
+    """GradAccumKerasModel.train_step (neurst/training/gradaccum_keras_model.py:228-233): tf.clip_by_value on every
+    gradient, else tf.clip_by_norm PER gradient tensor (t * clip_norm / max(||t||_2, clip_norm))."""
+    out = {}
+    for n, g in grads.items():
+        if clip_value:
+            out[n] = g.clamp(-clip_value, clip_value)
+        elif clip_norm:
+            out[n] = g * (clip_norm / torch.maximum(g.norm(), torch.tensor(float(clip_norm), dtype=g.dtype)))
+        else:
+            out[n] = g
+    return out
+
+
 def average_gradients(per_rank_grads):
     """hvd.Average over ranks (neurst/training/hvd_utils.py:46-62): elementwise mean of
     the per-rank gradients (each rank's gradient is of its LOCAL token-mean loss)."""

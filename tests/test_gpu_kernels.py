@@ -635,3 +635,39 @@ def test_errors_are_reported_not_fatal(K):
         K.layernorm_fwd(torch.zeros(2, 5000, device=DEV), torch.ones(5000, device=DEV), torch.zeros(5000, device=DEV), 1e-6)
     with pytest.raises(RuntimeError):
         K.layernorm_fwd(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ gradient clipping
+@pytest.mark.parametrize("mode", ["value", "norm"])
+def test_grad_clip_matches_oracle(K, mode):
+    """nst_grad_clip on a flat buffer of ragged tensors (some below, some above the threshold; one longer than a table
+    entry) against oracle.clip_gradients (gradaccum_keras_model.py:228-233), with the 1/world pre-scale folded in."""
+    from neurst_amd.runtime import ParamStore
+    g = torch.Generator().manual_seed(4)
+    shapes = {"a/kernel": (37, 11), "a/bias": (11,), "b/kernel": (130, 70), "c/gamma": (5,), "d/kernel": (3, 3, 1, 16), "e/big": (9000,)}
+    store = ParamStore()
+    for n, shp in shapes.items():
+        store.add(n, shp, torch.zeros(shp))
+    store.finalize(DEV, torch.float32)
+    grads = {n: torch.randn(shp, generator=g) * (3.0 if "kernel" in n else 0.02) for n, shp in shapes.items()}
+    for n, p in store.params.items():
+        p.grad.copy_(grads[n].to(DEV))
+    pad_before = store.grad.clone()
+    pre = 0.25
+    table, nentries, seg_first, nseg = store.clip_tables()
+    assert nseg == len(shapes) and nentries == sum((int(np.prod(s)) + 4095) // 4096 for s in shapes.values())
+    kw = {"clip_value": 0.5} if mode == "value" else {"clip_norm": 2.0}
+    K.grad_clip(store.grad, table, nentries, seg_first, nseg, pre_scale=pre, **kw)
+    want = O.clip_gradients({n: v.double() * pre for n, v in grads.items()}, **kw)
+    for n, p in store.params.items():
+        close(f"grad_clip[{mode}].{n}", p.grad, want[n], torch.float32)
+    if mode == "norm":
+        norms = {n: float(p.grad.norm()) for n, p in store.params.items()}
+        assert all(v <= 2.0 * (1 + 1e-5) for v in norms.values()) and norms["a/bias"] < 0.1     # small tensors untouched
+    # the alignment padding between tensors is never written
+    mask = torch.ones_like(store.grad, dtype=torch.bool)
+    for p in store.params.values():
+        mask[p.offset:p.offset + p.numel] = False
+    assert torch.equal(store.grad[mask], pad_before[mask])
+    with pytest.raises(RuntimeError):
+        K.grad_clip(store.grad, table, nentries, seg_first, nseg, clip_value=1.0, clip_norm=1.0)

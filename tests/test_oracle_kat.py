@@ -3,6 +3,7 @@ data-parallel averaging): closed forms and finite differences.  Parity for these
 reference; these tests only guarantee the restatement is self-consistent with the documented math."""
 import math
 
+import pytest
 import torch
 
 from oracle import neurst_oracle as O
@@ -124,3 +125,13 @@ def test_dp_average_equals_single_process_when_token_counts_match():
     n = "target_symbol_modality/shared/bias"
     assert not torch.allclose((g0[n] + g2[n]) / 2, gc2[n], atol=1e-6)
     assert torch.allclose((5 * g0[n] + 2 * g2[n]) / 7, gc2[n], atol=1e-10)
+
+
+def test_clip_gradients_known_answers():
+    """tf.clip_by_value / tf.clip_by_norm semantics per tensor (gradaccum_keras_model.py:228-233)."""
+    g = {"a": torch.tensor([3.0, -4.0]), "b": torch.tensor([0.3, 0.4])}
+    byv = O.clip_gradients(g, clip_value=1.0)
+    assert byv["a"].tolist() == [1.0, -1.0] and byv["b"].tolist() == pytest.approx([0.3, 0.4])
+    byn = O.clip_gradients(g, clip_norm=1.0)
+    assert byn["a"].tolist() == pytest.approx([0.6, -0.8]) and byn["b"].tolist() == pytest.approx([0.3, 0.4])   # ||b|| = 0.5 < 1
+    assert O.clip_gradients(g)["a"] is g["a"]
