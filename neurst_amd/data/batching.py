@@ -53,6 +53,60 @@ def adjust_batch_size(batch_size=None, batch_size_per_gpu=None, num_replicas_in_
     return int(batch_size // num_replicas_in_sync * num_replicas_in_sync)
 
 
+_MIN_BUCKET_BOUNDARY = 8
+_BUCKET_BOUNDARY_SCALE = 1.1
+
+
+def create_batch_bucket_boundaries(max_length, min_boundary=_MIN_BUCKET_BOUNDARY, boundary_scale=_BUCKET_BOUNDARY_SCALE):
+    """dataset_utils.py:125-147: token-length bucket bounds 8, 9, ... growing by 10 % (at least 1), last = max_length + 1."""
+    bounds = []
+    x = min_boundary
+    while x < max_length:
+        bounds.append(x)
+        x = max(x + 1, int(x * boundary_scale))
+    if bounds[-1] < max_length + 1:
+        bounds = bounds + [max_length + 1]
+    return bounds
+
+
+def associated_bucket_boundaries(a, b):
+    """dataset_utils.py:150-178: two boundary lists resampled to the same (shorter) length."""
+    l1, l2 = len(a), len(b)
+    if l1 == l2:
+        return a, b
+    if l1 > l2:
+        s1, s2 = l1 * 1. / l2, 1
+    else:
+        s1, s2 = 1, l2 * 1. / l1
+    n1, n2 = [], []
+    i = 1
+    while i < min(l1, l2) + 1:
+        n1.append(a[int(math.ceil(i * s1)) - 1])
+        n2.append(b[int(math.ceil(i * s2)) - 1])
+        i += 1
+    return n1, n2
+
+
+def text_bucket_plan(max_src_len, max_trg_len, batch_size, batch_size_per_gpu, batch_by_tokens=True, num_replicas_in_sync=1):
+    """The training bucket table of Seq2Seq.create_and_batch_tfds (tasks/seq2seq.py:247-264): associated source / target
+    bounds and, per bucket, batch_size // max(bound) sentences (a multiple of the replica count) when batching by tokens,
+    else a fixed sentence count.  Returns dict(src_bounds, trg_bounds, batch_sizes)."""
+    if max_src_len is None:
+        raise RuntimeError("Must provide `max_src_len` for training.")
+    if max_trg_len is None:
+        raise RuntimeError("Must provide `max_trg_len` for training.")
+    sb, tb = associated_bucket_boundaries(create_batch_bucket_boundaries(max_src_len), create_batch_bucket_boundaries(max_trg_len))
+    if batch_size is None and batch_size_per_gpu is None:
+        raise ValueError("At least one of the `batch_size` and `batch_size_per_gpu` should be provided.")
+    if batch_size_per_gpu is not None:
+        batch_size = int(batch_size_per_gpu * num_replicas_in_sync)
+    if batch_by_tokens:
+        sizes = [int(batch_size // max(s, t) // num_replicas_in_sync * num_replicas_in_sync) for s, t in zip(sb, tb)]
+    else:
+        sizes = [int(batch_size // num_replicas_in_sync * num_replicas_in_sync)] * len(sb)
+    return {"src_bounds": list(sb), "trg_bounds": list(tb), "batch_sizes": sizes}
+
+
 def speech_bucket_plan(max_src_len, max_trg_len, min_src_bucket_boundary, batch_size, batch_size_per_gpu,
                        num_replicas_in_sync=1, disable_batch_efficiency=False, frame_transcript_ratio=None):
     """The training bucket table of speech2text.py:293-336.

@@ -73,6 +73,13 @@ def gen_buckets():
         out[f"case{i}"] = np.asarray([mx, -1 if mn is None else mn] + list(f(mx, mn)), dtype=np.int64)
     vals = [(v, k) for v in (1, 7, 8, 9, 75, 3001, 4096) for k in (8, 3)]
     out["minimal_multiple"] = np.asarray([[v, k, mm(v, k)] for v, k in vals], dtype=np.int64)
+    cb = _exec_function("neurst/data/dataset_utils.py", "create_batch_bucket_boundaries",
+                        {"_MIN_BUCKET_BOUNDARY": 8, "_BUCKET_BOUNDARY_SCALE": 1.1})
+    ab = _exec_function("neurst/data/dataset_utils.py", "associated_bucket_boundaries")
+    for i, (ms, mt) in enumerate([(80, 80), (128, 64), (50, 200), (256, 256), (9, 300)]):
+        a, b = ab(cb(ms), cb(mt))
+        out[f"text{i}"] = np.asarray([ms, mt, len(a)] + list(a) + list(b), dtype=np.int64)
+        out[f"textraw{i}"] = np.asarray(cb(ms), dtype=np.int64)
     mg.save("bucket_boundaries", **out)
 
 

@@ -369,3 +369,106 @@ def test_reference_recipe_yaml_layout_builds_task_and_dataset(tmp_path):
                             "lr_schedule.params": args["entry.params"]["lr_schedule.params"]})
     assert abs(lr(24999) - 3.5 * 256 ** -0.5 * 25000 ** -0.5) < 1e-12
     assert abs(lr(99999) - 1.5 * 256 ** -0.5 * 100000 ** -0.5) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ text side (Seq2Seq)
+def test_text_bucket_boundaries_match_reference():
+    """create_batch_bucket_boundaries / associated_bucket_boundaries: outputs of the reference functions (dataset_utils.py:125-178)."""
+    g = np.load(os.path.join(GOLD, "bucket_boundaries.npz"))
+    for i in range(5):
+        v = g[f"text{i}"].tolist()
+        ms, mt, n = v[0], v[1], v[2]
+        assert batching.create_batch_bucket_boundaries(ms) == g[f"textraw{i}"].tolist()
+        a, b = batching.associated_bucket_boundaries(batching.create_batch_bucket_boundaries(ms), batching.create_batch_bucket_boundaries(mt))
+        assert list(a) == v[3:3 + n] and list(b) == v[3 + n:3 + 2 * n]
+    plan = batching.text_bucket_plan(80, 80, 4096, None, True, 1)
+    assert plan["src_bounds"][0] == 8 and plan["src_bounds"][-1] == 81
+    assert plan["batch_sizes"][0] == 4096 // 8 and plan["batch_sizes"][-1] == 4096 // 81
+    assert batching.text_bucket_plan(80, 80, None, 32, False, 4)["batch_sizes"][0] == 128
+    with pytest.raises(RuntimeError):
+        batching.text_bucket_plan(None, 80, 4096, None)
+
+
+def test_seq2seq_feed_from_tensorflow_written_records(tmp_path):
+    """The Translation task trained from `parallel_tfrecord` shards: here the shard is the fixture TensorFlow wrote (the head
+    of the reference's tests/examples/train.tfrecords-00000-of-00004), so ids, EOS and lengths are the reference's own."""
+    import shutil
+    gold = np.load(os.path.join(GOLD, "tfrecord_seq2seq_head.npz"))
+    d = tmp_path / "data"
+    d.mkdir()
+    shutil.copy(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"), d / "train.tfrecords-00000-of-00001")
+    vs, vt = int(gold["vocab_size_src"]) + 3, int(gold["vocab_size_trg"]) + 3
+    task = build_task({"task.class": "Translation", "task.params": {"src_vocab_size": vs, "trg_vocab_size": vt, "max_src_len": 60,
+                                                                    "max_trg_len": 60, "batch_size": 1, "batch_by_tokens": False}})
+    ds = build_dataset({"dataset.class": "ParallelTFRecordDataset", "dataset.params": {"data_path": str(d)}})
+    assert ds.status == compat.DataStatus.PROJECTED and ds.batched is False
+    exs = list(ds.build_iterator()())
+    assert len(exs) == 12 and all(e["label"][-1] == vt - 1 and e["feature"][-1] == vs - 1 for e in exs)   # EOS = last id
+    it = task.create_and_batch(ds, compat.ModeKeys.TRAIN, seed=0)
+    plan = batching.text_bucket_plan(60, 60, 1, None, False)
+    for e in exs:                                          # window size 1: every example comes out at once, in order
+        b = next(it)
+        k = plan["src_bounds"].index(b["feature"].shape[1])
+        assert b["label"].shape == (1, plan["trg_bounds"][k]) and len(e["feature"]) <= plan["src_bounds"][k] and len(e["label"]) <= plan["trg_bounds"][k]
+        assert k == 0 or len(e["feature"]) > plan["src_bounds"][k - 1] or len(e["label"]) > plan["trg_bounds"][k - 1]   # smallest bucket that fits
+        assert b["feature"][0, :len(e["feature"])].tolist() == e["feature"].tolist() and (b["feature"][0, len(e["feature"]):] == vs - 1).all()
+        x = task.example_to_input({n: torch.from_numpy(v) for n, v in b.items()}, compat.ModeKeys.TRAIN)
+        assert x["trg_length"].tolist() == [len(e["label"])] and x["src_length"].tolist() == [len(e["feature"])]
+        assert x["trg_input"][0, 0] == vt - 2 and x["trg_input"][0, 1:len(e["label"])].tolist() == e["label"][:-1].tolist()
+    assert np.array_equal(next(it)["feature"][0, :len(exs[0]["feature"])], exs[0]["feature"])               # second epoch
+    # token-sized windows on a larger synthetic shard
+    rng = np.random.RandomState(1)
+    recs = []
+    for _ in range(400):
+        ls, lt = int(rng.randint(3, 50)), int(rng.randint(3, 50))
+        recs.append(tfrecord.encode_example({"feature": np.r_[rng.randint(0, 50, ls - 1), vs - 1], "label": np.r_[rng.randint(0, 50, lt - 1), vt - 1]}))
+    d2 = tmp_path / "big"
+    d2.mkdir()
+    tfrecord.write_records(str(d2 / "train.tfrecords-00000-of-00001"), recs)
+    ds2 = build_dataset({"dataset.class": "parallel_tfrecord", "dataset.params": {"data_path": str(d2)}})
+    plan = batching.text_bucket_plan(40, 40, 600, None)
+    it2 = task.create_and_batch(ds2, compat.ModeKeys.TRAIN, args={"batch_size": 600, "batch_by_tokens": True, "max_src_len": 40,
+                                                                 "max_trg_len": 40, "shuffle_buffer": 32}, seed=2)
+    for _ in range(10):
+        b = next(it2)
+        k = plan["src_bounds"].index(b["feature"].shape[1])
+        assert b["label"].shape[1] == plan["trg_bounds"][k] and b["feature"].shape[0] == plan["batch_sizes"][k]
+        assert b["feature"].shape[0] * max(b["feature"].shape[1], b["label"].shape[1]) <= 600
+        real_s = (b["feature"] != vs - 1).sum(1) + 1
+        assert (real_s <= 40).all()                                                                      # the length filter ran
+    ev = list(task.create_and_batch(ds, compat.ModeKeys.EVAL, args={"batch_size": 5}))
+    assert [b["feature"].shape[0] for b in ev] == [5, 5, 2]
+    assert ev[0]["feature"].shape[1] == max(len(e["feature"]) for e in exs[:5])
+
+
+def test_parallel_text_dataset_with_vocabulary_pipelines(tmp_path):
+    gold = np.load(os.path.join(GOLD, "tfrecord_seq2seq_head.npz"))
+    (tmp_path / "src.txt").write_text("\n".join(str(x) for x in gold["src_lines"]) + "\n", encoding="utf-8")
+    (tmp_path / "trg.txt").write_text("\n".join("  " + str(x) + " " for x in gold["trg_lines"]) + "\n", encoding="utf-8")
+
+    def vocab(side):
+        n = int(gold[f"vocab_size_{side}"])
+        toks = [f"<tok{i}>" for i in range(n)]
+        for i, t in zip(gold[f"{side}_ids"], gold[f"{side}_tokens"]):
+            toks[int(i)] = str(t)
+        return toks
+    task = build_task({"task.class": "Seq2Seq", "task.params": {
+        "src_data_pipeline.params": {"vocab_path": vocab("src")}, "trg_data_pipeline.params": {"vocab_path": vocab("trg")},
+        "max_src_len": 60, "max_trg_len": 60, "batch_size": 400, "truncate_trg": True}})
+    assert task.src_meta["vocab_size"] == int(gold["vocab_size_src"]) + 3
+    ds = build_dataset({"dataset.class": "ParallelTextDataset",
+                        "dataset.params": {"src_file": str(tmp_path / "src.txt"), "trg_file": str(tmp_path / "trg.txt"), "data_is_processed": True}})
+    assert ds.status == compat.DataStatus.PROCESSED
+    prep = task.get_data_preprocess_fn(compat.ModeKeys.TRAIN, ds.status)
+    got = [prep(e) for e in ds.build_iterator()()]
+    # the same ids TensorFlow stored for these very sentences
+    recs = [tfrecord.parse_example(r) for r in tfrecord.read_records(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"))]
+    for g_, r in zip(got, recs):
+        assert g_["feature"].tolist() == r["feature"][1].tolist() and g_["label"].tolist() == r["label"][1].tolist()
+    # contiguous range sharding by the reference's 1-based counter (parallel_text_dataset.py:121-149)
+    parts = [[e["feature"] for e in ds.build_iterator(shard_id=s, total_shards=3)()] for s in range(3)]
+    assert [len(p) for p in parts] == [3, 4, 5] and sum(parts, []) == [" ".join(str(x).split()) for x in gold["src_lines"]]
+    # truncation keeps the head and the EOS
+    short = task.get_data_preprocess_fn(compat.ModeKeys.TRAIN, ds.status, {"max_trg_len": 4})(next(ds.build_iterator()()))
+    assert len(short["label"]) == 4 and short["label"][-1] == task.trg_meta["eos_id"] and short["label"][:3].tolist() == recs[0]["label"][1][:3].tolist()
+    assert ds.targets[0] == str(gold["trg_lines"][0])
