@@ -1,0 +1,68 @@
+"""SequenceGenerator, entry "predict" / "generation" (neurst/exps/sequence_generator.py:36-235): restores the latest
+checkpoint of model_dir, decodes the dataset batch by batch with the configured search layer and writes one hypothesis
+per line.  Evaluation metrics (BLEU / WER, :163-235) are out of scope: `output_file` is the product; without a target
+vocabulary pipeline the hypotheses are written as space-separated ids.
+"""
+import logging
+
+import torch
+
+from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
+from neurst_amd.layers.search import SequenceSearch, build_search_layer
+from neurst_amd.utils import compat
+from neurst_amd.utils.checkpoints import restore_checkpoint_if_possible
+from neurst_amd.utils.flags_core import Flag, ModuleFlag
+
+
+@register_exp(["predict", "generation"])
+class SequenceGenerator(BaseExperiment):
+    def __init__(self, args, **kwargs):
+        super().__init__(**kwargs)
+        self._output_file = args.get("output_file", None)
+        self._batch_size = args.get("batch_size", None) or 32
+        self._search_layer = build_search_layer(args) or build_search_layer({"search_method.class": "beam_search"})
+
+    @staticmethod
+    def class_or_method_args():
+        return [
+            ModuleFlag(SequenceSearch.REGISTRY_NAME, default="beam_search", help="The search layer for sequence generation."),
+            Flag("output_file", dtype=Flag.TYPE.STRING, default=None, help="The path to a file for generated outputs."),
+            Flag("batch_size", dtype=Flag.TYPE.INTEGER, default=32, help="Utterances / sentences per decoding batch."),
+        ]
+
+    def postprocess_generation(self, hypotheses):
+        """sequence_generator.py:112-116: ids -> text through the task's target pipeline (cut at the first EOS)."""
+        dp = getattr(self.task, "_trg_data_pipeline", None)
+        eos = self.task.trg_meta["eos_id"]
+        out = []
+        for row in hypotheses:
+            row = [int(x) for x in row]
+            if dp is not None:
+                out.append(dp.decode(row))
+            else:
+                out.append(" ".join(str(x) for x in (row[:row.index(eos)] if eos in row else row)))
+        return out
+
+    def run(self):
+        model = self.model
+        if self.model_dir:
+            got = restore_checkpoint_if_possible(model, self.model_dir)
+            logging.info("checkpoint: %s", got or "none restored (random weights)")
+        results = []
+        if getattr(self.custom_dataset, "batched", True):
+            batches = self.custom_dataset.build_iterator(shard_id=0, total_shards=1, device=model.rt.device)
+        else:
+            def _batches():
+                for b in self.task.create_and_batch(self.custom_dataset, compat.ModeKeys.INFER, args={"batch_size": self._batch_size}):
+                    yield {k: torch.from_numpy(v).to(model.rt.device) for k, v in b.items()}
+            batches = _batches()
+        for batch in batches:
+            inputs = self.task.example_to_input(batch, compat.ModeKeys.INFER)
+            hyp, _ = self._search_layer(model, inputs)
+            top_k = self._search_layer.top_k
+            results.extend(self.postprocess_generation(hyp.view(-1, top_k, hyp.shape[-1])[:, 0].cpu().tolist()))
+        if self._output_file:
+            with open(self._output_file, "w", encoding="utf-8") as fw:
+                fw.write("\n".join(results) + "\n")
+            logging.info("Saving generation results into %s", self._output_file)
+        return results

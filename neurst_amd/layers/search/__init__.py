@@ -1,1 +1,2 @@
-from neurst_amd.layers.search.beam_search import BeamSearch, sequence_beam_search  # noqa: F401
+from neurst_amd.layers.search.beam_search import (BeamSearch, SequenceSearch, build_search_layer,  # noqa: F401
+                                                  sequence_beam_search)

@@ -14,7 +14,21 @@ HIP path).  Semantics kept from the reference:
 """
 import torch
 
+from neurst_amd.utils.flags_core import Flag
+from neurst_amd.utils.registry import setup_registry
+
 FLOAT_MIN = -1.e9  # neurst/utils/compat.py FLOAT_MIN
+
+
+class SequenceSearch(object):
+    REGISTRY_NAME = "search_method"
+
+    @staticmethod
+    def class_or_method_args():
+        return []
+
+
+build_search_layer, register_search_layer = setup_registry(SequenceSearch.REGISTRY_NAME, base_class=SequenceSearch, backend="pt")
 
 
 def stack_beam_size(x, beam_size):
@@ -102,16 +116,38 @@ def sequence_beam_search(symbols_to_logits_fn, generation_initializer, top_k=1, 
     return hyp, top_scores.reshape(-1)
 
 
-class BeamSearch(object):
+@register_search_layer(["beam_search", "BeamSearch"])
+class BeamSearch(SequenceSearch):
     """SequenceSearch "beam_search" (beam_search.py:443-551): binds the search hyper-parameters, drives a model."""
 
-    def __init__(self, beam_size=4, length_penalty=0.6, top_k=1, maximum_decode_length=None, minimum_decode_length=0,
+    def __init__(self, args=None, beam_size=4, length_penalty=0.6, top_k=1, maximum_decode_length=None, minimum_decode_length=0,
                  extra_decode_length=50, enable_unk=False, use_graphs=False):
-        self.use_graphs = use_graphs
-        self.beam_size, self.length_penalty, self.top_k = beam_size, length_penalty, top_k
-        self.maximum_decode_length, self.minimum_decode_length = maximum_decode_length, minimum_decode_length
-        self.extra_decode_length, self.enable_unk = extra_decode_length, enable_unk
-        assert top_k <= beam_size
+        a = dict(beam_size=beam_size, length_penalty=length_penalty, top_k=top_k, maximum_decode_length=maximum_decode_length,
+                 minimum_decode_length=minimum_decode_length, extra_decode_length=extra_decode_length, enable_unk=enable_unk,
+                 use_graphs=use_graphs)
+        a.update({k: v for k, v in (args or {}).items() if v is not None and k in a})
+        if (args or {}).get("padded_decode", None):
+            pass  # the cache is preallocated to the maximum length anyway: nothing to switch
+        self.use_graphs = bool(a["use_graphs"])
+        self.beam_size, self.length_penalty, self.top_k = a["beam_size"], a["length_penalty"], a["top_k"]
+        self.maximum_decode_length, self.minimum_decode_length = a["maximum_decode_length"], a["minimum_decode_length"] or 0
+        self.extra_decode_length, self.enable_unk = a["extra_decode_length"], bool(a["enable_unk"])
+        assert self.top_k <= self.beam_size
+
+    @staticmethod
+    def class_or_method_args():
+        return [
+            Flag("beam_size", dtype=Flag.TYPE.INTEGER, default=4, help="The beam width of beam search inference."),
+            Flag("length_penalty", dtype=Flag.TYPE.FLOAT, default=0.6, help="The length penalty of beam search inference."),
+            Flag("top_k", dtype=Flag.TYPE.INTEGER, default=1, help="The number of reserved predictions with top scores."),
+            Flag("maximum_decode_length", dtype=Flag.TYPE.INTEGER, default=None, help="The maximum decoding length."),
+            Flag("minimum_decode_length", dtype=Flag.TYPE.INTEGER, default=0, help="The minimum decoding length."),
+            Flag("extra_decode_length", dtype=Flag.TYPE.INTEGER, default=50,
+                 help="The extra decoding length versus the (encoded) source length."),
+            Flag("padded_decode", dtype=Flag.TYPE.BOOLEAN, default=None, help="Accepted for compatibility (static cache always)."),
+            Flag("enable_unk", dtype=Flag.TYPE.BOOLEAN, default=None, help="Whether the search may generate UNK."),
+            Flag("use_graphs", dtype=Flag.TYPE.BOOLEAN, default=None, help="Replay the decoding step as a captured HIP graph."),
+        ]
 
     def __call__(self, model, inputs):
         max_len = self.maximum_decode_length or 256

@@ -472,6 +472,16 @@ def test_cli_training_from_tfrecord_shards(tmp_path):
                              "--dtype", "float32", "--distribution_strategy", "none", "--train_steps", "33", "--save_checkpoint_steps", "33"])
     REPORT["cli_tfrecord.resumed_loss"] = float(resumed)
     assert float(resumed) < float(first) and (model_dir / "ckpt-33.index").exists()
+    # the "predict" entry (exps/sequence_generator.py): restore the checkpoint, beam-search every utterance, one line each
+    out = tmp_path / "hyp.txt"
+    hyps = run_exp._main(["--config_paths", str(cfg_path), "--hparams_set", "speech_transformer_toy", "--model_dir", str(model_dir),
+                          "--dtype", "float32", "--distribution_strategy", "none", "--entry", "predict", "--output_file", str(out),
+                          "--batch_size", "50", "--search_method", "beam_search", "--beam_size", "2", "--maximum_decode_length", "12"])
+    lines = out.read_text().splitlines()
+    assert len(hyps) == len(lines) == 128 and hyps == lines
+    ids = [[int(t) for t in line.split()] for line in lines]
+    assert all(len(r) <= 12 and all(0 <= t < V - 3 for t in r) for r in ids)          # no EOS / BOS / UNK inside a hypothesis
+    assert sum(len(r) for r in ids) > 0
     saved = yaml.safe_load((model_dir / "model_configs.yml").read_text())
     assert saved["task.class"] == "SpeechToText" and saved["task.params"]["audio_feature_dim"] == fdim
 
