@@ -14,6 +14,7 @@ from neurst_amd.criterions import Criterion, build_criterion
 from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
 from neurst_amd.optimizers import build_lr_schedule, build_optimizer
 from neurst_amd.training.distributed import GradientReducer
+from neurst_amd.training.criterion_validator import Validator, build_validator
 from neurst_amd.training.train_step import TrainStep
 from neurst_amd.utils import compat
 from neurst_amd.utils.checkpoints import NameBasedCheckpointManager, restore_checkpoint_if_possible
@@ -35,6 +36,7 @@ class Trainer(BaseExperiment):
         self._lr_args = {"lr_schedule.class": args["lr_schedule.class"], "lr_schedule.params": args["lr_schedule.params"]}
         self._bucket_mb = args.get("allreduce_bucket_mb", 32) or 32
         self._clip_value, self._clip_norm = args.get("clip_value", None), args.get("clip_norm", None)
+        self._validator = build_validator(args)
         self._max_to_keep = args.get("checkpoints_max_to_keep", 8) or 8
         self._pretrain_model = args.get("pretrain_model", None)
         self._ckpt_manager = None
@@ -45,6 +47,7 @@ class Trainer(BaseExperiment):
             ModuleFlag(Criterion.REGISTRY_NAME, default="label_smoothed_cross_entropy", help="The training criterion."),
             ModuleFlag("optimizer", default="Adam", help="The optimizer for training."),
             ModuleFlag("lr_schedule", default=None, help="The learning schedule for training."),
+            ModuleFlag(Validator.REGISTRY_NAME, default=None, help="The validation process while training."),
             Flag("train_steps", dtype=Flag.TYPE.INTEGER, default=10000000, help="The maximum steps for training."),
             Flag("summary_steps", dtype=Flag.TYPE.INTEGER, default=200, help="Doing summary (logging) every N steps."),
             Flag("save_checkpoint_steps", dtype=Flag.TYPE.INTEGER, default=1000, help="Saving checkpoints every N steps."),
@@ -114,6 +117,10 @@ class Trainer(BaseExperiment):
                     yield self.task.example_to_input({k: torch.from_numpy(v).to(rt.device, non_blocking=True)
                                                       for k, v in b.items()}, compat.ModeKeys.TRAIN)
             it = _feed()
+        if self._validator is not None and rank == 0:
+            self._validator.build(self.task, model, self.model_dir)
+            if self._validator._eval_on_begin:
+                self._validator.validate(start_step)
         t0, frames, last_loss = time.time(), 0.0, None
         for step in range(start_step + 1, self._train_steps + 1):
             try:
@@ -134,4 +141,6 @@ class Trainer(BaseExperiment):
                 frames = frames + float(0)  # keep host free of syncs between summaries
             if rank == 0 and self._save_checkpoint_steps and step % self._save_checkpoint_steps == 0:
                 self._save(step)
+            if rank == 0 and self._validator is not None and self._validator.due(step):
+                self._validator.validate(step)
         return last_loss
