@@ -265,6 +265,11 @@ int nst_grad_clip(float* grad, const void* table, int nentries, const int32_t* s
 int nst_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 int nst_cast_bf16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------ host helper of the data feed
+ * CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a byte range, continuing from `crc` (0 to start): the
+ * checksum of TFRecord frames (neurst/data/dataset_utils.py:256-326 reads them through TensorFlow).  Pure host code. */
+uint32_t nst_crc32c(const void* data, int64_t n, uint32_t crc);
+
 /* ------------------------------------------------------------------ probes (used by tests only)
  * nst_probe_mfma: writes the raw lane->value maps of the MFMA / LDS-transpose-read instructions the
  * kernels rely on, so the layout assumptions are verified on real hardware. */

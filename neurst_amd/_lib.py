@@ -60,6 +60,7 @@ SIGNATURES = {
     "nst_abi_version": [],
     "nst_last_error_string": [],
     "nst_grad_clip": [_P, _P, _I, _P, _I, _P, _L, _F, _F, _F, _P],
+    "nst_crc32c": [_P, _L, C.c_uint32],
     "nst_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
@@ -98,7 +99,8 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "nst_last_error_string"
-                      else C.c_int64 if name == "nst_attention_dropout_mask_bytes" else C.c_int)
+                      else C.c_int64 if name == "nst_attention_dropout_mask_bytes"
+                      else C.c_uint32 if name == "nst_crc32c" else C.c_int)
     ver = lib.nst_abi_version()
     if ver != NST_ABI_VERSION:
         raise ImportError(f"libneurst_hip.so ABI version {ver} != expected {NST_ABI_VERSION}")

@@ -14,3 +14,39 @@ void nst_set_error(const char* fmt, ...) {
 
 extern "C" int nst_abi_version(void) { return NST_ABI_VERSION; }
 extern "C" const char* nst_last_error_string(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// Host helper of the data feed: CRC-32C (Castagnoli) of TFRecord frames, slicing-by-8 (the Python table walk in
+// neurst_amd/data/tfrecord.py does ~2 MB/s; a 900-frame utterance is 288 KB).
+// ---------------------------------------------------------------------------------------------
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_ready = false;
+
+static void crc32c_init() {
+  for (int i = 0; i < 256; ++i) {
+    uint32_t c = (uint32_t)i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (int i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xFF];
+  g_crc_ready = true;
+}
+
+extern "C" uint32_t nst_crc32c(const void* data, int64_t n, uint32_t crc) {
+  if (!g_crc_ready) crc32c_init();  // idempotent; racing initialisers write the same values
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = crc ^ 0xFFFFFFFFu;
+  while (n > 0 && ((uintptr_t)p & 7)) { c = g_crc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8); --n; }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = g_crc_tab[7][w & 0xFF] ^ g_crc_tab[6][(w >> 8) & 0xFF] ^ g_crc_tab[5][(w >> 16) & 0xFF] ^ g_crc_tab[4][(w >> 24) & 0xFF] ^
+        g_crc_tab[3][(w >> 32) & 0xFF] ^ g_crc_tab[2][(w >> 40) & 0xFF] ^ g_crc_tab[1][(w >> 48) & 0xFF] ^ g_crc_tab[0][(w >> 56) & 0xFF];
+    p += 8;
+    n -= 8;
+  }
+  while (n-- > 0) c = g_crc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}

@@ -11,6 +11,7 @@ import time
 import torch
 
 from neurst_amd.criterions import Criterion, build_criterion
+from neurst_amd.data.prefetch import Prefetcher
 from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
 from neurst_amd.optimizers import build_lr_schedule, build_optimizer
 from neurst_amd.training.distributed import GradientReducer
@@ -112,10 +113,13 @@ class Trainer(BaseExperiment):
             # GPU is the reference's Horovod arrangement: every worker batches its own file shard with
             # num_replicas_in_sync = 1 (training_utils.py:146-151), i.e. `batch_size` is per worker.
             def _feed():
-                for b in self.task.create_and_batch(self.custom_dataset, compat.ModeKeys.TRAIN, num_replicas_in_sync=1,
-                                                    shard_id=rank, total_shards=world, seed=self._args.get("seed", None) or 1234):
+                host_batches = Prefetcher(self.task.create_and_batch(
+                    self.custom_dataset, compat.ModeKeys.TRAIN, num_replicas_in_sync=1, shard_id=rank, total_shards=world,
+                    seed=self._args.get("seed", None) or 1234), depth=4)   # parsing / bucketing / padding run ahead in a thread
+                for b in host_batches:
                     yield self.task.example_to_input({k: torch.from_numpy(v).to(rt.device, non_blocking=True)
                                                       for k, v in b.items()}, compat.ModeKeys.TRAIN)
+
             it = _feed()
         if self._validator is not None and rank == 0:
             self._validator.build(self.task, model, self.model_dir)

@@ -30,6 +30,14 @@ def test_crc32c_known_answers():
     assert tfrecord.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
     assert tfrecord.crc32c(b"123456789") == 0xE3069283
     assert tfrecord.crc32c(b"") == 0
+    # the library's slicing-by-8 routine (nst_crc32c) and the Python table walk agree, also across chunk boundaries
+    rng = np.random.RandomState(0)
+    blob = rng.bytes(5000)
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 4999):
+        for off in (0, 1, 3):
+            assert tfrecord.crc32c(blob[off:off + n]) == tfrecord.crc32c_py(blob[off:off + n])
+    assert tfrecord.crc32c(blob[100:], tfrecord.crc32c(blob[:100])) == tfrecord.crc32c_py(blob)
+    assert tfrecord.crc32c_py(b"123456789") == 0xE3069283
 
 
 def _pipeline(gold, side):
@@ -472,3 +480,36 @@ def test_parallel_text_dataset_with_vocabulary_pipelines(tmp_path):
     short = task.get_data_preprocess_fn(compat.ModeKeys.TRAIN, ds.status, {"max_trg_len": 4})(next(ds.build_iterator()()))
     assert len(short["label"]) == 4 and short["label"][-1] == task.trg_meta["eos_id"] and short["label"][:3].tolist() == recs[0]["label"][1][:3].tolist()
     assert ds.targets[0] == str(gold["trg_lines"][0])
+
+
+def test_prefetcher_order_errors_and_end():
+    import time
+    from neurst_amd.data.prefetch import Prefetcher
+
+    def slow():
+        for i in range(20):
+            time.sleep(0.001)
+            yield i
+    assert list(Prefetcher(slow(), depth=3)) == list(range(20))
+
+    def boom():
+        yield 1
+        yield 2
+        raise ValueError("bad record")
+    it = Prefetcher(boom())
+    assert next(it) == 1 and next(it) == 2
+    with pytest.raises(ValueError, match="bad record"):
+        next(it)
+    with pytest.raises(StopIteration):
+        next(it)
+    # an endless producer is stopped by close(), it does not block on the full queue forever
+    def forever():
+        i = 0
+        while True:
+            yield i
+            i += 1
+    it = Prefetcher(forever(), depth=2)
+    assert [next(it) for _ in range(5)] == [0, 1, 2, 3, 4]
+    it.close()
+    it._thread.join(timeout=2.0)
+    assert not it._thread.is_alive()
