@@ -71,6 +71,7 @@ class CriterionValidator(Validator):
         self._task, self._model = task, model
         crit_cls = self.args.get("eval_criterion.class", None) or "label_smoothed_cross_entropy"
         self._criterion = build_criterion({"criterion.class": crit_cls, "criterion.params": self.args.get("eval_criterion.params", None) or {}})
+        self._start = time.time()
         if self.args.get("eval_dataset.class", None) is None:
             logging.info("WARNING: no validation dataset is provided in CriterionValidator for validation process.")
             return self

@@ -480,6 +480,11 @@ def test_cli_training_from_tfrecord_shards(tmp_path):
                              "--dtype", "float32", "--distribution_strategy", "none", "--train_steps", "33", "--save_checkpoint_steps", "33"])
     REPORT["cli_tfrecord.resumed_loss"] = float(resumed)
     assert float(resumed) < float(first) and (model_dir / "ckpt-33.index").exists()
+    # the "evaluation" entry: NLL / PPL of the restored checkpoint over the same shards, better than chance after training
+    ev = run_exp._main(["--config_paths", str(cfg_path), "--hparams_set", "speech_transformer_toy", "--model_dir", str(model_dir),
+                        "--dtype", "float32", "--distribution_strategy", "none", "--entry", "evaluation", "--batch_size", "40"])
+    REPORT["cli_tfrecord.eval_ppl"] = float(ev["PPL"])
+    assert set(ev) == {"NLL", "PPL"} and 1.0 < ev["PPL"] < V
     # the "predict" entry (exps/sequence_generator.py): restore the checkpoint, beam-search every utterance, one line each
     out = tmp_path / "hyp.txt"
     hyps = run_exp._main(["--config_paths", str(cfg_path), "--hparams_set", "speech_transformer_toy", "--model_dir", str(model_dir),
