@@ -104,3 +104,42 @@ def test_single_process_reducer_is_identity():
     red.component_ready(["b/"])
     assert red.finish() == 1.0 and float(st.grad.sum()) == 2.0 * st.total
     assert red.reduce_metrics({"x": 4.0}) == {"x": 4.0}
+
+
+def _bcast_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurst_amd.training.distributed import GradientReducer
+
+    class _S(object):
+        pass
+    st = _S()
+    st.grad = torch.zeros(8)
+    st.master = torch.full((8,), float(rank))
+    st.params, st.total = {}, 8
+    st.refresh_shadow = lambda: None
+    red = GradientReducer(st, overlap=False)
+    red.broadcast_parameters(0)
+    m, v = torch.full((5,), 3.0 + rank), torch.full((5,), 7.0 + rank)
+    red.broadcast_tensors([m, v], 0)                       # optimizer moments after a resume (exps/trainer.py)
+    start = red.reduce_metrics({"start_step": 40.0 if rank == 0 else 0.0})["start_step"]
+    q.put((rank, st.master.tolist(), m.tolist(), v.tolist(), start))
+    dist.destroy_process_group()
+
+
+def test_resume_state_is_broadcast_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29731
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, master, m, v, start in out:
+        assert master == [0.0] * 8 and m == [3.0] * 5 and v == [7.0] * 5 and start == 40.0
