@@ -237,7 +237,8 @@ def main():
         except Exception:
             pass
     out = {
-        "metric": "audio frames/sec, SpeechTransformer-base (speech_transformer_s) training, whole job",
+        "metric": ("audio frames/sec, SpeechTransformer-base (speech_transformer_s) training, whole job" if args.model == "speech_transformer_s"
+                   else f"audio frames/sec, SpeechTransformer ({args.model}) training, whole job"),
         "value": value, "unit": "frames/s", "value_per_gpu": value / world, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
