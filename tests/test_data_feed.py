@@ -513,3 +513,45 @@ def test_prefetcher_order_errors_and_end():
     it.close()
     it._thread.join(timeout=2.0)
     assert not it._thread.is_alive()
+
+
+def test_create_tfrecords_reproduces_tensorflow_bytes(tmp_path):
+    """neurst_amd.cli.create_tfrecords on the fixture's sentences (parallel text + the two vocabularies, the layout of the
+    reference's tests/examples/example_create_seq2seq_tfrecrods.yml) writes records byte-identical to the ones TensorFlow
+    wrote for these sentences."""
+    import yaml
+    import neurst_amd.cli.create_tfrecords as ct
+    gold = np.load(os.path.join(GOLD, "tfrecord_seq2seq_head.npz"))
+    (tmp_path / "src.txt").write_text("\n".join(str(x) for x in gold["src_lines"]) + "\n", encoding="utf-8")
+    (tmp_path / "trg.txt").write_text("\n".join(str(x) for x in gold["trg_lines"]) + "\n", encoding="utf-8")
+
+    def vocab(side):
+        n = int(gold[f"vocab_size_{side}"])
+        toks = [f"<tok{i}>" for i in range(n)]
+        for i, t in zip(gold[f"{side}_ids"], gold[f"{side}_tokens"]):
+            toks[int(i)] = str(t)
+        (tmp_path / f"vocab.{side}").write_text("\n".join(toks) + "\n", encoding="utf-8")
+        return str(tmp_path / f"vocab.{side}")
+    cfg = {"dataset.class": "ParallelTextDataset",
+           "dataset.params": {"src_file": str(tmp_path / "src.txt"), "trg_file": str(tmp_path / "trg.txt"), "data_is_processed": True},
+           "task.class": "Seq2Seq",
+           "task.params": {"src_data_pipeline.class": "TextDataPipeline", "src_data_pipeline.params": {"vocab_path": vocab("src")},
+                           "trg_data_pipeline.class": "TextDataPipeline", "trg_data_pipeline.params": {"vocab_path": vocab("trg")}},
+           "processor_id": 0, "num_processors": 1, "num_output_shards": 1, "output_range_begin": 0, "output_range_end": 1,
+           "output_template": str(tmp_path / "out" / "train.tfrecords-%5.5d-of-%5.5d")}
+    (tmp_path / "create.yml").write_text(yaml.safe_dump(cfg))
+    paths = ct._main(["--config_paths", str(tmp_path / "create.yml")])
+    assert [os.path.basename(p) for p in paths] == ["train.tfrecords-00000-of-00001"] and not os.path.exists(paths[0] + ".incomplete")
+    assert open(paths[0], "rb").read() == open(os.path.join(GOLD, "tfrecord_seq2seq_head.bin"), "rb").read()
+    # several shards and processors: every example lands in exactly one shard of the processor's range
+    cfg.update({"num_output_shards": 4, "output_range_begin": 1, "output_range_end": 3, "seed": 5})
+    (tmp_path / "create.yml").write_text(yaml.safe_dump(cfg))
+    paths = ct._main(["--config_paths", str(tmp_path / "create.yml")])
+    assert [os.path.basename(p) for p in paths] == ["train.tfrecords-00001-of-00004", "train.tfrecords-00002-of-00004"]
+    got = sorted(r for p in paths for r in tfrecord.read_records(p))
+    assert got == sorted(tfrecord.read_records(os.path.join(GOLD, "tfrecord_seq2seq_head.bin")))
+    # audio examples: float features + ids, as the speech recipes store them
+    ex = {"audio": np.arange(12, dtype=np.float32) / 7, "transcript": np.array([3, 1, 2]), "uuid": "utt-1"}
+    rec = tfrecord.encode_example({k: ct._feature_value(v) for k, v in ex.items()})
+    back = tfrecord.parse_example(rec)
+    assert back["audio"][0] == "float" and np.array_equal(back["audio"][1], ex["audio"]) and back["uuid"] == ("bytes", [b"utt-1"])
