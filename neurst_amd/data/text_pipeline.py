@@ -9,6 +9,7 @@ unprocessed text instead of silently skipping it.
 """
 import json
 
+from neurst_amd.data.bpe import BPE
 from neurst_amd.utils import compat
 
 
@@ -95,6 +96,11 @@ class TextDataPipeline(Vocab):
         self._language = language
         self._reverse_sequence = reverse_sequence
         self._tokenizer, self._subtokenizer = tokenizer, subtokenizer
+        self._bpe = None
+        if subtokenizer is not None and str(subtokenizer).lower() == "bpe":
+            if subtokenizer_codes is None:
+                raise ValueError("subtokenizer=bpe needs subtokenizer_codes")
+            self._bpe = BPE(subtokenizer_codes, glossaries=glossaries)
         tokens = Vocab.load_tokens(tokens=vocab_path) if isinstance(vocab_path, list) else Vocab.load_tokens(vocab_path=vocab_path)
         unk_token = Vocab.get_unique(tokens, "<UNK>") if unk_id is None else tokens[unk_id]
         bos_token = Vocab.get_unique(tokens, "<SEQ_BEG>") if bos_id is None else tokens[bos_id]
@@ -117,11 +123,18 @@ class TextDataPipeline(Vocab):
                 "padding_mode": compat.PaddingMode.EOS_AS_PADDING if self._eos_id == self._pad_id else compat.PaddingMode.DEFAULT}
 
     def preprocess(self, text):
-        if self._tokenizer or self._subtokenizer:
-            raise NotImplementedError(
-                f"tokenizer={self._tokenizer} / subtokenizer={self._subtokenizer}: only already processed text "
-                f"(is_processed=True, or projected ids in the TFRecords) is supported on this path")
+        """text_data_pipeline.py:93-99: tokenizer, then sub-tokenizer.  Built: no / whitespace tokenizer, BPE sub-tokenizer;
+        anything else (moses, jieba, sentencepiece ...) raises instead of being skipped."""
+        if self._tokenizer and str(self._tokenizer).lower() not in ("none", "space", "whitespace"):
+            raise NotImplementedError(f"tokenizer={self._tokenizer} is not built: pass tokenised text or projected ids")
+        if self._subtokenizer and self._bpe is None and str(self._subtokenizer).lower() != "none":
+            raise NotImplementedError(f"subtokenizer={self._subtokenizer} is not built (only bpe)")
+        if self._bpe is not None:
+            text = self._bpe.tokenize(text, return_str=True)
         return text
+
+    def postprocess(self, text):
+        return self._bpe.detokenize(text) if self._bpe is not None else text
 
     def encode(self, text, is_processed=False):
         """text_data_pipeline.py:109-125."""
@@ -144,4 +157,4 @@ class TextDataPipeline(Vocab):
         toks = self.map_id_to_token(ids)
         if self._reverse_sequence:
             toks = toks[::-1]
-        return " ".join(toks)
+        return self.postprocess(" ".join(toks))

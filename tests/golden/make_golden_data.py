@@ -125,7 +125,26 @@ def gen_tfrecord_head(nrec=12):
             src_ids=used["zh"][0], src_tokens=used["zh"][1], trg_ids=used["en"][0], trg_tokens=used["en"][1])
 
 
+def gen_bpe(nlines=60):
+    """The reference's BPE data: codes.bpe4k.en and lines of train.example.en.tok.bpe.txt.  Checks, here, that re-applying the
+    codes to EVERY de-BPE'd line of both languages reproduces the file; commits the English merge table and a sample."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from neurst_amd.data.bpe import BPE
+    ex = os.path.join(REF, "tests", "examples")
+    for lang, name in (("en", "train.example.en.tok.bpe.txt"), ("zh", "train.example.zh.jieba.bpe.txt")):
+        b = BPE(os.path.join(ex, "codes.bpe4k." + lang))
+        lines = open(os.path.join(ex, name), encoding="utf-8").read().split("\n")
+        bad = [l for l in lines if b.tokenize(b.detokenize(l), return_str=True) != " ".join(l.split())]
+        assert not bad, (lang, bad[:3])
+    codes = open(os.path.join(ex, "codes.bpe4k.en"), encoding="utf-8").read().split("\n")
+    lines = open(os.path.join(ex, "train.example.en.tok.bpe.txt"), encoding="utf-8").read().split("\n")
+    sample = [l for l in lines if "@@" in l][:nlines]
+    mg.save("bpe_en", codes=np.frombuffer("\n".join(codes).encode("utf-8"), dtype=np.uint8),
+            lines=np.frombuffer("\n".join(sample).encode("utf-8"), dtype=np.uint8))
+
+
 if __name__ == "__main__":
+    gen_bpe()
     gen_specaug()
     gen_buckets()
     gen_tfrecord_head()
