@@ -13,6 +13,23 @@ from neurst_amd.data.bpe import BPE
 from neurst_amd.utils import compat
 
 
+class SentencePiece(object):
+    """The `spm` sub-tokenizer (neurst/data/text/spm.py:28-91): EncodeAsPieces / DecodePieces of the same library."""
+
+    def __init__(self, model_path):
+        import sentencepiece
+        self._sp = sentencepiece.SentencePieceProcessor()
+        assert self._sp.Load(model_path), "Fail to load spm model: {}".format(model_path)
+
+    def tokenize(self, text, return_str=False):
+        pieces = self._sp.EncodeAsPieces(text if isinstance(text, str) else " ".join(text))
+        return " ".join(pieces) if return_str else pieces
+
+    def detokenize(self, text, return_str=True):
+        out = self._sp.DecodePieces(text.split() if isinstance(text, str) else list(text))
+        return out if return_str else out.split()
+
+
 class Vocab(object):
     def __init__(self, tokens, extra_tokens=None, lowercase=False):
         assert isinstance(tokens, list), "`tokens` must be a list of string tokens"
@@ -101,6 +118,10 @@ class TextDataPipeline(Vocab):
             if subtokenizer_codes is None:
                 raise ValueError("subtokenizer=bpe needs subtokenizer_codes")
             self._bpe = BPE(subtokenizer_codes, glossaries=glossaries)
+        elif subtokenizer is not None and str(subtokenizer).lower() in ("spm", "sentencepiece"):
+            if subtokenizer_codes is None:
+                raise ValueError("subtokenizer=spm needs subtokenizer_codes (the SentencePiece model file)")
+            self._bpe = SentencePiece(subtokenizer_codes)
         tokens = Vocab.load_tokens(tokens=vocab_path) if isinstance(vocab_path, list) else Vocab.load_tokens(vocab_path=vocab_path)
         unk_token = Vocab.get_unique(tokens, "<UNK>") if unk_id is None else tokens[unk_id]
         bos_token = Vocab.get_unique(tokens, "<SEQ_BEG>") if bos_id is None else tokens[bos_id]
@@ -123,12 +144,12 @@ class TextDataPipeline(Vocab):
                 "padding_mode": compat.PaddingMode.EOS_AS_PADDING if self._eos_id == self._pad_id else compat.PaddingMode.DEFAULT}
 
     def preprocess(self, text):
-        """text_data_pipeline.py:93-99: tokenizer, then sub-tokenizer.  Built: no / whitespace tokenizer, BPE sub-tokenizer;
-        anything else (moses, jieba, sentencepiece ...) raises instead of being skipped."""
+        """text_data_pipeline.py:93-99: tokenizer, then sub-tokenizer.  Built: no / whitespace tokenizer, BPE and SentencePiece
+        sub-tokenizers; anything else (moses, jieba ...) raises instead of being skipped."""
         if self._tokenizer and str(self._tokenizer).lower() not in ("none", "space", "whitespace"):
             raise NotImplementedError(f"tokenizer={self._tokenizer} is not built: pass tokenised text or projected ids")
         if self._subtokenizer and self._bpe is None and str(self._subtokenizer).lower() != "none":
-            raise NotImplementedError(f"subtokenizer={self._subtokenizer} is not built (only bpe)")
+            raise NotImplementedError(f"subtokenizer={self._subtokenizer} is not built (only bpe and spm)")
         if self._bpe is not None:
             text = self._bpe.tokenize(text, return_str=True)
         return text

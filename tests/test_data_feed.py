@@ -581,4 +581,22 @@ def test_bpe_reproduces_reference_lines(tmp_path):
     with pytest.raises(NotImplementedError):
         TextDataPipeline(vocab_path=vocab, tokenizer="moses").encode("a b")
     with pytest.raises(NotImplementedError):
-        TextDataPipeline(vocab_path=vocab, subtokenizer="spm").encode("a b")
+        TextDataPipeline(vocab_path=vocab, subtokenizer="wordpiece").encode("a b")
+
+
+def test_sentencepiece_subtokenizer(tmp_path):
+    """`spm` sub-tokenizer: the pieces are SentencePiece's own (same library as the reference's wrapper, spm.py:28-91)."""
+    import sentencepiece as spm
+    g = np.load(os.path.join(GOLD, "bpe_en.npz"))
+    from neurst_amd.data.bpe import BPE
+    raw = [BPE(g["codes"].tobytes().decode("utf-8").split("\n")).detokenize(l) for l in g["lines"].tobytes().decode("utf-8").split("\n")]
+    (tmp_path / "corpus.txt").write_text("\n".join(raw * 4) + "\n", encoding="utf-8")
+    spm.SentencePieceTrainer.Train(f"--input={tmp_path / 'corpus.txt'} --model_prefix={tmp_path / 'm'} --vocab_size=120 "
+                                   "--model_type=bpe --hard_vocab_limit=false --minloglevel=2")
+    sp = spm.SentencePieceProcessor()
+    sp.Load(str(tmp_path / "m.model"))
+    vocab = [sp.IdToPiece(i) for i in range(sp.GetPieceSize())]
+    dp = TextDataPipeline(vocab_path=vocab, subtokenizer="spm", subtokenizer_codes=str(tmp_path / "m.model"))
+    ids = dp.encode(raw[0], is_processed=False)
+    assert [vocab[i] for i in ids[:-1]] == sp.EncodeAsPieces(raw[0]) and ids[-1] == dp.meta["eos_id"]
+    assert dp.decode(ids) == raw[0]
