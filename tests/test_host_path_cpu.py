@@ -1,0 +1,307 @@
+"""Host-side logic of the path on CPU: the hand-scheduled forward / backward of the layer classes, the gradient
+bookkeeping in the flat buffer, the train step and the data-parallel hooks are ordinary Python -- they are exercised
+here WITHOUT a GPU by installing oracle/kernel_emulation.py (a float64 restatement of the C-ABI contracts) over
+`neurst_amd.kernels` for the duration of a test, and compared with oracle/neurst_oracle.py (autograd).
+
+This does not test the HIP kernels (tests/test_gpu_*.py do, through the C ABI); it pins the orchestration around
+them, so that a scheduling mistake in a backward pass shows up in the `-m "not gpu"` suite already."""
+import inspect
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import kernel_emulation as E
+from oracle import neurst_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    return E.install(monkeypatch)
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double(), ref.detach().double()
+    assert got.shape == ref.shape, f"{tuple(got.shape)} vs {tuple(ref.shape)}"
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+
+
+def test_emulation_covers_every_kernel_entry_point(cpu_kernels):
+    """Every function of neurst_amd.kernels that reaches the library has an emulated namesake with the same signature."""
+    from neurst_amd import kernels as K
+    patched = {n for n, f in vars(K).items() if inspect.isfunction(f) and f.__module__ == "oracle.kernel_emulation"}
+    assert patched == set(cpu_kernels)
+    import ast
+    text = open(os.path.join(ROOT, "neurst_amd", "kernels.py")).read()
+    tree = ast.parse(text)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and "lib.nst_" in ast.get_source_segment(text, node) \
+                and not node.name.startswith("_") and node.name != "probe_mfma":
+            assert node.name in cpu_kernels, f"kernels.{node.name} has no CPU emulation"
+            want = [a.arg for a in node.args.args]
+            got = list(inspect.signature(getattr(E, node.name)).parameters)
+            assert got == want, f"{node.name}: emulation signature {got} != {want}"
+    assert K.gemm is E.gemm
+
+
+def _speech_model(case, dropout=0.0, **extra):
+    cases = {  # d, H, enc, dec, ffn, C, B, T, F, L, V, ragged
+        "toy": (8, 2, 2, 2, 10, 5, 2, 11, 80, 3, 5, False),
+        "small": (32, 2, 2, 2, 64, 8, 3, 38, 16, 9, 50, True),
+    }
+    d, H, ne, nd, ffn, C, B, T, F, L, V, ragged = cases[case]
+    from neurst_amd.models import build_model
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    p = dict(get_hyper_parameters("speech_transformer_toy")["model.params"])
+    p.update({"modality.dim": d, "modality.source.channels": C, "encoder.num_layers": ne, "decoder.num_layers": nd,
+              "encoder.hidden_size": d, "decoder.hidden_size": d, "encoder.num_attention_heads": H,
+              "decoder.num_attention_heads": H, "encoder.filter_size": ffn, "decoder.filter_size": ffn})
+    for k in list(p):
+        if k.endswith("dropout_rate"):
+            p[k] = dropout
+    p.update(extra)
+    model = build_model({"model.class": "SpeechTransformer", "model.params": p},
+                        {"audio_feature_dim": F, "audio_feature_channels": 1},
+                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device="cpu",
+                        dtype="float32", init_seed=3)
+    g = torch.Generator().manual_seed(11)
+    sd = {}
+    for n, prm in model.store.params.items():
+        if n.endswith("/bias") or n.endswith("/beta"):
+            sd[n] = torch.randn(prm.shape, generator=g) * 0.05
+        elif n.endswith("/gamma"):
+            sd[n] = 1.0 + torch.randn(prm.shape, generator=g) * 0.1
+    model.store.load_state_dict(sd, strict=False)
+    cfg = {"num_enc": ne, "num_dec": nd, "num_heads": H, "layer_norm": True}
+    return model, cfg, (B, T, F, L, V, ragged)
+
+
+def _speech_inputs(shape, seed=11):
+    B, T, F, L, V, ragged = shape
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, T, F, 1, generator=g)
+    if ragged:
+        src_len = torch.tensor([T - (i * T) // (2 * B) for i in range(B)])
+        trg_len = torch.tensor([L - i for i in range(B)]).clamp(min=1)
+    else:
+        src_len, trg_len = torch.full((B,), T), torch.full((B,), L)
+    trg = torch.randint(0, V - 3, (B, L), generator=g)
+    trg = torch.where(torch.arange(L)[None] >= (trg_len[:, None] - 1), torch.full_like(trg, V - 1), trg)
+    trg_input = torch.cat([torch.full((B, 1), V - 2), trg[:, :-1]], 1)
+    return {"src": src, "src_length": src_len, "trg": trg, "trg_input": trg_input, "trg_length": trg_len}
+
+
+def _oracle_step(model, inputs, cfg, fn=O.train_step_reference):
+    W = {n: p.data.detach().clone().double() for n, p in model.store.params.items()}
+    return fn(W, {k: (v.double() if v.is_floating_point() else v) for k, v in inputs.items()}, cfg, 0.1)
+
+
+@pytest.mark.parametrize("case", ["toy", "small"])
+def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
+    """logits, loss and every parameter gradient of the layer classes' explicit forward / backward == oracle autograd."""
+    from neurst_amd.criterions import build_criterion
+    model, cfg, shape = _speech_model(case)
+    inputs = _speech_inputs(shape)
+    loss_ref, logits_ref, grads_ref = _oracle_step(model, inputs, cfg)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(inputs, is_training=True)
+    loss = crit.reduce_loss(inputs, logits)
+    model.backward(crit.backward())
+    assert rel_err(logits, logits_ref) < 1e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for n, p in model.store.params.items():
+        assert rel_err(p.grad, grads_ref[n]) < 2e-5, n
+    # the padding elements between parameters of the flat buffer stay zero (the reducer sends them too)
+    used = torch.zeros(model.store.total, dtype=torch.bool)
+    for p in model.store.params.values():
+        used[p.offset:p.offset + p.numel] = True
+    assert float(model.store.grad[~used].abs().sum()) == 0.0
+
+
+def test_gradient_accumulation_and_clipping_on_cpu(cpu_kernels):
+    """TrainStep with update_cycle = 2 averages the micro-batch gradients (gradaccum_keras_model.py:62-109), clips the
+    averaged gradients per tensor (:228-233) and applies Keras Adam -- against the oracle's functions."""
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.train_step import TrainStep
+    model, cfg, shape = _speech_model("toy")
+    b1, b2 = _speech_inputs(shape, 5), _speech_inputs(shape, 6)
+    W0 = {n: p.data.detach().clone() for n, p in model.store.params.items()}
+    _, _, g1 = _oracle_step(model, b1, cfg)
+    _, _, g2 = _oracle_step(model, b2, cfg)
+    mean = {n: (g1[n] + g2[n]) / 2 for n in g1}
+    clipped = O.clip_gradients(mean, clip_norm=0.05)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
+    step = TrainStep(model, crit, opt, None, update_cycle=2, clip_norm=0.05)
+    step([b1, b2])
+    for n, p in model.store.params.items():
+        assert rel_err(p.grad, clipped[n]) < 2e-5, n
+        # Adam is checked on the gradient the path itself produced: the first Keras-Adam step is ~lr * sign(g), which
+        # turns fp32 rounding of near-zero components into O(lr) differences if the oracle's gradient were used
+        w, _, _ = O.keras_adam_step(W0[n].double(), p.grad.double(), torch.zeros_like(W0[n]).double(),
+                                    torch.zeros_like(W0[n]).double(), 1, 1e-2)
+        assert float((p.data.double() - w).abs().max()) < 1e-6, n
+    assert model.rt.step == 1 and opt.iterations == 1
+
+
+def test_text_transformer_and_waitk_host_schedule(cpu_kernels):
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.models.transformer import Transformer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils import compat
+    d, H, ne, nd, ffn, B, S, L, Vs, Vt = 16, 2, 2, 2, 32, 3, 9, 7, 23, 19
+    for wait_k in (None, 2):
+        p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+        p.update({"modality.dim": d, "encoder.num_layers": ne, "decoder.num_layers": nd, "encoder.hidden_size": d,
+                  "decoder.hidden_size": d, "encoder.num_attention_heads": H, "decoder.num_attention_heads": H,
+                  "encoder.filter_size": ffn, "decoder.filter_size": ffn})
+        for k in list(p):
+            if k.endswith("dropout_rate"):
+                p[k] = 0.0
+        task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": Vs, "trg_vocab_size": Vt}})
+        if wait_k is None:
+            model = task.build_model({"model.class": "Transformer", "model.params": p}, device="cpu", dtype="float32", init_seed=5)
+        else:
+            model = task.build_model({"model.class": "WaitkTransformer", "model.params": dict(p, wait_k=wait_k)},
+                                     device="cpu", dtype="float32", init_seed=5)
+        g = torch.Generator().manual_seed(21)
+
+        def side(Lx, V, lens):
+            ids = torch.randint(0, V - 3, (B, Lx), generator=g)
+            return torch.where(torch.arange(Lx)[None] >= (lens[:, None] - 1), torch.full_like(ids, V - 1), ids)
+        src_len = torch.tensor([S - i for i in range(B)])
+        trg_len = torch.tensor([L - i for i in range(B)])
+        inputs = task.example_to_input({"feature": side(S, Vs, src_len), "label": side(L, Vt, trg_len)}, compat.ModeKeys.TRAIN)
+        cfg = {"num_enc": ne, "num_dec": nd, "num_heads": H}
+        if wait_k is not None:
+            cfg.update({"attention_monotonic": True, "wait_k": wait_k})
+        loss_ref, logits_ref, grads_ref = _oracle_step(model, inputs, cfg, O.text_train_step_reference)
+        crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+        logits = model(inputs, is_training=True)
+        loss = crit.reduce_loss(inputs, logits)
+        model.backward(crit.backward())
+        assert rel_err(logits, logits_ref) < 1e-5 and abs(float(loss) - float(loss_ref)) < 1e-5
+        for n, prm in model.store.params.items():
+            assert rel_err(prm.grad, grads_ref[n]) < 2e-5, (wait_k, n)
+
+
+def test_reference_golden_logits_through_the_host_path(cpu_kernels):
+    """The reference's own full-model golden logits (tests/neurst/models/transformer_test.py:23-666) through the layer
+    classes + emulated kernels: pins the host wiring (variable names, layouts, call order) on CPU."""
+    from neurst_amd.models import build_model
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    r, W = load_golden("transformer_toy_logits")
+    model = build_model(get_hyper_parameters("transformer_toy"), dict(vocab_size=8, eos_id=7, bos_id=6, unk_id=5),
+                        dict(vocab_size=5, eos_id=4, bos_id=3, unk_id=2), device="cpu", dtype="float32")
+    zero = {n: torch.zeros(p.shape) for n, p in model.store.params.items() if n.endswith("/bias")}
+    model.store.load_state_dict(zero, strict=False)
+    model.store.load_state_dict({k: v for k, v in W.items() if k in model.store.params}, strict=False)
+    inputs = {"src": torch.from_numpy(r["src"]), "src_padding": torch.from_numpy(r["src_padding"]),
+              "trg_input": torch.from_numpy(r["trg_input"])}
+    logits = model(inputs, is_training=False)
+    assert float(((logits.double() - torch.from_numpy(r["expected"]).double()) ** 2).sum()) < 1e-9
+
+
+def test_incremental_decoding_equals_teacher_forcing_on_cpu(cpu_kernels):
+    """The per-layer K/V caches of the decoder (multi_head_attention.py:254-290): step t of the incremental path
+    reproduces position t of the full teacher-forced forward."""
+    model, cfg, shape = _speech_model("toy")
+    inputs = _speech_inputs(shape)
+    full = model(inputs, is_training=False)
+    enc_inputs = {k: v for k, v in inputs.items() if k.startswith("src")}
+    step_fn, init, _ = model.get_symbols_to_logits_fn(enc_inputs, beam_size=1, decode_padded_length=8)
+    assert init["decoder_input"].tolist() == [shape[4] - 2] * shape[0]   # BOS
+    cache = init["decoder_internal_cache"]
+    for t in range(inputs["trg_input"].shape[1]):
+        logits_t = step_fn(inputs["trg_input"][:, t], cache, t)
+        assert rel_err(logits_t, full[:, t]) < 1e-5, t
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, gloo, world 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from neurst_amd import kernels as K
+    for n in E._NAMES:
+        setattr(K, n, getattr(E, n))
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.distributed import GradientReducer, init_distributed
+    from neurst_amd.training.train_step import TrainStep
+    init_distributed(backend="gloo")
+    model, cfg, shape = _speech_model("toy")
+    red = GradientReducer(model.store, bucket_bytes=2048)
+    red.broadcast_parameters(0)
+    fired = []
+    orig = red.component_ready
+    red.component_ready = lambda prefixes: (fired.append(list(prefixes)), orig(prefixes))[1]
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
+    step = TrainStep(model, crit, opt, red)
+    losses = [float(step(_speech_inputs(shape, 100 + 10 * s + rank))) for s in range(2)]
+    q.put((rank, model.store.master.numpy().copy(), losses, fired))   # numpy: no fd passing after exit
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_world2_gloo_matches_oracle_average():
+    """Two ranks, different batches: after two steps both ranks hold the weights the oracle gets from the MEAN of the two
+    per-rank gradients (hvd.Average, hvd_utils.py:46-62) under Keras Adam; the component hooks fire in backward order."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [(r, torch.from_numpy(w), l, f) for r, w, l, f in res]
+    assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
+    assert res[0][3] == res[1][3] and [f[0] for f in res[0][3][:4]] == [
+        "TransformerDecoder/", "target_symbol_modality/", "TransformerEncoder/", "input_audio_modality/"]
+
+    # single-process oracle of the same two steps
+    model, cfg, shape = _speech_model("toy")   # same init seed as the workers (rank 0's weights are broadcast)
+    W = {n: p.data.detach().clone().double() for n, p in model.store.params.items()}
+    m = {n: torch.zeros_like(w) for n, w in W.items()}
+    v = {n: torch.zeros_like(w) for n, w in W.items()}
+    # Adam divides by sqrt(v): where the true gradient is zero (e.g. the key bias, softmax is shift invariant) the update
+    # is lr * sign(rounding noise); those elements are excluded from the weight comparison
+    solid = {n: torch.ones_like(w, dtype=torch.bool) for n, w in W.items()}
+    for s in range(2):
+        per_rank = []
+        for rank in range(world):
+            inp = _speech_inputs(shape, 100 + 10 * s + rank)
+            loss, _, g = O.train_step_reference(W, {k: (t.double() if t.is_floating_point() else t) for k, t in inp.items()}, cfg, 0.1)
+            per_rank.append(g)
+            assert abs(float(loss) - res[rank][2][s]) < 1e-5
+        names = sorted(W)
+        avg = dict(zip(names, O.average_gradients([[g[n] for n in names] for g in per_rank])))
+        gmax = max(float(g.abs().max()) for g in avg.values())
+        for n in W:
+            solid[n] &= avg[n].abs() > 1e-4 * gmax
+            W[n], m[n], v[n] = O.keras_adam_step(W[n], avg[n].double(), m[n], v[n], s + 1, 1e-2)
+    assert sum(int(x.sum()) for x in solid.values()) > 0.5 * sum(x.numel() for x in solid.values())
+    for n, p in model.store.params.items():
+        got = res[0][1][p.offset:p.offset + p.numel].view(p.shape).double()
+        assert float(((got - W[n]).abs() * solid[n]).max()) < 2e-5, n
