@@ -67,8 +67,9 @@ class MultiHeadAttention(Layer):
             self._saved = (query, memory, q, kv, ctx, (lse, dmask), memory_bias, B, Tq, Tk, p, lag)
         return out
 
-    def backward(self, dz, dmemory=None, dmemory_accumulate=False):
-        """Returns d(query); d(memory) is written (or accumulated) into `dmemory` [B*Tk, d]."""
+    def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None):
+        """Returns d(query) (+ residual, post-norm wrapper); d(memory) is written (or accumulated) into `dmemory`
+        [B*Tk, d]."""
         query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p, lag = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
@@ -85,7 +86,7 @@ class MultiHeadAttention(Layer):
         self.kv_transform.backward_params(memory, dkv)
         if dmemory is not None:
             self.kv_transform.backward_input(dkv, out=dmemory, accumulate=dmemory_accumulate)
-        return self.q_transform.backward_input(dq)
+        return self.q_transform.backward_input(dq, **({} if residual is None else {"residual": residual}))
 
 
 class MultiHeadSelfAttention(MultiHeadAttention):
@@ -122,7 +123,7 @@ class MultiHeadSelfAttention(MultiHeadAttention):
             self._saved = (x, qkv, ctx, (lse, dmask), bias, causal, B, T, p)
         return out
 
-    def backward(self, dz):
+    def backward(self, dz, residual=None):
         x, qkv, ctx, (lse, dmask), bias, causal, B, T, p = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
@@ -134,4 +135,4 @@ class MultiHeadSelfAttention(MultiHeadAttention):
                         g3[..., d:2 * d], g3[..., 2 * d:], H, dh, key_bias=bias, causal=causal, dropout_p=p,
                         seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask)
         self.qkv_transform.backward_params(x, dqkv)
-        return self.qkv_transform.backward_input(dqkv)
+        return self.qkv_transform.backward_input(dqkv, **({} if residual is None else {"residual": residual}))

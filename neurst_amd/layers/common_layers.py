@@ -159,38 +159,52 @@ class TransformerFFN(Layer):
             self._saved = (x, h, p)
         return y
 
-    def backward(self, dz):
+    def backward(self, dz, residual=None):
+        """residual (post-norm wrapper): added to the returned input gradient in the last GEMM's epilogue."""
         x, h, p = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
         dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=K.dropout_inv_keep(p))
         self.dense1.backward_params(x, dh)
-        return self.dense1.backward_input(dh)
+        return self.dense1.backward_input(dh, **({} if residual is None else {"residual": residual}))
 
 
 class PrePostProcessingWrapper(Layer):
-    """PrePostProcessingWrapper, pre-norm branch (common_layers.py:73-85):  inputs + dropout(layer(LN(inputs))).
-    The dropout and the residual add are fused into the wrapped layer's last GEMM epilogue; in backward the
-    residual gradient is fused into the LayerNorm backward kernel."""
+    """PrePostProcessingWrapper (common_layers.py:73-92).
+    pre-norm  (:73-85):  inputs + dropout(layer(LN(inputs)))
+    post-norm (:86-92):  LN(inputs + dropout(layer(inputs)))
+    Either way the dropout and the residual add are fused into the wrapped layer's last GEMM epilogue.  In the pre-norm
+    backward the residual gradient is fused into the LayerNorm backward kernel; in the post-norm backward it is fused
+    into the epilogue of the wrapped layer's last input-gradient GEMM."""
 
-    def __init__(self, rt, name, layer, dim, dropout_rate, epsilon):
+    def __init__(self, rt, name, layer, dim, dropout_rate, epsilon, pre_norm=True):
         super().__init__(rt, name)
         self.layer = layer
         self.norm = LayerNorm(rt, name + "/ln", dim, epsilon)
         self.rate = dropout_rate
+        self.pre_norm = pre_norm
         self.site = self._site()
 
     def forward(self, x, is_training, **kwargs):
         p = self.rate if is_training else 0.0
-        y = self.norm.forward(x, save=is_training)
-        epi = dict(residual=x, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
         self._p = p
+        epi = dict(residual=x, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+        if not self.pre_norm:
+            s = self.layer.forward(x, is_training=is_training, epilogue=epi, **kwargs)
+            return self.norm.forward(s, save=is_training)
+        y = self.norm.forward(x, save=is_training)
         return self.layer.forward(y, is_training=is_training, epilogue=epi, **kwargs)
 
     def drop_rate(self):
         return self._p
 
     def backward(self, dy, consumer=None):
+        """consumer: the dropout site that meets the returned gradient next -- on the pre-norm residual chain only; a
+        post-norm wrapper hands its gradient to the previous wrapper's LayerNorm, no mask in between."""
+        if not self.pre_norm:
+            ds = self.norm.backward(dy, consumer=self)     # d(inputs + dropout(layer)); its masked copy rides along
+            dz = dropped_grad(self.rt, ds, self._p, self.site)
+            return self.layer.backward(dz, residual=ds)    # layer'(dz) + ds in the last dgrad epilogue
         dz = dropped_grad(self.rt, dy, self._p, self.site)
         dn = self.layer.backward(dz)
         return self.norm.backward(dn, dres=dy, consumer=consumer)

@@ -22,8 +22,6 @@ class TransformerDecoder(Decoder):
                          layer_postprocess_dropout_rate=layer_postprocess_dropout_rate,
                          layer_postprocess_epsilon=layer_postprocess_epsilon, post_normalize=post_normalize,
                          no_cross_attn_layer_list=no_cross_attn_layer_list or [])
-        if post_normalize:
-            raise NotImplementedError("post_normalize=True is off the hot path")
         self.name = name or self.__class__.__name__
 
     def build(self, rt, gen):
@@ -36,8 +34,9 @@ class TransformerDecoder(Decoder):
                                     p["layer_postprocess_epsilon"], p["post_normalize"],
                                     with_cross_attention=(i not in p["no_cross_attn_layer_list"]))
             for i in range(p["num_layers"])]
-        self._output_norm_layer = LayerNorm(rt, f"{self.name}/output_ln", p["hidden_size"],
-                                            p["layer_postprocess_epsilon"])
+        # post-norm stacks end with the last wrapper's LayerNorm: no output_ln (transformer_decoder.py:98-101)
+        self._output_norm_layer = None if p["post_normalize"] else LayerNorm(
+            rt, f"{self.name}/output_ln", p["hidden_size"], p["layer_postprocess_epsilon"])
         self._site = rt.new_dropout_site()
         return self
 
@@ -89,7 +88,7 @@ class TransformerDecoder(Decoder):
         x = decoder_inputs
         for i, layer in enumerate(self._stacking_layers):
             x = layer.forward(x, Bp, 1, mem2, Tm, memory_bias, is_training=False, cache=cache["decoding_states"][f"layer_{i}"])
-        return self._output_norm_layer.forward(x, save=False)
+        return x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=False)
 
     def forward(self, decoder_inputs, cache, decode_lagging=None, is_training=True, decode_loop_step=None):
         """decoder_inputs [B,L,d]; cache from create_decoding_internal_cache -> [B,L,d]."""
@@ -110,7 +109,7 @@ class TransformerDecoder(Decoder):
             x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
         for layer in self._stacking_layers:
             x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
-        out = self._output_norm_layer.forward(x, save=is_training)
+        out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
         self._shapes = (B, L, d, Tm)
         return out.view(B, L, d)
 
@@ -121,8 +120,11 @@ class TransformerDecoder(Decoder):
         B, L, d, Tm = self._shapes
         dmemory = torch.empty(B * Tm, d, dtype=dout.dtype, device=dout.device) if Tm else None
         layers = self._stacking_layers
-        dx = self._output_norm_layer.backward(dout.reshape(B * L, d),
-                                              consumer=layers[-1].first_backward_site if layers else self)
+        dx = dout.reshape(B * L, d)
+        if self._output_norm_layer is not None:
+            dx = self._output_norm_layer.backward(dx, consumer=layers[-1].first_backward_site if layers else self)
+        elif not dx.is_contiguous():
+            dx = dx.contiguous()
         first = True
         for i in range(len(layers) - 1, -1, -1):
             dx = layers[i].backward(dx, dmemory, dmemory_accumulate=not first,

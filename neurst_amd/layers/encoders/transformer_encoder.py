@@ -21,8 +21,10 @@ class TransformerEncoder(Encoder):
                          layer_postprocess_dropout_rate=layer_postprocess_dropout_rate,
                          layer_postprocess_epsilon=layer_postprocess_epsilon, post_normalize=post_normalize,
                          attention_monotonic=attention_monotonic, return_all_layers=return_all_layers)
-        if return_all_layers or post_normalize:
-            raise NotImplementedError("return_all_layers / post_normalize are off the hot path")
+        assert post_normalize or not return_all_layers, \
+            "`return_all_layers` is only available when `post_normalize`=True."   # transformer_encoder.py:74-75
+        if return_all_layers:
+            raise NotImplementedError("return_all_layers (BERT-style feature extraction) is off the path")
         self.name = name or self.__class__.__name__
         self._built = False
 
@@ -36,8 +38,9 @@ class TransformerEncoder(Encoder):
                                     p["attention_type"], p["ffn_dropout_rate"], p["layer_postprocess_dropout_rate"],
                                     p["layer_postprocess_epsilon"], p["post_normalize"])
             for i in range(p["num_layers"])]
-        self._output_norm_layer = LayerNorm(rt, f"{self.name}/output_ln", p["hidden_size"],
-                                            p["layer_postprocess_epsilon"])
+        # post-norm stacks end with the last wrapper's LayerNorm: no output_ln (transformer_encoder.py:97-100)
+        self._output_norm_layer = None if p["post_normalize"] else LayerNorm(
+            rt, f"{self.name}/output_ln", p["hidden_size"], p["layer_postprocess_epsilon"])
         self._site = rt.new_dropout_site()
         self._built = True
         return self
@@ -56,7 +59,7 @@ class TransformerEncoder(Encoder):
         causal = bool(self._params["attention_monotonic"])
         for layer in self._stacking_layers:
             x = layer.forward(x, B, T, bias, is_training=is_training, causal=causal)
-        out = self._output_norm_layer.forward(x, save=is_training)
+        out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
         return out.view(B, T, d)
 
     __call__ = forward
@@ -66,8 +69,11 @@ class TransformerEncoder(Encoder):
         layers = self._stacking_layers
         # every gradient on the residual chain next meets a dropout mask: the LayerNorm backward that produces it also
         # emits the masked copy (consumer = that dropout site), saving one element-wise pass per sublayer
-        dx = self._output_norm_layer.backward(dout.reshape(B * T, d),
-                                              consumer=layers[-1].first_backward_site if layers else self)
+        dx = dout.reshape(B * T, d)
+        if self._output_norm_layer is not None:
+            dx = self._output_norm_layer.backward(dx, consumer=layers[-1].first_backward_site if layers else self)
+        elif not dx.is_contiguous():
+            dx = dx.contiguous()
         for i in range(len(layers) - 1, -1, -1):
             dx = layers[i].backward(dx, consumer=layers[i - 1].first_backward_site if i > 0 else self)
         dx = dropped_grad(self.rt, dx, self._p, self._site)

@@ -1,4 +1,4 @@
-"""TransformerEncoderLayer / TransformerDecoderLayer (neurst/layers/transformer_layers.py:21-234), pre-norm."""
+"""TransformerEncoderLayer / TransformerDecoderLayer (neurst/layers/transformer_layers.py:21-234), pre- or post-norm."""
 from neurst_amd.layers.attentions.multi_head_attention import MultiHeadAttention, MultiHeadSelfAttention
 from neurst_amd.layers.common_layers import Layer, PrePostProcessingWrapper, TransformerFFN
 
@@ -8,19 +8,18 @@ class TransformerEncoderLayer(Layer):
                  attention_dropout_rate=0., attention_type="dot_product", ffn_dropout_rate=0.,
                  layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False):
         super().__init__(rt, name)
-        if post_normalize:
-            raise NotImplementedError("post_normalize=True is not on the hot path (hparams sets use pre-norm)")
+        pre = not post_normalize
         if ffn_activation != "relu":
             raise NotImplementedError(f"ffn_activation={ffn_activation}")
         self._selfatt_layer = PrePostProcessingWrapper(
             rt, name + "/self_attention_prepost_wrapper",
             MultiHeadSelfAttention(rt, name + "/self_attention_prepost_wrapper/self_attention", num_attention_heads,
                                    hidden_size, attention_dropout_rate, gen, attention_type),
-            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
         self._ffn_layer = PrePostProcessingWrapper(
             rt, name + "/ffn_prepost_wrapper",
             TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
-            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
 
     def forward(self, x, B, T, x_bias, is_training=True, causal=False):
         y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=causal)
@@ -47,8 +46,8 @@ class _CrossAttentionAdapter(object):
         return self.att.forward(y, memory, B, Tq, Tk, memory_bias=memory_bias, is_training=is_training,
                                 epilogue=epilogue, cache=cache, lagging=lagging)
 
-    def backward(self, dz):
-        return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate)
+    def backward(self, dz, residual=None):
+        return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate, residual=residual)
 
 
 class TransformerDecoderLayer(Layer):
@@ -57,8 +56,7 @@ class TransformerDecoderLayer(Layer):
                  layer_postprocess_dropout_rate=0., layer_postprocess_epsilon=1e-6, post_normalize=False,
                  with_cross_attention=True):
         super().__init__(rt, name)
-        if post_normalize:
-            raise NotImplementedError("post_normalize=True is not on the hot path")
+        pre = not post_normalize
         if ffn_activation != "relu":
             raise NotImplementedError(f"ffn_activation={ffn_activation}")
         self._with_cross_attention = with_cross_attention
@@ -66,18 +64,18 @@ class TransformerDecoderLayer(Layer):
             rt, name + "/self_attention_prepost_wrapper",
             MultiHeadSelfAttention(rt, name + "/self_attention_prepost_wrapper/self_attention", num_attention_heads,
                                    hidden_size, attention_dropout_rate, gen, attention_type),
-            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
         if with_cross_attention:
             self._cross = _CrossAttentionAdapter(
                 MultiHeadAttention(rt, name + "/encdec_attention_prepost_wrapper/encdec_attention",
                                    num_attention_heads, hidden_size, attention_dropout_rate, gen, attention_type))
             self._crossatt_layer = PrePostProcessingWrapper(
                 rt, name + "/encdec_attention_prepost_wrapper", self._cross, hidden_size,
-                layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+                layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
         self._ffn_layer = PrePostProcessingWrapper(
             rt, name + "/ffn_prepost_wrapper",
             TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
-            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon)
+            hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
 
     def forward(self, x, B, L, memory, Tm, memory_bias, is_training=True, cache=None, lagging=None):
         """cache (incremental decoding, L == 1): {"self_attention": {...}, "encdec_attention": {...}} of this layer

@@ -96,7 +96,7 @@ class SpeechTransformer(EncoderDecoderModel):
                     decoder_params[f.name[8:]] = args[f.name]
         encoder = build_encoder({"encoder.class": "TransformerEncoder", "encoder.params": encoder_params}).build(rt, gen)
         decoder = build_decoder({"decoder.class": "TransformerDecoder", "decoder.params": decoder_params}).build(rt, gen)
-        model = cls(args, src_meta, trg_meta, src_modality, trg_modality, encoder, decoder, name=name, rt=rt)
+        model = cls(args, src_meta, trg_meta, src_modality, trg_modality, encoder, decoder, name=name, rt=rt, gen=gen)
         return model.finalize()
 
     def _src_padding(self, inputs, embedded_inputs):

@@ -54,7 +54,7 @@ class Transformer(EncoderDecoderModel):
                  if f.name.startswith("decoder.") and f.name in args}
         encoder = build_encoder({"encoder.class": "TransformerEncoder", "encoder.params": enc_p}).build(rt, gen)
         decoder = build_decoder({"decoder.class": "TransformerDecoder", "decoder.params": dec_p}).build(rt, gen)
-        return cls(args, src_meta, trg_meta, src_modality, trg_modality, encoder, decoder, name=name, rt=rt).finalize()
+        return cls(args, src_meta, trg_meta, src_modality, trg_modality, encoder, decoder, name=name, rt=rt, gen=gen).finalize()
 
     @classmethod
     def build_model_args_by_name(cls, name):

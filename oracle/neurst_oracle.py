@@ -127,9 +127,12 @@ def ffn(x, W, prefix, rate=0.0, is_training=False, generator=None):
     return h @ W[prefix + "/dense2/kernel"] + W[prefix + "/dense2/bias"]
 
 
-def prepost(x, fn, W, prefix, eps, rate=0.0, is_training=False, generator=None):
-    """PrePostProcessingWrapper.call, pre-norm branch (common_layers.py:73-85):
-    LN -> layer -> dropout -> residual."""
+def prepost(x, fn, W, prefix, eps, rate=0.0, is_training=False, generator=None, pre_norm=True):
+    """PrePostProcessingWrapper.call (common_layers.py:73-92).  pre-norm: LN -> layer -> dropout -> residual;
+    post-norm (pre_norm=False, :86-92): layer -> dropout -> residual -> LN."""
+    if not pre_norm:
+        y = dropout(fn(x), rate, is_training, generator)
+        return layer_norm(x + y, W[prefix + "/ln/gamma"], W[prefix + "/ln/beta"], eps)
     y = layer_norm(x, W[prefix + "/ln/gamma"], W[prefix + "/ln/beta"], eps)
     y = fn(y)
     y = dropout(y, rate, is_training, generator)
@@ -183,9 +186,12 @@ def waitk_attention_bias(memory_length, waitk_lagging, query_length, dtype=torch
 
 
 def transformer_encoder(x, padding, W, scope, num_layers, num_heads, eps=1e-6,
-                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, monotonic=False):
+                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, monotonic=False,
+                        post_normalize=False):
     """TransformerEncoder.call (neurst/layers/encoders/transformer_encoder.py:104-136)
-    with TransformerEncoderLayer.call (transformer_layers.py:90-98); attention_monotonic :121-123."""
+    with TransformerEncoderLayer.call (transformer_layers.py:90-98); attention_monotonic :121-123;
+    post_normalize: post-norm wrappers (transformer_layers.py:73,85) and no output_ln (:97-100, 131-134)."""
+    pre = not post_normalize
     bias = input_padding_to_bias(padding)
     if monotonic:
         bias = torch.minimum(bias[:, None, None, :], lower_triangle_attention_bias(x.shape[1], x.dtype))
@@ -196,18 +202,23 @@ def transformer_encoder(x, padding, W, scope, num_layers, num_heads, eps=1e-6,
         _ensure_ln(W, p + "/ffn_prepost_wrapper/ln", x.shape[-1], x.dtype)
         x = prepost(x, lambda y: self_attention(y, W, p + "/self_attention_prepost_wrapper/self_attention",
                                                 num_heads, bias, att_rate, is_training, generator),
-                    W, p + "/self_attention_prepost_wrapper", eps, post_rate, is_training, generator)
+                    W, p + "/self_attention_prepost_wrapper", eps, post_rate, is_training, generator, pre)
         x = prepost(x, lambda y: ffn(y, W, p + "/ffn_prepost_wrapper/ffn", ffn_rate, is_training, generator),
-                    W, p + "/ffn_prepost_wrapper", eps, post_rate, is_training, generator)
+                    W, p + "/ffn_prepost_wrapper", eps, post_rate, is_training, generator, pre)
+    if post_normalize:
+        return x
     _ensure_ln(W, scope + "/output_ln", x.shape[-1], x.dtype)
     return layer_norm(x, W[scope + "/output_ln/gamma"], W[scope + "/output_ln/beta"], eps)
 
 
 def transformer_decoder(x, memory, memory_padding, W, scope, num_layers, num_heads, eps=1e-6,
-                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, decode_lagging=None):
+                        att_rate=0.0, ffn_rate=0.0, post_rate=0.0, is_training=False, generator=None, decode_lagging=None,
+                        post_normalize=False):
     """TransformerDecoder.call, training branch (neurst/layers/decoders/transformer_decoder.py:171-228)
     with TransformerDecoderLayer.call (transformer_layers.py:213-234).  Cross-attention
-    K/V are projected from ``memory`` directly (the encoder's output_ln output)."""
+    K/V are projected from ``memory`` directly (the encoder's output_ln output).  post_normalize as in the encoder
+    (transformer_decoder.py:98-101, 224-227)."""
+    pre = not post_normalize
     memory_bias = input_padding_to_bias(memory_padding) if memory_padding is not None else None
     if memory_bias is not None and decode_lagging is not None:  # transformer_decoder.py:76-85 (3-d inputs)
         memory_bias = torch.minimum(memory_bias[:, None, :], waitk_attention_bias(
@@ -220,12 +231,14 @@ def transformer_decoder(x, memory, memory_padding, W, scope, num_layers, num_hea
             _ensure_ln(W, f"{p}/{w}/ln", x.shape[-1], x.dtype)
         x = prepost(x, lambda y: self_attention(y, W, p + "/self_attention_prepost_wrapper/self_attention",
                                                 num_heads, causal, att_rate, is_training, generator),
-                    W, p + "/self_attention_prepost_wrapper", eps, post_rate, is_training, generator)
+                    W, p + "/self_attention_prepost_wrapper", eps, post_rate, is_training, generator, pre)
         x = prepost(x, lambda y: cross_attention(y, memory, W, p + "/encdec_attention_prepost_wrapper/encdec_attention",
                                                  num_heads, memory_bias, att_rate, is_training, generator),
-                    W, p + "/encdec_attention_prepost_wrapper", eps, post_rate, is_training, generator)
+                    W, p + "/encdec_attention_prepost_wrapper", eps, post_rate, is_training, generator, pre)
         x = prepost(x, lambda y: ffn(y, W, p + "/ffn_prepost_wrapper/ffn", ffn_rate, is_training, generator),
-                    W, p + "/ffn_prepost_wrapper", eps, post_rate, is_training, generator)
+                    W, p + "/ffn_prepost_wrapper", eps, post_rate, is_training, generator, pre)
+    if post_normalize:
+        return x
     _ensure_ln(W, scope + "/output_ln", x.shape[-1], x.dtype)
     return layer_norm(x, W[scope + "/output_ln/gamma"], W[scope + "/output_ln/beta"], eps)
 
@@ -304,6 +317,21 @@ def length_to_padding(lengths, maxlen, dtype=torch.float32):
 # --------------------------------------------------------------------------
 # full models
 # --------------------------------------------------------------------------
+def _target_table(W):
+    """Target embedding table: `shared/weights` when tied to the softmax, `emb/weights` otherwise
+    (text_modalities.py:61-68)."""
+    return W["target_symbol_modality/shared/weights"] if "target_symbol_modality/shared/weights" in W \
+        else W["target_symbol_modality/emb/weights"]
+
+
+def output_logits(dec, W):
+    """EncoderDecoderModel.output_logits_layer (encoder_decoder_model.py:180-185): the tied table, or the separate Keras
+    Dense `softmax_linear` (:64-67) when modality.share_embedding_and_softmax_weights is off."""
+    if "softmax_linear/kernel" in W:
+        return dec @ W["softmax_linear/kernel"] + W["softmax_linear/bias"]
+    return tied_logits(dec, W["target_symbol_modality/shared/weights"], W.get("target_symbol_modality/shared/bias"))
+
+
 def speech_transformer_logits(inputs, W, cfg, is_training=False, generator=None, return_intermediates=False):
     """SpeechTransformer.call (speech_transformer.py:179-189 + encoder_decoder_model.py:211-279).
 
@@ -321,14 +349,16 @@ def speech_transformer_logits(inputs, W, cfg, is_training=False, generator=None,
     if cfg.get("timing", "sinusoids"):
         emb = position_embedding(emb)
     enc = transformer_encoder(emb, src_pad, W, "TransformerEncoder", cfg["num_enc"], cfg["num_heads"],
-                              cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator)
-    table = W["target_symbol_modality/shared/weights"]
+                              cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
+                              post_normalize=cfg.get("encoder_post_normalize", False))
+    table = _target_table(W)
     temb = word_embedding(inputs["trg_input"], table)
     if cfg.get("timing", "sinusoids"):
         temb = position_embedding(temb)
     dec = transformer_decoder(temb, enc, src_pad, W, "TransformerDecoder", cfg["num_dec"], cfg["num_heads"],
-                              cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator)
-    logits = tied_logits(dec, table, W.get("target_symbol_modality/shared/bias"))
+                              cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
+                              post_normalize=cfg.get("decoder_post_normalize", False))
+    logits = output_logits(dec, W)
     if return_intermediates:
         return logits, {"src_emb": emb, "enc_out": enc, "dec_out": dec, "src_padding": src_pad}
     return logits
@@ -345,15 +375,17 @@ def transformer_logits(inputs, W, cfg, is_training=False, generator=None):
         emb = position_embedding(emb)
     enc = transformer_encoder(emb, inputs["src_padding"], W, "TransformerEncoder", cfg["num_enc"],
                               cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
-                              monotonic=cfg.get("attention_monotonic", False))
-    table = W["target_symbol_modality/shared/weights"]
+                              monotonic=cfg.get("attention_monotonic", False),
+                              post_normalize=cfg.get("encoder_post_normalize", False))
+    table = _target_table(W)
     temb = word_embedding(inputs["trg_input"], table)
     if cfg.get("timing", "sinusoids"):
         temb = position_embedding(temb)
     dec = transformer_decoder(temb, enc, inputs["src_padding"], W, "TransformerDecoder", cfg["num_dec"],
                               cfg["num_heads"], cfg.get("eps", 1e-6), rate, rate, rate, is_training, generator,
-                              decode_lagging=cfg.get("wait_k", None))
-    return tied_logits(dec, table, W.get("target_symbol_modality/shared/bias"))
+                              decode_lagging=cfg.get("wait_k", None),
+                              post_normalize=cfg.get("decoder_post_normalize", False))
+    return output_logits(dec, W)
 
 
 # --------------------------------------------------------------------------

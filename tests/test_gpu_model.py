@@ -156,7 +156,7 @@ def test_frontend_matches_reference_neurst_pt_hip(tag):
 
 
 # ------------------------------------------------------------------------------------------------ model fwd/bwd vs oracle
-def _speech_case(name, dtype):
+def _speech_case(name, dtype, **extra):
     cases = {
         # d, H, enc, dec, ffn, C, B, T, F, L, V, ragged
         "toy": (8, 2, 2, 2, 10, 5, 2, 11, 80, 3, 5, False),
@@ -174,6 +174,7 @@ def _speech_case(name, dtype):
     for k in list(p):
         if k.endswith("dropout_rate"):
             p[k] = 0.0
+    p.update(extra)
     model = build_model({"model.class": "SpeechTransformer", "model.params": p},
                         {"audio_feature_dim": F, "audio_feature_channels": 1},
                         {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=DEV, dtype=dtype,

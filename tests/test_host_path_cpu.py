@@ -124,6 +124,51 @@ def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
     assert float(model.store.grad[~used].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("variant", ["post_norm", "post_norm_encoder_only", "untied_softmax", "post_norm_untied"])
+def test_post_norm_and_untied_softmax_host_schedule(cpu_kernels, variant):
+    """post_normalize (common_layers.py:86-92; no output_ln, transformer_encoder.py:97-100) and the separate
+    softmax_linear projection (encoder_decoder_model.py:63-67, 180-185) against the oracle's autograd."""
+    from neurst_amd.criterions import build_criterion
+    extra, cfg_extra = {}, {}
+    if variant.startswith("post_norm"):
+        extra["encoder.post_normalize"] = True
+        cfg_extra["encoder_post_normalize"] = True
+        if variant != "post_norm_encoder_only":
+            extra["decoder.post_normalize"] = True
+            cfg_extra["decoder_post_normalize"] = True
+    if "untied" in variant:
+        extra["modality.share_embedding_and_softmax_weights"] = False
+    model, cfg, shape = _speech_model("small", **extra)
+    cfg.update(cfg_extra)
+    names = set(model.store.params)
+    assert ("TransformerEncoder/output_ln/gamma" in names) == ("encoder_post_normalize" not in cfg_extra)
+    assert ("TransformerDecoder/output_ln/gamma" in names) == ("decoder_post_normalize" not in cfg_extra)
+    if "untied" in variant:
+        assert {"softmax_linear/kernel", "softmax_linear/bias", "target_symbol_modality/emb/weights"} <= names
+        assert not any(n.startswith("target_symbol_modality/shared/") for n in names)
+        assert tuple(model.store.params["softmax_linear/kernel"].shape) == (32, 50)
+    inputs = _speech_inputs(shape)
+    loss_ref, logits_ref, grads_ref = _oracle_step(model, inputs, cfg)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(inputs, is_training=True)
+    loss = crit.reduce_loss(inputs, logits)
+    fired = []
+    model.grad_ready_hook = fired.append
+    model.backward(crit.backward())
+    assert rel_err(logits, logits_ref) < 1e-5 and abs(float(loss) - float(loss_ref)) < 1e-5
+    for n, p in model.store.params.items():
+        assert rel_err(p.grad, grads_ref[n]) < 5e-5, n
+    if "untied" in variant:  # decoder + softmax_linear are reported together and form one contiguous slice
+        from neurst_amd.training.distributed import GradientReducer
+        assert fired[0] == ["TransformerDecoder/", "softmax_linear/"]
+        s, e = GradientReducer(model.store).range_of(fired[0])
+        inside = [p for p in model.store.params.values() if s <= p.offset < e]
+        assert all(p.name.startswith(("TransformerDecoder/", "softmax_linear/")) for p in inside)
+        assert e == model.store.total
+    # inference path agrees with the training path without dropout
+    assert rel_err(model(inputs, is_training=False), logits_ref) < 1e-5
+
+
 def test_gradient_accumulation_and_clipping_on_cpu(cpu_kernels):
     """TrainStep with update_cycle = 2 averages the micro-batch gradients (gradaccum_keras_model.py:62-109), clips the
     averaged gradients per tensor (:228-233) and applies Keras Adam -- against the oracle's functions."""
