@@ -52,13 +52,20 @@ class MultiHeadAttention(Layer):
         d, H, dh = self.num_units, self.num_heads, self.dh
         p = self.rate if is_training else 0.0
         q = self.q_transform.forward(query)
-        if cache is not None:
-            if "kv" not in cache:
-                cache["kv"] = self.kv_transform.forward(memory)
+        if cache is not None and "len" in cache:
+            # streaming memory (memorize()): the projected memory lives in a preallocated [B, Tmax, 2d] buffer
+            Tk = cache["len"]
             kv = cache["kv"]
+            kv3 = kv[:, :Tk]
         else:
-            kv = self.kv_transform.forward(memory)
-        q3, kv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d)
+            if cache is not None:
+                if "kv" not in cache:
+                    cache["kv"] = self.kv_transform.forward(memory)
+                kv = cache["kv"]
+            else:
+                kv = self.kv_transform.forward(memory)
+            kv3 = kv.view(B, Tk, 2 * d)
+        q3 = q.view(B, Tq, d)
         lag = None if lagging is None else max(int(lagging) - 1, 0)
         ctx, lse, dmask = K.attention_fwd(q3, kv3[..., :d], kv3[..., d:], H, dh, key_bias=memory_bias, causal=lag is not None,
                                    causal_offset=lag or 0, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
@@ -66,6 +73,16 @@ class MultiHeadAttention(Layer):
         if is_training:
             self._saved = (query, memory, q, kv, ctx, (lse, dmask), memory_bias, B, Tq, Tk, p, lag)
         return out
+
+    def memorize(self, memory_chunk, cache, B, n):
+        """Streaming input (TransformerDecoderLayer.memorize_memory + the concat of update_incremental_cache,
+        transformer_decoder.py:159-168): projects `n` new memory positions [B*n, d] and appends them to the layer's
+        preallocated key|value buffer cache["kv"] [B, Tmax, 2d]; cache["len"] counts the filled positions."""
+        t = cache["len"]
+        if t + n > cache["kv"].shape[1]:
+            raise RuntimeError(f"memory cache of {cache['kv'].shape[1]} positions is full")
+        cache["kv"][:, t:t + n] = self.kv_transform.forward(memory_chunk).view(B, n, 2 * self.num_units)
+        cache["len"] = t + n
 
     def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None):
         """Returns d(query) (+ residual, post-norm wrapper); d(memory) is written (or accumulated) into `dmemory`
@@ -100,21 +117,26 @@ class MultiHeadSelfAttention(MultiHeadAttention):
 
     def forward(self, x, B, T, bias=None, causal=False, is_training=True, epilogue=None, cache=None):
         """x [B*T, d]; bias [B,T] f32 key-padding bias or None; causal=True is the decoder's lower-triangle bias.
-        cache (decoding only, T == 1): {"keys", "values": [B, Tmax, d] buffers, "len": filled positions}."""
+        cache (inference only): {"keys", "values": [B, Tmax, d] buffers, "len": filled positions}; T == 1 for a decoding
+        step, T >= 1 for a chunk of the streaming encoder."""
         d, H, dh = self.num_units, self.num_heads, self.dh
         p = self.rate if is_training else 0.0
         qkv = self.qkv_transform.forward(x)
         if cache is not None:
-            assert T == 1 and not is_training
+            # T == 1: one decoding step.  T > 1: a chunk of a streaming (monotonic) encoder -- position i of the chunk
+            # sees the t cached positions and the chunk up to itself: the kernel's causal mask shifted by t
+            # (transformer_encoder.py:138-175 builds lower_triangle_attention_bias(t + T)[:, :, -T:]).
+            assert not is_training
             t = cache["len"]
-            if t >= cache["keys"].shape[1]:
-                raise RuntimeError(f"decoding cache of {cache['keys'].shape[1]} positions is full")
-            cache["keys"][:, t] = qkv[:, d:2 * d]
-            cache["values"][:, t] = qkv[:, 2 * d:]
-            cache["len"] = t + 1
-            ctx, _, _ = K.attention_fwd(qkv.view(B, 1, 3 * d)[..., :d], cache["keys"][:, :t + 1], cache["values"][:, :t + 1],
-                                        H, dh, key_bias=None, causal=False)
-            return self.output_transform.forward(ctx.view(B, d), **(epilogue or {}))
+            if t + T > cache["keys"].shape[1]:
+                raise RuntimeError(f"attention cache of {cache['keys'].shape[1]} positions is full")
+            v3 = qkv.view(B, T, 3 * d)
+            cache["keys"][:, t:t + T] = v3[..., d:2 * d]
+            cache["values"][:, t:t + T] = v3[..., 2 * d:]
+            cache["len"] = t + T
+            ctx, _, _ = K.attention_fwd(v3[..., :d], cache["keys"][:, :t + T], cache["values"][:, :t + T], H, dh,
+                                        key_bias=None, causal=T > 1, causal_offset=t if T > 1 else 0)
+            return self.output_transform.forward(ctx.view(B * T, d), **(epilogue or {}))
         v3 = qkv.view(B, T, 3 * d)
         ctx, lse, dmask = K.attention_fwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], H, dh, key_bias=bias, causal=causal,
                                    dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)

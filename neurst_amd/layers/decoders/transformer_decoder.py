@@ -64,6 +64,39 @@ class TransformerDecoder(Decoder):
             cache["self_attention_kv"] = kv_all
         return cache
 
+    def update_incremental_cache(self, cache, encoder_outputs, encoder_inputs_padding, max_source_length=1024,
+                                 decode_padded_length=256):
+        """Streaming input (transformer_decoder.py:149-169): appends newly encoded source positions `encoder_outputs`
+        [B, n, d] (+ their padding [B, n]) to the memory, the memory bias and every layer's projected memory.  The
+        reference concatenates tensors; here the cache created at the first call preallocates `max_source_length`
+        memory positions and `decode_padded_length` target positions and is filled in place."""
+        B, n, d = encoder_outputs.shape
+        if not cache:
+            L = self._params["num_layers"]
+            dt, dev = encoder_outputs.dtype, encoder_outputs.device
+            cache = {"decoding_states": {}, "memory_len": 0,
+                     "memory_buf": torch.zeros(B, max_source_length, d, dtype=dt, device=dev),
+                     "memory_bias_buf": torch.zeros(B, max_source_length, dtype=torch.float32, device=dev),
+                     "self_attention_kv": torch.zeros(L, 2, B, decode_padded_length, d, dtype=dt, device=dev),
+                     "memory_kv": torch.zeros(L, B, max_source_length, 2 * d, dtype=dt, device=dev)}
+            for i in range(L):
+                kv = cache["self_attention_kv"]
+                cache["decoding_states"][f"layer_{i}"] = {
+                    "self_attention": {"keys": kv[i, 0], "values": kv[i, 1], "len": 0},
+                    "encdec_attention": {"kv": cache["memory_kv"][i], "len": 0}}
+        t = cache["memory_len"]
+        if t + n > cache["memory_buf"].shape[1]:
+            raise RuntimeError(f"memory cache of {cache['memory_buf'].shape[1]} positions is full")
+        cache["memory_buf"][:, t:t + n] = encoder_outputs
+        cache["memory_bias_buf"][:, t:t + n] = layer_utils.input_padding_to_bias(encoder_inputs_padding)
+        cache["memory_len"] = t + n
+        cache["memory"] = cache["memory_buf"][:, :t + n]
+        cache["memory_bias"] = cache["memory_bias_buf"][:, :t + n]
+        chunk = encoder_outputs.reshape(B * n, d)
+        for i, layer in enumerate(self._stacking_layers):
+            layer.memorize_memory(chunk, cache["decoding_states"][f"layer_{i}"], B, n)
+        return cache
+
     @staticmethod
     def reorder_cache(cache, beam_ids):
         """tf.gather(cache, beam_ids) of the beam search (beam_search.py:409-410): only the self-attention buffers depend on
@@ -81,10 +114,13 @@ class TransformerDecoder(Decoder):
         Bp, d = decoder_inputs.shape
         memory, memory_bias = cache.get("memory", None), cache.get("memory_bias", None)
         Tm = memory.shape[1] if memory is not None else 0
-        mem2 = memory.reshape(Bp * Tm, d) if memory is not None else None
+        streaming = "memory_len" in cache   # update_incremental_cache: the layers hold the projected memory already
+        mem2 = memory.reshape(Bp * Tm, d) if memory is not None and not streaming else None
         if decode_lagging is not None and memory_bias is not None:
             seen = (torch.arange(Tm, device=memory_bias.device) < int(decode_lagging)).to(memory_bias.dtype)
             memory_bias = torch.minimum(memory_bias, layer_utils.FLOAT_MIN * (1.0 - seen)[None, :])
+        if memory_bias is not None and not memory_bias.is_contiguous():
+            memory_bias = memory_bias.contiguous()           # the kernel reads a dense [B, Tk] bias
         x = decoder_inputs
         for i, layer in enumerate(self._stacking_layers):
             x = layer.forward(x, Bp, 1, mem2, Tm, memory_bias, is_training=False, cache=cache["decoding_states"][f"layer_{i}"])

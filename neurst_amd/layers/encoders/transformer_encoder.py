@@ -64,6 +64,36 @@ class TransformerEncoder(Encoder):
 
     __call__ = forward
 
+    def create_incremental_cache(self, batch, max_length, dtype=None):
+        """Per-layer self-attention key / value buffers for streaming input (transformer_layers.py:100-108 creates
+        empty tensors and concatenates; here `max_length` positions are preallocated and filled in place)."""
+        d = self._params["hidden_size"]
+        kv = torch.zeros(self._params["num_layers"], 2, batch, max_length, d, dtype=dtype or self.rt.dtype,
+                         device=self.rt.device)
+        return {f"layer_{i}": {"self_attention": {"keys": kv[i, 0], "values": kv[i, 1], "len": 0}}
+                for i in range(self._params["num_layers"])}
+
+    def incremental_encode(self, inputs, cache, time=None, max_length=1024):
+        """Encoding of streaming input (transformer_encoder.py:138-175): `inputs` [B, n, d] (or [B, d]) are the embedded
+        positions time .. time+n-1; every layer attends over its cached keys / values of the earlier positions plus
+        the chunk itself under the causal mask.  Only for attention_monotonic encoders -- there the result equals the
+        rows of the full forward.  Returns (outputs [B, n, d], cache)."""
+        assert self._params["attention_monotonic"], \
+            "function `incremental_encode` only available when attention_monotonic=True"
+        x3 = inputs[:, None, :] if inputs.dim() == 2 else inputs
+        B, n, d = x3.shape
+        if not cache:
+            cache = self.create_incremental_cache(B, max_length, x3.dtype)
+        filled = cache["layer_0"]["self_attention"]["len"] if self._stacking_layers else 0
+        if time is not None and int(time) != filled:
+            raise ValueError(f"incremental_encode: chunk starts at time {time} but {filled} positions are cached")
+        x = x3.reshape(B * n, d).contiguous()
+        for i, layer in enumerate(self._stacking_layers):
+            x = layer.forward(x, B, n, None, is_training=False, cache=cache[f"layer_{i}"])
+        if self._output_norm_layer is not None:
+            x = self._output_norm_layer.forward(x, save=False)
+        return x.view(B, n, d), cache
+
     def backward(self, dout):
         B, T, d = dout.shape
         layers = self._stacking_layers

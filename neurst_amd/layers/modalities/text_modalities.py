@@ -30,12 +30,16 @@ class WordEmbeddingSharedWeights(Layer):
     def forward(self, inputs, mode="embedding", timing=None, is_training=True, time=None, **kw):
         d, V = self._embedding_dim, self._vocab_size
         if mode == "embedding" and time is not None:
-            # incremental decoding (common_layers.py:415-434 with `time`): ids [B'] of ONE position, signal row `time`
-            ids = inputs.long().reshape(-1, 1)
+            # incremental decoding / streaming encoding (common_layers.py:415-434 with `time`): ids [B'] of ONE position,
+            # or [B', n] of the n positions time .. time+n-1; the signal rows start at `time`
+            ids = inputs.long()
+            ids2 = ids.reshape(-1, 1) if ids.dim() == 1 else ids
+            n = ids2.shape[1]
             scale = float(d) ** 0.5 if timing == "sinusoids" else 1.0
-            table_len = max(512, 1 << int(time).bit_length())  # rows do not depend on the table length
-            pos = self.rt.posenc(table_len, d)[int(time):int(time) + 1].contiguous() if timing == "sinusoids" else None
-            return K.embedding_fwd(self._shared_weights.compute, ids, pos, 1, scale).view(-1, d)
+            table_len = max(512, 1 << (int(time) + n).bit_length())  # rows do not depend on the table length
+            pos = self.rt.posenc(table_len, d)[int(time):int(time) + n].contiguous() if timing == "sinusoids" else None
+            out = K.embedding_fwd(self._shared_weights.compute, ids2, pos, n, scale)
+            return out.view(-1, d) if ids.dim() == 1 else out
         if mode == "embedding":
             ids = inputs.long()
             L = ids.shape[-1]

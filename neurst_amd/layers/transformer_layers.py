@@ -21,8 +21,12 @@ class TransformerEncoderLayer(Layer):
             TransformerFFN(rt, name + "/ffn_prepost_wrapper/ffn", hidden_size, filter_size, ffn_dropout_rate, gen),
             hidden_size, layer_postprocess_dropout_rate, layer_postprocess_epsilon, pre_norm=pre)
 
-    def forward(self, x, B, T, x_bias, is_training=True, causal=False):
-        y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=causal)
+    def forward(self, x, B, T, x_bias, is_training=True, causal=False, cache=None):
+        """cache (streaming encoder, transformer_layers.py:100-108 `create_internal_cache`): {"self_attention": {...}}."""
+        if cache is None:
+            y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=x_bias, causal=causal)
+        else:
+            y = self._selfatt_layer.forward(x, is_training, B=B, T=T, bias=None, causal=False, cache=cache["self_attention"])
         return self._ffn_layer.forward(y, is_training)
 
     @property
@@ -88,6 +92,11 @@ class TransformerDecoderLayer(Layer):
             y = self._crossatt_layer.forward(y, is_training, memory=memory, B=B, Tq=L, Tk=Tm, memory_bias=memory_bias,
                                              lagging=lagging, **({} if cache is None else {"cache": cache["encdec_attention"]}))
         return self._ffn_layer.forward(y, is_training)
+
+    def memorize_memory(self, memory_chunk, cache, B, n):
+        """transformer_layers.py `memorize_memory`: appends the projection of new memory positions to this layer's cache."""
+        if self._with_cross_attention:
+            self._cross.att.memorize(memory_chunk, cache["encdec_attention"], B, n)
 
     @property
     def first_backward_site(self):

@@ -5,10 +5,13 @@ i + k source positions only.
   training   wait_k: an int, or a list of laggings one of which is drawn per step (:97-100; the draw here is a
              deterministic function of the runtime's step seed instead of tf.random);
   inference  with the full source available (the reference's offline generation path, get_decoder_output with `time`):
-             step t sees the first k + t positions (:103-104).  The streaming agent (incremental_encode /
-             SimulEval) is not built.
+             step t sees the first k + t positions (:103-104);
+  streaming  incremental_encode / incremental_decode (:117-139): source chunks are encoded as they arrive (monotonic
+             encoder over cached keys / values), appended to the decoder's memory, and one target position is
+             decoded against whatever has been read; neurst_amd/utils/simuleval_agents drives them.
 """
 import numpy as np
+import torch
 
 from neurst_amd.models.model import register_model
 from neurst_amd.models.transformer import Transformer
@@ -51,6 +54,40 @@ class WaitkTransformer(Transformer):
             args["model.class"] = cls.__name__
             args["model.params"]["encoder.attention_monotonic"] = True
         return args
+
+    # ------------------------------------------------------------------ streaming (waitk_transformer.py:117-139)
+    def incremental_encode(self, inputs, encoder_cache, decoder_cache, time=None, max_source_length=1024,
+                           decode_padded_length=256):
+        """inputs: {"src": ids [B, n] (or [B] with `time`) of the NEW source positions time .. time+n-1, "src_length"
+        [B] (valid positions of the chunk) or "src_padding" [B, n]}.  Returns (encoder_cache, decoder_cache)."""
+        dev = self.rt.device
+        src = torch.as_tensor(inputs["src"], dtype=torch.int64, device=dev)
+        assert not (src.dim() == 1 and time is None)
+        if src.dim() == 1:
+            src = src[:, None]
+        B, n = src.shape
+        time = 0 if time is None else int(time)
+        emb = self._src_modality.forward(src, is_training=False, time=time)   # signal rows time .. time+n-1
+        src_padding = inputs.get("src_padding", None)
+        if src_padding is None:
+            from neurst_amd.models.model_utils import input_length_to_padding
+            src_padding = input_length_to_padding(torch.as_tensor(inputs["src_length"], device=dev), n)
+        src_padding = torch.as_tensor(src_padding, dtype=torch.float32, device=dev)
+        enc_out, encoder_cache = self._encoder.incremental_encode(emb, encoder_cache, time, max_length=max_source_length)
+        decoder_cache = self._decoder.update_incremental_cache(decoder_cache, enc_out, src_padding,
+                                                               max_source_length=max_source_length,
+                                                               decode_padded_length=decode_padded_length)
+        return encoder_cache, decoder_cache
+
+    def incremental_decode(self, symbols, cache, time=None):
+        """One target position against the memory read so far; symbols: ids [B] (the previous output, or BOS / EOS at
+        time 0).  Returns (logits [B, V], cache).  The lagging is wait_k + time as in offline decoding -- positions
+        that have not been read yet simply do not exist in the memory."""
+        ids = torch.as_tensor(symbols, dtype=torch.int64, device=self.rt.device).reshape(-1)
+        time = 0 if time is None else int(time)
+        dec_in = self._trg_modality.forward(ids, is_training=False, time=time)
+        hidden = self._decoder.decode_step(dec_in, cache, decode_lagging=self.decode_lagging(False, time))
+        return self.output_logits_layer(hidden, is_training=False), cache
 
     def decode_lagging(self, is_training, time):
         lag = self.wait_k

@@ -174,3 +174,31 @@ class Seq2Seq(Task):
             input_dict["trg_length"] = deduce_text_length(lab, self._trg_meta["pad_id"], self._trg_meta["padding_mode"])
             input_dict["trg_input"] = torch.cat([bos[:, None], lab[:, :-1]], dim=1)
         return input_dict
+
+
+@register_task(["waitk_translation", "WaitkTranslation"])
+class WaitkTranslation(Seq2Seq):
+    """neurst/tasks/waitk_translation.py:22-56: Translation whose models are built with the wait-k lagging (`wait_k`: an int
+    or a list of laggings for multi-path training)."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        k = args.get("wait_k", None)
+        if isinstance(k, str):
+            import yaml
+            k = yaml.safe_load(k)
+        assert k, "Must provide wait_k as the decode lagging."
+        assert isinstance(k, (list, int)), f"Value error: {k}"
+        self._wait_k = k
+
+    def get_config(self):
+        cfg = super().get_config()
+        cfg["wait_k"] = self._wait_k
+        return cfg
+
+    @staticmethod
+    def class_or_method_args():
+        return Seq2Seq.class_or_method_args() + [Flag("wait_k", dtype=Flag.TYPE.STRING, default=None, help="The lagging k.")]
+
+    def build_model(self, args, name=None, **kwargs):
+        return super().build_model(args, name=name, waitk_lagging=self._wait_k, **kwargs)

@@ -32,6 +32,7 @@ def _ln_stats(x2, eps):
 
 
 def layernorm_fwd(x, gamma, beta, eps, relu=False):
+    assert x.is_contiguous()
     d = x.shape[-1]
     x2 = x.reshape(-1, d).to(F64)
     mean, rstd = _ln_stats(x2, eps)
@@ -42,6 +43,8 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None):
+    assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
+    assert dres is None or (dres.is_contiguous() and dres.dtype == x.dtype and y is None)
     d = x.shape[-1]
     g = dy.reshape(-1, d).to(F64)
     if y is not None:  # backward of relu(LN(x)): gate by the saved output
@@ -70,7 +73,12 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
          posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False):
     _no_dropout(dropout_p)
-    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype and A.stride(1) == 1 and B.stride(1) == 1
+    assert out is None or (out.dim() == 2 and out.stride(1) == 1)
+    assert residual is None or residual.stride(1) == 1
+    assert gate_src is None or (gate_src.stride(1) == 1 and gate_src.dtype == (out.dtype if out is not None else out_dtype or A.dtype))
+    assert posenc is None or (posenc.dtype == torch.float32 and posenc.is_contiguous() and posenc.shape[1] == N)
+    assert colsum_out is None or (colsum_out.dtype == torch.float32 and colsum_out.numel() == N and colsum_out.is_contiguous())
     a = (A.t() if trans_a else A).to(F64)
     b = (B.t() if trans_b else B).to(F64)
     assert a.shape == (M, K) and b.shape == (K, N), f"gemm operand shapes {tuple(a.shape)} x {tuple(b.shape)} vs {M,N,K}"
@@ -110,6 +118,7 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
 
 
 def colsum(x, out, accumulate=False):
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
     s = x.to(F64).sum(0).float()
     if accumulate:
         out.add_(s)
@@ -153,10 +162,20 @@ def _attn_probs(q, k, H, dh, key_bias, causal, causal_offset):
     return torch.exp(logits - lse[..., None]), lse
 
 
+def _check_attention_views(q, k, v, out, H, dh, key_bias, causal_offset):
+    """The stride / layout requirements the real binding enforces before it fills the descriptor."""
+    from neurst_amd import kernels as K
+    K._attn_desc(q, k, v, out, H, dh, False, 0.0, 0, 0, causal_offset)
+    assert q.shape[-1] == H * dh and k.shape[-1] == H * dh and v.shape[-1] == H * dh and k.shape[:2] == v.shape[:2]
+    assert causal_offset >= 0
+    if key_bias is not None:
+        assert key_bias.dtype == torch.float32 and key_bias.is_contiguous() and tuple(key_bias.shape) == (q.shape[0], k.shape[1])
+
+
 def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0, causal_offset=0):
     _no_dropout(dropout_p)
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
-    assert q.shape[-1] == H * dh and k.shape[-1] == H * dh and v.shape[-1] == H * dh
+    _check_attention_views(q, k, v, torch.empty(B, Tq, H * dh, dtype=q.dtype), H, dh, key_bias, causal_offset)
     P, lse = _attn_probs(q.to(F64), k.to(F64), H, dh, key_bias, causal, causal_offset)
     vh = v.to(F64).reshape(B, Tk, H, dh).permute(0, 2, 1, 3)
     out = (P @ vh).permute(0, 2, 1, 3).reshape(B, Tq, H * dh)
@@ -167,6 +186,9 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, cau
                   stream_id=0, drop_mask=None, causal_offset=0):
     _no_dropout(dropout_p)
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+    assert dout.is_contiguous() and out.is_contiguous()
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    _check_attention_views(q, k, v, out, H, dh, key_bias, causal_offset)
     qd, kd, vd = q.to(F64), k.to(F64), v.to(F64)
     P, _ = _attn_probs(qd, kd, H, dh, key_bias, causal, causal_offset)
     scale = float(dh) ** -0.5
@@ -196,6 +218,7 @@ def _conv1_pre(src, w1, b1):
 
 
 def conv1_ln_relu_fwd(src, w1, b1, gamma, beta, layer_norm, eps, out_dtype):
+    assert src.is_contiguous() and src.dtype == torch.float32 and w1.is_contiguous()
     z = _conv1_pre(src, w1, b1)
     mean = rstd = None
     if layer_norm:
@@ -208,6 +231,7 @@ def conv1_ln_relu_fwd(src, w1, b1, gamma, beta, layer_norm, eps, out_dtype):
 
 def conv1_ln_relu_bwd(src, w1, b1, gamma, beta, mean, rstd, dout, dw1, db1, dgamma, dbeta, layer_norm, eps,
                       accumulate=False):
+    assert dout.is_contiguous()
     w = w1.to(F64).clone().requires_grad_(True)
     b = b1.to(F64).clone().requires_grad_(True)
     leaves = [w, b]
@@ -233,6 +257,7 @@ def conv1_ln_relu_bwd(src, w1, b1, gamma, beta, mean, rstd, dout, dw1, db1, dgam
 
 
 def conv2_fwd(x, w2, b2, relu=False):
+    assert x.is_contiguous() and w2.is_contiguous() and w2.dtype == x.dtype
     y = _conv_s2(x.to(F64).permute(0, 3, 1, 2), w2, b2).permute(0, 2, 3, 1)
     if relu:
         y = y.clamp_min(0)
@@ -240,6 +265,7 @@ def conv2_fwd(x, w2, b2, relu=False):
 
 
 def conv2_dgrad(dy, w2, T1, F1):
+    assert dy.is_contiguous() and w2.dtype == dy.dtype
     B, T2, F2, C = dy.shape
     x = torch.zeros(B, C, T1, F1, dtype=F64, requires_grad=True)
     y = _conv_s2(x, w2, None)
@@ -248,6 +274,7 @@ def conv2_dgrad(dy, w2, T1, F1):
 
 
 def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
+    assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
     w = torch.zeros(dw2.shape, dtype=F64, requires_grad=True)
     y = _conv_s2(x.to(F64).permute(0, 3, 1, 2), w, None)
     (g,) = torch.autograd.grad(y, w, dy.to(F64).permute(0, 3, 1, 2))
@@ -265,6 +292,7 @@ def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
 # ---------------------------------------------------------------------------------------------------- embedding / elementwise
 def embedding_fwd(table, ids, posenc, L, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
     _no_dropout(dropout_p)
+    assert ids.dtype == torch.int64 and (posenc is None or (posenc.is_contiguous() and posenc.shape[0] >= min(L, ids.numel())))
     d = table.shape[1]
     flat = ids.reshape(-1)
     out = table.to(F64)[flat] * emb_scale
@@ -275,6 +303,7 @@ def embedding_fwd(table, ids, posenc, L, emb_scale, dropout_p=0.0, seed=0, strea
 
 def embedding_bwd(dout, ids, dtable, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
     _no_dropout(dropout_p)
+    assert dout.is_contiguous() and dtable.dtype == torch.float32
     d = dtable.shape[1]
     acc = torch.zeros(dtable.shape, dtype=F64)
     acc.index_add_(0, ids.reshape(-1), dout.reshape(-1, d).to(F64) * emb_scale)
@@ -283,6 +312,7 @@ def embedding_bwd(dout, ids, dtable, emb_scale, dropout_p=0.0, seed=0, stream_id
 
 def scale_posenc_dropout_fwd(x, posenc, period, scale, dropout_p=0.0, seed=0, stream_id=0):
     _no_dropout(dropout_p)
+    assert x.is_contiguous()
     d = x.shape[-1]
     y = x.reshape(-1, d).to(F64) * scale
     if posenc is not None:
@@ -292,6 +322,7 @@ def scale_posenc_dropout_fwd(x, posenc, period, scale, dropout_p=0.0, seed=0, st
 
 def scale_dropout_bwd(dy, scale, dropout_p=0.0, seed=0, stream_id=0):
     _no_dropout(dropout_p)
+    assert dy.is_contiguous()
     return (dy.to(F64) * scale).to(dy.dtype)
 
 
@@ -304,6 +335,7 @@ def _xent_consts(V, ls):
 
 
 def ls_xent_fwd(logits, labels, weights, label_smoothing):
+    assert logits.dim() == 2 and logits.stride(1) == 1
     rows, V = logits.shape
     conf, low, norm = _xent_consts(V, label_smoothing)
     lg = logits.to(F64)

@@ -220,7 +220,12 @@ def transformer_decoder(x, memory, memory_padding, W, scope, num_layers, num_hea
     (transformer_decoder.py:98-101, 224-227)."""
     pre = not post_normalize
     memory_bias = input_padding_to_bias(memory_padding) if memory_padding is not None else None
-    if memory_bias is not None and decode_lagging is not None:  # transformer_decoder.py:76-85 (3-d inputs)
+    if memory_bias is not None and isinstance(decode_lagging, (list, tuple, torch.Tensor)):
+        # streaming decode: target position i was decoded when only decode_lagging[i] memory positions were visible
+        vis = torch.as_tensor(decode_lagging).reshape(-1, 1)
+        keep = (torch.arange(memory_bias.shape[1])[None, :] < vis).to(x.dtype)
+        memory_bias = torch.minimum(memory_bias[:, None, :], (FLOAT_MIN * (1.0 - keep))[None, :, :])[:, None, :, :]
+    elif memory_bias is not None and decode_lagging is not None:  # transformer_decoder.py:76-85 (3-d inputs)
         memory_bias = torch.minimum(memory_bias[:, None, :], waitk_attention_bias(
             memory_bias.shape[1], decode_lagging, x.shape[1], x.dtype)[None, :, :])[:, None, :, :]
     causal = lower_triangle_attention_bias(x.shape[1], x.dtype)
