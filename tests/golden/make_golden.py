@@ -252,13 +252,16 @@ def _install_shim():
     def is_nested(x):
         return isinstance(x, (list, tuple, dict))
 
-    def map_structure(fn, *xs):
+    def map_structure(fn, *xs, **unused):
         x0 = xs[0]
         if isinstance(x0, (list, tuple)):
             return type(x0)(map_structure(fn, *ys) for ys in zip(*xs))
         if isinstance(x0, dict):
             return {k: map_structure(fn, *[x[k] for x in xs]) for k in x0}
-        return fn(*xs)
+        r = fn(*xs)
+        # neurst_pt scales q IN PLACE on a view produced by torch.split (multi_head_attention.py:180), which current torch
+        # refuses under autograd; handing out a copy of the reshaped tensor is the identity and lifts the restriction
+        return r.clone() if hasattr(r, "clone") and getattr(r, "requires_grad", False) else r
 
     def pack_sequence_as(structure, flat):
         flat = list(flat)
@@ -369,6 +372,182 @@ def gen_neurst_pt_frontend():
              **{k: np.ascontiguousarray(v) for k, v in w.items()})
 
 
+def _functional_registry():
+    """Replaces the shim's inert `setup_registry` by a working one (name table + `cls(**params)` / `cls.new(params, ...)`,
+    the subset of neurst/utils/registry.py:60-108 the neurst_pt model needs) and executes the package __init__ files of
+    neurst_pt.layers / .encoders / .decoders so that their build_* / register_* functions exist."""
+    import re
+    tables = {}
+
+    def setup_registry(name, base_class=None, create_fn=None, verbose_creation=False, backend="tf"):
+        table = tables.setdefault((backend, name), {})
+
+        def build(args, *extra, **kw):
+            cls_ = args.get("class", None) or args.get(f"{name}.class", None)
+            params = dict(args.get("params", None) or args.get(f"{name}.params", None) or {})
+            cls_ = table[cls_] if isinstance(cls_, str) else cls_
+            if create_fn is not None:
+                for f in cls_.class_or_method_args():
+                    params.setdefault(f.name, f.default)
+                return getattr(cls_, create_fn)(params, *extra, **kw)
+            params.update(kw)
+            return cls_(*extra, **params)
+
+        def register(x):
+            def reg(c, names=()):
+                snake = "_".join(re.sub("([A-Z])", r" \1", c.__name__).lower().strip().split())
+                for n in set(list(names) + [c.__name__, c.__name__.lower(), snake]):
+                    table[n] = c
+                return c
+            if isinstance(x, str):
+                return lambda c: reg(c, [x])
+            if isinstance(x, list):
+                return lambda c: reg(c, x)
+            return reg(x)
+        return build, register
+    sys.modules["neurst.utils.registry"].setup_registry = setup_registry
+
+    def extract_constructor_params(locals_of_this_fn, keep_out_list=None, verbose=True, verbose_title=None):
+        """neurst/utils/configurable.py:108-136 without the logging."""
+        params = {}
+        for k, v in locals_of_this_fn.items():
+            if k in ("self", "_") or k.startswith("__") or k in (keep_out_list or []):
+                continue
+            if k == "kwargs" and isinstance(v, dict):
+                params.update(v)
+            else:
+                params[k] = v
+        return params
+    sys.modules["neurst.utils.configurable"].extract_constructor_params = extract_constructor_params
+    for pkg in ("neurst_pt.models",):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+    sys.modules["neurst_pt.models"].build_model, sys.modules["neurst_pt.models"].register_model = \
+        setup_registry("model", create_fn="new", backend="pt")
+    for pkg in ("neurst_pt.layers", "neurst_pt.layers.encoders", "neurst_pt.layers.decoders"):
+        mod = sys.modules[pkg]
+        init = os.path.join(REF, *pkg.split("."), "__init__.py")
+        mod.__file__ = init
+        exec(compile(open(init).read(), init, "exec"), mod.__dict__)
+
+
+def _tf_names_of_pt_speech_transformer(model, n_enc, n_dec):
+    """PT module parameters -> TF variable names / layouts: the inverse of the assignment list of the reference's own
+    TF<->PT equivalence test (tests/neurst_pt/models/speech_transformer_test.py:57-155), generalised over layers."""
+    out = {}
+    fe = getattr(model._src_modality, "embedding_layer", model._src_modality)
+    A = "input_audio_modality"
+    out[f"{A}/conv1/kernel"] = (fe._conv_layer1.weight, lambda w: w.permute(2, 3, 1, 0))
+    out[f"{A}/conv1/bias"] = (fe._conv_layer1.bias, None)
+    out[f"{A}/conv2/kernel"] = (fe._conv_layer2.weight, lambda w: w.permute(2, 3, 1, 0))
+    out[f"{A}/conv2/bias"] = (fe._conv_layer2.bias, None)
+    out[f"{A}/ln1/gamma"], out[f"{A}/ln1/beta"] = (fe._norm_layer1.weight, None), (fe._norm_layer1.bias, None)
+    out[f"{A}/ln2/gamma"], out[f"{A}/ln2/beta"] = (fe._norm_layer2.weight, None), (fe._norm_layer2.bias, None)
+    out[f"{A}/output_dense/kernel"] = (fe._dense_layer.weight, lambda w: w.t())
+    out[f"{A}/output_dense/bias"] = (fe._dense_layer.bias, None)
+    te = getattr(model._trg_modality, "embedding_layer", model._trg_modality)
+    out["target_symbol_modality/shared/weights"] = (te._shared_weights, None)
+    out["target_symbol_modality/shared/bias"] = (te._bias, None)
+
+    def att(prefix, layer, names):
+        for tf_name, attr in names:
+            sub = getattr(layer._layer, attr)
+            out[f"{prefix}/{tf_name}/kernel"] = (sub._kernel, None)
+            out[f"{prefix}/{tf_name}/bias"] = (sub._bias, None)
+        out[f"{prefix.rsplit('/', 1)[0]}/ln/gamma"] = (layer._norm_layer.weight, None)
+        out[f"{prefix.rsplit('/', 1)[0]}/ln/beta"] = (layer._norm_layer.bias, None)
+
+    def ffn(prefix, layer):
+        out[f"{prefix}/ffn/dense1/kernel"] = (layer._layer._dense1.weight, lambda w: w.t())
+        out[f"{prefix}/ffn/dense1/bias"] = (layer._layer._dense1.bias, None)
+        out[f"{prefix}/ffn/dense2/kernel"] = (layer._layer._dense2.weight, lambda w: w.t())
+        out[f"{prefix}/ffn/dense2/bias"] = (layer._layer._dense2.bias, None)
+        out[f"{prefix}/ln/gamma"], out[f"{prefix}/ln/beta"] = (layer._norm_layer.weight, None), (layer._norm_layer.bias, None)
+    for i in range(n_enc):
+        L = model._encoder._stacking_layers[i]
+        p = f"TransformerEncoder/layer_{i}"
+        att(f"{p}/self_attention_prepost_wrapper/self_attention", L[0],
+            [("qkv_transform", "_qkv_transform_layer"), ("output_transform", "_output_transform_layer")])
+        ffn(f"{p}/ffn_prepost_wrapper", L[1])
+    out["TransformerEncoder/output_ln/gamma"] = (model._encoder._output_norm_layer.weight, None)
+    out["TransformerEncoder/output_ln/beta"] = (model._encoder._output_norm_layer.bias, None)
+    for i in range(n_dec):
+        L = model._decoder._stacking_layers[i]
+        p = f"TransformerDecoder/layer_{i}"
+        att(f"{p}/self_attention_prepost_wrapper/self_attention", L[0],
+            [("qkv_transform", "_qkv_transform_layer"), ("output_transform", "_output_transform_layer")])
+        att(f"{p}/encdec_attention_prepost_wrapper/encdec_attention", L[1],
+            [("q_transform", "_q_transform_layer"), ("kv_transform", "_kv_transform_layer"),
+             ("output_transform", "_output_transform_layer")])
+        ffn(f"{p}/ffn_prepost_wrapper", L[2])
+    out["TransformerDecoder/output_ln/gamma"] = (model._decoder._output_norm_layer.weight, None)
+    out["TransformerDecoder/output_ln/beta"] = (model._decoder._output_norm_layer.bias, None)
+    return out
+
+
+def gen_neurst_pt_speech_transformer():
+    """The reference's own PyTorch SpeechTransformer (neurst_pt/models/speech_transformer.py -- its test pins it to the
+    TensorFlow model at 5e-6) executed here: full-model logits AND, through torch autograd over the reference's forward,
+    the gradient of a label-smoothed token-mean cross entropy w.r.t. every variable.  Two cases: the test's own shape
+    (1+1 layers, one utterance) and a ragged 2+2-layer batch with sinusoid timing."""
+    import torch
+    import torch.nn.functional as F
+    _install_shim()
+    _functional_registry()
+    st = _load("neurst_pt.models.speech_transformer")
+    cases = {"st_1x1": dict(n_enc=1, n_dec=1, timing=None, B=1, T=11, L=3, V=5, lens=[11], tlens=[3]),
+             "st_2x2_ragged": dict(n_enc=2, n_dec=2, timing="sinusoids", B=3, T=23, L=5, V=9, lens=[23, 17, 9], tlens=[5, 4, 2])}
+    for tag, c in cases.items():
+        torch.manual_seed(11)
+        rng = np.random.RandomState(11)
+        d, H, ffn_, C, Fdim = 8, 2, 10, 5, 80     # speech_transformer_toy (neurst/models/speech_transformer.py:201-208)
+        args = {f.name: f.default for f in st.SpeechTransformer.class_or_method_args()}
+        args.update({"modality.source.kernel_size": 3, "modality.source.strides": 2, "modality.source.channels": C,
+                     "modality.source.layer_norm": True, "modality.dim": d,
+                     "modality.share_embedding_and_softmax_weights": True, "modality.timing": c["timing"]})
+        for side, n in (("encoder", c["n_enc"]), ("decoder", c["n_dec"])):
+            args.update({f"{side}.num_layers": n, f"{side}.hidden_size": d, f"{side}.num_attention_heads": H,
+                         f"{side}.filter_size": ffn_, f"{side}.attention_dropout_rate": 0.0,
+                         f"{side}.ffn_dropout_rate": 0.0, f"{side}.layer_postprocess_dropout_rate": 0.0})
+        model = st.SpeechTransformer.new(args, dict(audio_feature_dim=Fdim, audio_feature_channels=1),
+                                         dict(vocab_size=c["V"], eos_id=c["V"] - 1, bos_id=c["V"] - 2, unk_id=c["V"] - 3))
+        names = _tf_names_of_pt_speech_transformer(model, c["n_enc"], c["n_dec"])
+        for n, (prm, _) in names.items():   # non-trivial biases / LayerNorm affine so every gradient path is exercised
+            if n.endswith("/bias") or n.endswith("/beta"):
+                prm.data = torch.tensor(rng.uniform(-0.2, 0.2, tuple(prm.shape)), dtype=torch.float32)
+            elif n.endswith("/gamma"):
+                prm.data = torch.tensor(rng.uniform(0.7, 1.3, tuple(prm.shape)), dtype=torch.float32)
+        covered = {id(prm) for prm, _ in names.values()}
+        assert all(id(q) in covered for q in model.parameters()), "unmapped reference parameter"
+        src = rng.randn(c["B"], c["T"], Fdim, 1).astype(np.float32)
+        trg = rng.randint(0, c["V"] - 3, (c["B"], c["L"])).astype(np.int64)
+        for b, tl in enumerate(c["tlens"]):
+            trg[b, tl - 1:] = c["V"] - 1
+        trg_input = np.concatenate([np.full((c["B"], 1), c["V"] - 2, np.int64), trg[:, :-1]], 1)
+        inputs = {"src": torch.tensor(src), "src_length": torch.tensor(c["lens"]), "trg_input": torch.tensor(trg_input)}
+        logits = model(inputs, is_training=False)
+        # label-smoothed CE, token mean (label_smoothed_cross_entropy.py:46-53, 114-157), written with plain torch ops
+        ls, V = 0.1, c["V"]
+        logp = F.log_softmax(logits, -1)
+        soft = torch.full_like(logp, ls / (V - 1)).scatter_(-1, torch.tensor(trg)[..., None], 1.0 - ls)
+        norm = -((1.0 - ls) * np.log(1.0 - ls) + (V - 1) * (ls / (V - 1)) * np.log(ls / (V - 1) + 1e-20))
+        w = (torch.arange(c["L"])[None, :] < torch.tensor(c["tlens"])[:, None]).float()
+        loss = (((-(soft * logp).sum(-1)) - norm) * w).sum() / w.sum()
+        params = [prm for prm, _ in names.values()]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        arrays = {"src": src, "src_length": np.array(c["lens"], np.int64), "trg": trg, "trg_input": trg_input,
+                  "trg_length": np.array(c["tlens"], np.int64), "expected_logits": logits.detach().numpy(),
+                  "expected_loss": np.array(float(loss.detach()), np.float64), "n_enc": np.array(c["n_enc"]),
+                  "n_dec": np.array(c["n_dec"]), "timing": np.array(c["timing"] or "")}
+        for (n, (prm, tr)), g in zip(names.items(), grads):
+            val = prm.detach() if tr is None else tr(prm.detach())
+            arrays["w:" + n] = np.ascontiguousarray(val.numpy())
+            gg = torch.zeros_like(prm) if g is None else g
+            arrays["g:" + n] = np.ascontiguousarray((gg if tr is None else tr(gg)).numpy())
+        save("neurst_pt_" + tag, **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -376,6 +555,7 @@ def main():
     gen_position_embedding()
     gen_transformer()
     gen_neurst_pt_frontend()
+    gen_neurst_pt_speech_transformer()
 
 
 if __name__ == "__main__":

@@ -80,6 +80,25 @@ def test_frontend_matches_reference_neurst_pt(tag):
     np.testing.assert_allclose(out.numpy(), r["expected"], atol=5e-5, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged"])
+def test_full_speech_transformer_logits_and_gradients_match_reference_neurst_pt(tag):
+    """The reference's own PyTorch SpeechTransformer (neurst_pt/models/speech_transformer.py; its test pins it to the TF
+    model at 5e-6, tests/neurst_pt/models/speech_transformer_test.py:157) executed under the shim of make_golden.py:
+    full-model logits, and -- torch autograd over the REFERENCE's forward -- the gradient of the label-smoothed token-mean
+    cross entropy w.r.t. every variable, mapped to TF names with the test's own assignment list.  Pins the oracle's
+    forward AND backward of the whole encoder-decoder (ragged batch, sinusoid timing) on the reference itself."""
+    from conftest import load_reference_pt_case
+    inputs, W, cfg, logits_ref, loss_ref, grads_ref = load_reference_pt_case(tag)
+    inputs = dict(inputs, src=inputs["src"].double())
+    loss, logits, grads = O.train_step_reference({k: v.double() for k, v in W.items()}, inputs, cfg, 0.1)
+    assert float((logits - logits_ref.double()).abs().max()) < 5e-6
+    assert abs(float(loss) - loss_ref) < 1e-6
+    assert set(grads_ref) == set(W)
+    for n, g in grads_ref.items():
+        err = float((grads[n].double() - g.double()).abs().max()) / max(float(g.abs().max()), 1e-6)
+        assert err < 2e-5, (n, err)
+
+
 def test_causal_bias_matrix():
     # tests/neurst_pt/layers/layer_utils_test.py:20
     b = O.lower_triangle_attention_bias(3)[0, 0]
