@@ -38,3 +38,30 @@ def load_reference_pt_case(tag):
     cfg = {"num_enc": int(r["n_enc"]), "num_dec": int(r["n_dec"]), "num_heads": 2, "layer_norm": True,
            "timing": str(r["timing"]) or None}
     return inputs, W, cfg, torch.from_numpy(r["expected_logits"]), float(r["expected_loss"]), grads
+
+
+def load_reference_pt_text_case(tag):
+    """Same for the reference's PyTorch text Transformer (gen_neurst_pt_transformer)."""
+    import torch
+    r, W = load_golden(tag)
+    grads = {k[2:]: torch.from_numpy(v) for k, v in r.items() if k.startswith("g:")}
+    inputs = {k: torch.from_numpy(r[k]) for k in ("src", "src_length", "trg", "trg_input", "trg_length")}
+    cfg = {"num_enc": 2, "num_dec": 2, "num_heads": 2}
+    return inputs, W, cfg, torch.from_numpy(r["expected_logits"]), float(r["expected_loss"]), grads, bool(int(r["share"]))
+
+
+def build_text_model_for_reference_case(W, logits_ref, share, device, dtype="float32"):
+    from neurst_amd.models import build_model
+    from neurst_amd.models.transformer import Transformer
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    p["modality.share_source_target_embedding"] = share
+    for k in list(p):
+        if k.endswith("dropout_rate"):
+            p[k] = 0.0
+    Vt = logits_ref.shape[-1]
+    Vs = Vt if share else W["input_symbol_modality/emb/weights"].shape[0]
+    meta = lambda V: {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}   # noqa: E731
+    model = build_model({"model.class": "Transformer", "model.params": p}, meta(Vs), meta(Vt), device=device, dtype=dtype)
+    assert set(model.store.params) == set(W), set(model.store.params) ^ set(W)
+    model.store.load_state_dict(W)
+    return model

@@ -437,6 +437,16 @@ def _tf_names_of_pt_speech_transformer(model, n_enc, n_dec):
     TF<->PT equivalence test (tests/neurst_pt/models/speech_transformer_test.py:57-155), generalised over layers."""
     out = {}
     fe = getattr(model._src_modality, "embedding_layer", model._src_modality)
+    if not hasattr(fe, "_conv_layer1"):     # text Transformer (tests/neurst_pt/models/transformer_test.py:59-64)
+        te = getattr(model._trg_modality, "embedding_layer", model._trg_modality)
+        if fe is te:
+            out["shared_symbol_modality/shared/weights"] = (te._shared_weights, None)
+            out["shared_symbol_modality/shared/bias"] = (te._bias, None)
+        else:
+            out["input_symbol_modality/emb/weights"] = (fe._shared_weights, None)
+            out["target_symbol_modality/shared/weights"] = (te._shared_weights, None)
+            out["target_symbol_modality/shared/bias"] = (te._bias, None)
+        return _tf_names_of_pt_stacks(model, n_enc, n_dec, out)
     A = "input_audio_modality"
     out[f"{A}/conv1/kernel"] = (fe._conv_layer1.weight, lambda w: w.permute(2, 3, 1, 0))
     out[f"{A}/conv1/bias"] = (fe._conv_layer1.bias, None)
@@ -449,7 +459,10 @@ def _tf_names_of_pt_speech_transformer(model, n_enc, n_dec):
     te = getattr(model._trg_modality, "embedding_layer", model._trg_modality)
     out["target_symbol_modality/shared/weights"] = (te._shared_weights, None)
     out["target_symbol_modality/shared/bias"] = (te._bias, None)
+    return _tf_names_of_pt_stacks(model, n_enc, n_dec, out)
 
+
+def _tf_names_of_pt_stacks(model, n_enc, n_dec, out):
     def att(prefix, layer, names):
         for tf_name, attr in names:
             sub = getattr(layer._layer, attr)
@@ -548,6 +561,67 @@ def gen_neurst_pt_speech_transformer():
         save("neurst_pt_" + tag, **arrays)
 
 
+def gen_neurst_pt_transformer():
+    """Same for the reference's PyTorch text Transformer (neurst_pt/models/transformer.py, pinned to TF by
+    tests/neurst_pt/models/transformer_test.py): separate and shared source/target embeddings, ragged batches."""
+    import torch
+    import torch.nn.functional as F
+    _install_shim()
+    _functional_registry()
+    tr = _load("neurst_pt.models.transformer")
+    cases = {"tr_2x2": dict(share=False, Vs=11, Vt=9, B=3, S=6, L=5, slens=[6, 4, 2], tlens=[5, 3, 2]),
+             "tr_2x2_shared": dict(share=True, Vs=10, Vt=10, B=2, S=5, L=4, slens=[5, 3], tlens=[4, 2])}
+    for tag, c in cases.items():
+        torch.manual_seed(13)
+        rng = np.random.RandomState(13)
+        d, H, ffn_ = 8, 2, 10
+        args = {f.name: f.default for f in tr.Transformer.class_or_method_args()}
+        args.update({"modality.dim": d, "modality.share_embedding_and_softmax_weights": True,
+                     "modality.share_source_target_embedding": c["share"], "modality.timing": "sinusoids"})
+        for side in ("encoder", "decoder"):
+            args.update({f"{side}.num_layers": 2, f"{side}.hidden_size": d, f"{side}.num_attention_heads": H,
+                         f"{side}.filter_size": ffn_, f"{side}.attention_dropout_rate": 0.0,
+                         f"{side}.ffn_dropout_rate": 0.0, f"{side}.layer_postprocess_dropout_rate": 0.0})
+        meta = lambda V: dict(vocab_size=V, eos_id=V - 1, bos_id=V - 2, unk_id=V - 3)
+        model = tr.Transformer.new(args, meta(c["Vs"]), meta(c["Vt"]))
+        names = _tf_names_of_pt_speech_transformer(model, 2, 2)
+        for n, (prm, _) in names.items():
+            if n.endswith("/bias") or n.endswith("/beta"):
+                prm.data = torch.tensor(rng.uniform(-0.2, 0.2, tuple(prm.shape)), dtype=torch.float32)
+            elif n.endswith("/gamma"):
+                prm.data = torch.tensor(rng.uniform(0.7, 1.3, tuple(prm.shape)), dtype=torch.float32)
+        covered = {id(prm) for prm, _ in names.values()}
+        assert all(id(q) in covered for q in model.parameters()), "unmapped reference parameter"
+
+        def side(Lx, V, lens):
+            ids = rng.randint(0, V - 3, (c["B"], Lx)).astype(np.int64)
+            for b, n in enumerate(lens):
+                ids[b, n - 1:] = V - 1
+            return ids
+        src, trg = side(c["S"], c["Vs"], c["slens"]), side(c["L"], c["Vt"], c["tlens"])
+        trg_input = np.concatenate([np.full((c["B"], 1), c["Vt"] - 2, np.int64), trg[:, :-1]], 1)
+        src_padding = (np.arange(c["S"])[None, :] >= np.array(c["slens"])[:, None]).astype(np.float32)
+        logits = model({"src": torch.tensor(src), "src_padding": torch.tensor(src_padding),
+                        "trg_input": torch.tensor(trg_input)}, is_training=False)
+        ls, V = 0.1, c["Vt"]
+        logp = F.log_softmax(logits, -1)
+        soft = torch.full_like(logp, ls / (V - 1)).scatter_(-1, torch.tensor(trg)[..., None], 1.0 - ls)
+        norm = -((1.0 - ls) * np.log(1.0 - ls) + (V - 1) * (ls / (V - 1)) * np.log(ls / (V - 1) + 1e-20))
+        w = (torch.arange(c["L"])[None, :] < torch.tensor(c["tlens"])[:, None]).float()
+        loss = (((-(soft * logp).sum(-1)) - norm) * w).sum() / w.sum()
+        grads = torch.autograd.grad(loss, [prm for prm, _ in names.values()], allow_unused=True)
+        arrays = {"src": src, "src_padding": src_padding, "src_length": np.array(c["slens"], np.int64), "trg": trg,
+                  "trg_input": trg_input, "trg_length": np.array(c["tlens"], np.int64),
+                  "expected_logits": logits.detach().numpy(), "expected_loss": np.array(float(loss.detach()), np.float64),
+                  "share": np.array(int(c["share"]))}
+        for (n, (prm, tf_layout)), g in zip(names.items(), grads):
+            val = prm.detach() if tf_layout is None else tf_layout(prm.detach())
+            gg = torch.zeros_like(prm) if g is None else g
+            arrays["w:" + n] = np.ascontiguousarray(val.numpy())
+            arrays["g:" + n] = np.ascontiguousarray((gg if tf_layout is None else tf_layout(gg)).numpy())
+        save("neurst_pt_" + tag, **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -556,6 +630,7 @@ def main():
     gen_transformer()
     gen_neurst_pt_frontend()
     gen_neurst_pt_speech_transformer()
+    gen_neurst_pt_transformer()
 
 
 if __name__ == "__main__":

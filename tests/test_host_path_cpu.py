@@ -197,6 +197,21 @@ def test_host_path_matches_the_reference_neurst_pt_speech_transformer(cpu_kernel
         assert rel_err(model.store.params[n].grad, g) < 2e-5, n
 
 
+@pytest.mark.parametrize("tag", ["neurst_pt_tr_2x2", "neurst_pt_tr_2x2_shared"])
+def test_host_path_matches_the_reference_neurst_pt_text_transformer(cpu_kernels, tag):
+    from conftest import build_text_model_for_reference_case, load_reference_pt_text_case
+    from neurst_amd.criterions import build_criterion
+    inputs, W, cfg, logits_ref, loss_ref, grads_ref, share = load_reference_pt_text_case(tag)
+    model = build_text_model_for_reference_case(W, logits_ref, share, "cpu")
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(inputs, is_training=True)
+    loss = crit.reduce_loss(inputs, logits)
+    model.backward(crit.backward())
+    assert float((logits - logits_ref).abs().max()) < 5e-6 and abs(float(loss) - loss_ref) < 1e-6
+    for n, g in grads_ref.items():
+        assert rel_err(model.store.params[n].grad, g) < 2e-5, n
+
+
 def test_gradient_accumulation_and_clipping_on_cpu(cpu_kernels):
     """TrainStep with update_cycle = 2 averages the micro-batch gradients (gradaccum_keras_model.py:62-109), clips the
     averaged gradients per tensor (:228-233) and applies Keras Adam -- against the oracle's functions."""

@@ -99,6 +99,20 @@ def test_full_speech_transformer_logits_and_gradients_match_reference_neurst_pt(
         assert err < 2e-5, (n, err)
 
 
+@pytest.mark.parametrize("tag", ["neurst_pt_tr_2x2", "neurst_pt_tr_2x2_shared"])
+def test_text_transformer_logits_and_gradients_match_reference_neurst_pt(tag):
+    """The reference's own PyTorch text Transformer (neurst_pt/models/transformer.py, pinned to TF by
+    tests/neurst_pt/models/transformer_test.py) + torch autograd: separate and shared source/target embeddings."""
+    from conftest import load_reference_pt_text_case
+    inputs, W, cfg, logits_ref, loss_ref, grads_ref, _ = load_reference_pt_text_case(tag)
+    loss, logits, grads = O.text_train_step_reference({k: v.double() for k, v in W.items()}, inputs, cfg, 0.1)
+    assert float((logits - logits_ref.double()).abs().max()) < 5e-6 and abs(float(loss) - loss_ref) < 1e-6
+    assert set(grads_ref) == set(W)
+    for n, g in grads_ref.items():
+        err = float((grads[n].double() - g.double()).abs().max()) / max(float(g.abs().max()), 1e-6)
+        assert err < 2e-5, (n, err)
+
+
 def test_causal_bias_matrix():
     # tests/neurst_pt/layers/layer_utils_test.py:20
     b = O.lower_triangle_attention_bias(3)[0, 0]

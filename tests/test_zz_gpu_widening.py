@@ -186,3 +186,19 @@ def test_hip_path_matches_the_reference_neurst_pt_speech_transformer(tag):
     assert abs(float(loss) - loss_ref) < 1e-5
     for n, g in grads_ref.items():
         check(f"ref_pt[{tag}].grad.{n}", model.store.params[n].grad, g.double(), 1e-3)
+
+
+@pytest.mark.parametrize("tag", ["neurst_pt_tr_2x2", "neurst_pt_tr_2x2_shared"])
+def test_hip_path_matches_the_reference_neurst_pt_text_transformer(tag):
+    from conftest import build_text_model_for_reference_case, load_reference_pt_text_case
+    from neurst_amd.criterions import build_criterion
+    inputs, W, cfg, logits_ref, loss_ref, grads_ref, share = load_reference_pt_text_case(tag)
+    model = build_text_model_for_reference_case(W, logits_ref, share, DEV)
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    loss = crit.reduce_loss(dinp, logits)
+    model.backward(crit.backward())
+    assert float((logits.float().cpu() - logits_ref).abs().max()) < 5e-5 and abs(float(loss) - loss_ref) < 1e-5
+    for n, g in grads_ref.items():
+        check(f"ref_pt[{tag}].grad.{n}", model.store.params[n].grad, g.double(), 1e-3)
