@@ -142,7 +142,8 @@ class SimulTransTextAgent(TextAgent):
         super().__init__(args)
         self.wait_k = args.wait_k
         if task is None:
-            task, models = build_task_and_model(args.model_dir, self.wait_k)
+            task, models = build_task_and_model(args.model_dir, self.wait_k, device=getattr(args, "device", None) or "cuda:0",
+                                                dtype=getattr(args, "dtype", None) or "float32")
         self.task, self.models = task, models
         self.force_segment = getattr(args, "force_segment", False)
         self.max_len = getattr(args, "max_len", 200)
@@ -155,6 +156,8 @@ class SimulTransTextAgent(TextAgent):
         parser.add_argument("-k", "--wait-k", type=int, dest="wait_k", default=3)
         parser.add_argument("--force-segment", default=False, action="store_true", dest="force_segment")
         parser.add_argument("--max-len", type=int, default=200, dest="max_len", help="Max length of translation")
+        parser.add_argument("--device", type=str, default="cuda:0", help="The GPU this agent's model lives on.")
+        parser.add_argument("--dtype", type=str, default="float32", help="Compute dtype: float32 or bfloat16.")
 
     # ------------------------------------------------------------------ states
     def build_states(self, args, client, sentence_id):

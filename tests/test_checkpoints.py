@@ -181,3 +181,40 @@ def test_checkpoint_manager_save_restore_scope_mapping_and_rotation(tmp_path):
     bad.store.params["target_symbol_modality/shared/weights"] = _Param(torch.zeros(12, 4))
     ck.restore_checkpoint_if_possible(bad, d)
     assert float(bad.store.params["target_symbol_modality/shared/weights"].data.abs().sum()) == 0.0
+
+
+def test_avg_checkpoint_cli(tmp_path):
+    """avg_checkpoint.py:49-103: running mean over the checkpoints of a directory, `_`-prefixed variables dropped, one
+    ckpt + state file + model_configs.yml written; the result restores through the normal manager path."""
+    import numpy as np
+    from neurst_amd.cli.avg_checkpoint import average_checkpoints
+    from neurst_amd.utils import tensor_bundle as tb
+    from neurst_amd.utils.checkpoints import latest_checkpoint, list_variables
+    d = tmp_path / "run"
+    d.mkdir()
+    rng = np.random.RandomState(0)
+    vals = []
+    lines = []
+    for step in (10, 20, 30):
+        w, b = rng.randn(4, 3).astype(np.float32), rng.randn(3).astype(np.float32)
+        vals.append((w, b))
+        tb.write_bundle(str(d / f"ckpt-{step}"), {
+            tb.checkpoint_key("SpeechTransformer/enc/kernel"): w, tb.checkpoint_key("SpeechTransformer/enc/bias"): b,
+            "_optimizer/step": np.asarray(step, dtype=np.int64), "_optimizer/m": np.ones(5, np.float32),
+            tb.OBJECT_GRAPH_KEY: [tb.object_graph_proto(["SpeechTransformer/enc/kernel", "SpeechTransformer/enc/bias"])]})
+        lines.append(f'all_model_checkpoint_paths: "ckpt-{step}"')
+    (d / "checkpoint").write_text('model_checkpoint_path: "ckpt-30"\n' + "\n".join(lines) + "\n")
+    (d / "model_configs.yml").write_text("model.class: SpeechTransformer\n")
+    out = tmp_path / "avg"
+    prefix, paths = average_checkpoints(str(d), str(out))
+    assert len(paths) == 3 and latest_checkpoint(str(out)) == prefix
+    got = {tb.variable_name(k): v for k, v in tb.read_bundle(prefix).items() if k != tb.OBJECT_GRAPH_KEY}
+    assert set(got) == {"SpeechTransformer/enc/kernel", "SpeechTransformer/enc/bias"}
+    np.testing.assert_allclose(got["SpeechTransformer/enc/kernel"], np.mean([w for w, _ in vals], 0), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(got["SpeechTransformer/enc/bias"], np.mean([b for _, b in vals], 0), rtol=1e-6, atol=1e-7)
+    assert sorted(n for n, _ in list_variables(prefix)) == sorted(got)
+    assert (out / "model_configs.yml").read_text().startswith("model.class")
+    # explicit prefixes, comma separated
+    prefix2, paths2 = average_checkpoints(f"{d}/ckpt-10,{d}/ckpt-30", str(tmp_path / "avg2"))
+    got2 = {tb.variable_name(k): v for k, v in tb.read_bundle(prefix2).items() if k != tb.OBJECT_GRAPH_KEY}
+    np.testing.assert_allclose(got2["SpeechTransformer/enc/bias"], (vals[0][1] + vals[2][1]) / 2, rtol=1e-6, atol=1e-7)

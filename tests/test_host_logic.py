@@ -247,3 +247,19 @@ def test_synthetic_text_dataset_shapes_and_eos_padding():
     assert b["feature"].shape == (4, 9) and b["label"].shape == (4, 7)
     assert (b["feature"][:, -1] == 49).all() and (b["label"][:, -1] == 59).all()
     assert int(b["feature"].max()) <= 49 and int(b["label"][:, :-1].min()) >= 0
+
+
+def test_inverse_sqrt_and_piecewise_schedules():
+    """inverse_sqrt_schedule.py:57-70, piecewise_schedule.py:66-82 (known answers from the formulas)."""
+    from neurst_amd.optimizers import build_lr_schedule
+    s = build_lr_schedule({"lr_schedule.class": "inverse_sqrt",
+                           "lr_schedule.params": {"peak_lr": 5e-4, "init_lr": 1e-7, "warmup_steps": 4000}})
+    assert abs(s(0) - (1e-7 + 1 * (5e-4 - 1e-7) / 4000)) < 1e-15          # global step 0 -> step 1
+    assert abs(s(1998) - (1e-7 + 1999 * (5e-4 - 1e-7) / 4000)) < 1e-15
+    assert abs(s(3999) - 5e-4) < 1e-12                                      # step 4000: the peak
+    assert abs(s(15999) - 5e-4 * (4000 / 16000) ** 0.5) < 1e-12
+    p = build_lr_schedule({"lr_schedule.class": "piecewise",
+                           "lr_schedule.params": {"schedule_steps": "[100, 200, 400]", "schedule_lrs": [1e-3, 5e-4, 1e-4, 1e-5]}})
+    assert abs(p(0) - 1e-3 / 100) < 1e-15 and abs(p(49) - 0.5e-3) < 1e-15
+    assert p(99) == 5e-4 and p(198) == 5e-4 and p(199) == 1e-4 and p(398) == 1e-4 and p(399) == 1e-5 and p(10 ** 6) == 1e-5
+    assert p.get_config()["schedule_steps"] == [100, 200, 400]

@@ -572,3 +572,49 @@ def test_simul_trans_text_agent_wait_k_policy_and_streaming_predictions(cpu_kern
     # the hypothesis is the de-tokenised unit sequence
     text = "".join(trg_pipe.tokens[u] for u in y if u != eos).replace("▁", " ").split()
     assert res["hypothesis"] == text
+
+
+def test_simuleval_cli_from_a_model_dir(cpu_kernels, tmp_path, capsys):
+    """The whole inference flow of examples/simultaneous_translation: a model_dir (model_configs.yml with the task's text
+    pipelines + a TensorFlow-format checkpoint) -> simuleval_cli -> agent -> hypotheses + Average Lagging.  Also the
+    checkpoint-averaging CLI in front of it (the recipe averages the last checkpoints before evaluating)."""
+    import json
+    from neurst_amd.cli import simuleval_cli
+    from neurst_amd.cli.avg_checkpoint import average_checkpoints
+    from neurst_amd.models.transformer import Transformer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils.checkpoints import NameBasedCheckpointManager
+    from neurst_amd.utils.configurable import ModelConfigs
+    src_vocab = ["ich", "bin", "ein", "haus", "und", "du"]
+    trg_vocab = ["▁i", "▁am", "▁a", "▁house", "▁and", "▁you", "s"]
+    task_params = {"src_data_pipeline.params": {"vocab_path": src_vocab, "language": "de"},
+                   "trg_data_pipeline.params": {"vocab_path": trg_vocab, "language": "en"}, "wait_k": 2}
+    task = build_task({"task.class": "WaitkTranslation", "task.params": task_params})
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    model = task.build_model({"model.class": "WaitkTransformer", "model.params": p}, device="cpu", dtype="float32", init_seed=2)
+    run = tmp_path / "run"
+    mgr = NameBasedCheckpointManager(model, str(run), max_to_keep=3)
+    w0 = model.store.master.clone()
+    mgr.save(10)
+    model.store.master.mul_(3.0)
+    mgr.save(20)
+    ModelConfigs.dump({"model.class": "WaitkTransformer", "model.params": model.args, "task.class": "WaitkTranslation",
+                       "task.params": task.get_config()}, str(run))
+    avg = tmp_path / "avg"
+    average_checkpoints(str(run), str(avg))
+    (tmp_path / "src.txt").write_text("ich bin ein haus\ndu und ich\n")
+    res = simuleval_cli.main(["--source", str(tmp_path / "src.txt"), "--model-dir", str(avg), "--wait-k", "2", "--max-len", "6",
+                              "--device", "cpu", "--output", str(tmp_path / "out")])
+    report = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert report["sentences"] == 2 and report["AL"] >= 2.0 - 1e-9
+    full = [[0, 1, 2, 3, len(src_vocab) + 2], [5, 4, 0, len(src_vocab) + 2]]             # ids + EOS closing the source
+    assert len(res) == 2 and all(r["source_units"] == f[:len(r["source_units"])] for r, f in zip(res, full))
+    assert res[0]["actions"][:2] == ["read", "read"]
+    lines = (tmp_path / "out" / "instances.log").read_text().strip().splitlines()
+    assert len(lines) == 2 and json.loads(lines[0])["delays"] == res[0]["delays"]
+    # the agent's model holds the AVERAGE of the two checkpoints (w0 and 3 w0 -> 2 w0)
+    from neurst_amd.utils.simuleval_agents import simul_trans_text_agent as A
+    import argparse
+    agent = A.SimulTransTextAgent(argparse.Namespace(wait_k=2, model_dir=str(avg), device="cpu", max_len=6))
+    assert torch.allclose(agent.models[0].store.master, 2.0 * w0, rtol=1e-6, atol=1e-7)
+    assert agent.models[0].wait_k == 2 and agent.src_pipeline.meta["language"] == "de"
