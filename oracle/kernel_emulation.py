@@ -8,20 +8,26 @@ gpu"` tests therefore install THIS module over `neurst_amd.kernels` with `instal
 layer code against `oracle/neurst_oracle.py`.  Nothing in `neurst_amd/` imports this file; `bench.py` does not either.
 
 Each function mirrors the signature of its namesake in neurst_amd/kernels.py and the semantics documented in
-include/neurst_hip.h (the reference lines it stands for are cited there).  Dropout is not emulated: the device masks
-come from the kernels' own Philox streams, so every call here requires dropout_p == 0.
+include/neurst_hip.h (the reference lines it stands for are cited there).  Dropout: every mask outside attention is the
+kernels' own (oracle/philox.py restates the generator: Philox4x32-7 keyed by (seed, site), 16-bit field of the element's
+linear index), so forward and backward regenerate the same mask exactly like the device does.  The dropout on attention
+probabilities uses the same generator over the linear index of [B, H, Tq, Tk] -- NOT the device's bit layout (the HIP
+forward writes its keep bits to a buffer the backward reads; here the mask tensor itself plays that buffer).
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from oracle import philox
+
 FLOAT_MIN = -1.0e9
 F64 = torch.float64
 
 
-def _no_dropout(p):
-    if p and p > 0:
-        raise NotImplementedError("the CPU emulation of the kernels has no dropout (device Philox masks)")
+def _keep(p, seed, site, shape):
+    """float64 keep multipliers (0 or 1/keep) of a tensor of `shape` whose elements are numbered in row-major order."""
+    n = int(np.prod(shape))
+    return torch.from_numpy(philox.keep_multiplier(seed, site, n, p)).reshape(tuple(shape))
 
 
 # ---------------------------------------------------------------------------------------------------- LayerNorm
@@ -63,8 +69,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
         dx = dx + dres.reshape(-1, d).to(F64)
     dx = dx.to(x.dtype).reshape(x.shape)
     if emit_dropout is not None:
-        _no_dropout(emit_dropout[0])
-        return dx, dx.clone()
+        p, seed, site = emit_dropout
+        return dx, (dx.to(F64) * _keep(p, seed, site, dx.shape)).to(dx.dtype)
     return dx
 
 
@@ -72,7 +78,6 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
          posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False):
-    _no_dropout(dropout_p)
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype and A.stride(1) == 1 and B.stride(1) == 1
     assert out is None or (out.dim() == 2 and out.stride(1) == 1)
     assert residual is None or residual.stride(1) == 1
@@ -94,6 +99,9 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
         v = v + bias.to(F64)
     if relu:
         v = v.clamp_min(0)
+    if dropout_p > 0:
+        assert split_k <= 1
+        v = v * _keep(dropout_p, seed, stream_id, (M, N))     # element index row * N + col
     if residual is not None:
         assert residual.dtype == out.dtype
         v = v + residual.to(F64)
@@ -173,18 +181,18 @@ def _check_attention_views(q, k, v, out, H, dh, key_bias, causal_offset):
 
 
 def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0, stream_id=0, causal_offset=0):
-    _no_dropout(dropout_p)
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
     _check_attention_views(q, k, v, torch.empty(B, Tq, H * dh, dtype=q.dtype), H, dh, key_bias, causal_offset)
     P, lse = _attn_probs(q.to(F64), k.to(F64), H, dh, key_bias, causal, causal_offset)
     vh = v.to(F64).reshape(B, Tk, H, dh).permute(0, 2, 1, 3)
-    out = (P @ vh).permute(0, 2, 1, 3).reshape(B, Tq, H * dh)
-    return out.to(q.dtype).contiguous(), lse.float().contiguous(), None
+    mask = _keep(dropout_p, seed, stream_id, P.shape) if dropout_p > 0 else None
+    out = ((P if mask is None else P * mask) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, H * dh)
+    return out.to(q.dtype).contiguous(), lse.float().contiguous(), mask
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
                   stream_id=0, drop_mask=None, causal_offset=0):
-    _no_dropout(dropout_p)
+    assert (dropout_p > 0) == (drop_mask is not None), "attention_bwd: dropout needs the mask written by attention_fwd"
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
     assert dout.is_contiguous() and out.is_contiguous()
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
@@ -196,8 +204,11 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, cau
     vh = vd.reshape(B, Tk, H, dh).permute(0, 2, 1, 3)
     qh = qd.reshape(B, Tq, H, dh).permute(0, 2, 1, 3)
     kh = kd.reshape(B, Tk, H, dh).permute(0, 2, 1, 3)
-    dV = P.transpose(-1, -2) @ do
+    Pd = P if drop_mask is None else P * drop_mask          # the probabilities the forward multiplied with V
+    dV = Pd.transpose(-1, -2) @ do
     dP = do @ vh.transpose(-1, -2)
+    if drop_mask is not None:
+        dP = dP * drop_mask
     dS = P * (dP - (dP * P).sum(-1, keepdim=True))
     dQ = (dS @ kh) * scale
     dK = (dS.transpose(-1, -2) @ qh) * scale
@@ -291,39 +302,45 @@ def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
 
 # ---------------------------------------------------------------------------------------------------- embedding / elementwise
 def embedding_fwd(table, ids, posenc, L, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
-    _no_dropout(dropout_p)
     assert ids.dtype == torch.int64 and (posenc is None or (posenc.is_contiguous() and posenc.shape[0] >= min(L, ids.numel())))
     d = table.shape[1]
     flat = ids.reshape(-1)
     out = table.to(F64)[flat] * emb_scale
     if posenc is not None:
         out = out + posenc.to(F64)[torch.arange(flat.numel()) % L]
+    if dropout_p > 0:
+        out = out * _keep(dropout_p, seed, stream_id, out.shape)
     return out.to(table.dtype).reshape(*ids.shape, d)
 
 
 def embedding_bwd(dout, ids, dtable, emb_scale, dropout_p=0.0, seed=0, stream_id=0):
-    _no_dropout(dropout_p)
     assert dout.is_contiguous() and dtable.dtype == torch.float32
     d = dtable.shape[1]
     acc = torch.zeros(dtable.shape, dtype=F64)
-    acc.index_add_(0, ids.reshape(-1), dout.reshape(-1, d).to(F64) * emb_scale)
+    g = dout.reshape(-1, d).to(F64) * emb_scale
+    if dropout_p > 0:
+        g = g * _keep(dropout_p, seed, stream_id, g.shape)
+    acc.index_add_(0, ids.reshape(-1), g)
     dtable.add_(acc.float())  # always accumulates (neurst_hip.h)
 
 
 def scale_posenc_dropout_fwd(x, posenc, period, scale, dropout_p=0.0, seed=0, stream_id=0):
-    _no_dropout(dropout_p)
     assert x.is_contiguous()
     d = x.shape[-1]
     y = x.reshape(-1, d).to(F64) * scale
     if posenc is not None:
         y = y + posenc.to(F64)[torch.arange(y.shape[0]) % period]
+    if dropout_p > 0:
+        y = y * _keep(dropout_p, seed, stream_id, y.shape)
     return y.to(x.dtype).reshape(x.shape)
 
 
 def scale_dropout_bwd(dy, scale, dropout_p=0.0, seed=0, stream_id=0):
-    _no_dropout(dropout_p)
     assert dy.is_contiguous()
-    return (dy.to(F64) * scale).to(dy.dtype)
+    g = dy.to(F64) * scale
+    if dropout_p > 0:
+        g = g * _keep(dropout_p, seed, stream_id, g.shape)
+    return g.to(dy.dtype)
 
 
 # ---------------------------------------------------------------------------------------------------- criterion / optimizer

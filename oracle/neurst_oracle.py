@@ -48,10 +48,14 @@ def layer_norm(x, gamma, beta, eps):
     return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
 
 
-def dropout(x, rate, is_training, generator=None):
-    """tf.nn.dropout (inverted dropout).  Parity tests use rate 0."""
+def dropout(x, rate, is_training, generator=None, tag=None):
+    """tf.nn.dropout (inverted dropout).  `generator` is a torch.Generator (masks drawn here), or -- to compare against a
+    path whose masks are known -- an object with mask_for(tag, shape, rate) returning the keep multipliers (0 or
+    1/keep) of the dropout site `tag` (the variable-scope name of the layer that owns the site)."""
     if not is_training or rate == 0.0:
         return x
+    if hasattr(generator, "mask_for"):
+        return x * generator.mask_for(tag, tuple(x.shape), rate).to(x.dtype)
     keep = (torch.rand(x.shape, generator=generator, dtype=x.dtype) >= rate).to(x.dtype)
     return x * keep / (1.0 - rate)
 
@@ -78,7 +82,7 @@ def multi_head_dense(x, kernel, bias, num_heads, output_units, is_output_transfo
     return outs if isinstance(output_units, (list, tuple)) else outs[0]
 
 
-def attention_core(q, k, v, bias, attention_dropout_rate=0.0, is_training=False, generator=None):
+def attention_core(q, k, v, bias, attention_dropout_rate=0.0, is_training=False, generator=None, tag=None):
     """att_fn + weighted sum (neurst/layers/attentions/multi_head_attention.py:124-164, 203-215).
 
     q [B,F,H,dh] (NOT yet scaled), k,v [B,T,H,dh]; bias [B,T] (key padding),
@@ -94,7 +98,7 @@ def attention_core(q, k, v, bias, attention_dropout_rate=0.0, is_training=False,
             bias = bias[:, None]
         logits = logits + bias
     weights = torch.softmax(logits, dim=-1)                # :160
-    weights = dropout(weights, attention_dropout_rate, is_training, generator)  # :207-208
+    weights = dropout(weights, attention_dropout_rate, is_training, generator, tag)  # :207-208; [B, H, Tq, Tk]
     return torch.einsum("bhft,bthd->bfhd", weights, v)     # :215
 
 
@@ -103,7 +107,7 @@ def self_attention(x, W, prefix, num_heads, bias, rate=0.0, is_training=False, g
     d_in = W[prefix + "/qkv_transform/kernel"].shape[1] // 3
     q, k, v = multi_head_dense(x, W[prefix + "/qkv_transform/kernel"], W.get(prefix + "/qkv_transform/bias"),
                                num_heads, [d_in, d_in, d_in])
-    ctx = attention_core(q, k, v, bias, rate, is_training, generator)
+    ctx = attention_core(q, k, v, bias, rate, is_training, generator, prefix)
     return multi_head_dense(ctx, W[prefix + "/output_transform/kernel"], W.get(prefix + "/output_transform/bias"),
                             num_heads, None, is_output_transform=True)
 
@@ -115,7 +119,7 @@ def cross_attention(x, memory, W, prefix, num_heads, memory_bias, rate=0.0, is_t
     q = multi_head_dense(x, W[prefix + "/q_transform/kernel"], W.get(prefix + "/q_transform/bias"), num_heads, dq)
     k, v = multi_head_dense(memory, W[prefix + "/kv_transform/kernel"], W.get(prefix + "/kv_transform/bias"),
                             num_heads, [dkv, dkv])
-    ctx = attention_core(q, k, v, memory_bias, rate, is_training, generator)
+    ctx = attention_core(q, k, v, memory_bias, rate, is_training, generator, prefix)
     return multi_head_dense(ctx, W[prefix + "/output_transform/kernel"], W.get(prefix + "/output_transform/bias"),
                             num_heads, None, is_output_transform=True)
 
@@ -123,7 +127,7 @@ def cross_attention(x, memory, W, prefix, num_heads, memory_bias, rate=0.0, is_t
 def ffn(x, W, prefix, rate=0.0, is_training=False, generator=None):
     """TransformerFFN.call (neurst/layers/common_layers.py:145-160), relu."""
     h = F.relu(x @ W[prefix + "/dense1/kernel"] + W[prefix + "/dense1/bias"])
-    h = dropout(h, rate, is_training, generator)
+    h = dropout(h, rate, is_training, generator, prefix)
     return h @ W[prefix + "/dense2/kernel"] + W[prefix + "/dense2/bias"]
 
 
@@ -131,11 +135,11 @@ def prepost(x, fn, W, prefix, eps, rate=0.0, is_training=False, generator=None, 
     """PrePostProcessingWrapper.call (common_layers.py:73-92).  pre-norm: LN -> layer -> dropout -> residual;
     post-norm (pre_norm=False, :86-92): layer -> dropout -> residual -> LN."""
     if not pre_norm:
-        y = dropout(fn(x), rate, is_training, generator)
+        y = dropout(fn(x), rate, is_training, generator, prefix)
         return layer_norm(x + y, W[prefix + "/ln/gamma"], W[prefix + "/ln/beta"], eps)
     y = layer_norm(x, W[prefix + "/ln/gamma"], W[prefix + "/ln/beta"], eps)
     y = fn(y)
-    y = dropout(y, rate, is_training, generator)
+    y = dropout(y, rate, is_training, generator, prefix)
     return x + y
 
 
@@ -195,7 +199,7 @@ def transformer_encoder(x, padding, W, scope, num_layers, num_heads, eps=1e-6,
     bias = input_padding_to_bias(padding)
     if monotonic:
         bias = torch.minimum(bias[:, None, None, :], lower_triangle_attention_bias(x.shape[1], x.dtype))
-    x = dropout(x, post_rate, is_training, generator)
+    x = dropout(x, post_rate, is_training, generator, scope)
     for i in range(num_layers):
         p = f"{scope}/layer_{i}"
         _ensure_ln(W, p + "/self_attention_prepost_wrapper/ln", x.shape[-1], x.dtype)
@@ -229,7 +233,7 @@ def transformer_decoder(x, memory, memory_padding, W, scope, num_layers, num_hea
         memory_bias = torch.minimum(memory_bias[:, None, :], waitk_attention_bias(
             memory_bias.shape[1], decode_lagging, x.shape[1], x.dtype)[None, :, :])[:, None, :, :]
     causal = lower_triangle_attention_bias(x.shape[1], x.dtype)
-    x = dropout(x, post_rate, is_training, generator)
+    x = dropout(x, post_rate, is_training, generator, scope)
     for i in range(num_layers):
         p = f"{scope}/layer_{i}"
         for w in ("self_attention_prepost_wrapper", "encdec_attention_prepost_wrapper", "ffn_prepost_wrapper"):
@@ -558,10 +562,11 @@ def init_speech_transformer_weights(cfg, vocab_size, feature_dim=80, in_channels
     return W
 
 
-def train_step_reference(W, inputs, cfg, label_smoothing, is_training=False):
-    """One forward + loss + backward on the oracle.  Returns (loss, logits, grads by name)."""
+def train_step_reference(W, inputs, cfg, label_smoothing, is_training=False, generator=None):
+    """One forward + loss + backward on the oracle.  Returns (loss, logits, grads by name).  With is_training and
+    cfg["dropout"] > 0, `generator` supplies the masks (see dropout())."""
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
-    logits = speech_transformer_logits(inputs, Wg, cfg, is_training=is_training)
+    logits = speech_transformer_logits(inputs, Wg, cfg, is_training=is_training, generator=generator)
     nll, _, ntok = label_smoothed_cross_entropy(logits, inputs["trg"], inputs["trg_length"], label_smoothing)
     loss = reduce_loss(nll, ntok)
     names = list(Wg.keys())
@@ -570,7 +575,7 @@ def train_step_reference(W, inputs, cfg, label_smoothing, is_training=False):
                                             for n, g in zip(names, grads)}
 
 
-def text_train_step_reference(W, inputs, cfg, label_smoothing, is_training=False):
+def text_train_step_reference(W, inputs, cfg, label_smoothing, is_training=False, generator=None):
     """train_step_reference for the text Transformer (transformer_logits): inputs carry src ids, src_length,
     trg, trg_length, trg_input; the source padding follows EncoderDecoderModel.get_symbols_to_logits_fn /
     call (encoder_decoder_model.py:211-224: padding = 1 - sequence_mask(src_length))."""
@@ -585,7 +590,7 @@ def text_train_step_reference(W, inputs, cfg, label_smoothing, is_training=False
             Wg2["target_symbol_modality/shared/bias"] = Wg["shared_symbol_modality/shared/bias"]
     else:
         Wg2 = Wg
-    logits = transformer_logits(inp, Wg2, cfg, is_training=is_training)
+    logits = transformer_logits(inp, Wg2, cfg, is_training=is_training, generator=generator)
     nll, _, ntok = label_smoothed_cross_entropy(logits, inputs["trg"], inputs["trg_length"], label_smoothing)
     loss = reduce_loss(nll, ntok)
     names = list(Wg.keys())

@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE -- numpy restatement of the dropout mask generator of the HIP kernels (neurst_amd/csrc/nst_common.h:
+Philox4x32 with SEVEN rounds, counter = (idx / 8, stream id), key = seed; element idx takes the 16-bit field idx % 8 of the
+four output words, low half first; kept when field >= round(p * 65536), multiplier 65536 / (65536 - threshold)).
+
+Used by oracle/kernel_emulation.py (so that the CPU tests of the host logic can run WITH dropout: forward and backward
+must regenerate the same mask per site) and by the GPU test that compares the device masks bit for bit.
+The 10-round variant is the Random123 generator; `tests/test_oracle_kat.py` checks it against Random123's published
+known-answer vectors, which pins the round function, the multipliers and the key schedule used here.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=7):
+    """Vectorised Philox4x32: counters c0..c3 (uint32 arrays or scalars), key k0, k1 (python ints) -> 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK32 for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(rounds):
+        p0, p1 = M0 * c0, M1 * c2                     # 32 x 32 -> 64 bit products (no overflow in uint64)
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return tuple(np.asarray(c, dtype=np.uint64).astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def dropout_params16(p):
+    """nst_dropout_params16: (threshold, keep multiplier)."""
+    t = min(max(int(p * 65536.0 + 0.5), 0), 65535)
+    return t, 65536.0 / (65536.0 - t)
+
+
+def fields16(seed, stream, n):
+    """The 16-bit field of elements 0 .. n-1 under (seed, stream): uint16 array [n]."""
+    groups = (n + 7) // 8
+    ctr = np.arange(groups, dtype=np.uint64)
+    w = philox4x32(ctr & MASK32, ctr >> np.uint64(32), int(stream) & 0xFFFFFFFF, (int(stream) >> 32) & 0xFFFFFFFF,
+                   int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    words = np.stack(w, axis=1)                                              # [groups, 4]
+    f = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=2)  # [groups, 4 words, (low, high)]
+    return f.reshape(-1)[:n].astype(np.uint16)
+
+
+def keep_multiplier(seed, stream, n, p):
+    """float64 array [n]: 0 where element idx is dropped, inv_keep where it is kept (dropout_keep_scale)."""
+    t, inv = dropout_params16(p)
+    return np.where(fields16(seed, stream, n).astype(np.uint32) >= t, inv, 0.0)
+
+
+class SiteMasks(object):
+    """Mask provider for oracle/neurst_oracle.py::dropout: the masks a model on the HIP path (or on the kernel emulation)
+    applies in the step whose seed is `seed`.  `sites` maps the variable-scope name of a layer to its dropout site id
+    (see model_dropout_sites)."""
+
+    def __init__(self, seed, sites):
+        self.seed, self.sites = int(seed), dict(sites)
+        self.used = []
+
+    def mask_for(self, tag, shape, rate):
+        import torch
+        self.used.append(tag)
+        n = int(np.prod(shape))
+        return torch.from_numpy(keep_multiplier(self.seed, self.sites[tag], n, rate)).reshape(shape)
+
+
+def model_dropout_sites(model):
+    """{scope name: site id} of every dropout site of an EncoderDecoderModel of neurst_amd (wrappers, FFN hidden
+    dropout, attention-probability dropout, encoder / decoder input dropout)."""
+    sites = {model._encoder.name: model._encoder.site, model._decoder.name: model._decoder.site}
+    for stack in (model._encoder._stacking_layers, model._decoder._stacking_layers):
+        for layer in stack:
+            for w in (getattr(layer, "_selfatt_layer", None), getattr(layer, "_crossatt_layer", None),
+                      getattr(layer, "_ffn_layer", None)):
+                if w is None:
+                    continue
+                sites[w.name] = w.site
+                inner = getattr(w.layer, "att", w.layer)
+                sites[inner.name] = inner.site
+    return sites

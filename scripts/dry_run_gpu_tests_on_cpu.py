@@ -30,9 +30,9 @@ class _Emulate(object):
             setattr(K, n, getattr(E, n))
 
     def pytest_collection_modifyitems(self, session, config, items):
-        for it in items:
-            if getattr(it.module, "DEV", None) is not None:
-                it.module.DEV = "cpu"
+        for mod in list(sys.modules.values()):   # test modules import helpers (and DEV) from each other
+            if getattr(mod, "__name__", "").startswith("test_") and getattr(mod, "DEV", None) is not None:
+                mod.DEV = "cpu"
 
     @pytest.hookimpl(hookwrapper=True)
     def pytest_runtest_call(self, item):

@@ -212,6 +212,38 @@ def test_host_path_matches_the_reference_neurst_pt_text_transformer(cpu_kernels,
         assert rel_err(model.store.params[n].grad, g) < 2e-5, n
 
 
+@pytest.mark.parametrize("variant", ["pre_norm", "post_norm"])
+def test_training_step_with_dropout_regenerates_the_same_masks_in_backward(cpu_kernels, variant):
+    """Dropout 0.3 at every site (attention probabilities, FFN hidden, wrapper outputs, encoder / decoder inputs): the
+    backward pass regenerates each site's mask from (step seed, site id) -- partly inside the LayerNorm backward kernel
+    that emits the masked gradient for the next sublayer.  The oracle runs with exactly those masks (oracle/philox.py
+    restates the kernels' generator), so logits, loss and every gradient must agree as tightly as without dropout."""
+    from neurst_amd.criterions import build_criterion
+    from oracle import philox
+    extra = {"encoder.post_normalize": True, "decoder.post_normalize": True} if variant == "post_norm" else {}
+    model, cfg, shape = _speech_model("small", dropout=0.3, **extra)
+    if variant == "post_norm":
+        cfg.update({"encoder_post_normalize": True, "decoder_post_normalize": True})
+    cfg["dropout"] = 0.3
+    inputs = _speech_inputs(shape)
+    model.rt.step = 5
+    masks = philox.SiteMasks(model.rt.step_seed, philox.model_dropout_sites(model))
+    W = {n: p.data.detach().clone().double() for n, p in model.store.params.items()}
+    loss_ref, logits_ref, grads_ref = O.train_step_reference(
+        W, {k: (v.double() if v.is_floating_point() else v) for k, v in inputs.items()}, cfg, 0.1, is_training=True,
+        generator=masks)
+    assert len(set(masks.used)) == len(masks.sites) == 2 + 2 * (2 + 2) + 2 * (3 + 3)   # every site was visited once
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(inputs, is_training=True)
+    loss = crit.reduce_loss(inputs, logits)
+    model.backward(crit.backward())
+    assert rel_err(logits, logits_ref) < 1e-5 and abs(float(loss) - float(loss_ref)) < 1e-5
+    for n, p in model.store.params.items():
+        assert rel_err(p.grad, grads_ref[n]) < 5e-5, n
+    # and the masks matter: the eval-mode logits differ
+    assert rel_err(model(inputs, is_training=False), logits_ref) > 1e-2
+
+
 def test_gradient_accumulation_and_clipping_on_cpu(cpu_kernels):
     """TrainStep with update_cycle = 2 averages the micro-batch gradients (gradaccum_keras_model.py:62-109), clips the
     averaged gradients per tensor (:228-233) and applies Keras Adam -- against the oracle's functions."""

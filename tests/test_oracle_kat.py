@@ -3,6 +3,8 @@ data-parallel averaging): closed forms and finite differences.  Parity for these
 reference; these tests only guarantee the restatement is self-consistent with the documented math."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -135,3 +137,24 @@ def test_clip_gradients_known_answers():
     byn = O.clip_gradients(g, clip_norm=1.0)
     assert byn["a"].tolist() == pytest.approx([0.6, -0.8]) and byn["b"].tolist() == pytest.approx([0.3, 0.4])   # ||b|| = 0.5 < 1
     assert O.clip_gradients(g)["a"] is g["a"]
+
+
+def test_philox4x32_matches_random123_known_answers():
+    """oracle/philox.py against Random123's published known-answer vectors (kat_vectors: philox4x32 with 10 and 7 rounds);
+    the kernels run the 7-round variant of the same round function (nst_common.h)."""
+    from oracle import philox as P
+
+    def run(ctr, key, rounds):
+        out = P.philox4x32([ctr[0]], [ctr[1]], [ctr[2]], [ctr[3]], key[0], key[1], rounds=rounds)
+        return [int(w[0]) for w in out]
+    assert run((0, 0, 0, 0), (0, 0), 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run((0xffffffff,) * 4, (0xffffffff,) * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), 10) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert run((0, 0, 0, 0), (0, 0), 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    # 16-bit fields: element idx -> word (idx % 8) // 2 of group idx // 8, low half first; threshold semantics
+    f = P.fields16(seed=0, stream=0, n=8)
+    assert [int(x) for x in f] == [0xb709, 0x5f6f, 0x3f64, 0x0d89, 0x1f81, 0x4f12, 0x0a48, 0x4f73]
+    assert P.dropout_params16(0.25) == (16384, 65536.0 / 49152.0) and P.dropout_params16(0.0)[0] == 0
+    k = P.keep_multiplier(123, 9, 1 << 16, 0.25)
+    assert abs(float((k > 0).mean()) - 0.75) < 0.01 and set(np.unique(k)) == {0.0, 65536.0 / 49152.0}

@@ -202,3 +202,73 @@ def test_hip_path_matches_the_reference_neurst_pt_text_transformer(tag):
     assert float((logits.float().cpu() - logits_ref).abs().max()) < 5e-5 and abs(float(loss) - loss_ref) < 1e-5
     for n, g in grads_ref.items():
         check(f"ref_pt[{tag}].grad.{n}", model.store.params[n].grad, g.double(), 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ dropout masks, bit for bit
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_device_dropout_masks_equal_the_philox_restatement(dtype):
+    """oracle/philox.py (pinned on Random123's known answers) against the masks the kernels really apply: the stand-alone
+    element-wise kernel, the GEMM epilogue and the LayerNorm-backward emission share (seed, site, linear element index)."""
+    from neurst_amd import kernels as K
+    from oracle import philox as P
+    td = torch.float32 if dtype == "float32" else torch.bfloat16
+    for (M, N, p, seed, site) in ((64, 256, 0.1, 7000021, 3), (37, 50, 0.3, (1 << 40) + 12345, 17), (5, 8, 0.5, 1, (1 << 33) + 2)):
+        want = torch.from_numpy(P.keep_multiplier(seed, site, M * N, p)).reshape(M, N)
+        ones = torch.ones(M, N, dtype=td, device=DEV)
+        got = K.scale_dropout_bwd(ones, 1.0, p, seed, site).float().cpu()
+        assert torch.equal(got != 0, want != 0), (M, N, p)
+        check(f"dropout_mask_value[{dtype},{M}x{N}]", got, want, TOL[dtype])
+        eye = torch.eye(N, dtype=td, device=DEV)
+        out = K.gemm(ones, eye, M, N, N, dropout_p=p, seed=seed, stream_id=site).float().cpu()   # ones @ I = ones
+        assert torch.equal(out != 0, want != 0), ("gemm epilogue", M, N, p)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_training_step_with_dropout_matches_oracle_under_the_same_masks(dtype):
+    """The benchmark configuration's dropout sites outside attention (FFN hidden, wrapper outputs, encoder / decoder inputs)
+    switched ON: the oracle applies the masks of oracle/philox.py, the device regenerates them in forward and backward
+    (partly inside the LayerNorm backward kernel).  Attention-probability dropout stays off here: its masks are the
+    kernel's stored keep bits, pinned at kernel level in tests/test_gpu_kernels.py."""
+    from neurst_amd.criterions import build_criterion
+    from oracle import philox
+    rate = 0.1
+    extra = {}
+    for side in ("encoder", "decoder"):
+        extra[f"{side}.ffn_dropout_rate"] = rate
+        extra[f"{side}.layer_postprocess_dropout_rate"] = rate
+    model, inputs, cfg = _speech_case("small", dtype, **extra)
+    model.rt.step = 3
+    masks = philox.SiteMasks(model.rt.step_seed, philox.model_dropout_sites(model))
+
+    class _NoAttention(object):   # rate 0 on the attention sites, `rate` elsewhere
+        def mask_for(self, tag, shape, r):
+            if tag.endswith("_attention"):
+                return torch.ones(shape, dtype=torch.float64)
+            return masks.mask_for(tag, shape, r)
+    cfg["dropout"] = rate
+    W = {n: p.data.detach().cpu().clone() for n, p in model.store.params.items()}
+    if dtype == "bfloat16":
+        for n, p in model.store.params.items():
+            if n.endswith("/kernel") and "conv1" not in n or n.endswith("/weights"):
+                W[n] = p.compute.detach().float().cpu()
+    loss_ref, logits_ref, grads_ref = O.train_step_reference(
+        {k: v.double() for k, v in W.items()}, {k: (v.double() if v.is_floating_point() else v) for k, v in inputs.items()},
+        cfg, 0.1, is_training=True, generator=_NoAttention())
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    loss = crit.reduce_loss(dinp, logits)
+    model.backward(crit.backward())
+    tol, tag = TOL[dtype], f"st_dropout[{dtype}]"
+    check(tag + ".logits", logits, logits_ref, tol * (3 if dtype == "bfloat16" else 1))
+    assert abs(float(loss) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
+    num = den = 0.0
+    for n, p in model.store.params.items():
+        g, r = p.grad.detach().float().cpu().double(), grads_ref[n].double()
+        num += float(((g - r) ** 2).sum())
+        den += float((r ** 2).sum())
+        if dtype == "float32":
+            check(f"{tag}.grad.{n}", p.grad, grads_ref[n], 2e-3)
+    glob = math.sqrt(num / max(den, 1e-30))
+    REPORT[tag + ".grad_global_rel_l2"] = glob
+    assert glob <= (1e-3 if dtype == "float32" else 5e-2), f"{tag}: global gradient rel-L2 error {glob:.3e}"
