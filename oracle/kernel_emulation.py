@@ -136,7 +136,8 @@ def colsum(x, out, accumulate=False):
 
 
 def grad_clip(grad, table, nentries, seg_first, nseg, pre_scale=1.0, clip_value=None, clip_norm=None):
-    assert bool(clip_value) != bool(clip_norm), "exactly one of clip_value / clip_norm"
+    if bool(clip_value) == bool(clip_norm):   # the library reports NST_ERR_INVALID_ARG, the binding raises
+        raise RuntimeError("grad_clip: exactly one of clip_value / clip_norm must be positive")
     rows = table.cpu().numpy().view(np.dtype([("off", "<i8"), ("n", "<i4"), ("seg", "<i4")]))
     first = seg_first.cpu().tolist()
     assert len(rows) == nentries and len(first) == nseg + 1
