@@ -80,3 +80,41 @@ def model_dropout_sites(model):
                 inner = getattr(w.layer, "att", w.layer)
                 sites[inner.name] = inner.site
     return sites
+
+
+def decode_attention_keep_bits(mask, B, H, Tq, Tk):
+    """Keep bits the HIP attention forward stored (nst_attention.hip header; NstAttnDesc.dropout_mask) -> {0,1} tensor
+    [B, H, Tq, Tk].  One u16 per lane and (query block of 16, key tile of 64): lane = g*16 + lc, bit e = f*4 + r stand for
+    query qb*16 + lc and key kt*64 + f*16 + g*4 + r.  (Same decoding as tests/test_gpu_kernels.py::
+    test_attention_dropout_long.)  A floating-point `mask` is the kernel emulation's multiplier tensor: returned as 0/1."""
+    import torch
+    if mask.is_floating_point():
+        return (mask != 0).double()
+    nqb, nkt = (Tq + 15) // 16, (Tk + 63) // 64
+    words = mask.cpu().view(torch.int16).to(torch.int32).bitwise_and(0xffff).reshape(B, H, nqb, nkt, 64)
+    bits = (words[..., None] >> torch.arange(16)) & 1
+    bits = bits.reshape(B, H, nqb, nkt, 4, 16, 4, 4)
+    return bits.permute(0, 1, 2, 5, 3, 6, 4, 7).reshape(B, H, nqb * 16, nkt * 64)[:, :, :Tq, :Tk].double()
+
+
+def model_attention_keep_masks(model):
+    """{scope name of the attention layer: keep mask [B, H, Tq, Tk]} decoded from what the LAST training forward of
+    `model` saved for its backward (call between forward and backward)."""
+    out = {}
+    for stack in (model._encoder._stacking_layers, model._decoder._stacking_layers):
+        for layer in stack:
+            for w in (getattr(layer, "_selfatt_layer", None), getattr(layer, "_crossatt_layer", None)):
+                if w is None:
+                    continue
+                att = getattr(w.layer, "att", w.layer)
+                saved = att._saved
+                (lse, dmask) = next(x for x in saved if isinstance(x, tuple) and len(x) == 2)
+                if dmask is None:
+                    continue
+                Bq, Hh, Tq = lse.shape
+                if hasattr(att, "qkv_transform"):
+                    Tk = Tq
+                else:
+                    Tk = saved[9]     # (query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p, lag)
+                out[att.name] = decode_attention_keep_bits(dmask, Bq, Hh, Tq, Tk)
+    return out

@@ -224,11 +224,12 @@ def test_device_dropout_masks_equal_the_philox_restatement(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-def test_training_step_with_dropout_matches_oracle_under_the_same_masks(dtype):
-    """The benchmark configuration's dropout sites outside attention (FFN hidden, wrapper outputs, encoder / decoder inputs)
-    switched ON: the oracle applies the masks of oracle/philox.py, the device regenerates them in forward and backward
-    (partly inside the LayerNorm backward kernel).  Attention-probability dropout stays off here: its masks are the
-    kernel's stored keep bits, pinned at kernel level in tests/test_gpu_kernels.py."""
+@pytest.mark.parametrize("attention_dropout", [False, True])
+def test_training_step_with_dropout_matches_oracle_under_the_same_masks(attention_dropout, dtype):
+    """The benchmark configuration's dropout (rate 0.1 at every site) switched ON.  Outside attention the oracle applies the
+    masks of oracle/philox.py, which the device regenerates in forward and backward (partly inside the LayerNorm backward
+    kernel).  The attention-probability masks are the keep bits each attention forward stored for its backward: they are
+    decoded (documented layout) between the device's forward and backward and handed to the oracle."""
     from neurst_amd.criterions import build_criterion
     from oracle import philox
     rate = 0.1
@@ -236,14 +237,27 @@ def test_training_step_with_dropout_matches_oracle_under_the_same_masks(dtype):
     for side in ("encoder", "decoder"):
         extra[f"{side}.ffn_dropout_rate"] = rate
         extra[f"{side}.layer_postprocess_dropout_rate"] = rate
+        if attention_dropout:
+            extra[f"{side}.attention_dropout_rate"] = rate
     model, inputs, cfg = _speech_case("small", dtype, **extra)
     model.rt.step = 3
     masks = philox.SiteMasks(model.rt.step_seed, philox.model_dropout_sites(model))
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    att_keep = philox.model_attention_keep_masks(model) if attention_dropout else {}
+    assert len(att_keep) == (2 + 2 * 2 if attention_dropout else 0)
+    loss = crit.reduce_loss(dinp, logits)
+    model.backward(crit.backward())
 
-    class _NoAttention(object):   # rate 0 on the attention sites, `rate` elsewhere
+    class _Masks(object):
         def mask_for(self, tag, shape, r):
             if tag.endswith("_attention"):
-                return torch.ones(shape, dtype=torch.float64)
+                if not attention_dropout:
+                    return torch.ones(shape, dtype=torch.float64)
+                keep = att_keep[tag]
+                assert tuple(keep.shape) == tuple(shape) and abs(float(keep.mean()) - (1 - r)) < 0.05
+                return keep / (1.0 - r)
             return masks.mask_for(tag, shape, r)
     cfg["dropout"] = rate
     W = {n: p.data.detach().cpu().clone() for n, p in model.store.params.items()}
@@ -253,13 +267,8 @@ def test_training_step_with_dropout_matches_oracle_under_the_same_masks(dtype):
                 W[n] = p.compute.detach().float().cpu()
     loss_ref, logits_ref, grads_ref = O.train_step_reference(
         {k: v.double() for k, v in W.items()}, {k: (v.double() if v.is_floating_point() else v) for k, v in inputs.items()},
-        cfg, 0.1, is_training=True, generator=_NoAttention())
-    dinp = {k: v.to(DEV) for k, v in inputs.items()}
-    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
-    logits = model(dinp, is_training=True)
-    loss = crit.reduce_loss(dinp, logits)
-    model.backward(crit.backward())
-    tol, tag = TOL[dtype], f"st_dropout[{dtype}]"
+        cfg, 0.1, is_training=True, generator=_Masks())
+    tol, tag = TOL[dtype], f"st_dropout[{dtype},att{int(attention_dropout)}]"
     check(tag + ".logits", logits, logits_ref, tol * (3 if dtype == "bfloat16" else 1))
     assert abs(float(loss) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
     num = den = 0.0
