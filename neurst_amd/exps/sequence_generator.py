@@ -1,7 +1,8 @@
 """SequenceGenerator, entry "predict" / "generation" (neurst/exps/sequence_generator.py:36-235): restores the latest
 checkpoint of model_dir, decodes the dataset batch by batch with the configured search layer and writes one hypothesis
-per line.  Evaluation metrics (BLEU / WER, :163-235) are out of scope: `output_file` is the product; without a target
-vocabulary pipeline the hypotheses are written as space-separated ids.
+per line; with `--metric` (tok_bleu / detok_bleu / WER ..., neurst_amd/metrics) and a dataset that carries references the
+score is logged and returned in `self.metric_result` (:163-235).  Without a target vocabulary pipeline the hypotheses
+are written as space-separated ids.
 """
 import logging
 
@@ -9,6 +10,7 @@ import torch
 
 from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
 from neurst_amd.layers.search import SequenceSearch, build_search_layer
+from neurst_amd.metrics import Metric, build_metric
 from neurst_amd.utils import compat
 from neurst_amd.utils.checkpoints import restore_checkpoint_if_possible
 from neurst_amd.utils.flags_core import Flag, ModuleFlag
@@ -21,11 +23,16 @@ class SequenceGenerator(BaseExperiment):
         self._output_file = args.get("output_file", None)
         self._batch_size = args.get("batch_size", None) or 32
         self._search_layer = build_search_layer(args) or build_search_layer({"search_method.class": "beam_search"})
+        self._metric = build_metric(args) if args.get("metric.class", None) else None
+        if self._metric is not None:
+            self._metric.flag = args["metric.class"]
+        self.metric_result = None
 
     @staticmethod
     def class_or_method_args():
         return [
             ModuleFlag(SequenceSearch.REGISTRY_NAME, default="beam_search", help="The search layer for sequence generation."),
+            ModuleFlag(Metric.REGISTRY_NAME, default=None, help="The evaluation metric for the generation results."),
             Flag("output_file", dtype=Flag.TYPE.STRING, default=None, help="The path to a file for generated outputs."),
             Flag("batch_size", dtype=Flag.TYPE.INTEGER, default=32, help="Utterances / sentences per decoding batch."),
         ]
@@ -65,4 +72,8 @@ class SequenceGenerator(BaseExperiment):
             with open(self._output_file, "w", encoding="utf-8") as fw:
                 fw.write("\n".join(results) + "\n")
             logging.info("Saving generation results into %s", self._output_file)
+        refs = getattr(self.custom_dataset, "raw_targets", None) or getattr(self.custom_dataset, "targets", None)
+        if self._metric is not None and refs is not None and len(refs) == len(results) and all(isinstance(r, str) for r in refs):
+            self.metric_result = self._metric(results, list(refs))
+            logging.info("Evaluation Result: %s", ", ".join(f"{k}={v:.2f}" for k, v in self.metric_result.items()))
         return results

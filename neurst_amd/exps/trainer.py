@@ -15,6 +15,7 @@ from neurst_amd.data.prefetch import Prefetcher
 from neurst_amd.exps.base_experiment import BaseExperiment, register_exp
 from neurst_amd.optimizers import build_lr_schedule, build_optimizer
 from neurst_amd.training.distributed import GradientReducer
+from neurst_amd.training import seq_generation_validator  # noqa: F401  (registers SeqGenerationValidator)
 from neurst_amd.training.criterion_validator import Validator, build_validator
 from neurst_amd.training.train_step import TrainStep
 from neurst_amd.utils import compat
@@ -145,6 +146,12 @@ class Trainer(BaseExperiment):
                 frames = frames + float(0)  # keep host free of syncs between summaries
             if rank == 0 and self._save_checkpoint_steps and step % self._save_checkpoint_steps == 0:
                 self._save(step)
-            if rank == 0 and self._validator is not None and self._validator.due(step):
-                self._validator.validate(step)
+            if self._validator is not None and self._validator.due(step):
+                if rank == 0:
+                    self._validator.validate(step)
+                # early stopping (eval_estop_patience) is decided on rank 0 and agreed on by every rank at the same step
+                stop = reducer.reduce_metrics({"stop": 1.0 if (rank == 0 and getattr(self._validator, "should_stop", False)) else 0.0})
+                if stop["stop"] > 0:
+                    logging.info("early stop at step %d", step)
+                    break
         return last_loss

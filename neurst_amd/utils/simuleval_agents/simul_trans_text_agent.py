@@ -14,7 +14,6 @@ SimulEval itself is not installed in this image.  When it is importable the clas
 actions / states; otherwise the stand-ins at the bottom of this file provide the few attributes the agent touches and
 `run_agent_on_sentence` plays the client loop for one sentence, so the agent (and its latency) can be exercised locally.
 """
-import collections
 import logging
 
 import torch

@@ -622,6 +622,48 @@ def gen_neurst_pt_transformer():
         save("neurst_pt_" + tag, **arrays)
 
 
+def gen_metrics():
+    """Outputs of the reference's pure-Python metric functions (neurst/metrics/bleu.py: bleu_count, corpus_bleu,
+    sentence_bleu, commonly_tokenize, unescape; neurst/metrics/wer.py: _wer) on a small multi-reference corpus, stored as
+    JSON.  The modules import sacrebleu / sacremoses-based tokenizers at the top: those imports are stubbed (the functions
+    recorded here do not touch them)."""
+    import json
+    _install_shim()
+    for name in ("sacrebleu", "neurst.data", "neurst.data.text", "neurst.data.text.character",
+                 "neurst.data.text.moses_tokenizer", "neurst.data.text.thai_tokenizer", "neurst.data.data_pipelines",
+                 "neurst.data.data_pipelines.data_pipeline", "neurst.metrics"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["neurst.data.text.character"].Character = object
+    sys.modules["neurst.data.text.moses_tokenizer"].MosesTokenizer = object
+    sys.modules["neurst.data.text.thai_tokenizer"].ThaiTokenizer = object
+    sys.modules["neurst.data.data_pipelines.data_pipeline"].lowercase_and_remove_punctuations = None
+    sys.modules["neurst.metrics"].register_metric = lambda names: (lambda c: c)
+    _load("neurst.metrics.metric")
+    bleu, wer = _load("neurst.metrics.bleu"), _load("neurst.metrics.wer")
+    hyps = ["the cat sat on the mat .", "there is a cat on the mat", "he said : &quot; hello , world ! &quot;",
+            "a", "the the the the the the the", "prices rose 3.5 % in 2020 , e.g. by 1,000 $", ""]
+    refs = [["the cat is on the mat .", "there is a cat on the mat ."], ["the cat sat on the mat", "a cat is on the mat"],
+            ["he said : \" hello world ! \"", "he says hello , world"], ["a b", "a"],
+            ["the cat is on the mat", "there is a cat on the mat"], ["prices rose 3.5 % in 2020", "prices rose by 1,000 $ , e.g."],
+            ["nothing", "at all here"]]
+    raw = ["Hello, world! It's 3.5-4% (approx.) -- e.g. U.S.A.", "a&amp;b &lt;tag&gt; x-\ny 10-12", "don&apos;t [stop] | now",
+           "end.", "1,234.5 and .5, 5."]
+    out = {"hyps": hyps, "refs": refs, "raw": raw,
+           "bleu_count": bleu.bleu_count(hyps[:6], refs[:6]), "corpus_bleu": bleu.corpus_bleu(hyps[:6], refs[:6]),
+           "corpus_bleu_single": bleu.corpus_bleu(hyps[:3], [r[:1] for r in refs[:3]]),
+           "corpus_bleu_2gram": bleu.corpus_bleu(hyps[:6], refs[:6], max_n=2),
+           "sentence_bleu": [bleu.sentence_bleu(h, r) for h, r in zip(hyps, refs) if h],
+           "commonly_tokenize": [bleu.commonly_tokenize(x) for x in raw + hyps], "unescape": [bleu.unescape(x) for x in raw + hyps],
+           "wer": [list(wer._wer(r[0].split(), h.split())) for h, r in zip(hyps, refs)]
+           + [list(wer._wer(list("kitten"), list("sitting"))), list(wer._wer([], ["a"])), list(wer._wer(["a", "b"], []))]}
+    path = os.path.join(OUT, "metrics.json")
+    with open(path, "w") as fp:
+        json.dump(out, fp, indent=1, ensure_ascii=False)
+    print("wrote", path)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -631,6 +673,7 @@ def main():
     gen_neurst_pt_frontend()
     gen_neurst_pt_speech_transformer()
     gen_neurst_pt_transformer()
+    gen_metrics()
 
 
 if __name__ == "__main__":

@@ -6,7 +6,6 @@ here WITHOUT a GPU by installing oracle/kernel_emulation.py (a float64 restateme
 This does not test the HIP kernels (tests/test_gpu_*.py do, through the C ABI); it pins the orchestration around
 them, so that a scheduling mistake in a backward pass shows up in the `-m "not gpu"` suite already."""
 import inspect
-import math
 import os
 import socket
 import sys
@@ -650,3 +649,57 @@ def test_simuleval_cli_from_a_model_dir(cpu_kernels, tmp_path, capsys):
     agent = A.SimulTransTextAgent(argparse.Namespace(wait_k=2, model_dir=str(avg), device="cpu", max_len=6))
     assert torch.allclose(agent.models[0].store.master, 2.0 * w0, rtol=1e-6, atol=1e-7)
     assert agent.models[0].wait_k == 2 and agent.src_pipeline.meta["language"] == "de"
+
+
+def test_seq_generation_validator_keeps_and_averages_the_best_checkpoints(cpu_kernels, tmp_path):
+    """SeqGenerationValidator (seq_generation_validator.py:30-290): decode the validation set with beam search, score with
+    the registered metric, keep the best checkpoints under <model_dir>_best, refresh their average, stop after
+    `eval_estop_patience` validations without improvement."""
+    from neurst_amd.models.transformer import Transformer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.training import seq_generation_validator  # noqa: F401  (registers the class)
+    from neurst_amd.training.criterion_validator import build_validator
+    from neurst_amd.utils.checkpoints import latest_checkpoint
+    words = ["a", "b", "c", "d", "e"]
+    task = build_task({"task.class": "Seq2Seq", "task.params": {"src_data_pipeline.params": {"vocab_path": words},
+                                                                 "trg_data_pipeline.params": {"vocab_path": words}}})
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    model = task.build_model({"model.class": "Transformer", "model.params": p}, device="cpu", dtype="float32", init_seed=4)
+    (tmp_path / "src.txt").write_text("a b c\nd e\nc c a b\n")
+    (tmp_path / "trg.txt").write_text("a b c\nd e\nc c a b\n")
+    model_dir = str(tmp_path / "run")
+    v = build_validator({"validator.class": "SeqGenerationValidator", "validator.params": {
+        "eval_steps": 10, "eval_dataset.class": "ParallelTextDataset",
+        "eval_dataset.params": {"src_file": str(tmp_path / "src.txt"), "trg_file": str(tmp_path / "trg.txt"), "data_is_processed": True},
+        "eval_metric.class": "tok_bleu", "eval_search_method.class": "beam_search",
+        "eval_search_method.params": {"beam_size": 2, "maximum_decode_length": 6, "extra_decode_length": 2},
+        "eval_top_checkpoints_to_keep": 2, "eval_estop_patience": 2, "eval_batch_size": 2}})
+    assert v.due(10) and not v.due(15)
+    v.build(task, model, model_dir)
+    hyps = v.generate()
+    assert len(hyps) == 3 and all(isinstance(h, str) for h in hyps)
+
+    scores = iter([5.0, 7.0, 6.0, 6.5])     # the metric's verdicts for steps 10..40 (the toy model itself is random)
+
+    class _Scripted(type(v._gen_metric)):
+        def call(self, hypothesis, groundtruth=None):
+            assert len(hypothesis) == 3
+            return {"tok_bleu": next(scores)}
+    v._gen_metric.__class__ = _Scripted
+    w0 = model.store.master.clone()
+    res = v.validate(10)
+    assert res["tok_bleu"] == 5.0 and "NLL" in res and v.gen_best["tok_bleu"] == 5.0
+    model.store.master.mul_(2.0)
+    v.validate(20)                            # better: second checkpoint, average of both
+    assert v.gen_best["tok_bleu"] == 7.0 and latest_checkpoint(model_dir + "_best").endswith("ckpt-20")
+    from neurst_amd.utils import tensor_bundle as tb
+    avg = tb.read_bundle(latest_checkpoint(model_dir + "_best_avg"))
+    name, prm = next(iter(model.store.params.items()))
+    key = tb.checkpoint_key(f"{model.name or model.__class__.__name__}/{name}")
+    want = 1.5 * w0[prm.offset:prm.offset + prm.numel].view(prm.shape)
+    assert torch.allclose(torch.from_numpy(avg[key]), want, rtol=1e-6, atol=1e-7)
+    v.validate(30)
+    assert not v.should_stop and v.gen_best["tok_bleu"] == 7.0
+    v.validate(40)
+    assert v.should_stop and [s for s, _ in v.gen_history] == [10, 20, 30, 40]
+    assert sorted(f for f in os.listdir(model_dir + "_best") if f.endswith(".index")) == ["ckpt-10.index", "ckpt-20.index"]
