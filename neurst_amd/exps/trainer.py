@@ -135,7 +135,8 @@ class Trainer(BaseExperiment):
             frames_dev = sum(b["src_length"].sum() for b in batches)
             last_loss = step_fn(batches)
             if step % self._summary_steps == 0 or step == self._train_steps:
-                torch.cuda.synchronize()
+                if rt.device.type == "cuda":
+                    torch.cuda.synchronize()
                 dt = time.time() - t0
                 m = reducer.reduce_metrics({"loss": float(last_loss) / world, "src_real_tokens": float(frames_dev) + frames})
                 if rank == 0:

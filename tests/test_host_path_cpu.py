@@ -703,3 +703,72 @@ def test_seq_generation_validator_keeps_and_averages_the_best_checkpoints(cpu_ke
     v.validate(40)
     assert v.should_stop and [s for s, _ in v.gen_history] == [10, 20, 30, 40]
     assert sorted(f for f in os.listdir(model_dir + "_best") if f.endswith(".index")) == ["ckpt-10.index", "ckpt-20.index"]
+
+
+def test_cli_flow_train_validate_resume_predict_on_cpu(cpu_kernels, tmp_path):
+    """The `neurst-run` flow end to end over the emulated kernels: flag / yaml parsing (run_exp.py), Trainer with a
+    SeqGenerationValidator, TensorFlow-format checkpoints + model_configs.yml, resume, then the `predict` entry with a
+    metric.  (tests/test_gpu_model.py::test_cli_training_from_tfrecord_shards is the same flow on the MI355X.)"""
+    import random
+    import yaml
+    import neurst_amd.utils.flags_core as flags_core
+    from neurst_amd.cli import run_exp as R
+    from neurst_amd.data.datasets import build_dataset
+    from neurst_amd.exps import build_exp
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils.checkpoints import latest_checkpoint
+    words = [chr(ord("a") + i) for i in range(8)]
+    rng = random.Random(1)
+    lines = [" ".join(rng.choice(words) for _ in range(rng.randint(2, 5))) for _ in range(64)]
+    for name, rows in (("train", lines), ("dev", lines[:6])):
+        (tmp_path / f"{name}.src").write_text("\n".join(rows) + "\n")
+        (tmp_path / f"{name}.trg").write_text("\n".join(rows) + "\n")        # copy task
+    (tmp_path / "vocab.txt").write_text("\n".join(words) + "\n")
+    dp = {"vocab_path": str(tmp_path / "vocab.txt")}
+    cfg = {"task.class": "translation",
+           "task.params": {"src_data_pipeline.params": dp, "trg_data_pipeline.params": dp, "batch_size": 160, "max_src_len": 12,
+                           "max_trg_len": 12, "batch_by_tokens": True},
+           "dataset.class": "ParallelTextDataset",
+           "dataset.params": {"src_file": str(tmp_path / "train.src"), "trg_file": str(tmp_path / "train.trg"), "data_is_processed": True},
+           "entry.class": "trainer",
+           "entry.params": {"train_steps": 40, "summary_steps": 20, "save_checkpoint_steps": 20, "optimizer.class": "Adam",
+                            "optimizer.params": {"learning_rate": 0.01, "beta_1": 0.9, "beta_2": 0.98, "epsilon": 1e-9},
+                            "lr_schedule.class": "piecewise",
+                            "lr_schedule.params": {"schedule_steps": [5], "schedule_lrs": [0.01, 0.01]},
+                            "validator.class": "SeqGenerationValidator",
+                            "validator.params": {"eval_steps": 20, "eval_dataset.class": "ParallelTextDataset",
+                                                 "eval_dataset.params": {"src_file": str(tmp_path / "dev.src"),
+                                                                         "trg_file": str(tmp_path / "dev.trg"), "data_is_processed": True},
+                                                 "eval_metric.class": "tok_bleu", "eval_search_method.class": "beam_search",
+                                                 "eval_search_method.params": {"beam_size": 2, "maximum_decode_length": 8},
+                                                 "eval_top_checkpoints_to_keep": 2}}}
+    (tmp_path / "cfg.yml").write_text(yaml.dump(cfg))
+    model_dir = str(tmp_path / "out")
+
+    def launch(extra):
+        argv = ["--config_paths", str(tmp_path / "cfg.yml"), "--hparams_set", "transformer_toy", "--model_dir", model_dir,
+                "--dtype", "float32", "--distribution_strategy", "none"] + extra
+        parser = flags_core.define_flags(R.FLAG_LIST, argv=argv)
+        args, _ = flags_core.intelligent_parse_flags(R.FLAG_LIST, parser, R._pre_load_args, argv=argv)
+        task = build_task(args)
+        ds = build_dataset(args)
+        model = task.build_model(args, device="cpu", dtype="float32", seed=args["seed"])   # run_experiment() with device=cpu
+        for k in list(model.args):
+            assert not k.endswith("dropout_rate") or model.args[k] == 0.1
+        entry = build_exp(args, strategy="none", model=model, task=task, model_dir=args["model_dir"], custom_dataset=ds)
+        return entry, entry.run()
+    trainer, loss = launch([])
+    assert float(loss) < 2.2                                   # from ~2.4 (ln 11 + smoothing) on the copy task
+    assert latest_checkpoint(model_dir).endswith("ckpt-40") and os.path.exists(os.path.join(model_dir, "model_configs.yml"))
+    v = trainer._validator
+    assert [s for s, _ in v.gen_history] == [20, 40] and [s for s, _ in v.history] == [20, 40]
+    assert latest_checkpoint(model_dir + "_best") is not None and latest_checkpoint(model_dir + "_best_avg") is not None
+    # resume: the second invocation starts at step 41 (optimizer state restored) and stops at train_steps
+    trainer2, _ = launch(["--train_steps", "45"])
+    assert latest_checkpoint(model_dir).endswith("ckpt-40") and trainer2.model.rt.step == 5
+    # predict entry with a metric, from the same model_dir
+    out = tmp_path / "hyp.txt"
+    gen, hyps = launch(["--entry", "predict", "--dataset.params", yaml.dump(cfg["entry.params"]["validator.params"]["eval_dataset.params"]),
+                        "--output_file", str(out), "--metric", "tok_bleu", "--search_method.params", "{'beam_size': 2, 'maximum_decode_length': 8}"])
+    assert len(hyps) == 6 and out.read_text().strip().splitlines() == hyps
+    assert gen.metric_result is not None and 0.0 <= gen.metric_result["tok_bleu"] <= 100.0
