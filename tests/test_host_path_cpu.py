@@ -772,3 +772,25 @@ def test_cli_flow_train_validate_resume_predict_on_cpu(cpu_kernels, tmp_path):
                         "--output_file", str(out), "--metric", "tok_bleu", "--search_method.params", "{'beam_size': 2, 'maximum_decode_length': 8}"])
     assert len(hyps) == 6 and out.read_text().strip().splitlines() == hyps
     assert gen.metric_result is not None and 0.0 <= gen.metric_result["tok_bleu"] <= 100.0
+
+
+def test_top_sampling_with_k1_equals_greedy_beam_search_on_the_model(cpu_kernels):
+    """The registered `TopSampling` search drives the model's incremental decoder like the beam search does: with top_k = 1
+    its hypotheses are the greedy ones (beam_size 1, no length penalty effect on a single beam)."""
+    from neurst_amd.layers.search import build_search_layer
+    model, cfg, shape = _speech_model("toy")
+    inputs = {k: v for k, v in _speech_inputs(shape).items() if k.startswith("src")}
+    greedy = build_search_layer({"search_method.class": "beam_search",
+                                 "search_method.params": {"beam_size": 1, "maximum_decode_length": 6, "extra_decode_length": 2}})
+    samp = build_search_layer({"search_method.class": "TopSampling",
+                               "search_method.params": {"top_k": 1, "maximum_decode_length": 6, "extra_decode_length": 2, "seed": 7}})
+    h_greedy, _ = greedy(model, inputs)
+    h_samp, _ = samp(model, inputs)
+    eos = shape[4] - 1
+    for a, b in zip(h_greedy.tolist(), h_samp.tolist()):     # compare up to and including the first EOS
+        cut = a.index(eos) + 1 if eos in a else len(a)
+        assert a[:cut] == b[:cut]
+    three = build_search_layer({"search_method.class": "TopSampling",
+                                "search_method.params": {"sample_num": 3, "top_p": 0.8, "maximum_decode_length": 6, "seed": 1}})
+    h3, _ = three(model, inputs)
+    assert h3.shape == (shape[0] * 3, 6) and three.top_k == 3

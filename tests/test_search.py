@@ -93,3 +93,62 @@ def test_beam_search_matches_oracle(beam, top_k, alpha, min_len, eos_boost, enab
     if min_len:
         assert all((row + [eos]).index(eos) >= min_len - 1 for row in got_h.tolist())
     assert (got_h[:, 9:] == eos).all()            # min(5 + 4, 12) = 9 search steps, the rest is EOS padding
+
+
+# ------------------------------------------------------------------------------------------------ sampling search
+def test_top_k_and_top_p_filters():
+    """sampling.py:67-92 on hand-checked rows."""
+    import math
+    from neurst_amd.layers.search.sampling import top_k_logits, top_p_logits
+    FM = -1e9
+    lg = torch.tensor([[1.0, 3.0, 2.0, 0.0], [0.5, 0.5, -1.0, 4.0]])
+    assert torch.equal(top_k_logits(lg, 0), lg)
+    assert top_k_logits(lg, 2).tolist() == [[FM, 3.0, 2.0, FM], [0.5, 0.5, FM, 4.0]]      # ties at the k-th value stay
+    assert top_k_logits(lg, 1).tolist() == [[FM, 3.0, FM, FM], [FM, FM, FM, 4.0]]
+    # probabilities of row 0 in descending order: 3 -> .644, 2 -> .237, 1 -> .087, 0 -> .032
+    p = torch.softmax(lg[0], -1)
+    assert abs(float(p[1]) - math.exp(3) / sum(math.exp(x) for x in (1, 3, 2, 0))) < 1e-6
+    assert top_p_logits(lg[:1], 0.5).tolist() == [[FM, 3.0, FM, FM]]          # .644 already reaches .5
+    assert top_p_logits(lg[:1], 0.7).tolist() == [[FM, 3.0, 2.0, FM]]         # .644 < .7 <= .881
+    assert top_p_logits(lg[:1], 0.9).tolist() == [[1.0, 3.0, 2.0, FM]]
+    assert top_p_logits(lg[:1], 1.0).tolist()[0][:3] == [1.0, 3.0, 2.0]
+
+
+def test_sampling_search_on_a_toy_language_model():
+    """sequence_sampling_search (sampling.py:95-283): top_k = 1 is the greedy roll-out; UNK is never drawn; EOS is not drawn
+    before the minimum length; `sample_num` continuations per input; reproducible for a seed."""
+    from neurst_amd.layers.search.sampling import Sampling, sequence_sampling_search, top_k_logits
+    V, eos, unk, bos = 7, 6, 4, 5
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(V, V, generator=g) * 2.0
+
+    def fn(ids, cache, time):       # a first-order "language model": next-token logits depend on the previous token and time
+        return table[ids] + 0.1 * time
+    init = {"decoder_input": torch.tensor([bos, 1, 2]), "decoder_internal_cache": {}, "encoder_inputs_maxlen": 5, "eos_id": eos,
+            "unk_id": unk}
+    hyp = sequence_sampling_search(fn, init, lambda lg: top_k_logits(lg, 1), sample_num=1, extra_decode_length=3,
+                                   maximum_decode_length=12, minimum_decode_length=0)
+    assert hyp.shape == (3, 12)
+    for b, first in enumerate((bos, 1, 2)):
+        prev, t = first, 0
+        while t < 8:
+            lg = table[prev] + 0.1 * t
+            lg[unk] = -1e9
+            nxt = int(lg.argmax())
+            assert int(hyp[b, t]) == nxt
+            prev, t = nxt, t + 1
+            if nxt == eos:
+                break
+    assert (hyp[:, 8:] == eos).all()                                    # 5 + 3 search steps, then EOS padding
+    gen = torch.Generator().manual_seed(3)
+    many = sequence_sampling_search(fn, init, lambda lg: lg, sample_num=50, extra_decode_length=3, maximum_decode_length=8,
+                                    minimum_decode_length=4, generator=gen, sync_every=1)
+    assert many.shape == (150, 8) and not (many == unk).any() and not (many[:, :3] == eos).any()
+    assert len({tuple(r) for r in many[:50].tolist()}) > 5              # the copies of one input really differ
+    again = sequence_sampling_search(fn, init, lambda lg: lg, sample_num=50, extra_decode_length=3, maximum_decode_length=8,
+                                     minimum_decode_length=4, generator=torch.Generator().manual_seed(3), sync_every=1)
+    assert torch.equal(many, again)
+    s = Sampling({"sample_num": 2, "top_p": 0.9, "maximum_decode_length": 8, "seed": 1})
+    assert s.top_k == 2
+    with pytest.raises(NotImplementedError):
+        Sampling({"top_p": 0.5, "top_k": 3})
