@@ -35,9 +35,30 @@ def load_reference_pt_case(tag):
     r, W = load_golden(tag)
     grads = {k[2:]: torch.from_numpy(v) for k, v in r.items() if k.startswith("g:")}
     inputs = {k: torch.from_numpy(r[k]) for k in ("src", "src_length", "trg", "trg_input", "trg_length")}
+    post = bool(int(r["post_norm"])) if "post_norm" in r else False
     cfg = {"num_enc": int(r["n_enc"]), "num_dec": int(r["n_dec"]), "num_heads": 2, "layer_norm": True,
-           "timing": str(r["timing"]) or None}
+           "timing": str(r["timing"]) or None, "encoder_post_normalize": post, "decoder_post_normalize": post}
     return inputs, W, cfg, torch.from_numpy(r["expected_logits"]), float(r["expected_loss"]), grads
+
+
+def build_speech_model_for_reference_case(W, cfg, logits_ref, device, dtype="float32"):
+    """speech_transformer_toy with the layer counts / timing / post-norm / weight tying of a reference-PT golden case,
+    loaded with the golden's weights."""
+    from neurst_amd.models import build_model
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    p = dict(get_hyper_parameters("speech_transformer_toy")["model.params"])
+    p.update({"encoder.num_layers": cfg["num_enc"], "decoder.num_layers": cfg["num_dec"], "modality.timing": cfg["timing"],
+              "encoder.post_normalize": cfg["encoder_post_normalize"], "decoder.post_normalize": cfg["decoder_post_normalize"],
+              "modality.share_embedding_and_softmax_weights": "softmax_linear/kernel" not in W})
+    for k in list(p):
+        if k.endswith("dropout_rate"):
+            p[k] = 0.0
+    V = logits_ref.shape[-1]
+    model = build_model({"model.class": "SpeechTransformer", "model.params": p}, {"audio_feature_dim": 80, "audio_feature_channels": 1},
+                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=device, dtype=dtype)
+    assert set(model.store.params) == set(W), set(model.store.params) ^ set(W)
+    model.store.load_state_dict(W)
+    return model
 
 
 def load_reference_pt_text_case(tag):

@@ -457,8 +457,13 @@ def _tf_names_of_pt_speech_transformer(model, n_enc, n_dec):
     out[f"{A}/output_dense/kernel"] = (fe._dense_layer.weight, lambda w: w.t())
     out[f"{A}/output_dense/bias"] = (fe._dense_layer.bias, None)
     te = getattr(model._trg_modality, "embedding_layer", model._trg_modality)
-    out["target_symbol_modality/shared/weights"] = (te._shared_weights, None)
-    out["target_symbol_modality/shared/bias"] = (te._bias, None)
+    if getattr(model, "_output_linear_layer", None) is not None:   # untied logits (encoder_decoder_model.py:61-63): Keras Dense
+        out["target_symbol_modality/emb/weights"] = (te._shared_weights, None)
+        out["softmax_linear/kernel"] = (model._output_linear_layer.weight, lambda w: w.t())
+        out["softmax_linear/bias"] = (model._output_linear_layer.bias, None)
+    else:
+        out["target_symbol_modality/shared/weights"] = (te._shared_weights, None)
+        out["target_symbol_modality/shared/bias"] = (te._bias, None)
     return _tf_names_of_pt_stacks(model, n_enc, n_dec, out)
 
 
@@ -483,8 +488,9 @@ def _tf_names_of_pt_stacks(model, n_enc, n_dec, out):
         att(f"{p}/self_attention_prepost_wrapper/self_attention", L[0],
             [("qkv_transform", "_qkv_transform_layer"), ("output_transform", "_output_transform_layer")])
         ffn(f"{p}/ffn_prepost_wrapper", L[1])
-    out["TransformerEncoder/output_ln/gamma"] = (model._encoder._output_norm_layer.weight, None)
-    out["TransformerEncoder/output_ln/beta"] = (model._encoder._output_norm_layer.bias, None)
+    if hasattr(model._encoder, "_output_norm_layer"):      # absent in post-norm stacks (transformer_encoder.py:101-102)
+        out["TransformerEncoder/output_ln/gamma"] = (model._encoder._output_norm_layer.weight, None)
+        out["TransformerEncoder/output_ln/beta"] = (model._encoder._output_norm_layer.bias, None)
     for i in range(n_dec):
         L = model._decoder._stacking_layers[i]
         p = f"TransformerDecoder/layer_{i}"
@@ -494,8 +500,9 @@ def _tf_names_of_pt_stacks(model, n_enc, n_dec, out):
             [("q_transform", "_q_transform_layer"), ("kv_transform", "_kv_transform_layer"),
              ("output_transform", "_output_transform_layer")])
         ffn(f"{p}/ffn_prepost_wrapper", L[2])
-    out["TransformerDecoder/output_ln/gamma"] = (model._decoder._output_norm_layer.weight, None)
-    out["TransformerDecoder/output_ln/beta"] = (model._decoder._output_norm_layer.bias, None)
+    if hasattr(model._decoder, "_output_norm_layer"):
+        out["TransformerDecoder/output_ln/gamma"] = (model._decoder._output_norm_layer.weight, None)
+        out["TransformerDecoder/output_ln/beta"] = (model._decoder._output_norm_layer.bias, None)
     return out
 
 
@@ -510,7 +517,12 @@ def gen_neurst_pt_speech_transformer():
     _functional_registry()
     st = _load("neurst_pt.models.speech_transformer")
     cases = {"st_1x1": dict(n_enc=1, n_dec=1, timing=None, B=1, T=11, L=3, V=5, lens=[11], tlens=[3]),
-             "st_2x2_ragged": dict(n_enc=2, n_dec=2, timing="sinusoids", B=3, T=23, L=5, V=9, lens=[23, 17, 9], tlens=[5, 4, 2])}
+             "st_2x2_ragged": dict(n_enc=2, n_dec=2, timing="sinusoids", B=3, T=23, L=5, V=9, lens=[23, 17, 9], tlens=[5, 4, 2]),
+             # post-norm wrappers (common_layers.py:105-110 of neurst_pt), no output_ln, untied logits: the flags are not in
+             # the PT model's flag list, so the encoder / decoder are built with them directly (new()'s own steps); no timing:
+             # the PT untied path reads `embedding_dim` off the position wrapper, which does not define it
+             "st_2x2_postnorm_untied": dict(n_enc=2, n_dec=2, timing=None, B=3, T=19, L=4, V=9, lens=[19, 12, 9],
+                                            tlens=[4, 3, 2], post_norm=True, untied=True)}
     for tag, c in cases.items():
         torch.manual_seed(11)
         rng = np.random.RandomState(11)
@@ -523,8 +535,22 @@ def gen_neurst_pt_speech_transformer():
             args.update({f"{side}.num_layers": n, f"{side}.hidden_size": d, f"{side}.num_attention_heads": H,
                          f"{side}.filter_size": ffn_, f"{side}.attention_dropout_rate": 0.0,
                          f"{side}.ffn_dropout_rate": 0.0, f"{side}.layer_postprocess_dropout_rate": 0.0})
-        model = st.SpeechTransformer.new(args, dict(audio_feature_dim=Fdim, audio_feature_channels=1),
-                                         dict(vocab_size=c["V"], eos_id=c["V"] - 1, bos_id=c["V"] - 2, unk_id=c["V"] - 3))
+        src_meta = dict(audio_feature_dim=Fdim, audio_feature_channels=1)
+        trg_meta = dict(vocab_size=c["V"], eos_id=c["V"] - 1, bos_id=c["V"] - 2, unk_id=c["V"] - 3)
+        if c.get("untied"):
+            args["modality.share_embedding_and_softmax_weights"] = False
+        if c.get("post_norm"):
+            src_mod, trg_mod = st.SpeechTransformer.build_modalities(args, src_meta, trg_meta)
+            enc_p = {k[8:]: v for k, v in args.items() if k.startswith("encoder.")}
+            dec_p = {k[8:]: v for k, v in args.items() if k.startswith("decoder.")}
+            enc_p["post_normalize"] = dec_p["post_normalize"] = True
+            from neurst_pt.layers.decoders import build_decoder
+            from neurst_pt.layers.encoders import build_encoder
+            model = st.SpeechTransformer(args, src_meta, trg_meta, src_mod, trg_mod,
+                                         build_encoder({"encoder.class": "TransformerEncoder", "encoder.params": enc_p}),
+                                         build_decoder({"decoder.class": "TransformerDecoder", "decoder.params": dec_p}))
+        else:
+            model = st.SpeechTransformer.new(args, src_meta, trg_meta)
         names = _tf_names_of_pt_speech_transformer(model, c["n_enc"], c["n_dec"])
         for n, (prm, _) in names.items():   # non-trivial biases / LayerNorm affine so every gradient path is exercised
             if n.endswith("/bias") or n.endswith("/beta"):
@@ -552,7 +578,8 @@ def gen_neurst_pt_speech_transformer():
         arrays = {"src": src, "src_length": np.array(c["lens"], np.int64), "trg": trg, "trg_input": trg_input,
                   "trg_length": np.array(c["tlens"], np.int64), "expected_logits": logits.detach().numpy(),
                   "expected_loss": np.array(float(loss.detach()), np.float64), "n_enc": np.array(c["n_enc"]),
-                  "n_dec": np.array(c["n_dec"]), "timing": np.array(c["timing"] or "")}
+                  "n_dec": np.array(c["n_dec"]), "timing": np.array(c["timing"] or ""),
+                  "post_norm": np.array(int(bool(c.get("post_norm")))), "untied": np.array(int(bool(c.get("untied"))))}
         for (n, (prm, tr)), g in zip(names.items(), grads):
             val = prm.detach() if tr is None else tr(prm.detach())
             arrays["w:" + n] = np.ascontiguousarray(val.numpy())

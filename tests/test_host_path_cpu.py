@@ -168,25 +168,15 @@ def test_post_norm_and_untied_softmax_host_schedule(cpu_kernels, variant):
     assert rel_err(model(inputs, is_training=False), logits_ref) < 1e-5
 
 
-@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged"])
+@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged", "neurst_pt_st_2x2_postnorm_untied"])
 def test_host_path_matches_the_reference_neurst_pt_speech_transformer(cpu_kernels, tag):
     """Logits, loss and every gradient of the layer classes (over the emulated kernels) against the reference's own
-    PyTorch SpeechTransformer + autograd (tests/golden/make_golden.py: gen_neurst_pt_speech_transformer)."""
-    from conftest import load_reference_pt_case
+    PyTorch SpeechTransformer + autograd (tests/golden/make_golden.py: gen_neurst_pt_speech_transformer), including its
+    post-norm stacks with untied logits."""
+    from conftest import build_speech_model_for_reference_case, load_reference_pt_case
     from neurst_amd.criterions import build_criterion
-    from neurst_amd.models import build_model
-    from neurst_amd.utils.hparams_sets import get_hyper_parameters
     inputs, W, cfg, logits_ref, loss_ref, grads_ref = load_reference_pt_case(tag)
-    p = dict(get_hyper_parameters("speech_transformer_toy")["model.params"])
-    p.update({"encoder.num_layers": cfg["num_enc"], "decoder.num_layers": cfg["num_dec"], "modality.timing": cfg["timing"]})
-    for k in list(p):
-        if k.endswith("dropout_rate"):
-            p[k] = 0.0
-    V = logits_ref.shape[-1]
-    model = build_model({"model.class": "SpeechTransformer", "model.params": p}, {"audio_feature_dim": 80, "audio_feature_channels": 1},
-                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device="cpu", dtype="float32")
-    assert set(model.store.params) == set(W)
-    model.store.load_state_dict(W)
+    model = build_speech_model_for_reference_case(W, cfg, logits_ref, "cpu")
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     logits = model(inputs, is_training=True)
     loss = crit.reduce_loss(inputs, logits)

@@ -80,13 +80,14 @@ def test_frontend_matches_reference_neurst_pt(tag):
     np.testing.assert_allclose(out.numpy(), r["expected"], atol=5e-5, rtol=0)
 
 
-@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged"])
+@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged", "neurst_pt_st_2x2_postnorm_untied"])
 def test_full_speech_transformer_logits_and_gradients_match_reference_neurst_pt(tag):
     """The reference's own PyTorch SpeechTransformer (neurst_pt/models/speech_transformer.py; its test pins it to the TF
     model at 5e-6, tests/neurst_pt/models/speech_transformer_test.py:157) executed under the shim of make_golden.py:
     full-model logits, and -- torch autograd over the REFERENCE's forward -- the gradient of the label-smoothed token-mean
     cross entropy w.r.t. every variable, mapped to TF names with the test's own assignment list.  Pins the oracle's
-    forward AND backward of the whole encoder-decoder (ragged batch, sinusoid timing) on the reference itself."""
+    forward AND backward of the whole encoder-decoder (ragged batch, sinusoid timing) on the reference itself; the third case
+    runs the reference's post-norm wrappers (no output_ln) with untied logits (its own softmax Linear)."""
     from conftest import load_reference_pt_case
     inputs, W, cfg, logits_ref, loss_ref, grads_ref = load_reference_pt_case(tag)
     inputs = dict(inputs, src=inputs["src"].double())

@@ -158,25 +158,15 @@ def test_streaming_waitk_decoding_equals_offline_waitk_decoding(wait_k, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ reference PT model goldens
-@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged"])
+@pytest.mark.parametrize("tag", ["neurst_pt_st_1x1", "neurst_pt_st_2x2_ragged", "neurst_pt_st_2x2_postnorm_untied"])
 def test_hip_path_matches_the_reference_neurst_pt_speech_transformer(tag):
     """fp32 HIP path against the reference's own PyTorch SpeechTransformer + autograd (golden generated by
-    tests/golden/make_golden.py: gen_neurst_pt_speech_transformer): logits, loss, every gradient."""
-    from conftest import load_reference_pt_case
+    tests/golden/make_golden.py: gen_neurst_pt_speech_transformer): logits, loss, every gradient -- pre-norm / tied and
+    post-norm / untied."""
+    from conftest import build_speech_model_for_reference_case, load_reference_pt_case
     from neurst_amd.criterions import build_criterion
-    from neurst_amd.models import build_model
-    from neurst_amd.utils.hparams_sets import get_hyper_parameters
     inputs, W, cfg, logits_ref, loss_ref, grads_ref = load_reference_pt_case(tag)
-    p = dict(get_hyper_parameters("speech_transformer_toy")["model.params"])
-    p.update({"encoder.num_layers": cfg["num_enc"], "decoder.num_layers": cfg["num_dec"], "modality.timing": cfg["timing"]})
-    for k in list(p):
-        if k.endswith("dropout_rate"):
-            p[k] = 0.0
-    V = logits_ref.shape[-1]
-    model = build_model({"model.class": "SpeechTransformer", "model.params": p}, {"audio_feature_dim": 80, "audio_feature_channels": 1},
-                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=DEV, dtype="float32")
-    assert set(model.store.params) == set(W)
-    model.store.load_state_dict(W)
+    model = build_speech_model_for_reference_case(W, cfg, logits_ref, DEV)
     dinp = {k: v.to(DEV) for k, v in inputs.items()}
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     logits = model(dinp, is_training=True)
