@@ -575,7 +575,14 @@ def gen_neurst_pt_speech_transformer():
         loss = (((-(soft * logp).sum(-1)) - norm) * w).sum() / w.sum()
         params = [prm for prm, _ in names.values()]
         grads = torch.autograd.grad(loss, params, allow_unused=True)
+        # the reference's INCREMENTAL decoding (encoder_decoder_model.py:176-231 of neurst_pt: per-layer key / value caches,
+        # `time` offset of the target timing signal): the logits of every step when fed the same target prefix
+        with torch.no_grad():
+            fn, init = model.get_symbols_to_logits_fn(dict(inputs), is_training=False, is_inference=True)
+            cache = init["decoder_internal_cache"]
+            step_logits = np.stack([fn(torch.tensor(trg_input[:, t]), cache, t).numpy() for t in range(c["L"])], 1)
         arrays = {"src": src, "src_length": np.array(c["lens"], np.int64), "trg": trg, "trg_input": trg_input,
+                  "expected_step_logits": step_logits,
                   "trg_length": np.array(c["tlens"], np.int64), "expected_logits": logits.detach().numpy(),
                   "expected_loss": np.array(float(loss.detach()), np.float64), "n_enc": np.array(c["n_enc"]),
                   "n_dec": np.array(c["n_dec"]), "timing": np.array(c["timing"] or ""),

@@ -184,6 +184,14 @@ def test_host_path_matches_the_reference_neurst_pt_speech_transformer(cpu_kernel
     assert float((logits - logits_ref).abs().max()) < 5e-6 and abs(float(loss) - loss_ref) < 1e-6
     for n, g in grads_ref.items():
         assert rel_err(model.store.params[n].grad, g) < 2e-5, n
+    # incremental decoding against the reference's own cached decoding of the same target prefix
+    from conftest import load_golden
+    steps_ref = torch.from_numpy(load_golden(tag)[0]["expected_step_logits"])
+    fn, init, _ = model.get_symbols_to_logits_fn({k: v for k, v in inputs.items() if k.startswith("src")}, beam_size=1,
+                                                 decode_padded_length=8)
+    for t in range(steps_ref.shape[1]):
+        got = fn(inputs["trg_input"][:, t], init["decoder_internal_cache"], t)
+        assert float((got - steps_ref[:, t]).abs().max()) < 5e-6, t
 
 
 @pytest.mark.parametrize("tag", ["neurst_pt_tr_2x2", "neurst_pt_tr_2x2_shared"])

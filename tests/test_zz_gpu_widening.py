@@ -176,6 +176,14 @@ def test_hip_path_matches_the_reference_neurst_pt_speech_transformer(tag):
     assert abs(float(loss) - loss_ref) < 1e-5
     for n, g in grads_ref.items():
         check(f"ref_pt[{tag}].grad.{n}", model.store.params[n].grad, g.double(), 1e-3)
+    # incremental decoding against the reference's own cached decoding of the same target prefix
+    from conftest import load_golden
+    steps_ref = torch.from_numpy(load_golden(tag)[0]["expected_step_logits"])
+    fn, init, _ = model.get_symbols_to_logits_fn({k: v for k, v in dinp.items() if k.startswith("src")}, beam_size=1,
+                                                 decode_padded_length=8)
+    for t in range(steps_ref.shape[1]):
+        got = fn(dinp["trg_input"][:, t], init["decoder_internal_cache"], t).float().cpu()
+        assert float((got - steps_ref[:, t]).abs().max()) < 5e-5, t
 
 
 @pytest.mark.parametrize("tag", ["neurst_pt_tr_2x2", "neurst_pt_tr_2x2_shared"])
