@@ -698,6 +698,94 @@ def gen_metrics():
     print("wrote", path)
 
 
+def _tf_on_torch():
+    """A torch-backed stand-in for the handful of TensorFlow primitives the reference's criterion calls (tf.cast, one_hot,
+    nn.softmax_cross_entropy_with_logits, math.log, shape, reduce_sum, expand_dims, sequence_mask, name_scope), each with
+    its documented TensorFlow semantics.  With it the UNMODIFIED criterion code of the reference runs on torch tensors --
+    and torch autograd gives the gradient of its loss."""
+    import contextlib
+    import math
+    import torch
+
+    class T(torch.Tensor):
+        def get_shape(self):
+            return tuple(self.shape)
+
+    def wrap(x):
+        return x.as_subclass(T) if isinstance(x, torch.Tensor) else x
+    tf = types.ModuleType("tensorflow")
+    tf.float32, tf.int32, tf.int64 = torch.float32, torch.int32, torch.int64
+    tf.Tensor = torch.Tensor
+    tf.is_tensor = lambda x: isinstance(x, torch.Tensor)
+    tf.cast = lambda x, dtype: wrap(torch.as_tensor(x).to(dtype))
+    tf.shape = lambda x: tuple(x.shape)
+    tf.name_scope = lambda name: contextlib.nullcontext()
+    tf.reduce_sum = lambda x, axis=None: wrap(x.sum() if axis is None else x.sum(dim=axis))
+    tf.expand_dims = lambda x, axis: wrap(torch.as_tensor(x).unsqueeze(axis))
+
+    def one_hot(indices, depth, on_value=1.0, off_value=0.0):
+        out = torch.full(tuple(indices.shape) + (int(depth),), float(off_value), dtype=torch.float32)
+        return wrap(out.scatter_(-1, indices.long().unsqueeze(-1), float(on_value)))
+    tf.one_hot = one_hot
+    tf.nn = types.SimpleNamespace(softmax_cross_entropy_with_logits=lambda logits, labels: wrap(
+        -(labels * torch.log_softmax(logits, dim=-1)).sum(-1)))
+    tf.math = types.SimpleNamespace(log=lambda x: torch.log(x) if isinstance(x, torch.Tensor) else math.log(x))
+    tf.sequence_mask = lambda lengths, maxlen, dtype: wrap(
+        (torch.arange(int(maxlen))[None, :] < torch.as_tensor(lengths)[:, None].long()).to(dtype))
+    tf.dtypes = types.SimpleNamespace(as_dtype=lambda x: torch.float32)
+    return tf
+
+
+def gen_criterion():
+    """LabelSmoothedCrossEntropy (neurst/criterions/label_smoothed_cross_entropy.py:27-157): the reference's OWN criterion
+    code (and `input_length_to_nonpadding`, models/model_utils.py:44-59) executed over the torch-backed stand-in of its
+    TensorFlow primitives: (nll_sum, n_samples, n_tokens), reduce_loss, reduce_metrics and d(reduce_loss)/d(logits) for
+    smoothed / unsmoothed targets, `trg_length` and `trg_padding` + `mask` inputs."""
+    import torch
+    _install_shim()
+    sys.modules["tensorflow"] = _tf_on_torch()
+    sys.modules["neurst.utils.compat"].is_tf_tensor = lambda x: isinstance(x, torch.Tensor)
+    sys.modules["neurst.utils.compat"].CUSTOM_GLOBAL_FLOATX = "float32"
+    for name in ("neurst.criterions", "neurst.metrics", "neurst.models", "neurst.data", "neurst.data.text",
+                 "neurst.data.text.vocab", "neurst.utils.misc"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["neurst.criterions"].register_criterion = lambda c: c
+    sys.modules["neurst.data.text.vocab"].PaddingMode = object
+    sys.modules["neurst.utils.misc"].to_numpy_or_python_type = lambda x: [
+        tuple(np.asarray(t.detach() if hasattr(t, "detach") else t) for t in row) for row in x] if isinstance(x, list) else x
+    sys.modules["neurst.utils"].compat = sys.modules["neurst.utils.compat"]
+    _load("neurst.metrics.metric")
+    _load("neurst.criterions.criterion")
+    _load("neurst.models.model_utils")
+    mod = _load("neurst.criterions.label_smoothed_cross_entropy")
+    rng = np.random.RandomState(5)
+    B, L, V = 4, 6, 11
+    logits = (rng.randn(B, L, V) * 2.0).astype(np.float32)
+    trg = rng.randint(0, V, (B, L)).astype(np.int64)
+    lengths = np.array([6, 4, 1, 3], np.int64)
+    padding = (np.arange(L)[None, :] >= lengths[:, None]).astype(np.float32)
+    mask = (rng.rand(B, L) > 0.3).astype(np.float32)
+    arrays = {"logits": logits, "trg": trg, "trg_length": lengths, "trg_padding": padding, "mask": mask}
+    for ls in (0.0, 0.1, 0.35):
+        crit = mod.LabelSmoothedCrossEntropy({"label_smoothing": ls})
+        for variant, inp in (("length", {"trg": torch.tensor(trg), "trg_length": torch.tensor(lengths)}),
+                             ("padding_mask", {"trg": torch.tensor(trg), "trg_padding": torch.tensor(padding),
+                                               "mask": torch.tensor(mask)})):
+            lg = torch.tensor(logits, requires_grad=True)
+            nll_sum, n_samples, n_tokens = crit(inp, lg)
+            loss = crit.reduce_loss(inp, lg)
+            (dlogits,) = torch.autograd.grad(loss, lg)
+            metrics = crit.reduce_metrics([(nll_sum, n_samples, n_tokens)])
+            key = f"ls{ls}_{variant}"
+            arrays.update({f"{key}:nll_sum": nll_sum.detach().numpy(), f"{key}:n_samples": np.asarray(n_samples.detach()),
+                           f"{key}:n_tokens": n_tokens.detach().numpy(), f"{key}:loss": np.array(float(loss.detach())),
+                           f"{key}:dlogits": dlogits.numpy(),
+                           f"{key}:metrics": np.array([float(metrics["NLL"]), float(metrics["PPL"])])})
+    save("criterion_reference", **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -708,6 +796,7 @@ def main():
     gen_neurst_pt_speech_transformer()
     gen_neurst_pt_transformer()
     gen_metrics()
+    gen_criterion()
 
 
 if __name__ == "__main__":

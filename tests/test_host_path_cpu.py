@@ -241,6 +241,32 @@ def test_training_step_with_dropout_regenerates_the_same_masks_in_backward(cpu_k
     assert rel_err(model(inputs, is_training=False), logits_ref) > 1e-2
 
 
+@pytest.mark.parametrize("variant", ["length", "padding_mask"])
+@pytest.mark.parametrize("ls", [0.0, 0.1, 0.35])
+def test_criterion_class_matches_the_reference_code(cpu_kernels, ls, variant):
+    """The criterion class (weights from trg_length, or from trg_padding * mask; metrics; backward with the device-side
+    1 / sum(tokens)) against the reference's own criterion code (tests/golden/criterion_reference.npz)."""
+    from conftest import load_golden
+    from neurst_amd.criterions import build_criterion
+    r, _ = load_golden("criterion_reference")
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": ls}})
+    inp = {"trg": torch.from_numpy(r["trg"])}
+    if variant == "length":
+        inp["trg_length"] = torch.from_numpy(r["trg_length"])
+    else:
+        inp.update({"trg_padding": torch.from_numpy(r["trg_padding"]), "mask": torch.from_numpy(r["mask"])})
+    logits = torch.from_numpy(r["logits"])
+    key = f"ls{ls}_{variant}"
+    nll_sum, n_samples, n_tokens = crit(inp, logits)
+    assert torch.allclose(nll_sum, torch.from_numpy(r[key + ":nll_sum"]), rtol=2e-6, atol=2e-6)
+    assert n_samples.tolist() == r[key + ":n_samples"].tolist() and n_tokens.tolist() == r[key + ":n_tokens"].tolist()
+    m = crit.reduce_metrics([(nll_sum, n_samples, n_tokens)])
+    assert abs(m["NLL"] - r[key + ":metrics"][0]) < 1e-5 and abs(m["PPL"] / r[key + ":metrics"][1] - 1) < 1e-5
+    loss = crit.reduce_loss(inp, logits)
+    assert abs(float(loss) - float(r[key + ":loss"])) < 2e-6
+    assert float((crit.backward() - torch.from_numpy(r[key + ":dlogits"])).abs().max()) < 2e-7
+
+
 def test_gradient_accumulation_and_clipping_on_cpu(cpu_kernels):
     """TrainStep with update_cycle = 2 averages the micro-batch gradients (gradaccum_keras_model.py:62-109), clips the
     averaged gradients per tensor (:228-233) and applies Keras Adam -- against the oracle's functions."""

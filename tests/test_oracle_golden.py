@@ -114,6 +114,23 @@ def test_text_transformer_logits_and_gradients_match_reference_neurst_pt(tag):
         assert err < 2e-5, (n, err)
 
 
+@pytest.mark.parametrize("ls", [0.0, 0.1, 0.35])
+def test_criterion_matches_the_reference_code(ls):
+    """criterion_reference.npz: the reference's own LabelSmoothedCrossEntropy code executed over a torch-backed stand-in of
+    the TensorFlow primitives it calls (make_golden.py::gen_criterion): per-sentence NLL sums, token counts, the reduced
+    loss and its gradient w.r.t. the logits."""
+    r, _ = load_golden("criterion_reference")
+    logits = torch.from_numpy(r["logits"]).double().requires_grad_(True)
+    nll, _, ntok = O.label_smoothed_cross_entropy(logits, torch.from_numpy(r["trg"]), torch.from_numpy(r["trg_length"]), ls)
+    loss = O.reduce_loss(nll, ntok)
+    (g,) = torch.autograd.grad(loss, logits)
+    key = f"ls{ls}_length"
+    np.testing.assert_allclose(nll.detach().numpy(), r[key + ":nll_sum"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ntok.numpy(), r[key + ":n_tokens"], rtol=0, atol=0)
+    assert abs(float(loss.detach()) - float(r[key + ":loss"])) < 2e-6
+    np.testing.assert_allclose(g.numpy(), r[key + ":dlogits"], rtol=0, atol=2e-7)
+
+
 def test_causal_bias_matrix():
     # tests/neurst_pt/layers/layer_utils_test.py:20
     b = O.lower_triangle_attention_bias(3)[0, 0]

@@ -279,3 +279,27 @@ def test_training_step_with_dropout_matches_oracle_under_the_same_masks(attentio
     glob = math.sqrt(num / max(den, 1e-30))
     REPORT[tag + ".grad_global_rel_l2"] = glob
     assert glob <= (1e-3 if dtype == "float32" else 5e-2), f"{tag}: global gradient rel-L2 error {glob:.3e}"
+
+
+@pytest.mark.parametrize("variant", ["length", "padding_mask"])
+@pytest.mark.parametrize("ls", [0.0, 0.1, 0.35])
+def test_criterion_kernels_match_the_reference_code(ls, variant):
+    """nst_ls_xent_{fwd,bwd} through the criterion class against the reference's own criterion code
+    (tests/golden/criterion_reference.npz, make_golden.py::gen_criterion)."""
+    from conftest import load_golden
+    from neurst_amd.criterions import build_criterion
+    r, _ = load_golden("criterion_reference")
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": ls}})
+    inp = {"trg": torch.from_numpy(r["trg"]).to(DEV)}
+    if variant == "length":
+        inp["trg_length"] = torch.from_numpy(r["trg_length"]).to(DEV)
+    else:
+        inp.update({"trg_padding": torch.from_numpy(r["trg_padding"]).to(DEV), "mask": torch.from_numpy(r["mask"]).to(DEV)})
+    logits = torch.from_numpy(r["logits"]).to(DEV)
+    key = f"ls{ls}_{variant}"
+    nll_sum, _, n_tokens = crit(inp, logits)
+    assert torch.allclose(nll_sum.cpu(), torch.from_numpy(r[key + ":nll_sum"]), rtol=1e-5, atol=1e-5)
+    assert n_tokens.cpu().tolist() == r[key + ":n_tokens"].tolist()
+    loss = crit.reduce_loss(inp, logits)
+    assert abs(float(loss) - float(r[key + ":loss"])) < 1e-5
+    assert float((crit.backward().cpu() - torch.from_numpy(r[key + ":dlogits"])).abs().max()) < 1e-6
