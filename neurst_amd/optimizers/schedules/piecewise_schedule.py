@@ -1,5 +1,10 @@
 """PiecewiseSchedule (neurst/optimizers/schedules/piecewise_schedule.py:23-90): linear warm-up to schedule_lrs[0] over
-schedule_steps[0] steps, then piecewise-constant rates."""
+schedule_steps[0] steps, then piecewise-constant rates.
+
+Bug-compatible on purpose: the reference builds its `tf.case` branches in a loop as `lambda: tf.constant(lr)` (:78-80), so
+every middle branch returns the LAST middle rate (Python closures bind late).  With steps [s0, s1, s2] and rates
+[a, b, c, d] the reference yields warm-up to a, then c on [s0, s2), then d -- `b` is never used.  The golden values in
+tests/golden/lr_schedules.json come from the reference class itself; `strict=True` gives the documented intent instead."""
 import yaml
 
 from neurst_amd.optimizers.registries import register_lr_schedule
@@ -13,7 +18,8 @@ def _as_list(v):
 
 @register_lr_schedule("piecewise")
 class PiecewiseSchedule(object):
-    def __init__(self, args):
+    def __init__(self, args, strict=False):
+        self._strict = bool(strict or args.get("strict", False))
         self._schedule_steps, self._schedule_lrs = _as_list(args["schedule_steps"]), _as_list(args["schedule_lrs"])
         assert len(self._schedule_steps) + 1 == len(self._schedule_lrs)
         self._initial_step = float(compat.get_registered_initial_step())
@@ -27,9 +33,10 @@ class PiecewiseSchedule(object):
         s = float(global_step) + self._initial_step + 1.
         if s < self._schedule_steps[0]:
             return self._schedule_lrs[0] / float(self._schedule_steps[0]) * s
-        for step, lr in zip(self._schedule_steps[1:], self._schedule_lrs[1:-1]):
+        middle = self._schedule_lrs[1:-1]
+        for step, lr in zip(self._schedule_steps[1:], middle):
             if s < step:
-                return float(lr)
+                return float(lr if self._strict else middle[-1])
         return float(self._schedule_lrs[-1])
 
     def get_config(self):

@@ -733,6 +733,22 @@ def _tf_on_torch():
     tf.sequence_mask = lambda lengths, maxlen, dtype: wrap(
         (torch.arange(int(maxlen))[None, :] < torch.as_tensor(lengths)[:, None].long()).to(dtype))
     tf.dtypes = types.SimpleNamespace(as_dtype=lambda x: torch.float32)
+    # learning-rate schedules (optimizers/schedules/*.py): float32 scalars like in the reference
+    tf.convert_to_tensor = lambda x, dtype=None: wrap(torch.as_tensor(x, dtype=dtype))
+    tf.constant = lambda x, dtype=None: wrap(torch.as_tensor(x, dtype=dtype or torch.float32))
+    tf.minimum = lambda a, b: wrap(torch.minimum(torch.as_tensor(a, dtype=torch.float32), torch.as_tensor(b, dtype=torch.float32)))
+    tf.maximum = lambda a, b: wrap(torch.maximum(torch.as_tensor(a, dtype=torch.float32), torch.as_tensor(b, dtype=torch.float32)))
+    tf.sqrt = lambda x: wrap(torch.sqrt(x))
+    tf.less = lambda a, b: torch.as_tensor(a) < b
+
+    def case(pred_fn_pairs, default):   # tf.case: the first true predicate wins
+        for pred, fn in pred_fn_pairs:
+            if bool(pred):
+                return fn()
+        return default()
+    tf.case = case
+    tf.keras = types.SimpleNamespace(optimizers=types.SimpleNamespace(schedules=types.SimpleNamespace(
+        LearningRateSchedule=object)))
     return tf
 
 
@@ -786,6 +802,43 @@ def gen_criterion():
     save("criterion_reference", **arrays)
 
 
+def gen_schedules():
+    """NoamSchedule / InverseSquareRootSchedule / PiecewiseSchedule (neurst/optimizers/schedules/*.py): the reference's own
+    classes executed over the torch-backed TensorFlow stand-in (float32 scalars), from global step 0 and from a registered
+    initial step (resumed training)."""
+    import json
+    _install_shim()
+    sys.modules["tensorflow"] = _tf_on_torch()
+    compat = sys.modules["neurst.utils.compat"]
+    sys.modules["neurst.utils"].compat = compat
+    for name in ("neurst.optimizers", "neurst.optimizers.schedules"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["neurst.optimizers.schedules"].register_lr_schedule = lambda name: (lambda c: c)
+    noam = _load("neurst.optimizers.schedules.noam_schedule").NoamSchedule
+    isq = _load("neurst.optimizers.schedules.inverse_sqrt_schedule").InverseSquareRootSchedule
+    pw = _load("neurst.optimizers.schedules.piecewise_schedule").PiecewiseSchedule
+    steps = [0, 1, 2, 10, 99, 100, 101, 199, 200, 399, 400, 3998, 3999, 4000, 24998, 24999, 25000, 49999, 50000, 60000, 99999,
+             100000, 250000]
+    cases = {"noam_st_s": (noam, {"dmodel": 256, "warmup_steps": 25000, "initial_factor": 3.5, "end_factor": 1.5,
+                                  "start_decay_at": 50000, "decay_steps": 50000}),
+             "noam_plain": (noam, {"dmodel": 512, "warmup_steps": 4000, "initial_factor": 1.0, "end_factor": None,
+                                   "start_decay_at": None, "decay_steps": None}),
+             "inverse_sqrt": (isq, {"peak_lr": 5e-4, "init_lr": 1e-7, "warmup_steps": 4000}),
+             "piecewise": (pw, {"schedule_steps": [100, 200, 400], "schedule_lrs": [1e-3, 5e-4, 1e-4, 1e-5]})}
+    out = {"steps": steps}
+    for initial in (0, 1234):
+        compat.get_registered_initial_step = lambda initial=initial: initial
+        for name, (cls, args) in cases.items():
+            sched = cls(dict(args))
+            out[f"{name}@{initial}"] = {"args": args, "values": [float(sched(s)) for s in steps]}
+    path = os.path.join(OUT, "lr_schedules.json")
+    with open(path, "w") as fp:
+        json.dump(out, fp, indent=1)
+    print("wrote", path)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -797,6 +850,7 @@ def main():
     gen_neurst_pt_transformer()
     gen_metrics()
     gen_criterion()
+    gen_schedules()
 
 
 if __name__ == "__main__":

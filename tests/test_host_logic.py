@@ -261,5 +261,35 @@ def test_inverse_sqrt_and_piecewise_schedules():
     p = build_lr_schedule({"lr_schedule.class": "piecewise",
                            "lr_schedule.params": {"schedule_steps": "[100, 200, 400]", "schedule_lrs": [1e-3, 5e-4, 1e-4, 1e-5]}})
     assert abs(p(0) - 1e-3 / 100) < 1e-15 and abs(p(49) - 0.5e-3) < 1e-15
-    assert p(99) == 5e-4 and p(198) == 5e-4 and p(199) == 1e-4 and p(398) == 1e-4 and p(399) == 1e-5 and p(10 ** 6) == 1e-5
+    # the reference's late-binding closures make every middle segment use the LAST middle rate (see the module docstring)
+    assert p(99) == 1e-4 and p(198) == 1e-4 and p(199) == 1e-4 and p(398) == 1e-4 and p(399) == 1e-5 and p(10 ** 6) == 1e-5
     assert p.get_config()["schedule_steps"] == [100, 200, 400]
+    from neurst_amd.optimizers.schedules.piecewise_schedule import PiecewiseSchedule
+    q = PiecewiseSchedule({"schedule_steps": [100, 200, 400], "schedule_lrs": [1e-3, 5e-4, 1e-4, 1e-5]}, strict=True)
+    assert q(99) == 5e-4 and q(198) == 5e-4 and q(199) == 1e-4
+
+
+def test_lr_schedules_match_the_reference_classes():
+    """tests/golden/lr_schedules.json: values of the reference's own NoamSchedule / InverseSquareRootSchedule /
+    PiecewiseSchedule classes (executed over the torch-backed TensorFlow stand-in of make_golden.py, float32 scalars), from
+    step 0 and resumed at step 1234."""
+    import json
+    from neurst_amd.optimizers import build_lr_schedule
+    from neurst_amd.utils import compat
+    from oracle import neurst_oracle as O
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "lr_schedules.json")))
+    cls = {"noam_st_s": "noam", "noam_plain": "noam", "inverse_sqrt": "inverse_sqrt", "piecewise": "piecewise"}
+    try:
+        for key, rec in G.items():
+            if key == "steps":
+                continue
+            name, initial = key.split("@")
+            compat.register_initial_step(int(initial))
+            sched = build_lr_schedule({"lr_schedule.class": cls[name], "lr_schedule.params": dict(rec["args"])})
+            for step, want in zip(G["steps"], rec["values"]):
+                assert sched(step) == pytest.approx(want, rel=2e-6, abs=1e-12), (key, step)
+                if cls[name] == "noam" and int(initial) == 0:
+                    kw = {k: v for k, v in rec["args"].items() if v is not None}
+                    assert O.noam_lr(step, **kw) == pytest.approx(want, rel=2e-6, abs=1e-12)
+    finally:
+        compat.register_initial_step(0)
