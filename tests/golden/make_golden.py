@@ -241,6 +241,8 @@ def _install_shim():
     tensorflow/absl: tf.nest helpers, absl.logging, and stub
     neurst.utils.{registry,flags_core,configurable,compat}."""
     import logging as pylog
+    for name in [n for n in sys.modules if n == "tensorflow" or n.split(".")[0] in ("neurst", "neurst_pt", "sacrebleu")]:
+        del sys.modules[name]      # every generator starts from a clean slate (registries, stand-ins)
 
     def flatten(x):
         if isinstance(x, (list, tuple)):
@@ -717,7 +719,7 @@ def _tf_on_torch():
     tf.float32, tf.int32, tf.int64 = torch.float32, torch.int32, torch.int64
     tf.Tensor = torch.Tensor
     tf.is_tensor = lambda x: isinstance(x, torch.Tensor)
-    tf.cast = lambda x, dtype: wrap(torch.as_tensor(x).to(dtype))
+    tf.cast = lambda x, dtype: wrap(torch.as_tensor(x).to(torch.float32 if isinstance(dtype, str) else dtype))
     tf.shape = lambda x: tuple(x.shape)
     tf.name_scope = lambda name: contextlib.nullcontext()
     tf.reduce_sum = lambda x, axis=None: wrap(x.sum() if axis is None else x.sum(dim=axis))
@@ -747,6 +749,28 @@ def _tf_on_torch():
                 return fn()
         return default()
     tf.case = case
+    # layer_utils.py: masks
+    tf.ones = lambda shape, dtype=torch.float32: wrap(torch.ones(tuple(int(x) for x in shape), dtype=dtype))
+    tf.reshape = lambda x, shape: wrap(x.reshape(tuple(int(v) for v in shape)))
+
+    def band_part(x, num_lower, num_upper):   # tf.linalg.band_part: keep (m - n <= lower or lower < 0) and (n - m <= upper or upper < 0)
+        m = torch.arange(x.shape[-2])[:, None]
+        n = torch.arange(x.shape[-1])[None, :]
+        lo, up = int(num_lower), int(num_upper)
+        keep = ((m - n <= lo) if lo >= 0 else torch.ones_like(m - n, dtype=torch.bool)) & \
+               ((n - m <= up) if up >= 0 else torch.ones_like(m - n, dtype=torch.bool))
+        return wrap(x * keep.to(x.dtype))
+    tf.linalg = types.SimpleNamespace(band_part=band_part)
+    _seq_mask_1d = tf.sequence_mask
+
+    def sequence_mask(lengths, maxlen, dtype):   # scalar lengths -> a vector, like TensorFlow
+        if torch.as_tensor(lengths).dim() == 0:
+            return wrap((torch.arange(int(maxlen)) < int(lengths)).to(_dt(dtype)))
+        return wrap(_seq_mask_1d(lengths, maxlen, _dt(dtype)))
+
+    def _dt(dtype):
+        return torch.float32 if isinstance(dtype, str) else dtype
+    tf.sequence_mask = sequence_mask
     tf.keras = types.SimpleNamespace(optimizers=types.SimpleNamespace(schedules=types.SimpleNamespace(
         LearningRateSchedule=object)))
     return tf
@@ -839,6 +863,34 @@ def gen_schedules():
     print("wrote", path)
 
 
+def gen_layer_utils():
+    """The attention-bias builders of neurst/layers/layer_utils.py (:19-78) -- padding bias, lower-triangle bias and both forms
+    of the wait-k bias -- from the reference's own functions over the TensorFlow stand-in."""
+    import torch
+    _install_shim()
+    sys.modules["tensorflow"] = _tf_on_torch()
+    compat = sys.modules["neurst.utils.compat"]
+    compat.CUSTOM_GLOBAL_FLOATX = "float32"
+    sys.modules["neurst.utils"].compat = compat
+    for name in ("neurst.layers",):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, "neurst", "layers")]
+        sys.modules[name] = m
+    lu = _load("neurst.layers.layer_utils")
+    arrays = {}
+    cases = [(7, 3, 5), (7, 1, 5), (4, 3, 6), (5, 9, 3), (1, 1, 1), (12, 4, 12)]      # memory length, lagging, query length
+    arrays["waitk_cases"] = np.array(cases, np.int64)
+    for i, (m, k, q) in enumerate(cases):
+        arrays[f"waitk_train_{i}"] = lu.waitk_attention_bias(m, k, q).numpy()
+        arrays[f"waitk_step_{i}"] = lu.waitk_attention_bias(m, k).numpy()
+    for n in (1, 2, 5):
+        arrays[f"lower_triangle_{n}"] = lu.lower_triangle_attention_bias(n, torch.float32).numpy()
+    pad = np.array([[0, 0, 1, 1], [0, 0, 0, 0]], np.float32)
+    arrays["padding"] = pad
+    arrays["padding_bias"] = lu.input_padding_to_bias(torch.tensor(pad)).numpy()
+    save("layer_utils_reference", **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -851,6 +903,7 @@ def main():
     gen_metrics()
     gen_criterion()
     gen_schedules()
+    gen_layer_utils()
 
 
 if __name__ == "__main__":

@@ -131,6 +131,23 @@ def test_criterion_matches_the_reference_code(ls):
     np.testing.assert_allclose(g.numpy(), r[key + ":dlogits"], rtol=0, atol=2e-7)
 
 
+def test_attention_bias_builders_match_the_reference_functions():
+    """layer_utils_reference.npz: outputs of the reference's own padding / lower-triangle / wait-k bias builders
+    (layer_utils.py:19-78, run over the TensorFlow stand-in of make_golden.py).  The wait-k training bias is what the
+    attention kernels implement as `causal_offset = k - 1`; the step form is the decoder's `decode_lagging` mask."""
+    r, _ = load_golden("layer_utils_reference")
+    for i, (m, k, q) in enumerate(r["waitk_cases"].tolist()):
+        want = r[f"waitk_train_{i}"]
+        assert np.array_equal(O.waitk_attention_bias(m, k, q).numpy(), want)
+        ii, jj = np.arange(q)[:, None], np.arange(m)[None, :]
+        assert np.array_equal(want == 0, jj <= ii + (k - 1))                       # the kernels' causal_offset form
+        step = r[f"waitk_step_{i}"]
+        assert np.array_equal(step == 0, np.arange(m) < k) and set(np.unique(step)) <= {0.0, np.float32(O.FLOAT_MIN)}
+    for n in (1, 2, 5):
+        assert np.array_equal(O.lower_triangle_attention_bias(n).numpy(), r[f"lower_triangle_{n}"])
+    assert np.array_equal(O.input_padding_to_bias(torch.from_numpy(r["padding"])).numpy(), r["padding_bias"])
+
+
 def test_causal_bias_matrix():
     # tests/neurst_pt/layers/layer_utils_test.py:20
     b = O.lower_triangle_attention_bias(3)[0, 0]
