@@ -152,3 +152,29 @@ def test_sampling_search_on_a_toy_language_model():
     assert s.top_k == 2
     with pytest.raises(NotImplementedError):
         Sampling({"top_p": 0.5, "top_k": 3})
+
+
+def test_beam_search_matches_the_reference_search_code():
+    """tests/golden/beam_search_reference.npz: hypotheses and scores of the reference's OWN sequence_beam_search
+    (layers/search/beam_search.py:254-440 + layer_utils helpers, executed unmodified over the torch-backed TensorFlow
+    stand-in of tests/golden/make_golden.py) on the toy language model above -- first-beam-only step 0, finished beams,
+    UNK / minimum-length masks, both length penalties, top-k extraction, cache re-ordering, EOS padding."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "beam_search_reference.npz"))
+    vocab, batch, bos, eos, unk, enc_len, extra, max_len = (int(v) for v in z["setup"])
+    for i, (beam, top_k, alpha, min_len, eos_boost, enable_unk) in enumerate(z["configs"].tolist()):
+        beam, top_k, min_len, enable_unk = int(beam), int(top_k), int(min_len), bool(enable_unk)
+        lm = _ToyLM(vocab, batch, seed=beam * 10 + top_k, eos_boost=eos_boost)
+        fn, reorder = lm.step_fn(beam, eos)
+        init = {"decoder_input": torch.full((batch,), bos), "decoder_internal_cache": {"state": torch.zeros(batch * beam, dtype=torch.int64)},
+                "encoder_inputs_maxlen": enc_len, "eos_id": eos, "unk_id": unk}
+        hyp, scores = sequence_beam_search(fn, init, reorder_cache_fn=reorder, beam_size=beam, top_k=top_k, length_penalty=alpha,
+                                           extra_decode_length=extra, maximum_decode_length=max_len, minimum_decode_length=min_len,
+                                           enable_unk=enable_unk)
+        assert hyp.tolist() == z[f"hyp_{i}"].tolist(), i
+        assert np.allclose(scores.numpy(), z[f"scores_{i}"], rtol=1e-5, atol=1e-5), i
+        # and the independent hypothesis-list oracle agrees with the reference as well
+        want_h, want_s = BO.beam_search(lm.prefix_fn(eos), batch, bos, eos, unk, vocab, encoder_len=enc_len, beam_size=beam,
+                                        top_k=top_k, length_penalty=alpha, extra_decode_length=extra, maximum_decode_length=max_len,
+                                        minimum_decode_length=min_len, enable_unk=enable_unk)
+        assert want_h.tolist() == z[f"hyp_{i}"].tolist() and np.allclose(want_s, z[f"scores_{i}"], rtol=1e-5, atol=1e-5)
