@@ -855,6 +855,14 @@ def _tf_on_torch():
             v = list(body(*v))
         return v
     tf.while_loop = while_loop
+    # ---- layers/search/sampling.py: top_k_logits / top_p_logits
+    tf.newaxis = None
+    tf.sort = lambda x, direction="ASCENDING": wrap(torch.sort(x, dim=-1, descending=(direction == "DESCENDING")).values)
+    tf.cumsum = lambda x, axis=-1: wrap(torch.cumsum(x, dim=axis))
+    tf.where = lambda c, a, b: wrap(torch.where(c, a, b))
+    tf.ones_like = lambda x, dtype=None: wrap(torch.ones_like(x, dtype=dt(dtype)))
+    tf.reduce_min = lambda x, axis=None: wrap(x.min() if axis is None else x.min(dim=axis).values)
+    tf.reduce_max = lambda x, axis=None: wrap(x.max() if axis is None else x.max(dim=axis).values)
     return tf
 
 
@@ -1021,6 +1029,35 @@ def gen_beam_search():
     save("beam_search_reference", **arrays)
 
 
+def gen_sampling_filters():
+    """top_k_logits / top_p_logits of the reference (layers/search/sampling.py:67-92) over the TensorFlow stand-in."""
+    import torch
+    _install_shim()
+    tf = _tf_on_torch()
+    sys.modules["tensorflow"] = tf
+    compat = sys.modules["neurst.utils.compat"]
+    sys.modules["neurst.utils"].compat = compat
+    for name in ("neurst.layers", "neurst.layers.search", "neurst.layers.layer_utils"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["neurst.layers"].layer_utils = sys.modules["neurst.layers.layer_utils"]
+    sys.modules["neurst.layers.search"].register_search_layer = lambda name: (lambda c: c)
+    seq = types.ModuleType("neurst.layers.search.sequence_search")
+    seq.SequenceSearch = object
+    sys.modules["neurst.layers.search.sequence_search"] = seq
+    sp = _load("neurst.layers.search.sampling")
+    rng = np.random.RandomState(2)
+    logits = (rng.randn(5, 13) * 2.0).astype(np.float32)
+    logits[1, 3] = logits[1, 7]                           # a tie at some rank
+    arrays = {"logits": logits}
+    for k in (0, 1, 3, 13):
+        arrays[f"top_k_{k}"] = sp.top_k_logits(tf.convert_to_tensor(logits), k).numpy()
+    for p_ in (0.1, 0.5, 0.9, 0.999):
+        arrays[f"top_p_{p_}"] = sp.top_p_logits(tf.convert_to_tensor(logits), p_).numpy()
+    save("sampling_filters_reference", **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -1035,6 +1072,7 @@ def main():
     gen_schedules()
     gen_layer_utils()
     gen_beam_search()
+    gen_sampling_filters()
 
 
 if __name__ == "__main__":

@@ -178,3 +178,16 @@ def test_beam_search_matches_the_reference_search_code():
                                         top_k=top_k, length_penalty=alpha, extra_decode_length=extra, maximum_decode_length=max_len,
                                         minimum_decode_length=min_len, enable_unk=enable_unk)
         assert want_h.tolist() == z[f"hyp_{i}"].tolist() and np.allclose(want_s, z[f"scores_{i}"], rtol=1e-5, atol=1e-5)
+
+
+def test_sampling_filters_match_the_reference_code():
+    """tests/golden/sampling_filters_reference.npz: the reference's own top_k_logits / top_p_logits (sampling.py:67-92 over the
+    TensorFlow stand-in of make_golden.py), including a row with tied logits."""
+    import os
+    from neurst_amd.layers.search.sampling import top_k_logits, top_p_logits
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampling_filters_reference.npz"))
+    lg = torch.from_numpy(z["logits"])
+    for k in (0, 1, 3, 13):
+        assert np.array_equal(top_k_logits(lg, k).numpy(), z[f"top_k_{k}"]), k
+    for p in (0.1, 0.5, 0.9, 0.999):
+        assert np.array_equal(top_p_logits(lg, p).numpy(), z[f"top_p_{p}"]), p
