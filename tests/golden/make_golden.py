@@ -863,6 +863,9 @@ def _tf_on_torch():
     tf.ones_like = lambda x, dtype=None: wrap(torch.ones_like(x, dtype=dt(dtype)))
     tf.reduce_min = lambda x, axis=None: wrap(x.min() if axis is None else x.min(dim=axis).values)
     tf.reduce_max = lambda x, axis=None: wrap(x.max() if axis is None else x.max(dim=axis).values)
+    # ---- tasks/*.example_to_input, models/model_utils.deduce_text_length
+    tf.not_equal = lambda a, b: wrap(torch.as_tensor(a) != torch.as_tensor(b))
+    tf.argmin = lambda x, axis=-1: wrap(torch.argmin(x, dim=axis))     # first minimum, like TensorFlow
     return tf
 
 
@@ -1058,6 +1061,77 @@ def gen_sampling_filters():
     save("sampling_filters_reference", **arrays)
 
 
+def _method_from_source(path, cls_name, fn_name, namespace):
+    """Compiles ONE method of a reference class from its source text (the module itself imports half of the framework) and
+    returns the function object, executed in `namespace` (tf stand-in, compat, helpers)."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == fn_name)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace[fn_name]
+
+
+def gen_example_to_input():
+    """SpeechToText.example_to_input (tasks/speech2text.py:135-161), Seq2Seq.example_to_input (tasks/seq2seq.py:110-136) and
+    deduce_text_length (models/model_utils.py:23-41): the reference's method bodies, compiled from their source text and
+    executed over the TensorFlow stand-in, on ragged EOS-padded batches in TRAIN and INFER mode."""
+    import torch
+    _install_shim()
+    tf = _tf_on_torch()
+    sys.modules["tensorflow"] = tf
+    compat = sys.modules["neurst.utils.compat"]
+    compat.CUSTOM_GLOBAL_FLOATX = "float32"
+    compat.ModeKeys = types.SimpleNamespace(TRAIN="train", EVAL="eval", INFER="infer")
+    sys.modules["neurst.utils"].compat = compat
+    for name in ("neurst.data", "neurst.data.text", "neurst.data.text.vocab"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+
+    class PaddingMode(object):
+        DEFAULT, EOS_AS_PADDING = 0, 1
+    sys.modules["neurst.data.text.vocab"].PaddingMode = PaddingMode
+    mu = _load("neurst.models.model_utils")
+    ns = {"tf": tf, "compat": compat, "deduce_text_length": mu.deduce_text_length, "PaddingMode": PaddingMode}
+    st_fn = _method_from_source(os.path.join(REF, "neurst/tasks/speech2text.py"), "SpeechToText", "example_to_input", dict(ns))
+    s2s_fn = _method_from_source(os.path.join(REF, "neurst/tasks/seq2seq.py"), "Seq2Seq", "example_to_input", dict(ns))
+    rng = np.random.RandomState(8)
+    V, eos, bos = 12, 11, 10
+    meta = {"bos_id": bos, "eos_id": eos, "pad_id": eos, "padding_mode": PaddingMode.EOS_AS_PADDING}
+    B, T, Fd, L = 3, 7, 4, 6
+    audio = rng.randn(B, T * Fd).astype(np.float32)
+    audio_length = np.array([7, 5, 2], np.int64)
+    tlens = [6, 3, 1]                                     # EOS is the last real token, then EOS padding
+    transcript = rng.randint(0, V - 3, (B, L)).astype(np.int64)
+    for b, n in enumerate(tlens):
+        transcript[b, n - 1:] = eos
+    st = types.SimpleNamespace(_audio_feature_dim=Fd, _audio_feature_channels=1, _trg_data_pipeline=types.SimpleNamespace(meta=meta))
+    batch = {"audio": tf.convert_to_tensor(audio), "audio_length": tf.convert_to_tensor(audio_length),
+             "transcript": tf.convert_to_tensor(transcript)}
+    arrays = {"audio": audio, "audio_length": audio_length, "transcript": transcript, "dims": np.array([Fd, 1, V, bos, eos], np.int64)}
+    for mode in ("train", "infer"):
+        out = st_fn(st, dict(batch), mode)
+        for k, v in out.items():
+            arrays[f"st_{mode}:{k}"] = np.asarray(v)
+    feature = rng.randint(0, V - 3, (B, 5)).astype(np.int64)
+    for b, n in enumerate([5, 2, 4]):
+        feature[b, n - 1:] = eos
+    arrays["feature"] = feature
+    for tb in ("bos", "eos"):
+        s2s = types.SimpleNamespace(_src_data_pipeline=types.SimpleNamespace(meta=meta), _trg_data_pipeline=types.SimpleNamespace(meta=meta),
+                                    _target_begin_of_sentence=tb)
+        for mode in ("train", "infer"):
+            out = s2s_fn(s2s, {"feature": tf.convert_to_tensor(feature), "label": tf.convert_to_tensor(transcript)}, mode)
+            for k, v in out.items():
+                arrays[f"s2s_{tb}_{mode}:{k}"] = np.asarray(v)
+    pad0 = np.array([[3, 4, 0, 0], [1, 0, 0, 0], [5, 6, 7, 8]], np.int64)
+    arrays["default_pad_ids"] = pad0
+    arrays["default_pad_lengths"] = np.asarray(mu.deduce_text_length(tf.convert_to_tensor(pad0), 0, PaddingMode.DEFAULT))
+    save("example_to_input_reference", **arrays)
+
+
 def main():
     gen_attention()
     gen_encoder()
@@ -1073,6 +1147,7 @@ def main():
     gen_layer_utils()
     gen_beam_search()
     gen_sampling_filters()
+    gen_example_to_input()
 
 
 if __name__ == "__main__":

@@ -293,3 +293,38 @@ def test_lr_schedules_match_the_reference_classes():
                     assert O.noam_lr(step, **kw) == pytest.approx(want, rel=2e-6, abs=1e-12)
     finally:
         compat.register_initial_step(0)
+
+
+def test_example_to_input_matches_the_reference_methods():
+    """tests/golden/example_to_input_reference.npz: the bodies of the reference's SpeechToText.example_to_input
+    (tasks/speech2text.py:135-161), Seq2Seq.example_to_input (tasks/seq2seq.py:110-136) and deduce_text_length
+    (models/model_utils.py:23-41), compiled from their source and executed over the TensorFlow stand-in of make_golden.py."""
+    import numpy as np
+    from neurst_amd.models.model_utils import deduce_text_length
+    from neurst_amd.tasks import build_task
+    from neurst_amd.utils import compat
+    from oracle import neurst_oracle as O
+    z = np.load(os.path.join(ROOT, "tests", "golden", "example_to_input_reference.npz"))
+    Fd, C, V, bos, eos = (int(v) for v in z["dims"])
+    st = build_task({"task.class": "speech2text", "task.params": {"audio_feature_dim": Fd, "vocab_size": V}})
+    assert (st.trg_meta["bos_id"], st.trg_meta["eos_id"], st.trg_meta["pad_id"]) == (bos, eos, eos)
+    batch = {k: torch.from_numpy(z[k]) for k in ("audio", "audio_length", "transcript")}
+    for mode, key in ((compat.ModeKeys.TRAIN, "train"), (compat.ModeKeys.INFER, "infer")):
+        got = st.example_to_input(dict(batch), mode)
+        want = {k.split(":")[1]: z[k] for k in z.files if k.startswith(f"st_{key}:")}
+        assert set(want) <= set(got)
+        for k, v in want.items():
+            assert np.array_equal(got[k].numpy(), v), (key, k)
+    ref = O.example_to_input(batch["audio"], batch["audio_length"], batch["transcript"], Fd, C, bos, eos)
+    for k in ("src", "src_length", "trg", "trg_length", "trg_input"):
+        assert np.array_equal(ref[k].numpy(), z[f"st_train:{k}"]), k
+    for tb in ("bos", "eos"):
+        s2s = build_task({"task.class": "translation", "task.params": {"src_vocab_size": V, "trg_vocab_size": V,
+                                                                        "target_begin_of_sentence": tb}})
+        data = {"feature": torch.from_numpy(z["feature"]), "label": torch.from_numpy(z["transcript"])}
+        for mode, key in ((compat.ModeKeys.TRAIN, "train"), (compat.ModeKeys.INFER, "infer")):
+            got = s2s.example_to_input(dict(data), mode)
+            for k in (k for k in z.files if k.startswith(f"s2s_{tb}_{key}:")):
+                assert np.array_equal(got[k.split(":")[1]].numpy(), z[k]), k
+    assert deduce_text_length(torch.from_numpy(z["default_pad_ids"]), 0, compat.PaddingMode.DEFAULT).tolist() == \
+        z["default_pad_lengths"].tolist()
