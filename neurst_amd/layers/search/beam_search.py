@@ -52,10 +52,11 @@ def length_penalty_term(lengths, alpha, dtype=torch.float32):
 
 def sequence_beam_search(symbols_to_logits_fn, generation_initializer, top_k=1, beam_size=4, length_penalty=0.6,
                          extra_decode_length=50, maximum_decode_length=256, minimum_decode_length=0, enable_unk=False,
-                         reorder_cache_fn=None):
+                         reorder_cache_fn=None, ensemble_weights=None):
     """generation_initializer: {"decoder_input": int tensor [batch], "decoder_internal_cache": cache ALREADY stacked to
     batch * beam rows by the caller (the model owns its layout), "encoder_inputs_maxlen": int | None, "eos_id", "unk_id"}.
-    symbols_to_logits_fn(ids [batch*beam], cache, time) -> logits [batch*beam, vocab].
+    symbols_to_logits_fn(ids [batch*beam], cache, time) -> logits [batch*beam, vocab], or a list of them (an ENSEMBLE:
+    the step distribution is sum_i ensemble_weights[i] * softmax(logits_i), beam_search.py:104-116).
     reorder_cache_fn(cache, beam_ids) -> cache re-ordered like tf.gather(cache, beam_ids)."""
     ids = generation_initializer["decoder_input"]
     cache = generation_initializer["decoder_internal_cache"]
@@ -77,8 +78,14 @@ def sequence_beam_search(symbols_to_logits_fn, generation_initializer, top_k=1, 
     # EOS at zero cost (log-prob, length and ranking unchanged), the returned hypotheses are the same
     while time < max_steps and not (time % 4 == 0 and time > 0 and bool(finished.all())):
         logits = symbols_to_logits_fn(input_ids, cache, time)
-        vocab = logits.shape[-1]
-        step_lp = torch.log_softmax(logits.float(), dim=-1)
+        if isinstance(logits, (list, tuple)) and len(logits) > 1:
+            w = torch.as_tensor(ensemble_weights, dtype=torch.float32, device=dev)
+            assert w.numel() == len(logits), "one ensemble weight per sub-model"
+            step_lp = torch.log(sum(wi * torch.softmax(lg.float(), dim=-1) for wi, lg in zip(w, logits)))
+        else:
+            logits = logits[0] if isinstance(logits, (list, tuple)) else logits
+            step_lp = torch.log_softmax(logits.float(), dim=-1)
+        vocab = step_lp.shape[-1]
         # finished beams: only EOS, at no cost (beam_search.py:117-130)
         fin = finished.float()[:, None]
         fin_bias = torch.full((vocab,), FLOAT_MIN, dtype=torch.float32, device=dev)
@@ -149,11 +156,25 @@ class BeamSearch(SequenceSearch):
             Flag("use_graphs", dtype=Flag.TYPE.BOOLEAN, default=None, help="Replay the decoding step as a captured HIP graph."),
         ]
 
-    def __call__(self, model, inputs):
+    def __call__(self, model, inputs, ensemble_weights=None):
+        """model: one model, or a list of models decoded as an ENSEMBLE (sequence_generator.py builds
+        EncoderDecoderEnsembleModel from several model_dirs; `ensemble_weights`: "average" / None, or one weight per model)."""
         max_len = self.maximum_decode_length or 256
-        fn, init, reorder = model.get_symbols_to_logits_fn(inputs, beam_size=self.beam_size, decode_padded_length=max_len,
-                                                           use_graphs=self.use_graphs)
-        return sequence_beam_search(fn, init, top_k=self.top_k, beam_size=self.beam_size, length_penalty=self.length_penalty,
-                                    extra_decode_length=self.extra_decode_length, maximum_decode_length=max_len,
-                                    minimum_decode_length=self.minimum_decode_length, enable_unk=self.enable_unk,
-                                    reorder_cache_fn=reorder)
+        kw = dict(top_k=self.top_k, beam_size=self.beam_size, length_penalty=self.length_penalty,
+                  extra_decode_length=self.extra_decode_length, maximum_decode_length=max_len,
+                  minimum_decode_length=self.minimum_decode_length, enable_unk=self.enable_unk)
+        if not isinstance(model, (list, tuple)):
+            fn, init, reorder = model.get_symbols_to_logits_fn(inputs, beam_size=self.beam_size, decode_padded_length=max_len,
+                                                               use_graphs=self.use_graphs)
+            return sequence_beam_search(fn, init, reorder_cache_fn=reorder, **kw)
+        parts = [m.get_symbols_to_logits_fn(inputs, beam_size=self.beam_size, decode_padded_length=max_len) for m in model]
+        if ensemble_weights is None or ensemble_weights == "average":
+            ensemble_weights = [1.0 / len(parts)] * len(parts)
+        init = dict(parts[0][1], decoder_internal_cache=[p[1]["decoder_internal_cache"] for p in parts])
+
+        def fn(ids, caches, time):
+            return [p[0](ids, c, time) for p, c in zip(parts, caches)]
+
+        def reorder(caches, beam_ids):
+            return [p[2](c, beam_ids) for p, c in zip(parts, caches)]
+        return sequence_beam_search(fn, init, reorder_cache_fn=reorder, ensemble_weights=ensemble_weights, **kw)

@@ -1029,6 +1029,22 @@ def gen_beam_search():
             minimum_decode_length=min_len, enable_unk=enable_unk)
         arrays[f"hyp_{i}"] = np.asarray(hyp).astype(np.int64)
         arrays[f"scores_{i}"] = np.asarray(scores).astype(np.float32)
+    # an ensemble of two toy models (beam_search.py:104-116: weighted sum of the sub-models' probabilities)
+    beam, weights = 3, [0.7, 0.3]
+    lm_a, lm_b = _ToyLM(vocab, batch, seed=101, eos_boost=0.4), _ToyLM(vocab, batch, seed=202, eos_boost=0.2)
+    fa, fb = lm_a.step_fn(beam, eos)[0], lm_b.step_fn(beam, eos)[0]
+
+    def ens_fn(ids, cache, time):
+        i = torch.as_tensor(ids).long()
+        return [tf.convert_to_tensor(fa(i, cache["a"], int(time))), tf.convert_to_tensor(fb(i, cache["b"], int(time)))]
+    init = {"decoder_input": tf.convert_to_tensor(torch.full((batch,), bos, dtype=torch.int32)),
+            "decoder_internal_cache": {"a": {"state": tf.convert_to_tensor(torch.zeros(batch, dtype=torch.int64))},
+                                       "b": {"state": tf.convert_to_tensor(torch.zeros(batch, dtype=torch.int64))}},
+            "encoder_inputs_maxlen": 5, "eos_id": eos, "unk_id": unk}
+    hyp, scores = bs.sequence_beam_search(ens_fn, init, top_k=2, beam_size=beam, length_penalty=0.6, extra_decode_length=4,
+                                          maximum_decode_length=12, ensemble_weights=weights)
+    arrays["ens_hyp"], arrays["ens_scores"] = np.asarray(hyp).astype(np.int64), np.asarray(scores).astype(np.float32)
+    arrays["ens_weights"] = np.array(weights, np.float32)
     save("beam_search_reference", **arrays)
 
 

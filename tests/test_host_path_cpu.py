@@ -818,3 +818,20 @@ def test_top_sampling_with_k1_equals_greedy_beam_search_on_the_model(cpu_kernels
                                 "search_method.params": {"sample_num": 3, "top_p": 0.8, "maximum_decode_length": 6, "seed": 1}})
     h3, _ = three(model, inputs)
     assert h3.shape == (shape[0] * 3, 6) and three.top_k == 3
+
+
+def test_model_ensemble_beam_search(cpu_kernels):
+    """BeamSearch over a list of models (the reference's ensemble decoding): two copies of one model decode exactly like the
+    single model; two different models give a valid, different search (scores are those of the averaged distribution)."""
+    from neurst_amd.layers.search import build_search_layer
+    model, cfg, shape = _speech_model("toy")
+    other, _, _ = _speech_model("toy")
+    other.store.master.mul_(1.3)
+    inputs = {k: v for k, v in _speech_inputs(shape).items() if k.startswith("src")}
+    search = build_search_layer({"search_method.class": "beam_search",
+                                 "search_method.params": {"beam_size": 3, "top_k": 2, "maximum_decode_length": 6, "extra_decode_length": 2}})
+    h1, s1 = search(model, inputs)
+    h2, s2 = search([model, model], inputs)
+    assert torch.equal(h1, h2) and torch.allclose(s1, s2, rtol=1e-5, atol=1e-5)
+    h3, s3 = search([model, other], inputs, ensemble_weights=[0.5, 0.5])
+    assert h3.shape == h1.shape and bool(torch.isfinite(s3).all()) and not torch.allclose(s3, s1)

@@ -191,3 +191,28 @@ def test_sampling_filters_match_the_reference_code():
         assert np.array_equal(top_k_logits(lg, k).numpy(), z[f"top_k_{k}"]), k
     for p in (0.1, 0.5, 0.9, 0.999):
         assert np.array_equal(top_p_logits(lg, p).numpy(), z[f"top_p_{p}"]), p
+
+
+def test_ensemble_beam_search_matches_the_reference_search_code():
+    """Two sub-models: the step distribution is the weighted sum of their probabilities (beam_search.py:104-116); golden from
+    the reference's own search code (make_golden.py::gen_beam_search)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "beam_search_reference.npz"))
+    vocab, batch, bos, eos, unk, enc_len, extra, max_len = (int(v) for v in z["setup"])
+    beam = 3
+    lm_a, lm_b = _ToyLM(vocab, batch, seed=101, eos_boost=0.4), _ToyLM(vocab, batch, seed=202, eos_boost=0.2)
+    (fa, ra), (fb, rb) = lm_a.step_fn(beam, eos), lm_b.step_fn(beam, eos)
+
+    def fn(ids, cache, time):
+        return [fa(ids, cache["a"], time), fb(ids, cache["b"], time)]
+
+    def reorder(cache, beam_ids):
+        return {"a": ra(cache["a"], beam_ids), "b": rb(cache["b"], beam_ids)}
+    init = {"decoder_input": torch.full((batch,), bos), "encoder_inputs_maxlen": enc_len, "eos_id": eos, "unk_id": unk,
+            "decoder_internal_cache": {"a": {"state": torch.zeros(batch * beam, dtype=torch.int64)},
+                                       "b": {"state": torch.zeros(batch * beam, dtype=torch.int64)}}}
+    hyp, scores = sequence_beam_search(fn, init, reorder_cache_fn=reorder, beam_size=beam, top_k=2, length_penalty=0.6,
+                                       extra_decode_length=extra, maximum_decode_length=max_len,
+                                       ensemble_weights=z["ens_weights"].tolist())
+    assert hyp.tolist() == z["ens_hyp"].tolist()
+    assert np.allclose(scores.numpy(), z["ens_scores"], rtol=1e-5, atol=1e-5)
