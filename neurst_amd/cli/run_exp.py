@@ -17,43 +17,39 @@ from neurst_amd.training.distributed import init_distributed
 from neurst_amd.utils.configurable import ModelConfigs, deep_merge_dict, load_from_config_path, yaml_load_checking
 from neurst_amd.utils.hparams_sets import get_hyper_parameters
 
+_F, _M = flags_core.Flag, flags_core.ModuleFlag
 FLAG_LIST = [
-    flags_core.Flag("distribution_strategy", dtype=flags_core.Flag.TYPE.STRING, default="rccl",
-                    help="The distribution strategy: rccl (one process per GPU; horovod/byteps/mirrored are accepted "
-                         "as aliases) or none."),
-    flags_core.Flag("dtype", dtype=flags_core.Flag.TYPE.STRING, default="bfloat16",
-                    help="The computation type of the whole model: float32 or bfloat16."),
-    flags_core.Flag("enable_check_numerics", dtype=flags_core.Flag.TYPE.BOOLEAN, default=None,
-                    help="Check the loss for NaN/Inf at every summary step."),
-    flags_core.Flag("enable_xla", dtype=flags_core.Flag.TYPE.BOOLEAN, default=None, help="Ignored (no XLA here)."),
-    flags_core.Flag("hparams_set", dtype=flags_core.Flag.TYPE.STRING,
-                    help="A pre-defined hyper-parameter set, e.g. speech_transformer_s."),
-    flags_core.Flag("model_dir", dtype=flags_core.Flag.TYPE.STRING, help="The path for saving and loading checkpoints."),
-    flags_core.Flag("seed", dtype=flags_core.Flag.TYPE.INTEGER, default=1234, help="Dropout / data seed."),
-    flags_core.ModuleFlag(BaseExperiment.REGISTRY_NAME, help="The program."),
-    flags_core.ModuleFlag(Task.REGISTRY_NAME, help="The binding task."),
-    flags_core.ModuleFlag(BaseModel.REGISTRY_NAME, help="The model."),
-    flags_core.ModuleFlag(Dataset.REGISTRY_NAME, help="The dataset."),
+    _F("distribution_strategy", dtype=_F.TYPE.STRING, default="rccl",
+       help="rccl = one process per GPU (horovod / byteps / mirrored are accepted as aliases), or none."),
+    _F("dtype", dtype=_F.TYPE.STRING, default="bfloat16",
+       help="Compute dtype of activations and GEMM weights: bfloat16 (default) or float32."),
+    _F("enable_check_numerics", dtype=_F.TYPE.BOOLEAN, default=None, help="Stop when the logged loss is NaN or Inf."),
+    _F("enable_xla", dtype=_F.TYPE.BOOLEAN, default=None, help="Ignored (no XLA here)."),
+    _F("hparams_set", dtype=_F.TYPE.STRING,
+       help="Name of a registered hyper-parameter set (speech_transformer_s, transformer_big, ...)."),
+    _F("model_dir", dtype=_F.TYPE.STRING,
+       help="Directory of checkpoints and model_configs.yml (written by training, read by everything else)."),
+    _F("seed", dtype=_F.TYPE.INTEGER, default=1234, help="Base seed of dropout masks and synthetic data (+ rank)."),
+    _M(BaseExperiment.REGISTRY_NAME, help="What to run: trainer, evaluation, predict."),
+    _M(Task.REGISTRY_NAME, help="Task class (speech2text, translation, waitk_translation)."),
+    _M(BaseModel.REGISTRY_NAME, help="Model class (normally given by --hparams_set)."),
+    _M(Dataset.REGISTRY_NAME, help="Dataset class."),
 ]
 
 
 def _pre_load_args(args):
-    """run_exp.py:53-76: model_dir/model_configs.yml < hparams_set < --config_paths."""
-    paths = flags_core._flatten_string_list(getattr(args, "config_paths", None))
-    cfg_file_args = yaml_load_checking(load_from_config_path(paths))
-    model_dir = args.model_dir or cfg_file_args.get("model_dir", None)
-    hparams_set = args.hparams_set or cfg_file_args.get("hparams_set", None)
-    predefined = dict(get_hyper_parameters(hparams_set))
-    formatted = {}
-    for k in ("model.class", "model", "model.params"):
-        if k in predefined:
-            formatted[k] = predefined.pop(k)
-    if predefined:
-        formatted["entry.params"] = predefined
+    """Defaults below the command line, weakest first (run_exp.py:53-76): model_dir/model_configs.yml, then the named
+    hyper-parameter set (its model.* keys at top level, everything else as entry.params), then --config_paths files."""
+    from_files = yaml_load_checking(load_from_config_path(flags_core._flatten_string_list(getattr(args, "config_paths", None))))
+    named = dict(get_hyper_parameters(args.hparams_set or from_files.get("hparams_set", None)))
+    layered = {k: named.pop(k) for k in ("model.class", "model", "model.params") if k in named}
+    if named:
+        layered["entry.params"] = named
     try:
-        return deep_merge_dict(deep_merge_dict(ModelConfigs.load(model_dir), formatted), cfg_file_args)
+        stored = ModelConfigs.load(args.model_dir or from_files.get("model_dir", None))
     except Exception:
-        return deep_merge_dict(formatted, cfg_file_args)
+        return deep_merge_dict(layered, from_files)
+    return deep_merge_dict(deep_merge_dict(stored, layered), from_files)
 
 
 def run_experiment(args, remaining_argv):

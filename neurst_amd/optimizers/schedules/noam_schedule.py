@@ -25,12 +25,12 @@ class NoamSchedule(object):
     @staticmethod
     def class_or_method_args():
         return [
-            Flag("dmodel", dtype=Flag.TYPE.INTEGER, default=None, help="The model dimension in the hidden layers."),
-            Flag("warmup_steps", dtype=Flag.TYPE.INTEGER, default=4000, help="The number of linear warmup steps."),
-            Flag("initial_factor", dtype=Flag.TYPE.FLOAT, default=1., help="The initial learning rate scaling factor."),
-            Flag("end_factor", dtype=Flag.TYPE.FLOAT, default=None, help="The final decayed scaling factor."),
-            Flag("start_decay_at", dtype=Flag.TYPE.INTEGER, default=0, help="`initial_factor` starts to decay here."),
-            Flag("decay_steps", dtype=Flag.TYPE.INTEGER, default=None, help="Steps over which the factor decays."),
+            Flag("dmodel", dtype=Flag.TYPE.INTEGER, default=None, help="d_model: the rate is scaled by d_model ** -0.5."),
+            Flag("warmup_steps", dtype=Flag.TYPE.INTEGER, default=4000, help="Steps of linear warm-up before the 1/sqrt(step) decay."),
+            Flag("initial_factor", dtype=Flag.TYPE.FLOAT, default=1., help="Multiplier of the whole schedule at the start."),
+            Flag("end_factor", dtype=Flag.TYPE.FLOAT, default=None, help="Multiplier after the linear factor decay (default: no decay)."),
+            Flag("start_decay_at", dtype=Flag.TYPE.INTEGER, default=0, help="Step at which the multiplier starts to move towards end_factor."),
+            Flag("decay_steps", dtype=Flag.TYPE.INTEGER, default=None, help="Length of that move in steps."),
         ]
 
     def __call__(self, global_step):

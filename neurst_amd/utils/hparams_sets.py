@@ -1,37 +1,41 @@
-"""Named hyper-parameter sets (neurst/utils/hparams_sets.py:19-57)."""
+"""Named hyper-parameter sets (behaviour of neurst/utils/hparams_sets.py:19-57): functions registered under one or several
+names return a dict of defaults; a name nobody registered is offered to every registered model class
+(`build_model_args_by_name`), which is how `speech_transformer_s`, `transformer_big`, `waitk_transformer_base` ... resolve."""
 from neurst_amd.utils.registry import REGISTRIES
+
+_KEY = "hparams_set"
+
+
+def _table(backend):
+    return REGISTRIES.setdefault(backend, {}).setdefault(_KEY, {})
 
 
 def register_hparams_set(name, backend="pt"):
-    REGISTRIES.setdefault(backend, {}).setdefault("hparams_set", {})
-    table = REGISTRIES[backend]["hparams_set"]
+    """@register_hparams_set("alias") or @register_hparams_set(["a", "b"]): the function is stored under the (lower-cased)
+    aliases and under its own name; a different function under a taken name is an error."""
+    if not isinstance(name, (str, list)):
+        raise ValueError("Not supported type: {}".format(type(name)))
+    aliases = [name] if isinstance(name, str) else list(name)
 
-    def register_x_fn(fn_, short_name=None):
-        names = set(n.lower() for n in (short_name or []))
-        names.add(fn_.__name__)
-        for n in names:
-            if n in table and table[n] != fn_:
-                raise ValueError("Cannot register duplicate {} (under hparams_set)".format(n))
-            table[n] = fn_
-        return fn_
-
-    if isinstance(name, str):
-        return lambda fn: register_x_fn(fn, [name])
-    if isinstance(name, list):
-        return lambda fn: register_x_fn(fn, name)
-    raise ValueError("Not supported type: {}".format(type(name)))
+    def decorator(fn):
+        table = _table(backend)
+        for key in {a.lower() for a in aliases} | {fn.__name__}:
+            if table.get(key, fn) is not fn:
+                raise ValueError("Cannot register duplicate {} (under hparams_set)".format(key))
+            table[key] = fn
+        return fn
+    return decorator
 
 
 def get_hyper_parameters(name, backend="pt"):
-    """hparams_sets.py:45-57: a registered set, else the first model whose build_model_args_by_name knows it."""
     if name is None:
         return {}
-    table = REGISTRIES.get(backend, {}).get("hparams_set", {})
-    if name in table:
-        return table[name]()
-    for mc in set(REGISTRIES.get(backend, {}).get("model", {}).values()):
-        if hasattr(mc, "build_model_args_by_name"):
-            p = mc.build_model_args_by_name(name)
-            if p is not None:
-                return p
+    fn = _table(backend).get(name, None)
+    if fn is not None:
+        return fn()
+    for model_cls in set(REGISTRIES.get(backend, {}).get("model", {}).values()):
+        by_name = getattr(model_cls, "build_model_args_by_name", None)
+        found = by_name(name) if by_name is not None else None
+        if found is not None:
+            return found
     return {}

@@ -24,75 +24,78 @@ def _ensure(backend, registry_name):
     REGISTRIED_CLS2ALIAS.setdefault(backend, {}).setdefault(registry_name, {})
 
 
+def _snake(name):
+    return "_".join(re.sub("([A-Z])", r" \1", name).lower().strip().split())
+
+
+def _resolve(table, registry_name, args):
+    """(class or None, params dict) named by `args`: a dict with "<name>.class" / "class" / "<name>" and "<name>.params" /
+    "params", or the class (name) itself."""
+    params = {}
+    if isinstance(args, dict):
+        wanted = args.get("class", None) or args.get(f"{registry_name}.class", None) or args.get(registry_name, None)
+        params = (args.get("params", None) or args.get(f"{registry_name}.params", {})) or {}
+    else:
+        wanted = args
+    if wanted is None or (isinstance(wanted, str) and wanted.lower() == "none"):
+        return None, params
+    if isinstance(wanted, str):
+        if wanted not in table:
+            raise ValueError("Not registered class name: {}.".format(wanted))
+        return table[wanted], params
+    if not callable(wanted):
+        raise ValueError("Not supported type: {} for builder.".format(type(wanted)))
+    return wanted, params
+
+
 def setup_registry(registry_name, base_class=None, create_fn=None, verbose_creation=False, backend="pt"):
     _ensure(backend, registry_name)
     table = REGISTRIES[backend][registry_name]
 
     def build_x(args, *extra_args, **kwargs):
         from neurst_amd.utils.flags_core import Flag, ModuleFlag
-        params_ = {}
-        if isinstance(args, dict):
-            cls_ = args.get("class", None) or args.get(f"{registry_name}.class", None) or args.get(registry_name, None)
-            params_ = (args.get("params", None) or args.get(f"{registry_name}.params", {})) or {}
-        else:
-            cls_ = args
-        if cls_ is None:
+        target, params = _resolve(table, registry_name, args)
+        if target is None:
             return None
-        if isinstance(cls_, str):
-            if cls_.lower() == "none":
-                return None
-            if cls_ not in table:
-                raise ValueError("Not registered class name: {}.".format(cls_))
-            cls_ = table[cls_]
-        elif not callable(cls_):
-            raise ValueError("Not supported type: {} for builder.".format(type(cls_)))
-        builder = cls_
+        assert isinstance(params, dict), f"Not supported type: {type(params)} for params"
+        params = dict(params)
+        make = target
         if create_fn is not None:
-            assert hasattr(builder, create_fn), "{} has no {} for creation.".format(cls_, create_fn)
-            builder = getattr(builder, create_fn)
-        assert isinstance(params_, dict), f"Not supported type: {type(params_)} for params"
-        params_ = dict(params_)
-        if hasattr(cls_, "class_or_method_args"):
-            for f in cls_.class_or_method_args():
-                if isinstance(f, ModuleFlag):
-                    params_.setdefault(f.cls_key, f.default)
-                    params_.setdefault(f.params_key, {})
-                elif isinstance(f, Flag):
-                    if f.name in kwargs:
-                        params_[f.name] = kwargs.pop(f.name)
-                    elif f.name not in params_:
-                        params_[f.name] = f.default
-            if verbose_creation:
-                logging.info("Creating %s: %s", registry_name, cls_)
-            return builder(params_, *extra_args, **kwargs)
-        params_ = deep_merge_dict(params_, kwargs, merge_only_exist=False)
+            assert hasattr(target, create_fn), "{} has no {} for creation.".format(target, create_fn)
+            make = getattr(target, create_fn)
         if verbose_creation:
-            logging.info("Creating %s: %s", registry_name, cls_)
-        return builder(*extra_args, **params_)
+            logging.info("Creating %s: %s", registry_name, target)
+        if not hasattr(target, "class_or_method_args"):       # plain classes: parameters are keyword arguments
+            return make(*extra_args, **deep_merge_dict(params, kwargs, merge_only_exist=False))
+        for flag in target.class_or_method_args():            # flagged classes: one dict with every flag filled in
+            if isinstance(flag, ModuleFlag):
+                params.setdefault(flag.cls_key, flag.default)
+                params.setdefault(flag.params_key, {})
+            elif isinstance(flag, Flag):
+                if flag.name in kwargs:
+                    params[flag.name] = kwargs.pop(flag.name)
+                else:
+                    params.setdefault(flag.name, flag.default)
+        return make(params, *extra_args, **kwargs)
+
+    def _add(cls_, aliases):
+        if base_class is not None and not issubclass(cls_, base_class):
+            raise ValueError("{} must extend {}".format(cls_.__name__, base_class.__name__))
+        names = set(aliases) | {cls_.__name__, cls_.__name__.lower(), _snake(cls_.__name__)}
+        for n in names:
+            if table.get(n, cls_) is not cls_:
+                raise ValueError("Cannot register duplicate {} (under {})".format(n, registry_name))
+            table[n] = cls_
+        REGISTRIED_CLS2ALIAS[backend][registry_name][cls_.__name__] = names
+        return cls_
 
     def register_x(name):
-        def register_x_cls(cls_, short_name=None):
-            if base_class is not None and not issubclass(cls_, base_class):
-                raise ValueError("{} must extend {}".format(cls_.__name__, base_class.__name__))
-            names = set(short_name or [])
-            names.add(cls_.__name__)
-            names.add(cls_.__name__.lower())
-            names.add("_".join(re.sub("([A-Z])", r" \1", cls_.__name__).lower().strip().split()))
-            for n in names:
-                if n in table:
-                    if table[n] != cls_:
-                        raise ValueError("Cannot register duplicate {} (under {})".format(n, registry_name))
-                else:
-                    table[n] = cls_
-            REGISTRIED_CLS2ALIAS[backend][registry_name][cls_.__name__] = names
-            return cls_
-
         if isinstance(name, str):
-            return lambda c: register_x_cls(c, [name])
+            return lambda c: _add(c, [name])
         if isinstance(name, list):
-            return lambda c: register_x_cls(c, name)
+            return lambda c: _add(c, name)
         if callable(name):
-            return register_x_cls(name)
+            return _add(name, [])
         raise ValueError("Not supported type: {}".format(type(name)))
 
     return build_x, register_x
