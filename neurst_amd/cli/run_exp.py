@@ -52,23 +52,25 @@ def _pre_load_args(args):
     return deep_merge_dict(deep_merge_dict(stored, layered), from_files)
 
 
-def run_experiment(args, remaining_argv):
+def run_experiment(args, remaining_argv, device=None):
+    """`device` is for the host-logic tests only (they install emulated kernels and pass "cpu"); the product always runs
+    on this rank's GPU -- neurst_amd.kernels refuses anything else."""
     rank, local_rank, world = init_distributed()
     flags_core.verbose_flags(FLAG_LIST, args, remaining_argv)
     task = build_task(args)
     custom_dataset = build_dataset(args)
-    model = task.build_model(args, device=f"cuda:{local_rank}", dtype=args["dtype"], seed=args["seed"] + rank)
+    model = task.build_model(args, device=device or f"cuda:{local_rank}", dtype=args["dtype"], seed=args["seed"] + rank)
     entry = build_exp(args, strategy=args["distribution_strategy"], model=model, task=task,
                       model_dir=args["model_dir"], custom_dataset=custom_dataset)
     return entry.run()
 
 
-def _main(argv=None):
+def _main(argv=None, device=None):
     arg_parser = flags_core.define_flags(FLAG_LIST, argv=argv)
     args, remaining_argv = flags_core.intelligent_parse_flags(FLAG_LIST, arg_parser, _pre_load_args, argv=argv)
     if args["entry.class"] is None:
         raise ValueError("Must provide entry/entry.class.")
-    return run_experiment(args, remaining_argv)
+    return run_experiment(args, remaining_argv, device=device)
 
 
 def cli_main():

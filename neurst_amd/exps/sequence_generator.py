@@ -50,6 +50,21 @@ class SequenceGenerator(BaseExperiment):
                 out.append(" ".join(str(x) for x in (row[:row.index(eos)] if eos in row else row)))
         return out
 
+    def _references(self):
+        """sequence_generator.py:163-175: references are only looked at when a metric is configured, and only a dataset
+        that still holds TEXT transcripts has them (projected-id records carry none)."""
+        ds = self.custom_dataset
+        if getattr(ds, "_transcript_is_projected", False):
+            return None
+        for name in ("raw_targets", "targets"):
+            try:
+                refs = getattr(ds, name, None)
+            except (AssertionError, AttributeError, NotImplementedError):
+                refs = None
+            if refs:
+                return refs
+        return None
+
     def run(self):
         model = self.model
         if self.model_dir:
@@ -72,8 +87,8 @@ class SequenceGenerator(BaseExperiment):
             with open(self._output_file, "w", encoding="utf-8") as fw:
                 fw.write("\n".join(results) + "\n")
             logging.info("Saving generation results into %s", self._output_file)
-        refs = getattr(self.custom_dataset, "raw_targets", None) or getattr(self.custom_dataset, "targets", None)
-        if self._metric is not None and refs is not None and len(refs) == len(results) and all(isinstance(r, str) for r in refs):
+        refs = self._references() if self._metric is not None else None
+        if refs is not None and len(refs) == len(results) and all(isinstance(r, str) for r in refs):
             self.metric_result = self._metric(results, list(refs))
             logging.info("Evaluation Result: %s", ", ".join(f"{k}={v:.2f}" for k, v in self.metric_result.items()))
         return results

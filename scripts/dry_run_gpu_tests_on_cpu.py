@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SKIP_MARKERS = ("no dropout", "Torch not compiled with CUDA", "CUDA", "cuda", "ROCm device tensors", "probe")
+SKIP_MARKERS = ("No HIP GPUs", "no ROCm-capable device", "no dropout", "Torch not compiled with CUDA", "CUDA", "cuda", "ROCm device tensors", "probe")
 
 
 class _Emulate(object):
