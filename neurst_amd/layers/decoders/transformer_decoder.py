@@ -151,8 +151,8 @@ class TransformerDecoder(Decoder):
 
     __call__ = forward
 
-    def backward(self, dout):
-        """Returns (d decoder_inputs [B,L,d], d memory [B,Tm,d])."""
+    def backward(self, dout, layer_done=None):
+        """Returns (d decoder_inputs [B,L,d], d memory [B,Tm,d]).  layer_done: see TransformerEncoder.backward."""
         B, L, d, Tm = self._shapes
         dmemory = torch.empty(B * Tm, d, dtype=dout.dtype, device=dout.device) if Tm else None
         layers = self._stacking_layers
@@ -167,6 +167,8 @@ class TransformerDecoder(Decoder):
                                     consumer=layers[i - 1].first_backward_site if i > 0 else self)
             if layers[i]._with_cross_attention:
                 first = False
+            if layer_done is not None:
+                layer_done([layers[i].name + "/"])
         dx = dropped_grad(self.rt, dx, self._p, self._site)
         if dmemory is not None and first:
             dmemory.zero_()

@@ -94,7 +94,9 @@ class TransformerEncoder(Encoder):
             x = self._output_norm_layer.forward(x, save=False)
         return x.view(B, n, d), cache
 
-    def backward(self, dout):
+    def backward(self, dout, layer_done=None):
+        """layer_done(prefixes): called after each layer's backward has been QUEUED (its gradients are complete once the
+        streams that were current until then have drained) -- the data-parallel reducer's per-layer buckets."""
         B, T, d = dout.shape
         layers = self._stacking_layers
         # every gradient on the residual chain next meets a dropout mask: the LayerNorm backward that produces it also
@@ -106,6 +108,8 @@ class TransformerEncoder(Encoder):
             dx = dx.contiguous()
         for i in range(len(layers) - 1, -1, -1):
             dx = layers[i].backward(dx, consumer=layers[i - 1].first_backward_site if i > 0 else self)
+            if layer_done is not None:
+                layer_done([layers[i].name + "/"])
         dx = dropped_grad(self.rt, dx, self._p, self._site)
         return dx.view(B, T, d)
 

@@ -220,24 +220,23 @@ class EncoderDecoderModel(BaseModel):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
         self.rt.store.begin_backward(accumulate)
-        user_hook = self.grad_ready_hook or (lambda prefixes: None)
-
-        def hook(prefixes):  # a component's gradients are complete once its weight-gradient stream work is joined
-            self.rt.join_wgrad_stream()
-            user_hook(prefixes)
-
+        hook = self.grad_ready_hook or (lambda prefixes: None)
+        # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
+        # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
+        # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
         shared = self._src_modality is self._trg_modality
         ddec = self._output_logits_backward(dlogits)
-        ddec_in, dmemory = self._decoder.backward(ddec)
+        ddec_in, dmemory = self._decoder.backward(ddec, layer_done=hook)
         # softmax_linear (untied logits) is registered right after the decoder: one contiguous slice with it
         hook([self._decoder.name + "/"] + (["softmax_linear/"] if self._output_linear_layer is not None else []))
         self._trg_modality.backward(ddec_in, mode="embedding")
         if not shared:
             hook([self._modality_scope(self._trg_modality) + "/"])
-        denc_in = self._encoder.backward(dmemory)
+        denc_in = self._encoder.backward(dmemory, layer_done=hook)
         hook([self._encoder.name + "/"])
         self._src_modality.backward(denc_in, mode="embedding")
         hook([self._modality_scope(self._src_modality) + "/"])
+        self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here
 

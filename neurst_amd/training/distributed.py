@@ -9,9 +9,9 @@ with one packed all-reduce.
 MI355X-first differences:
   * gradients live in ONE flat fp32 buffer in forward order, so a "bucket" is a contiguous slice: no per-tensor
     collectives, no flatten/unflatten copies;
-  * the model's backward reports each finished component (decoder, embedding, encoder, front end); its slice is
-    all-reduced at once on a side HIP stream while the remaining backward (notably the conv front end, the
-    heaviest part) keeps the compute stream busy;
+  * the model's backward reports every finished LAYER (decoder 5..0, embedding, encoder 11..0, front end); adjacent
+    reports are merged into >= 8 MiB slices that are all-reduced on a side HIP stream while the remaining backward
+    keeps the compute stream busy; the side stream -- not the compute stream -- waits for the weight-gradient stream;
   * slices are cut into <= bucket_bytes pieces (default 32 MiB): on the fully connected 8-GPU xGMI mesh a ring is
     bound by one ~153 GB/s link, so few large messages beat many small ones;
   * the 1/N of the average is folded into the fused Adam kernel instead of a separate scaling pass.
@@ -36,26 +36,41 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # rank 0 alone validates / writes checkpoints while the others wait in the next collective: the default
+        # 10-minute watchdog would abort a long beam-search validation (NST_DIST_TIMEOUT_MIN overrides)
+        import datetime
+        timeout = datetime.timedelta(minutes=float(os.environ.get("NST_DIST_TIMEOUT_MIN", "180")))
         if backend == "nccl":
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
                                     device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     from neurst_amd.utils import compat
     compat.register_distributed_worker_setting(rank, world, "rccl" if world > 1 else None)
     return rank, local_rank, world
 
 
 class GradientReducer(object):
-    def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True):
+    """bucket_bytes: upper bound of one all-reduce message; min_bucket_bytes: ranges reported by the backward pass are
+    coalesced (they arrive in reverse registration order, i.e. adjacent) until at least this much is ready, so a
+    12-layer encoder becomes a handful of 8-16 MiB collectives that start while the earlier layers still
+    back-propagate, instead of one 63 MiB exchange after the whole encoder."""
+
+    def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True, min_bucket_bytes=8 << 20, extra_streams=()):
         self.store, self.group = store, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.min_elems = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.on_gpu = store.grad.is_cuda
         self.overlap = overlap and self.on_gpu and self.world > 1
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
+        # streams (besides the current one) whose queued work writes gradients: the exchange waits for them on the
+        # COMMUNICATION stream, so the compute streams never stall for a bucket
+        self.extra_streams = [s for s in extra_streams if s is not None]
         self._pending = []
         self._covered = []
+        self._open = None        # coalescing range [start, end) not yet issued
+        self.messages = 0        # collectives issued since the last finish() (introspection / tests)
 
     # ---- parameter ranges -------------------------------------------------------------------------------------
     def range_of(self, prefixes):
@@ -69,6 +84,19 @@ class GradientReducer(object):
         end = last.offset + (last.numel + 7) // 8 * 8
         return start, min(end, self.store.total)
 
+    def _uncovered(self, start, end):
+        """Pieces of [start, end) no earlier report of this step has covered."""
+        out, pos = [], start
+        for s, e in sorted(self._covered):
+            if e <= pos or s >= end:
+                continue
+            if s > pos:
+                out.append((pos, min(s, end)))
+            pos = max(pos, e)
+        if pos < end:
+            out.append((pos, end))
+        return out
+
     # ---- collectives ------------------------------------------------------------------------------------------
     def _allreduce_slice(self, start, end):
         g = self.store.grad
@@ -76,18 +104,40 @@ class GradientReducer(object):
             e = min(end, s + self.bucket_elems)
             h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append(h)
+            self.messages += 1
 
-    def reduce_range(self, start, end):
-        """Sums grad[start:end] over ranks, asynchronously when a side stream is available."""
-        self._covered.append((start, end))
-        if self.world <= 1:
+    def _issue(self, start, end):
+        if self.world <= 1 or end <= start:
             return
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s in self.extra_streams:
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 self._allreduce_slice(start, end)
         else:
+            for s in self.extra_streams:
+                torch.cuda.current_stream().wait_stream(s)
             self._allreduce_slice(start, end)
+
+    def flush(self):
+        if self._open is not None:
+            s, e = self._open
+            self._open = None
+            self._issue(s, e)
+
+    def reduce_range(self, start, end):
+        """Sums grad[start:end] over ranks (asynchronously on the side stream when there is one); adjacent reports are
+        merged until min_bucket_bytes are ready."""
+        for s, e in self._uncovered(start, end):
+            self._covered.append((s, e))
+            if self._open is not None and (e == self._open[0] or s == self._open[1]):
+                self._open = (min(s, self._open[0]), max(e, self._open[1]))
+            else:
+                self.flush()
+                self._open = (s, e)
+            if self._open[1] - self._open[0] >= self.min_elems:
+                self.flush()
 
     def component_ready(self, prefixes):
         r = self.range_of(prefixes)
@@ -97,18 +147,15 @@ class GradientReducer(object):
     def finish(self):
         """Reduces whatever the hooks did not cover, then makes the compute stream wait for the exchange.
         Returns the factor the optimizer must apply to the summed gradients (1/world: hvd.Average)."""
-        covered = sorted(self._covered)
-        pos = 0
-        for s, e in covered + [(self.store.total, self.store.total)]:
-            if s > pos:
-                self.reduce_range(pos, s)
-            pos = max(pos, e)
+        self.reduce_range(0, self.store.total)
+        self.flush()
         self._covered = []
         for h in self._pending:
             h.wait()
         self._pending = []
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.last_messages, self.messages = self.messages, 0
         return 1.0 / self.world
 
     def broadcast_parameters(self, src=0):

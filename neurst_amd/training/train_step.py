@@ -18,6 +18,9 @@ class TrainStep(object):
         self.update_cycle = max(1, int(update_cycle))
         if reducer is not None:
             model.grad_ready_hook = self._hook
+            ws = getattr(model.rt, "wgrad_stream", None)
+            if ws is not None and ws not in reducer.extra_streams:
+                reducer.extra_streams.append(ws)
         self._last_micro = True
 
     def _hook(self, prefixes):

@@ -124,9 +124,40 @@ def cross_attention(x, memory, W, prefix, num_heads, memory_bias, rate=0.0, is_t
                             num_heads, None, is_output_transform=True)
 
 
+_RELU_GATES = None
+
+
+class relu_gates(object):
+    """Diagnostic context (tests only): inside it the oracle's ReLUs use the 0/1 gates of ANOTHER path instead of the sign
+    of their own pre-activation -- `provider.gate_for(tag, shape)` returns the gate tensor of the ReLU owned by the
+    variable scope `tag` (an FFN's scope, or "<modality>/conv1|conv2"), or None to keep the oracle's own.  Running the
+    oracle under a reduced-precision path's gates separates that path's rounding error from the discrete ReLU flips of
+    near-zero pre-activations."""
+
+    def __init__(self, provider):
+        self.provider = provider
+
+    def __enter__(self):
+        global _RELU_GATES
+        self._old, _RELU_GATES = _RELU_GATES, self.provider
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_GATES
+        _RELU_GATES = self._old
+
+
+def relu(x, tag=None):
+    if _RELU_GATES is not None and tag is not None:
+        g = _RELU_GATES.gate_for(tag, tuple(x.shape))
+        if g is not None:
+            return x * g.to(x.dtype)
+    return F.relu(x)
+
+
 def ffn(x, W, prefix, rate=0.0, is_training=False, generator=None):
     """TransformerFFN.call (neurst/layers/common_layers.py:145-160), relu."""
-    h = F.relu(x @ W[prefix + "/dense1/kernel"] + W[prefix + "/dense1/bias"])
+    h = relu(x @ W[prefix + "/dense1/kernel"] + W[prefix + "/dense1/bias"], prefix)
     h = dropout(h, rate, is_training, generator, prefix)
     return h @ W[prefix + "/dense2/kernel"] + W[prefix + "/dense2/bias"]
 
@@ -306,7 +337,7 @@ def audio_conv_subsample(src, W, scope, layer_norm_on=True, kernel_size=3, strid
         if layer_norm_on:
             x = layer_norm(x.permute(0, 2, 3, 1), W[f"{scope}/ln{i}/gamma"], W[f"{scope}/ln{i}/beta"], 1e-6)
             x = x.permute(0, 3, 1, 2)
-        x = F.relu(x)
+        x = relu(x.permute(0, 2, 3, 1), f"{scope}/conv{i}").permute(0, 3, 1, 2)
     x = x.permute(0, 2, 3, 1)  # [B,T',F',C]
     x = x.reshape(x.shape[0], x.shape[1], -1)
     return x @ W[f"{scope}/output_dense/kernel"] + W[f"{scope}/output_dense/bias"]

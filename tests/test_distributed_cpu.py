@@ -49,10 +49,18 @@ def _worker(rank, world, port, q):
     pattern = torch.arange(st.total, dtype=torch.float32) % 7 - 3
     st.grad.copy_(pattern * (rank + 1))
     # the hooks fire in backward order: decoder, embedding, encoder, front end (see EncoderDecoderModel.backward)
+    # ... with the per-layer reports in between (last layer first); a component report only adds what its layers left
+    # (output_ln), adjacent reports coalesce, nothing is reduced twice
+    for i in (1, 0):
+        red.component_ready([f"TransformerDecoder/layer_{i}/"])
     red.component_ready(["TransformerDecoder/"])
     red.component_ready(["target_symbol_modality/"])
+    for i in (1, 0):
+        red.component_ready([f"TransformerEncoder/layer_{i}/"])
     red.component_ready(["TransformerEncoder/"])
+    assert red._uncovered(*red.range_of(["TransformerDecoder/"])) == []
     scale = red.finish()          # covers what the hooks did not (input_audio_modality + padding gaps)
+    assert red.last_messages >= 4
     avg = st.grad * scale
     expect = pattern * (sum(range(1, world + 1)) / world)
     ok_avg = torch.allclose(avg, expect, atol=1e-6)

@@ -160,8 +160,10 @@ def test_post_norm_and_untied_softmax_host_schedule(cpu_kernels, variant):
         assert rel_err(p.grad, grads_ref[n]) < 5e-5, n
     if "untied" in variant:  # decoder + softmax_linear are reported together and form one contiguous slice
         from neurst_amd.training.distributed import GradientReducer
-        assert fired[0] == ["TransformerDecoder/", "softmax_linear/"]
-        s, e = GradientReducer(model.store).range_of(fired[0])
+        comp = ["TransformerDecoder/", "softmax_linear/"]
+        n_dec = len(model._decoder._stacking_layers)    # per-layer reports first (last layer first), then the component
+        assert fired[:n_dec] == [[f"TransformerDecoder/layer_{i}/"] for i in range(n_dec - 1, -1, -1)] and fired[n_dec] == comp
+        s, e = GradientReducer(model.store).range_of(comp)
         inside = [p for p in model.store.params.values() if s <= p.offset < e]
         assert all(p.name.startswith(("TransformerDecoder/", "softmax_linear/")) for p in inside)
         assert e == model.store.total
@@ -421,8 +423,12 @@ def test_data_parallel_train_step_world2_gloo_matches_oracle_average():
         assert p.exitcode == 0
     res = [(r, torch.from_numpy(w), l, f) for r, w, l, f in res]
     assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
-    assert res[0][3] == res[1][3] and [f[0] for f in res[0][3][:4]] == [
+    # per-layer reports (last layer first) followed by the component report that sweeps up output_ln
+    comps = [f[0] for f in res[0][3] if "/layer_" not in f[0]]
+    assert res[0][3] == res[1][3] and comps[:4] == [
         "TransformerDecoder/", "target_symbol_modality/", "TransformerEncoder/", "input_audio_modality/"]
+    first = [f[0] for f in res[0][3]]
+    assert first[0].startswith("TransformerDecoder/layer_") and first.index("TransformerEncoder/") > first.index("TransformerEncoder/layer_0/")
 
     # single-process oracle of the same two steps
     model, cfg, shape = _speech_model("toy")   # same init seed as the workers (rank 0's weights are broadcast)
