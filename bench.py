@@ -7,9 +7,9 @@
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).  `value` is the whole-job
-frames/s with the inputs already resident in HBM.  `roofline` is measured live with HIP events around the launches
-of the dominant kernel (the conv2 implicit-GEMM forward: the largest single launch of the step) during the timed
-steps, on the stream they are launched on.  `cpu_baseline` times the CPU oracle (oracle/neurst_oracle.py, a torch-CPU
+frames/s with the inputs already resident in HBM.  `roofline` is measured live with HIP events around every launch
+of the MFMA kernel families in extra steps right after the timed region, on the stream each launch goes to; the object
+prices the family with the largest share of GPU time (the dense GEMMs), all families are in `roofline_families`.  `cpu_baseline` times the CPU oracle (oracle/neurst_oracle.py, a torch-CPU
 restatement of the reference math -- TensorFlow is not installable here) on the host cores, rank 0 at N=1 only.
 """
 import argparse
@@ -23,6 +23,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROBED = ("gemm", "ffn_fwd", "ffn_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "attention_fwd", "attention_bwd")
+FAMILY_KERNELS = {
+    "gemm": "dense_gemm_kernel_v3 family (every nst_gemm launch of a step: projections, logits, front dense, their input "
+            "and weight gradients incl. split-K reduce; work = sum 2MNK)",
+    "ffn_fwd": "ffn_fwd_fused_kernel (dense1 + ReLU + dropout + dense2 in one launch; work = 4*M*d*ffn)",
+    "ffn_bwd": "ffn_bwd_fused_kernel (d hidden + gate + d input in one launch; work = 4*M*d*ffn)",
+    "conv2_fwd": "conv2_fwd_patch_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C; LDS-resident input patch)",
+    "conv2_dgrad": "conv2_dgrad_patch_kernel", "conv2_wgrad": "conv2 weight gradient (implicit GEMM, K = pixels)",
+    "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd dK/dV + dQ kernels",
+}
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0
@@ -43,6 +53,7 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split over the ranks (default: per-GPU batch, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="extra un-timed steps with per-launch HIP events (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -199,14 +210,22 @@ def main():
     for i in range(args.warmup):
         step_fn(batches[i % len(batches)])
     barrier()
-    K.PROBE.start("conv2_fwd")
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
         loss = step_fn(batches[i % len(batches)])
     barrier()
     elapsed = time.perf_counter() - t0
-    probe_ms = K.PROBE.stop()
+    # roofline pass (un-timed, after the measurement): the same steps with HIP events around every launch of the MFMA kernel
+    # families, on the stream each launch goes to -- durations are therefore IN-STEP durations (the weight-gradient stream
+    # shares the CUs with the dgrad chain), the same thing `rocprofv3 --kernel-trace --stats` of this command reports
+    probe = {}
+    if rank == 0 and args.roofline_steps > 0:
+        K.PROBE.start(PROBED)
+        for i in range(args.roofline_steps):
+            step_fn(batches[i % len(batches)])
+        probe = K.PROBE.stop()
+    barrier()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,20 +239,35 @@ def main():
     step_flops = 3 * fl["forward"]
     value = frames / elapsed
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-    conv2_ms = sum(probe_ms) / max(len(probe_ms), 1) if probe_ms else None
-    roofline = {"kernel": "conv2_fwd_patch_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C; LDS-resident input patch)", "bound": "mfma",
-                "achieved": (fl["conv2"] / (conv2_ms * 1e-3) / 1e12) if conv2_ms else None, "peak": peak,
-                "unit": "TFLOP/s", "frac": None, "traffic": None, "launches_timed": len(probe_ms),
-                "avg_launch_ms": conv2_ms, "algorithmic_flops_per_launch": fl["conv2"]}
-    if roofline["achieved"]:
-        roofline["frac"] = roofline["achieved"] / peak
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv2_fwd_patch.json")
-    if args.dtype == "bf16" and B == 128 and T == 900 and os.path.exists(pmc):
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
-        # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in KB); not re-measured by this run.
+    families = {}
+    for name, rows in probe.items():
+        ms, work = sum(r[0] for r in rows), sum(r[1] for r in rows)
+        families[name] = {"kernel": FAMILY_KERNELS.get(name, name), "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                          "launches_per_step": len(rows) / args.roofline_steps, "ms_per_step": ms / args.roofline_steps,
+                          "avg_launch_ms": ms / max(len(rows), 1), "algorithmic_flops_per_step": work / args.roofline_steps,
+                          "achieved": (work / (ms * 1e-3) / 1e12) if ms > 0 else None, "traffic": None}
+        if families[name]["achieved"] is not None:
+            families[name]["frac"] = families[name]["achieved"] / peak
+    # the roofline object prices the family that takes the most GPU time in the step
+    roofline = None
+    if families:
+        top = max(families, key=lambda n: families[n]["ms_per_step"])
+        roofline = dict(families[top])
+        roofline["selected_as"] = "largest share of in-step GPU time among the MFMA kernel families (see roofline_families)"
+        pmc = os.path.join(ROOT, "profiles", f"r02_pmc_{top}.json")
+        if args.dtype == "bf16" and B == 128 and T == 900 and os.path.exists(pmc):
+            # HBM bytes per step of this family from the committed rocprofv3 --pmc passes of the same command
+            # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); not re-measured by this run
+            try:
+                roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_step"]
+                roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
+            except Exception:
+                pass
+    ffn_util = None
+    pmc_ffn = os.path.join(ROOT, "profiles", "r02_pmc_ffn_gemm.json")
+    if os.path.exists(pmc_ffn):
         try:
-            roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_conv2_fwd_patch.json"
+            ffn_util = {"source": "profiles/r02_pmc_ffn_gemm.json", **json.load(open(pmc_ffn))["summary"]}
         except Exception:
             pass
     out = {
@@ -250,6 +284,10 @@ def main():
         "model_mfma_frac": step_flops * args.steps / elapsed / 1e12 / peak,
         "final_loss": loss_val,
         "roofline": roofline,
+        "roofline_families": families,
+        "ffn_gemm_mfma_utilisation": ffn_util,
+        "rccl_world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
+        "reducer_messages_per_step": getattr(reducer, "last_messages", None),
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, T, F, L, V)

@@ -62,6 +62,8 @@ def run_experiment(args, remaining_argv, device=None):
     model = task.build_model(args, device=device or f"cuda:{local_rank}", dtype=args["dtype"], seed=args["seed"] + rank)
     entry = build_exp(args, strategy=args["distribution_strategy"], model=model, task=task,
                       model_dir=args["model_dir"], custom_dataset=custom_dataset)
+    if args.get("enable_check_numerics", None):
+        entry.enable_check_numerics = True   # the trainer raises on a non-finite logged loss (all ranks, same step)
     return entry.run()
 
 

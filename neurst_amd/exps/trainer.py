@@ -5,6 +5,7 @@ reference's logging (steps/sec, src_real_tokens_per_sec == audio frames/sec summ
 training/callbacks.py:209-245), checkpoint save of model weights + model_configs.yml on rank 0.
 """
 import logging
+import math
 import os
 import time
 
@@ -126,25 +127,34 @@ class Trainer(BaseExperiment):
             self._validator.build(self.task, model, self.model_dir)
             if self._validator._eval_on_begin:
                 self._validator.validate(start_step)
-        t0, frames, last_loss = time.time(), 0.0, None
+        # resume: the dropout masks are keyed by (seed, rt.step, site) -- continue the step count so a restarted run does not
+        # replay the masks of steps 0.. (the data iterator restarts with its epoch, like the reference's tf.data pipeline)
+        rt.step = start_step
+        t0, last_loss = time.time(), None
+        frames_acc, steps_acc = None, 0   # summed ON THE DEVICE between summaries: no host sync per step (callbacks.py:209-245)
+        check_numerics = bool(getattr(self, "enable_check_numerics", False) or self._args.get("enable_check_numerics", False))
         for step in range(start_step + 1, self._train_steps + 1):
             try:
                 batches = [next(it) for _ in range(self._update_cycle)]
             except StopIteration:
                 break
             frames_dev = sum(b["src_length"].sum() for b in batches)
+            frames_acc = frames_dev if frames_acc is None else frames_acc + frames_dev
+            steps_acc += 1
             last_loss = step_fn(batches)
             if step % self._summary_steps == 0 or step == self._train_steps:
                 if rt.device.type == "cuda":
                     torch.cuda.synchronize()
                 dt = time.time() - t0
-                m = reducer.reduce_metrics({"loss": float(last_loss) / world, "src_real_tokens": float(frames_dev) + frames})
+                m = reducer.reduce_metrics({"loss": float(last_loss) / world, "src_real_tokens": float(frames_acc)})
                 if rank == 0:
                     logging.info("step %d: loss=%.4f  %.3f steps/sec  %.1f src_real_tokens_per_sec  lr=%.3e", step,
-                                 m["loss"], self._summary_steps / dt, m["src_real_tokens"] / dt, optimizer.current_lr())
-                t0, frames = time.time(), 0.0
-            else:
-                frames = frames + float(0)  # keep host free of syncs between summaries
+                                 m["loss"], steps_acc / dt, m["src_real_tokens"] / dt, optimizer.current_lr())
+                self.last_summary = {"step": step, "loss": m["loss"], "steps_per_sec": steps_acc / dt,
+                                     "src_real_tokens_per_sec": m["src_real_tokens"] / dt}
+                if check_numerics and not math.isfinite(m["loss"]):   # the reduced loss: every rank raises at the same step
+                    raise FloatingPointError(f"--enable_check_numerics: loss is {m['loss']} at step {step}")
+                t0, frames_acc, steps_acc = time.time(), None, 0
             if rank == 0 and self._save_checkpoint_steps and step % self._save_checkpoint_steps == 0:
                 self._save(step)
             if self._validator is not None and self._validator.due(step):

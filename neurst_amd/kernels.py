@@ -55,33 +55,37 @@ def _stream():
 
 
 class _KernelProbe(object):
-    """HIP-event timing of one named kernel entry point on the stream it is launched on (bench.py's roofline).
-    Inactive unless start(name) was called; events are only read back in stop()."""
+    """HIP-event timing of kernel entry points on the stream they are launched on (bench.py's roofline pass).
+    Inactive unless start(names) was called; events are only read back in stop().  Every probed call reports its
+    algorithmic work (FLOP) so that a family of launches can be priced as sum(work) / sum(duration)."""
 
     def __init__(self):
-        self.name, self.events = None, []
+        self.names, self.events = (), []
 
-    def start(self, name):
-        self.name, self.events = name, []
+    def start(self, names):
+        self.names, self.events = ((names,) if isinstance(names, str) else tuple(names)), []
 
     def stop(self):
+        """-> {name: [(milliseconds, work), ...]}"""
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self.events]
-        self.name, self.events = None, []
-        return ms
+        out = {}
+        for name, a, b, work in self.events:
+            out.setdefault(name, []).append((a.elapsed_time(b), work))
+        self.names, self.events = (), []
+        return out
 
     def begin(self, name):
-        if self.name != name:
+        if name not in self.names:
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        return ev
+        return (name, ev)
 
-    def end(self, ev):
-        if ev is not None:
+    def end(self, tok, work=0.0):
+        if tok is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record(torch.cuda.current_stream())
-            self.events.append((ev, e2))
+            self.events.append((tok[0], tok[1], e2, float(work)))
 
 
 PROBE = _KernelProbe()
@@ -173,7 +177,9 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     if colsum_out is not None:
         assert colsum_out.dtype == torch.float32 and colsum_out.numel() == N and colsum_out.is_contiguous()
         d.colsum, d.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
+    ev = PROBE.begin("gemm")
     check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
+    PROBE.end(ev, 2.0 * M * N * K)
     return out
 
 
@@ -227,8 +233,10 @@ def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, se
     if dropout_p > 0:
         mask = torch.empty(lib.nst_attention_dropout_mask_bytes(C.byref(d)) // 8, dtype=torch.int64, device=q.device)
         d.dropout_mask, d.dropout_mask_bytes = mask.data_ptr(), mask.numel() * 8
+    ev = PROBE.begin("attention_fwd")
     check(lib.nst_attention_fwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(lse), _stream()),
           "attention_fwd")
+    PROBE.end(ev, 4.0 * B * H * Tq * k.shape[1] * dh)
     return out, lse, mask
 
 
@@ -241,8 +249,10 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, cau
     if dropout_p > 0:
         assert drop_mask is not None, "attention_bwd: dropout needs the mask written by attention_fwd"
         d.dropout_mask, d.dropout_mask_bytes = drop_mask.data_ptr(), drop_mask.numel() * 8
+    ev = PROBE.begin("attention_bwd")
     check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(dout), _p(lse), _p(delta),
                                 _p(dq), _p(dk), _p(dv), _stream()), "attention_bwd")
+    PROBE.end(ev, 8.0 * q.shape[0] * H * q.shape[1] * k.shape[1] * dh)
 
 
 # ------------------------------------------------------------------------------------------------ conv front end
@@ -275,7 +285,7 @@ def conv2_fwd(x, w2, b2, relu=False):
     y = torch.empty(B, (T1 + 1) // 2, (F1 + 1) // 2, Cc, dtype=x.dtype, device=x.device)
     ev = PROBE.begin("conv2_fwd")
     check(lib.nst_conv2_fwd(_p(x), _p(w2), _p(b2), _p(y), B, T1, F1, Cc, int(relu), _dt(x), _stream()), "conv2_fwd")
-    PROBE.end(ev)
+    PROBE.end(ev, 2.0 * y.numel() * 9 * Cc)
     return y
 
 
@@ -283,7 +293,9 @@ def conv2_dgrad(dy, w2, T1, F1):
     B, T2, F2, Cc = dy.shape
     assert dy.is_contiguous() and w2.dtype == dy.dtype
     dx = torch.empty(B, T1, F1, Cc, dtype=dy.dtype, device=dy.device)
+    ev = PROBE.begin("conv2_dgrad")
     check(lib.nst_conv2_dgrad(_p(dy), _p(w2), _p(dx), B, T1, F1, Cc, _dt(dy), _stream()), "conv2_dgrad")
+    PROBE.end(ev, 2.0 * dy.numel() * 9 * Cc)
     return dx
 
 
@@ -293,8 +305,10 @@ def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
     assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
     assert db2 is None or (db2.dtype == torch.float32 and db2.numel() == Cc and db2.is_contiguous())
     ws = _workspace(64 << 20, x.device)
+    ev = PROBE.begin("conv2_wgrad")
     check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), _p(db2), B, T1, F1, Cc, _dt(x), int(accumulate), ws.data_ptr(),
                               ws.numel(), _stream()), "conv2_wgrad")
+    PROBE.end(ev, 2.0 * dy.numel() * 9 * Cc)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise

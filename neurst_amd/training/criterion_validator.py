@@ -12,7 +12,7 @@ import torch
 from neurst_amd.criterions import Criterion, build_criterion
 from neurst_amd.data.datasets import Dataset, build_dataset
 from neurst_amd.utils import compat
-from neurst_amd.utils.checkpoints import NameBasedCheckpointManager
+from neurst_amd.utils.checkpoints import KeepBestCheckpointSaver
 from neurst_amd.utils.flags_core import Flag, ModuleFlag
 from neurst_amd.utils.registry import setup_registry
 
@@ -42,6 +42,21 @@ class Validator(object):
 
 
 build_validator, register_validator = setup_registry(Validator.REGISTRY_NAME, base_class=Validator, backend="pt")
+
+
+class _AsMetric(object):
+    """The comparison interface the checkpoint savers need (flag value of a result dict, direction) from a criterion's
+    as_metric() descriptor."""
+
+    def __init__(self, metric):
+        self.flag, self.greater_is_better = metric.flag, metric.greater_is_better
+
+    def get_value(self, result):
+        return float(result if isinstance(result, (int, float)) else result[self.flag])
+
+    def greater_or_eq(self, a, b):
+        a, b = self.get_value(a), self.get_value(b)
+        return a >= b if self.greater_is_better else a <= b
 
 
 @register_validator(["criterion", "CriterionValidator"])
@@ -78,7 +93,8 @@ class CriterionValidator(Validator):
         self._dataset = build_dataset({"dataset.class": self.args["eval_dataset.class"],
                                        "dataset.params": self.args.get("eval_dataset.params", None) or {}})
         if model_dir and self._top_keep > 0:
-            self._saver = NameBasedCheckpointManager(model, os.path.join(model_dir, "best"), max_to_keep=self._top_keep)
+            self._saver = KeepBestCheckpointSaver(model, os.path.join(model_dir, "best"), _AsMetric(self._criterion.as_metric()),
+                                                  max_to_keep=self._top_keep)
         self._start = time.time()
         return self
 
@@ -108,8 +124,8 @@ class CriterionValidator(Validator):
         better = self.best is None or (value >= self.best[metric.flag] if metric.greater_is_better else value <= self.best[metric.flag])
         if better:
             self.best = dict(res)
-            if self._saver is not None:
-                self._saver.save(step)
+        if self._saver is not None:     # keep-best rule of checkpoints.py:186-237: saved if fewer than K kept or >= the worst kept
+            self._saver.save(step, res)
         self.history.append((step, dict(res)))
         for k, v in res.items():
             logging.info("Evaluating (%s) validation set: %s=%.2f (Best %.2f)  step=%d\tElapsed %.2fs  FromSTART %.2fs",

@@ -17,7 +17,7 @@ from neurst_amd.layers.search import SequenceSearch, build_search_layer
 from neurst_amd.metrics import Metric, build_metric
 from neurst_amd.training.criterion_validator import CriterionValidator, register_validator
 from neurst_amd.utils import compat
-from neurst_amd.utils.checkpoints import NameBasedCheckpointManager
+from neurst_amd.utils.checkpoints import AverageCheckpointSaver, KeepBestCheckpointSaver
 from neurst_amd.utils.flags_core import Flag, ModuleFlag
 
 
@@ -72,9 +72,10 @@ class SeqGenerationValidator(CriterionValidator):
         self._gen_metric.set_groundtruth(self._references)
         if model_dir and self._gen_keep > 0:
             self._best_path = self.args.get("eval_best_checkpoint_path", None) or (model_dir.rstrip("/") + "_best")
-            self._gen_saver = NameBasedCheckpointManager(model, self._best_path, max_to_keep=self._gen_keep)
+            self._gen_saver = KeepBestCheckpointSaver(model, self._best_path, self._gen_metric, max_to_keep=self._gen_keep)
             if self.args.get("eval_auto_average_checkpoints", True):
                 self._avg_path = self.args.get("eval_best_avg_checkpoint_path", None) or (self._best_path.rstrip("/") + "_avg")
+                self._avg_saver = AverageCheckpointSaver(model, self._avg_path, self._gen_metric, max_to_keep=self._gen_keep)
         return self
 
     def _ids_to_text(self, ids):
@@ -110,13 +111,14 @@ class SeqGenerationValidator(CriterionValidator):
             raise RuntimeError(f"{len(hyps)} hypotheses for {len(self._references)} references")
         score = self._gen_metric(hyps)
         better = self.gen_best is None or self._gen_metric.greater_or_eq(score, self.gen_best)
+        # TrainingStatusRecorder.record (training_utils.py:335-372): both savers see EVERY validation and apply their own
+        # keep-best rule (checkpoints.py:186-312); the best result only drives the patience counter
+        if self._gen_saver is not None:
+            self._gen_saver.save(step, score)
+        if getattr(self, "_avg_saver", None) is not None:
+            self._avg_saver.save(step, score)
         if better:
             self.gen_best, self._bad_count = dict(score), 0
-            if self._gen_saver is not None:
-                self._gen_saver.save(step)
-                if self._avg_path:
-                    from neurst_amd.cli.avg_checkpoint import average_checkpoints
-                    average_checkpoints(self._best_path, self._avg_path)
         else:
             self._bad_count += 1
             if self._patience > 0 and self._bad_count >= self._patience:

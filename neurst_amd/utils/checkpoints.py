@@ -137,11 +137,14 @@ class NameBasedCheckpointManager(object):
         os.replace(tmp, os.path.join(self._directory, "checkpoint"))
 
     def save(self, checkpoint_number):
-        prefix = "{}-{}".format(self._checkpoint_name, checkpoint_number)
+        return self._write("{}-{}".format(self._checkpoint_name, checkpoint_number), time.time())
+
+    def _write(self, prefix, tag, state_dict=None):
+        """Writes the bundle `prefix` (weights from `state_dict` or the live model) and appends (prefix, tag) to the kept list."""
         scope = _model_scope(self._model)
         names = [f"{scope}/{n}" for n in self._model.store.params]
-        tensors = {tb.checkpoint_key(f"{scope}/{n}"): v.numpy().astype(np.float32)
-                   for n, v in self._model.store.state_dict().items()}
+        tensors = {tb.checkpoint_key(f"{scope}/{n}"): np.asarray(v, dtype=np.float32)
+                   for n, v in (state_dict or {k: t.numpy() for k, t in self._model.store.state_dict().items()}).items()}
         tensors[tb.OBJECT_GRAPH_KEY] = [tb.object_graph_proto(names)]
         if self._optimizer is not None:
             st = self._optimizer.state()
@@ -150,9 +153,66 @@ class NameBasedCheckpointManager(object):
             tensors["_optimizer/v"] = st["v"].detach().cpu().numpy().astype(np.float32)
         path = os.path.join(self._directory, prefix)
         tb.write_bundle(path, tensors)
-        self._all_model_checkpoints.append((prefix, time.time()))
+        self._all_model_checkpoints.append((prefix, tag))
+        self._after_append()
         self._update_checkpoint_meta()
         return path
 
+    def _after_append(self):
+        pass
+
     def restore(self, restore_path=None):
         return restore_checkpoint_if_possible(self._model, restore_path or self._directory, optimizer=self._optimizer)
+
+
+class KeepBestCheckpointSaver(NameBasedCheckpointManager):
+    """checkpoints.py:186-237: keeps the `max_to_keep` checkpoints with the best validation metric.  A checkpoint is written
+    whenever fewer than max_to_keep are kept or the new value is at least as good as the WORST kept one; the kept list is
+    ordered worst -> best (so rotation drops the worst and `model_checkpoint_path` names the best) and the value is part of
+    the name: ckpt-<step>-<value %.2f>."""
+
+    def __init__(self, model, directory, metric, max_to_keep=8, checkpoint_name="ckpt"):
+        super().__init__(model, directory, max_to_keep=max_to_keep, checkpoint_name=checkpoint_name)
+        self._metric = metric
+
+    def _accepts(self, value):
+        kept = self._all_model_checkpoints
+        return len(kept) < self._max_to_keep or self._metric.greater_or_eq(value, kept[0][1])
+
+    def _after_append(self):
+        import functools
+        ge = self._metric.greater_or_eq
+
+        def worse_first(x, y):
+            if x[1] == y[1]:
+                return 0
+            return -1 if ge(y[1], x[1]) else 1
+        self._all_model_checkpoints.sort(key=functools.cmp_to_key(worse_first))
+
+    def _state(self):
+        return None
+
+    def save(self, checkpoint_number, metric_value):
+        """-> path if a checkpoint was written, else None."""
+        value = float(self._metric.get_value(metric_value))
+        if not self._accepts(value):
+            return None
+        return self._write("{}-{}-{}".format(self._checkpoint_name, checkpoint_number, "%.2f" % value), value, self._state())
+
+
+class AverageCheckpointSaver(KeepBestCheckpointSaver):
+    """checkpoints.py:239-312: at every validation the current weights join a window of the latest `max_to_keep` evaluated
+    weight sets; under the same keep-best rule the AVERAGE of the window is written."""
+
+    def __init__(self, model, directory, metric, max_to_keep=8, checkpoint_name="ckpt"):
+        super().__init__(model, directory, metric, max_to_keep=max_to_keep, checkpoint_name=checkpoint_name)
+        self._window = []
+
+    def save(self, checkpoint_number, metric_value):
+        self._window.append({k: v.numpy().astype(np.float64) for k, v in self._model.store.state_dict().items()})
+        if len(self._window) > self._max_to_keep:
+            self._window.pop(0)
+        return super().save(checkpoint_number, metric_value)
+
+    def _state(self):
+        return {k: (sum(w[k] for w in self._window) / len(self._window)).astype(np.float32) for k in self._window[0]}

@@ -1,0 +1,107 @@
+"""Data-parallel step over RCCL (torch.distributed backend "nccl" on ROCm) with one process per GPU: runs wherever at least
+two GPUs are visible (the driver's multi-GPU box), skips on a single-GPU box.  The CPU tier covers the same logic over
+gloo (tests/test_distributed_cpu.py, tests/test_host_path_cpu.py); this is the first place the side-stream all-reduce,
+the wgrad-stream fence and the per-layer buckets meet the real collective library."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from oracle import neurst_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(device):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_model as T
+    T.DEV = device
+    return T._speech_case("small", "float32")
+
+
+def _inputs(inputs, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = dict(inputs)
+    out["src"] = torch.randn(inputs["src"].shape, generator=g)
+    return out
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.distributed import GradientReducer, init_distributed
+    from neurst_amd.training.train_step import TrainStep
+    r, lr, w = init_distributed()
+    dev = f"cuda:{lr}"
+    model, inputs, cfg = _build(dev)
+    red = GradientReducer(model.store, bucket_bytes=64 << 10, min_bucket_bytes=16 << 10)   # several messages per step
+    assert red.overlap and red.world == world
+    red.broadcast_parameters(0)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
+    step = TrainStep(model, crit, opt, red)
+    losses = []
+    for s in range(2):
+        batch = {k: v.to(dev) for k, v in _inputs(inputs, 100 + 10 * s + rank).items()}
+        losses.append(float(step(batch)))
+    torch.cuda.synchronize()
+    m = red.reduce_metrics({"loss": losses[-1], "ranks": 1.0})
+    q.put((rank, model.store.master.cpu().numpy().copy(), losses, red.last_messages, m))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_over_rccl_matches_oracle_average():
+    world = min(torch.cuda.device_count(), 2)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL path; the gloo tier runs everywhere)")
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    w0, w1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(w0, w1), "ranks diverged"
+    assert res[0][3] >= 3 and res[0][4]["ranks"] == world        # several bucket messages; the packed metric all-reduce
+    # the oracle's average-of-gradients Adam trajectory (hvd.Average, neurst/training/hvd_utils.py:46-62)
+    model, inputs, cfg = _build("cuda:0")
+    W = {n: p.data.detach().cpu().clone().double() for n, p in model.store.params.items()}
+    m = {n: torch.zeros_like(w) for n, w in W.items()}
+    v = {n: torch.zeros_like(w) for n, w in W.items()}
+    solid = {n: torch.ones_like(w, dtype=torch.bool) for n, w in W.items()}
+    for s in range(2):
+        per_rank = []
+        for rank in range(world):
+            inp = _inputs(inputs, 100 + 10 * s + rank)
+            loss, _, g = O.train_step_reference(W, {k: (t.double() if t.is_floating_point() else t) for k, t in inp.items()}, cfg, 0.1)
+            per_rank.append(g)
+            assert abs(float(loss) - res[rank][2][s]) < 1e-4
+        names = sorted(W)
+        avg = dict(zip(names, O.average_gradients([[g[n] for n in names] for g in per_rank])))
+        gmax = max(float(g.abs().max()) for g in avg.values())
+        for n in W:
+            solid[n] &= avg[n].abs() > 1e-3 * gmax
+            W[n], m[n], v[n] = O.keras_adam_step(W[n], avg[n].double(), m[n], v[n], s + 1, 1e-2)
+    for n, p in model.store.params.items():
+        got = w0[p.offset:p.offset + p.numel].view(p.shape).double()
+        assert float(((got - W[n]).abs() * solid[n]).max()) < 2e-4, n

@@ -722,7 +722,7 @@ def test_seq_generation_validator_keeps_and_averages_the_best_checkpoints(cpu_ke
     assert res["tok_bleu"] == 5.0 and "NLL" in res and v.gen_best["tok_bleu"] == 5.0
     model.store.master.mul_(2.0)
     v.validate(20)                            # better: second checkpoint, average of both
-    assert v.gen_best["tok_bleu"] == 7.0 and latest_checkpoint(model_dir + "_best").endswith("ckpt-20")
+    assert v.gen_best["tok_bleu"] == 7.0 and latest_checkpoint(model_dir + "_best").endswith("ckpt-20-7.00")
     from neurst_amd.utils import tensor_bundle as tb
     avg = tb.read_bundle(latest_checkpoint(model_dir + "_best_avg"))
     name, prm = next(iter(model.store.params.items()))
@@ -733,7 +733,11 @@ def test_seq_generation_validator_keeps_and_averages_the_best_checkpoints(cpu_ke
     assert not v.should_stop and v.gen_best["tok_bleu"] == 7.0
     v.validate(40)
     assert v.should_stop and [s for s, _ in v.gen_history] == [10, 20, 30, 40]
-    assert sorted(f for f in os.listdir(model_dir + "_best") if f.endswith(".index")) == ["ckpt-10.index", "ckpt-20.index"]
+    # keep-best rule of the reference's KeepBestCheckpointSaver (checkpoints.py:186-237): a checkpoint is written when fewer
+    # than K are kept or its score is >= the WORST kept one -- 6.0 replaced 5.0, 6.5 replaced 6.0; names carry the score
+    assert sorted(f for f in os.listdir(model_dir + "_best") if f.endswith(".index")) == ["ckpt-20-7.00.index", "ckpt-40-6.50.index"]
+    assert latest_checkpoint(model_dir + "_best").endswith("ckpt-20-7.00")          # model_checkpoint_path = the best kept
+    assert sorted(f for f in os.listdir(model_dir + "_best_avg") if f.endswith(".index")) == ["ckpt-20-7.00.index", "ckpt-40-6.50.index"]
 
 
 def test_cli_flow_train_validate_resume_predict_on_cpu(cpu_kernels, tmp_path):
@@ -796,7 +800,7 @@ def test_cli_flow_train_validate_resume_predict_on_cpu(cpu_kernels, tmp_path):
     assert latest_checkpoint(model_dir + "_best") is not None and latest_checkpoint(model_dir + "_best_avg") is not None
     # resume: the second invocation starts at step 41 (optimizer state restored) and stops at train_steps
     trainer2, _ = launch(["--train_steps", "45"])
-    assert latest_checkpoint(model_dir).endswith("ckpt-40") and trainer2.model.rt.step == 5
+    assert latest_checkpoint(model_dir).endswith("ckpt-40") and trainer2.model.rt.step == 45   # dropout-mask step count continues across the restart
     # predict entry with a metric, from the same model_dir
     out = tmp_path / "hyp.txt"
     gen, hyps = launch(["--entry", "predict", "--dataset.params", yaml.dump(cfg["entry.params"]["validator.params"]["eval_dataset.params"]),
