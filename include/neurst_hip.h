@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 2
+#define NST_ABI_VERSION 3
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -274,6 +274,56 @@ uint32_t nst_crc32c(const void* data, int64_t n, uint32_t crc);
  * nst_probe_mfma: writes the raw lane->value maps of the MFMA / LDS-transpose-read instructions the
  * kernels rely on, so the layout assumptions are verified on real hardware. */
 int nst_probe_mfma(float* out_c16, float* out_c16_f32, uint16_t* out_tr, void* stream);
+
+/* ------------------------------------------------------------------ fused position-wise feed-forward (d_model = 256, bf16)
+ * TransformerFFN.call inside PrePostProcessingWrapper.call (pre-norm), neurst/layers/common_layers.py:145-160, 73-85:
+ *     hidden = dropout(relu(x @ dense1/kernel + dense1/bias), ffn_dropout_rate)          [rows, filter_size]
+ *     y      = residual + dropout(hidden @ dense2/kernel + dense2/bias, layer_postprocess_dropout_rate)
+ * in ONE launch: the hidden tile never goes back through HBM between the two products (it is WRITTEN once, as the
+ * activation the backward pass needs).  Replaces two nst_gemm calls (tf.keras Dense x2 + tf.nn.relu + tf.nn.dropout x2
+ * + the residual add in the reference).  nst_ffn_bwd is the input-gradient half of TF autodiff over the same ops:
+ *     dhidden = (dy @ dense2/kernel^T) * (hidden > 0 ? 1/(1-p_hidden) : 0)                [rows, filter_size]
+ *     dx      = dhidden @ dense1/kernel^T (+ residual)
+ * (the two weight gradients x^T.dhidden and hidden^T.dy remain nst_gemm reductions over the rows, fed by dhidden / hidden).
+ *
+ * Weight operands:
+ *   nst_ffn_fwd reads TRANSPOSED bf16 copies  w1t [filter_size, 256] = dense1/kernel^T,  w2t [256, filter_size] =
+ *   dense2/kernel^T (made by nst_transpose_bf16 whenever the weights change: once per optimizer step);
+ *   nst_ffn_bwd reads the kernels in the reference's layout: w2 = dense2/kernel [filter_size, 256], w1 = dense1/kernel
+ *   [256, filter_size].
+ * Dropout masks are the library's Philox masks of nst_gemm: element (row, col) of the [rows, N] tensor, keyed by
+ * (seed (+ *seed_offset), stream_id) -- the hidden mask over N = filter_size, the output mask over N = 256.
+ * seed_offset (nullable): device scalar added to both seeds when the kernel runs, so a captured HIP graph draws new
+ * masks at every replay (the host bumps the scalar between replays).
+ * nst_ffn_supported(d_model, filter_size, dtype) != 0 tells whether this path exists for a shape (d_model 256,
+ * filter_size a multiple of 128, bf16); otherwise the caller composes the same math from nst_gemm. */
+typedef struct {
+  int64_t rows;
+  int d_model, filter_size, dtype;
+  float hidden_dropout_p;          /* ffn_dropout_rate */
+  uint64_t hidden_seed, hidden_stream_id;
+  float output_dropout_p;          /* layer_postprocess_dropout_rate (forward only) */
+  uint64_t output_seed, output_stream_id;
+  const uint64_t* seed_offset;     /* device scalar or NULL */
+} NstFfnDesc;
+
+int nst_ffn_supported(int d_model, int filter_size, int dtype);
+/* b1 [filter_size] f32 (nullable = 0), b2 [256] f32 (nullable), residual [rows,256] (nullable); hidden [rows, filter_size]
+ * and y [rows,256] are written. */
+int nst_ffn_fwd(const NstFfnDesc* desc, const void* x, const void* w1t, const float* b1, const void* w2t, const float* b2,
+                const void* residual, void* hidden, void* y, void* stream);
+/* hidden: the activation nst_ffn_fwd saved; residual (nullable, [rows,256]) is added to dx (post-norm wrapper). */
+int nst_ffn_bwd(const NstFfnDesc* desc, const void* dy, const void* hidden, const void* w2, const void* w1,
+                const void* residual, void* dhidden, void* dx, void* stream);
+
+/* Batched bf16 transposes dst[cols, rows] = src[rows, cols]^T, one launch for a table of matrices (device memory):
+ * tile0 = number of 64x64 tiles of all earlier jobs, tiles_c = ceil(cols / 64); total_tiles = sum over jobs. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int rows, cols, tiles_c, tile0;
+} NstTransposeJob;
+int nst_transpose_bf16(const NstTransposeJob* jobs_dev, int njobs, int total_tiles, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 2
+NST_ABI_VERSION = 3
 
 
 class NstGemmDesc(C.Structure):
@@ -53,6 +53,23 @@ class NstAttnDesc(C.Structure):
     ]
 
 
+class NstFfnDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64),
+        ("d_model", C.c_int), ("filter_size", C.c_int), ("dtype", C.c_int),
+        ("hidden_dropout_p", C.c_float),
+        ("hidden_seed", C.c_uint64), ("hidden_stream_id", C.c_uint64),
+        ("output_dropout_p", C.c_float),
+        ("output_seed", C.c_uint64), ("output_stream_id", C.c_uint64),
+        ("seed_offset", C.c_void_p),
+    ]
+
+
+class NstTransposeJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("tiles_c", C.c_int),
+                ("tile0", C.c_int)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 # name -> argtypes; every symbol declared in include/neurst_hip.h
@@ -86,6 +103,10 @@ SIGNATURES = {
     "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
     "nst_cast_bf16_to_f32": [_P, _P, _L, _P],
     "nst_probe_mfma": [_P, _P, _P, _P],
+    "nst_ffn_supported": [_I, _I, _I],
+    "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "nst_transpose_bf16": [_P, _I, _I, _P],
 }
 
 

@@ -1,0 +1,565 @@
+// Fused position-wise feed-forward pair for d_model = 256 (speech_transformer_s / transformer sets with d = 256), bf16.
+//
+//   forward  (neurst/layers/common_layers.py:145-160 inside the wrapper :73-85):
+//       H = dropout1(relu(X @ W1 + b1))            [M, F]   written once (saved for backward), never re-read
+//       Y = residual + dropout2(H @ W2 + b2)       [M, 256]
+//   backward (input gradient; the weight gradients stay separate reductions over M):
+//       dH = (dY @ W2^T) * gate(H)                 [M, F]   written once for the dense1 weight / bias gradient
+//       dX = dH @ W1^T (+ residual)                [M, 256]
+//
+// Both are the SAME two-GEMM chain  Z = mid(Xin @ WA^T) ; Out = Z @ WB^T  with
+//       WA [F][256]  (row = hidden unit, the 256-long reduction contiguous)   forward: W1^T     backward: W2
+//       WB [256][F]  (row = output column, hidden units contiguous)           forward: W2^T     backward: W1
+// so one kernel template serves both; the forward reads transposed bf16 copies of the two FFN weights (made once per
+// optimizer step by nst_transpose_bf16), the backward reads the weights as stored.
+//
+// Why one kernel: with d_model = 256 the two GEMMs of an FFN are HBM / launch bound on the [M, F] hidden tensor
+// (118 MB per encoder layer at the benchmark shape): separate kernels write it, read it, and each has only 4 K steps
+// (dense1) or a 256-wide output (dense2).  Here a workgroup owns 32*NW rows, walks the hidden dimension in chunks of 128
+// columns, and the hidden tile goes from the first product's accumulators straight into the second product's B operand
+// (registers; the reduction index of the second product is laid out on the accumulator rows of the first).
+//
+// Structure (one wave per SIMD, 32 rows per wave, v_mfma_f32_32x32x16_bf16, accumulators "transposed": MFMA A operand =
+// weights, B operand = activations, so a lane owns ONE row m = lane & 31 of the tile and 16 CONSECUTIVE columns per
+// 32-column block):
+//   * Xin fragments of the wave's 32 rows live in registers for the whole kernel (64 VGPRs);
+//   * the weights stream through an LDS ring of 16 KB pieces filled by LDS-DMA (global_load_lds_dwordx4, no VGPR
+//     staging), DEPTH pieces ahead; one phase = one piece = 16 MFMAs per wave; a phase opens with a COUNTED
+//     s_waitcnt vmcnt + s_barrier (never a drain);
+//        A piece [128 hidden rows][64 k]   (128-byte rows, 16-byte slot ^= (row >> 1) & 7)
+//        B piece [256 out rows][32 hidden] ( 64-byte rows, 16-byte slot ^= (row >> 2) & 3)
+//        G piece [64 rows][128 hidden]     (backward only: the saved activation, the gate; slot ^= row & 15)
+//     the XOR is applied to the DMA source address and to the fragment read (same involution), all fragment reads are
+//     ds_read_b128 and conflict free for the 16-lane groups of that instruction;
+//   * the A-operand row r of a 32-row block holds hidden unit pi(r) = 16*((r >> 2) & 1) + 4*(r >> 3) + (r & 3): the MFMA
+//     result rows 8q + 4h + i of lane half h then are the 16 consecutive hidden units 16h + 4q + i -- bias, ReLU, one
+//     Philox call per 8 units, two 16-byte stores per 32-column block, and the packed bf16 pairs ARE the B operand of
+//     the second product (k slots of half h in k-block (nb, t) = hidden units 32nb + 16h + 8t + 0..7; the WB fragment
+//     reads the same 8 contiguous units of its row);
+//   * the same permutation on the output rows of the second product gives every lane 16 consecutive output columns.
+#include "nst_common.h"
+
+#include <stdlib.h>
+
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float floatx16_t;
+
+constexpr int D = 256;            // d_model
+constexpr int CH = 128;           // hidden units per chunk
+constexpr int PIECE = 16384;      // bytes per ring slot
+enum { MODE_FWD = 0, MODE_BWD = 1 };
+
+struct FfnArgs {
+  const bf16_t* xin;       // [M, 256]
+  const bf16_t* wa;        // [F, 256]
+  const bf16_t* wb;        // [256, F]
+  const float* bias_a;     // [F]    forward: b1
+  const float* bias_b;     // [256]  forward: b2
+  const bf16_t* residual;  // [M, 256] or null
+  const bf16_t* gate;      // [M, F]   backward: saved activation H
+  bf16_t* mid_out;         // [M, F]   forward: H, backward: dH
+  bf16_t* out;             // [M, 256]
+  const uint64_t* seed_dev;  // optional device scalar added to both seeds (graph replay: the step counter)
+  int M, F;
+  uint32_t drop1_thresh, drop2_thresh;
+  float drop1_inv_keep, drop2_inv_keep;
+  float gate_scale;
+  uint64_t seed1, stream1, seed2, stream2;
+};
+
+__device__ __forceinline__ int pi32(int r) { return (((r >> 2) & 1) << 4) + ((r >> 3) << 2) + (r & 3); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One piece share of a wave: IPW LDS-DMA instructions (64 lanes x 16 bytes each -> LDS [dst + i*1024 + lane*16]) from
+// sbase + voff[i] (per lane), issued back to back from one asm block (M0 carries the LDS address; the s_nop 4 covers an
+// SGPR base the compiler may have produced with v_readfirstlane right in front of the statement).
+template <int IPW>
+__device__ __forceinline__ void glds_piece(const void* sbase, const uint32_t (&voff)[IPW], uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  if constexpr (IPW == 4) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds_addr_uniform)
+        : "memory", "scc");
+  } else {
+    static_assert(IPW == 8, "4 or 8 DMA instructions per wave and piece");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %9\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]),
+          "s"(sbase), "s"(lds_addr_uniform)
+        : "memory", "scc");
+  }
+}
+
+template <int MODE, int NW>
+struct Cfg {
+  static constexpr int NG = MODE == MODE_FWD ? 0 : (NW == 4 ? 2 : 1);   // 64-row gate pieces per chunk (backward)
+  static constexpr int PPC = 8 + NG;                      // pieces per chunk = ring slots (slot index is static)
+  static constexpr int DEPTH = PPC - 1;                   // pieces issued ahead of the one being consumed
+  static constexpr int IPW = 16 / NW;                     // DMA instructions per wave per piece
+  static constexpr int RING = PPC * PIECE;
+  // a phase opens once the piece it consumes AND the next one have landed (fragment reads run half a phase ahead of the
+  // MFMAs, so they reach into the next piece): DEPTH-2 younger pieces stay in flight
+  static constexpr int WAITN = IPW * (DEPTH - 2);
+  static_assert(WAITN <= 63, "vmcnt is a 6-bit counter");
+};
+
+// DROP: bit 0 = hidden dropout on, bit 1 = output dropout on (forward); FULL: M is a multiple of the workgroup's rows.
+// Both are template parameters so that a phase is ONE basic block: the scheduler can then place the mid epilogue's
+// VALU work between the MFMAs of the second product.
+template <int MODE, int NW, int DROP, bool FULL>
+__global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
+  typedef Cfg<MODE, NW> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m_l = lane & 31, h = lane >> 5;
+  const int F = a.F, M = a.M;
+  const int nch = F / CH;
+  const int m0 = blockIdx.x * (32 * NW);
+  const int row = m0 + wave * 32 + m_l;           // this lane's row of Xin / outputs
+  const bool row_ok = FULL || row < M;
+  const int row_c = row_ok ? row : M - 1;
+
+  uint64_t seed_off = 0;
+  if (a.seed_dev) seed_off = *a.seed_dev;
+
+  // ---------------------------------------------------------------- DMA source offsets (per lane, constant)
+  // A piece (chunk c, pa): rows 128c + r, bytes [128 pa, +128) of the 512-byte WA rows
+  // B piece (chunk c, pb): rows r (0..255), bytes [(128c + 32pb)*2, +64) of the 2F-byte WB rows
+  // G piece (chunk c, gi): rows min(m0 + 64gi + r, M-1), bytes [256c, +256) of the 2F-byte gate rows
+  uint32_t voff_a[C::IPW], voff_b[C::IPW], voff_g[C::NG > 0 ? C::NG : 1][C::IPW];
+#pragma unroll
+  for (int s = 0; s < C::IPW; ++s) {
+    const int t = wave * C::IPW + s;
+    {
+      const int r = 8 * t + (lane >> 3), sl = lane & 7;
+      voff_a[s] = (uint32_t)(r * (D * 2) + ((sl ^ ((r >> 1) & 7)) << 4));
+    }
+    {
+      const int r = 16 * t + (lane >> 2), sl = lane & 3;
+      voff_b[s] = (uint32_t)r * (uint32_t)(F * 2) + (uint32_t)((sl ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int gi = 0; gi < C::NG; ++gi) {
+      const int r = 4 * t + (lane >> 4), sl = lane & 15;
+      int rg = m0 + 64 * gi + r;
+      rg = rg < M ? rg : M - 1;
+      voff_g[gi][s] = (uint32_t)rg * (uint32_t)(F * 2) + (uint32_t)((sl ^ (r & 15)) << 4);
+    }
+  }
+  // issue the piece with static in-chunk index J of chunk c into ring slot J
+  auto issue_piece = [&](int c, auto jtag) {
+    constexpr int J = decltype(jtag)::value;
+    const uint32_t dst = smem_addr + (uint32_t)J * PIECE + (uint32_t)(wave * C::IPW) * 1024u;
+    if constexpr (J < 4) {
+      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wa) + ((int64_t)c * CH * D + J * 64) * 2, voff_a, dst);
+    } else if constexpr (J < 4 + C::NG) {
+      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.gate) + (int64_t)c * CH * 2, voff_g[J - 4], dst);
+    } else {
+      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wb) + ((int64_t)c * CH + (J - 4 - C::NG) * 32) * 2, voff_b, dst);
+    }
+  };
+  // prologue: pieces 0 .. DEPTH-1 of chunk 0 (DEPTH < PPC)
+  [&]<int... Js>(std::integer_sequence<int, Js...>) {
+    (issue_piece(0, std::integral_constant<int, Js>()), ...);
+  }(std::make_integer_sequence<int, C::DEPTH>());
+
+  // ---------------------------------------------------------------- Xin fragments (B operand of the first product)
+  bf16x8_t xf[16];
+  {
+    const bf16_t* xr = a.xin + (int64_t)row_c * D + h * 8;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) xf[kb] = *reinterpret_cast<const bf16x8_t*>(xr + kb * 16);
+  }
+  // bias of the first product: staged once into LDS behind the ring (forward only)
+  float* bias_lds = reinterpret_cast<float*>(smem + C::RING);
+  if (MODE == MODE_FWD) {
+    for (int i = tid; i < F; i += 64 * NW) bias_lds[i] = a.bias_a ? a.bias_a[i] : 0.f;
+  }
+
+  // ---------------------------------------------------------------- fragment read offsets (per lane, constant)
+  const int pr = pi32(m_l);
+  uint32_t offA[4];   // A piece: row (nb*32 + pr), slot (2*kbl + h) ^ ((row >> 1) & 7)   [(row>>1)&7 == (pr>>1)&7]
+#pragma unroll
+  for (int kbl = 0; kbl < 4; ++kbl) offA[kbl] = (uint32_t)(pr * 128 + (((2 * kbl + h) ^ ((pr >> 1) & 7)) << 4));
+  uint32_t offB[2];   // B piece: row (db*32 + pr), slot (2h + t) ^ ((row >> 2) & 3)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) offB[t] = (uint32_t)(pr * 64 + (((2 * h + t) ^ ((pr >> 2) & 3)) << 4));
+
+  floatx16_t accH[4], accY[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accY[i][v] = 0.f;
+
+  uint32_t P[4][8];  // the chunk's hidden tile of this lane as packed bf16 pairs: P[nb][2q + (i >> 1)]
+  uint4 gq[MODE == MODE_BWD ? 4 : 1][2];   // backward: the saved activation of the lane's 4 x 16 hidden units (the gate)
+  constexpr int B0 = 4 + C::NG;            // ring slot of the first B piece
+
+  // opens the phase that consumes piece J of chunk c: pieces J and J+1 have landed for every wave (counted wait: the
+  // DEPTH-2 younger pieces -- and any stores issued since -- stay in flight), and every wave is done reading the slot
+  // the piece DEPTH ahead goes to (= piece J-1: its fragment reads ended half a phase ago)
+  auto open_phase = [&](int c, auto jtag) {
+    constexpr int J = decltype(jtag)::value;
+    if (c == nch - 1 && J > C::PPC - C::DEPTH) wait_vm<0>();   // fewer than DEPTH-1 younger pieces exist: drain
+    else wait_vm<C::WAITN>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int JN = (J + C::DEPTH) % C::PPC;
+    const int cn = c + (J + C::DEPTH) / C::PPC;
+    if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
+  };
+
+  // The MFMAs of a chunk form a stream of 128 positions: s < 64: first product, phase pa = s >> 4, k-block kbl = (s >> 2) & 3,
+  // column block nb = s & 3; s >= 64: second product, phase pb = (s - 64) >> 4, k-block t = (s >> 3) & 1, row block db = s & 7.
+  // The weight fragment of position s is read PD positions early into a ring of PD registers quads.
+  constexpr int PD = 8;
+  bf16x8_t wq[PD];
+  auto read_frag = [&](auto stag) {
+    constexpr int S = decltype(stag)::value & 127;
+    if constexpr (S < 64) {
+      constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
+      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + pa * PIECE + nb * (32 * 128) + offA[kbl]);
+    } else {
+      constexpr int pb = (S - 64) >> 4, t = (S >> 3) & 1, db = S & 7;
+      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + (B0 + pb) * PIECE + db * (32 * 64) + offB[t]);
+    }
+  };
+  auto mfma_at = [&](auto stag) {
+    constexpr int S = decltype(stag)::value;
+    if constexpr (S < 64) {
+      constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
+      if constexpr (pa == 0 && kbl == 0) {
+        const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        accH[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], xf[0], zero, 0, 0, 0);
+      } else {
+        accH[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], xf[pa * 4 + kbl], accH[nb], 0, 0, 0);
+      }
+    } else {
+      constexpr int pb = (S - 64) >> 4, t = (S >> 3) & 1, db = S & 7;
+      union { uint32_t u[4]; bf16x8_t f; } pf;
+      pf.u[0] = P[pb][4 * t + 0]; pf.u[1] = P[pb][4 * t + 1]; pf.u[2] = P[pb][4 * t + 2]; pf.u[3] = P[pb][4 * t + 3];
+      accY[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], pf.f, accY[db], 0, 0, 0);
+    }
+  };
+
+  // mid epilogue of one 32-column block nb of chunk c: accumulators -> P[nb] (+ store)
+  auto mid_epilogue = [&](int c, int nb) {
+    const int col0 = c * CH + nb * 32 + 16 * h;   // this lane's 16 consecutive hidden units
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = accH[nb][e];
+    if (MODE == MODE_FWD) {
+      const float4* bp = reinterpret_cast<const float4*>(bias_lds + col0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = bp[q];
+        v[4 * q + 0] = fmaxf(v[4 * q + 0] + b.x, 0.f);
+        v[4 * q + 1] = fmaxf(v[4 * q + 1] + b.y, 0.f);
+        v[4 * q + 2] = fmaxf(v[4 * q + 2] + b.z, 0.f);
+        v[4 * q + 3] = fmaxf(v[4 * q + 3] + b.w, 0.f);
+      }
+      if constexpr ((DROP & 1) != 0) {
+        const uint64_t idx = (uint64_t)row * (uint64_t)F + (uint64_t)col0;   // multiple of 8
+        float k0[8], k1[8];
+        dropout_keep8(a.seed1 + seed_off, a.stream1, idx, a.drop1_thresh, a.drop1_inv_keep, k0);
+        dropout_keep8(a.seed1 + seed_off, a.stream1, idx + 8, a.drop1_thresh, a.drop1_inv_keep, k1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] *= k0[e]; v[8 + e] *= k1[e]; }
+      }
+    } else {
+      union { uint4 u[2]; short s[16]; } g;
+      g.u[0] = gq[nb][0];
+      g.u[1] = gq[nb][1];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = g.s[e] > 0 ? v[e] * a.gate_scale : 0.f;   // bf16 > 0 <=> its bits as int16 > 0
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) P[nb][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    if (row_ok) {
+      uint4* o = reinterpret_cast<uint4*>(a.mid_out + (int64_t)row * F + col0);
+      o[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
+      o[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
+    }
+  };
+
+  // pieces 0 and 1 of chunk 0 have landed: the first PD fragments
+  wait_vm<C::WAITN>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, I>()), ...); }(std::make_integer_sequence<int, PD>());
+
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    // ---- first product: 4 phases of 4 k-blocks x 4 column blocks
+    [&]<int... SS>(std::integer_sequence<int, SS...>) {
+      ([&] {
+        constexpr int S = SS;
+        if constexpr ((S & 15) == 0) open_phase(c, std::integral_constant<int, (S >> 4)>());
+        mfma_at(std::integral_constant<int, S>());
+        // the fragment PD positions ahead; in the backward the first fragments of the second product wait for the gate phases
+        if constexpr (S + PD < 64 || MODE == MODE_FWD) read_frag(std::integral_constant<int, S + PD>());
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }(), ...);
+    }(std::make_integer_sequence<int, 64>());
+    if constexpr (MODE == MODE_BWD) {
+      // the gate pieces (no MFMA work): the lane's 4 x 32 bytes go to registers -- their slots are refilled while the
+      // second product still runs
+      open_phase(c, std::integral_constant<int, 4>());
+      if constexpr (C::NG == 2) open_phase(c, std::integral_constant<int, 5>());
+      const int rr = (NW == 4 ? (wave & 1) : wave) * 32 + m_l;
+      const char* gslot = smem + (4 + (NW == 4 ? (wave >> 1) : 0)) * PIECE + rr * 256;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          gq[nb][s2] = *reinterpret_cast<const uint4*>(gslot + (((nb * 4 + 2 * h + s2) ^ (rr & 15)) << 4));
+      [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, 64 + I>()), ...); }(std::make_integer_sequence<int, PD>());
+    }
+    mid_epilogue(c, 0);
+    // ---- second product: 4 phases (one per 32-unit block) of 2 k-blocks x 8 output row blocks; the mid epilogue of the
+    //      NEXT block sits in the same scheduling region as this block's MFMAs
+    [&]<int... SS>(std::integer_sequence<int, SS...>) {
+      ([&] {
+        constexpr int S = 64 + SS;
+        if constexpr ((S & 15) == 0) {
+          open_phase(c, std::integral_constant<int, B0 + ((S - 64) >> 4)>());
+          if constexpr (S < 112) mid_epilogue(c, ((S - 64) >> 4) + 1);
+        }
+        mfma_at(std::integral_constant<int, S>());
+        read_frag(std::integral_constant<int, S + PD>());   // positions >= 128: the next chunk's first fragments (slot 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }(), ...);
+    }(std::make_integer_sequence<int, 64>());
+  }
+
+  // ---------------------------------------------------------------- final epilogue: 16 consecutive output columns per lane and block
+#pragma unroll
+  for (int db = 0; db < 8; ++db) {
+    const int col0 = db * 32 + 16 * h;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = accY[db][e];
+    if (MODE == MODE_FWD) {
+      if (a.bias_b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias_b + col0 + 4 * q);
+          v[4 * q + 0] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
+        }
+      }
+      if constexpr ((DROP & 2) != 0) {
+        const uint64_t idx = (uint64_t)row * (uint64_t)D + (uint64_t)col0;
+        float k0[8], k1[8];
+        dropout_keep8(a.seed2 + seed_off, a.stream2, idx, a.drop2_thresh, a.drop2_inv_keep, k0);
+        dropout_keep8(a.seed2 + seed_off, a.stream2, idx + 8, a.drop2_thresh, a.drop2_inv_keep, k1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] *= k0[e]; v[8 + e] *= k1[e]; }
+      }
+    }
+    if (a.residual) {
+      union { uint4 u[2]; bf16_t s[16]; } r;
+      const uint4* rp = reinterpret_cast<const uint4*>(a.residual + (int64_t)row_c * D + col0);
+      r.u[0] = rp[0];
+      r.u[1] = rp[1];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bf16_to_f32(r.s[e]);
+    }
+    if (row_ok) {
+      uint4* o = reinterpret_cast<uint4*>(a.out + (int64_t)row * D + col0);
+      o[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      o[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+    }
+  }
+}
+
+template <typename KernelT>
+void allow_lds(KernelT kernel, int bytes) {
+  static thread_local const void* done[16];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kernel) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 16) done[ndone++] = (const void*)kernel;
+}
+
+template <int MODE, int NW, int DROP, bool FULL>
+int launch_one(const FfnArgs& a, hipStream_t st) {
+  typedef Cfg<MODE, NW> C;
+  const int lds = C::RING + (MODE == MODE_FWD ? a.F * 4 : 0);
+  if (lds > 160 * 1024) {
+    nst_set_error("ffn: filter size %d needs %d bytes of LDS", a.F, lds);
+    return NST_ERR_UNSUPPORTED;
+  }
+  auto k = ffn_pair_kernel<MODE, NW, DROP, FULL>;
+  allow_lds(k, lds);
+  const int rows = 32 * NW;
+  k<<<(a.M + rows - 1) / rows, 64 * NW, lds, st>>>(a);
+  return NST_OK;
+}
+
+// Instantiated variants: the training configuration (both dropouts on / off) at full tiles, and one generic variant
+// (both dropout branches compiled in -- a rate of 0 has threshold 0, i.e. keeps everything -- and row predicates).
+template <int MODE, int NW>
+int launch_pair(const FfnArgs& a, hipStream_t st) {
+  const bool full = a.M % (32 * NW) == 0;
+  if constexpr (MODE == MODE_BWD) {
+    return full ? launch_one<MODE, NW, 0, true>(a, st) : launch_one<MODE, NW, 0, false>(a, st);
+  } else {
+    const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
+    if (full && drop == 3) return launch_one<MODE, NW, 3, true>(a, st);
+    if (full && drop == 0) return launch_one<MODE, NW, 0, true>(a, st);
+    return launch_one<MODE, NW, 3, false>(a, st);
+  }
+}
+
+// rows per workgroup: 128 when that still gives every CU a workgroup, else 64 (NST_FFN_NW overrides: 4 | 2)
+int pick_nw(int M) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("NST_FFN_NW"); forced = e ? atoi(e) : 0; }
+  if (forced == 2 || forced == 4) return forced;
+  return M >= 128 * 160 ? 4 : 2;
+}
+
+// [R, C] bf16 -> [C, R] bf16, 64x64 tiles through LDS, a table of matrices per launch
+struct TransposeJob { const bf16_t* src; bf16_t* dst; int rows, cols, tiles_c, tile0; };
+
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const TransposeJob* __restrict__ jobs, int njobs) {
+  __shared__ bf16_t tile[64][66];
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile0) ++j;
+  const TransposeJob q = jobs[j];
+  const int t = blockIdx.x - q.tile0, tr = t / q.tiles_c, tc = t - tr * q.tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    tile[r][c] = (r0 + r < q.rows && c0 + c < q.cols) ? q.src[(int64_t)(r0 + r) * q.cols + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, r = e & 63;
+    if (r0 + r < q.rows && c0 + c < q.cols) q.dst[(int64_t)(c0 + c) * q.rows + r0 + r] = tile[r][c];
+  }
+}
+
+}  // namespace
+
+extern "C" int nst_ffn_supported(int d_model, int filter_size, int dtype) {
+  return dtype == NST_BF16 && d_model == D && filter_size >= CH && filter_size % CH == 0 && filter_size <= 8192 ? 1 : 0;
+}
+
+extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, const float* b1, const void* w2t, const float* b2,
+                           const void* residual, void* hidden, void* y, void* stream) {
+  NST_CHECK_ARG(d && x && w1t && w2t && hidden && y, "ffn_fwd: null pointer");
+  NST_CHECK_ARG(nst_ffn_supported(d->d_model, d->filter_size, d->dtype), "ffn_fwd: unsupported shape d=%d ffn=%d dtype=%d",
+                d->d_model, d->filter_size, d->dtype);
+  NST_CHECK_ARG(d->rows >= 0 && d->rows < (1 << 30), "ffn_fwd: rows=%lld", (long long)d->rows);
+  NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(w1t) && nst_aligned16(w2t) && nst_aligned16(hidden) && nst_aligned16(y) &&
+                    (!residual || nst_aligned16(residual)) && (!b2 || nst_aligned16(b2)),
+                "ffn_fwd: operands must be 16-byte aligned");
+  NST_CHECK_ARG(d->hidden_dropout_p >= 0.f && d->hidden_dropout_p < 1.f && d->output_dropout_p >= 0.f && d->output_dropout_p < 1.f,
+                "ffn_fwd: dropout rate");
+  if (d->rows == 0) return NST_OK;
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xin = (const bf16_t*)x; a.wa = (const bf16_t*)w1t; a.wb = (const bf16_t*)w2t;
+  a.bias_a = b1; a.bias_b = b2; a.residual = (const bf16_t*)residual;
+  a.mid_out = (bf16_t*)hidden; a.out = (bf16_t*)y;
+  a.seed_dev = d->seed_offset;
+  a.M = (int)d->rows; a.F = d->filter_size;
+  nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
+  nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);
+  a.seed1 = d->hidden_seed; a.stream1 = d->hidden_stream_id; a.seed2 = d->output_seed; a.stream2 = d->output_stream_id;
+  const int rc = pick_nw(a.M) == 4 ? launch_pair<MODE_FWD, 4>(a, (hipStream_t)stream) : launch_pair<MODE_FWD, 2>(a, (hipStream_t)stream);
+  if (rc != NST_OK) return rc;
+  NST_CHECK_LAUNCH("ffn_fwd");
+  return NST_OK;
+}
+
+extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidden, const void* w2, const void* w1,
+                           const void* residual, void* dhidden, void* dx, void* stream) {
+  NST_CHECK_ARG(d && dy && hidden && w2 && w1 && dhidden && dx, "ffn_bwd: null pointer");
+  NST_CHECK_ARG(nst_ffn_supported(d->d_model, d->filter_size, d->dtype), "ffn_bwd: unsupported shape d=%d ffn=%d dtype=%d",
+                d->d_model, d->filter_size, d->dtype);
+  NST_CHECK_ARG(d->rows >= 0 && d->rows < (1 << 30), "ffn_bwd: rows=%lld", (long long)d->rows);
+  NST_CHECK_ARG(nst_aligned16(dy) && nst_aligned16(hidden) && nst_aligned16(w1) && nst_aligned16(w2) && nst_aligned16(dhidden) &&
+                    nst_aligned16(dx) && (!residual || nst_aligned16(residual)),
+                "ffn_bwd: operands must be 16-byte aligned");
+  if (d->rows == 0) return NST_OK;
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xin = (const bf16_t*)dy; a.wa = (const bf16_t*)w2; a.wb = (const bf16_t*)w1;
+  a.residual = (const bf16_t*)residual; a.gate = (const bf16_t*)hidden;
+  a.mid_out = (bf16_t*)dhidden; a.out = (bf16_t*)dx;
+  a.M = (int)d->rows; a.F = d->filter_size;
+  uint32_t th; float inv;
+  nst_dropout_params16(d->hidden_dropout_p, &th, &inv);
+  a.gate_scale = th ? inv : 1.0f;
+  // the gate pieces are 64 rows: a workgroup of 128 rows needs M >= 64 (row clamp), 64-row workgroups one piece
+  const int rc = (pick_nw(a.M) == 4 && a.M >= 64) ? launch_pair<MODE_BWD, 4>(a, (hipStream_t)stream)
+                                                  : launch_pair<MODE_BWD, 2>(a, (hipStream_t)stream);
+  if (rc != NST_OK) return rc;
+  NST_CHECK_LAUNCH("ffn_bwd");
+  return NST_OK;
+}
+
+extern "C" int nst_transpose_bf16(const NstTransposeJob* jobs_dev, int njobs, int total_tiles, void* stream) {
+  NST_CHECK_ARG(njobs >= 0 && total_tiles >= 0 && (njobs == 0 || jobs_dev), "transpose_bf16: bad arguments");
+  if (njobs == 0 || total_tiles == 0) return NST_OK;
+  static_assert(sizeof(TransposeJob) == sizeof(NstTransposeJob), "job table layout");
+  transpose_bf16_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>((const TransposeJob*)jobs_dev, njobs);
+  NST_CHECK_LAUNCH("transpose_bf16");
+  return NST_OK;
+}

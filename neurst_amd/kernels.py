@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from neurst_amd._lib import NST_BF16, NST_F32, NstAttnDesc, NstGemmDesc, check, lib
+from neurst_amd._lib import NST_BF16, NST_F32, NstAttnDesc, NstFfnDesc, NstGemmDesc, check, lib
 
 FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
 
@@ -181,6 +181,62 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
     PROBE.end(ev, 2.0 * M * N * K)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ fused feed-forward
+def ffn_supported(d_model, filter_size, dtype):
+    """Whether the one-launch feed-forward pair exists for this shape (d_model 256, filter a multiple of 128, bf16)."""
+    return dtype == torch.bfloat16 and bool(lib.nst_ffn_supported(int(d_model), int(filter_size), NST_BF16))
+
+
+def _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p=0.0, out_seed=0, out_site=0):
+    desc = NstFfnDesc()
+    desc.rows, desc.d_model, desc.filter_size, desc.dtype = rows, d, f, NST_BF16
+    desc.hidden_dropout_p, desc.hidden_seed, desc.hidden_stream_id = hidden_p, hidden_seed, hidden_site
+    desc.output_dropout_p, desc.output_seed, desc.output_stream_id = out_p, out_seed, out_site
+    return desc
+
+
+def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0, out_seed=0,
+            out_site=0):
+    """y = residual + dropout_out(dropout_hidden(relu(x @ w1 + b1)) @ w2 + b2) in one launch; w1t [F, d] / w2t [d, F] are the
+    TRANSPOSED bf16 copies of dense1/kernel [d, F] / dense2/kernel [F, d].  Returns (y, hidden); hidden is the saved activation."""
+    rows, d = x.shape
+    f = w1t.shape[0]
+    assert x.is_contiguous() and w1t.is_contiguous() and w2t.is_contiguous() and w1t.shape == (f, d) and w2t.shape == (d, f)
+    assert residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype)
+    assert rows * f * 2 < (1 << 32)
+    hidden = torch.empty(rows, f, dtype=x.dtype, device=x.device)
+    y = torch.empty_like(x)
+    desc = _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p, out_seed, out_site)
+    ev = PROBE.begin("ffn_fwd")
+    check(lib.nst_ffn_fwd(C.byref(desc), _p(x), _p(w1t), _p(b1), _p(w2t), _p(b2), _p(residual), _p(hidden), _p(y), _stream()),
+          "ffn_fwd")
+    PROBE.end(ev, 4.0 * rows * d * f)
+    return y, hidden
+
+
+def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None):
+    """dhidden = (dy @ w2^T) * gate(hidden); dx = dhidden @ w1^T (+ residual) in one launch; w2 [F, d], w1 [d, F] as stored.
+    Returns (dx, dhidden)."""
+    rows, d = dy.shape
+    f = w2.shape[0]
+    assert dy.is_contiguous() and hidden.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    assert w2.shape == (f, d) and w1.shape == (d, f) and hidden.shape == (rows, f)
+    assert residual is None or (residual.is_contiguous() and residual.shape == dy.shape and residual.dtype == dy.dtype)
+    dhidden = torch.empty_like(hidden)
+    dx = torch.empty_like(dy)
+    desc = _ffn_desc(rows, d, f, hidden_p, 0, 0)
+    ev = PROBE.begin("ffn_bwd")
+    check(lib.nst_ffn_bwd(C.byref(desc), _p(dy), _p(hidden), _p(w2), _p(w1), _p(residual), _p(dhidden), _p(dx), _stream()),
+          "ffn_bwd")
+    PROBE.end(ev, 4.0 * rows * d * f)
+    return dx, dhidden
+
+
+def transpose_bf16(table, njobs, total_tiles):
+    """Runs a device-resident table of NstTransposeJob (see ParamStore.finalize): dst[cols, rows] = src[rows, cols]^T."""
+    check(lib.nst_transpose_bf16(_p(table), njobs, total_tiles, _stream()), "transpose_bf16")
 
 
 def grad_clip(grad, table, nentries, seg_first, nseg, pre_scale=1.0, clip_value=None, clip_norm=None):

@@ -141,8 +141,13 @@ class MultiHeadDenseLayer(Dense):
 
 class TransformerFFN(Layer):
     """TransformerFFN (common_layers.py:95-160): dense1 + relu -> dropout -> dense2.
-    forward fuses bias+relu+dropout into the first GEMM epilogue and bias(+post dropout + residual, supplied by
-    the wrapper) into the second; backward recovers relu'/dropout from the saved hidden activation (h > 0)."""
+
+    bf16, d_model 256 (K.ffn_supported): ONE launch per direction -- nst_ffn_fwd computes both products, both dropouts and
+    the wrapper's residual add with the hidden tile staying on chip between the products (it is written once, as the saved
+    activation); nst_ffn_bwd does the same for the input gradient.  The two weight gradients remain reductions over the
+    rows on the weight-gradient stream.
+    Otherwise: two GEMMs with fused epilogues (bias+relu+dropout; bias + the wrapper's dropout + residual); backward
+    recovers relu'/dropout from the saved hidden activation (h > 0)."""
 
     def __init__(self, rt, name, hidden_size, filter_size, dropout_rate, gen):
         super().__init__(rt, name)
@@ -150,11 +155,21 @@ class TransformerFFN(Layer):
         self.dense2 = Dense(rt, name + "/dense2", filter_size, hidden_size, gen)
         self.rate = dropout_rate
         self.site = self._site()
+        self.fused = os.environ.get("NST_FFN_FUSED", "1") != "0" and K.ffn_supported(hidden_size, filter_size, rt.dtype)
+        if self.fused:
+            self._w1t = rt.store.add_transposed(self.dense1.kernel)
+            self._w2t = rt.store.add_transposed(self.dense2.kernel)
 
     def forward(self, x, is_training, epilogue=None):
         p = self.rate if is_training else 0.0
-        h = self.dense1.forward(x, relu=True, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
-        y = self.dense2.forward(h, **(epilogue or {}))
+        epi = epilogue or {}
+        if self.fused and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"}) and x.is_contiguous():
+            y, h = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
+                             residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed, hidden_site=self.site,
+                             out_p=epi.get("dropout_p", 0.0), out_seed=epi.get("seed", 0), out_site=epi.get("stream_id", 0))
+        else:
+            h = self.dense1.forward(x, relu=True, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
+            y = self.dense2.forward(h, **epi)
         if is_training:
             self._saved = (x, h, p)
         return y
@@ -164,6 +179,10 @@ class TransformerFFN(Layer):
         x, h, p = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
+        if self.fused and dz.is_contiguous():
+            dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual)
+            self.dense1.backward_params(x, dh)
+            return dx
         dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=K.dropout_inv_keep(p))
         self.dense1.backward_params(x, dh)
         return self.dense1.backward_input(dh, **({} if residual is None else {"residual": residual}))

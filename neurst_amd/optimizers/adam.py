@@ -39,6 +39,7 @@ class Adam(object):
         st = self.store
         K.adam_update(st.master, self.m, self.v, st.grad, st.shadow, lr_t, self.beta_1, self.beta_2, self.epsilon,
                       grad_scale)
+        st.refresh_transposed()   # the fused feed-forward reads transposed copies of its two kernels
         self.iterations = t
 
     def state(self):

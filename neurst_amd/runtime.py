@@ -30,12 +30,21 @@ class Param(object):
         return f"Param({self.name}, {self.shape})"
 
 
+class TransposedCopy(object):
+    """Handle of a transposed bf16 copy of a 2-D parameter (ParamStore.add_transposed)."""
+    __slots__ = ("param", "offset", "t")
+
+    def __init__(self, param):
+        self.param, self.offset, self.t = param, -1, None
+
+
 class ParamStore(object):
     def __init__(self):
         self.params = collections.OrderedDict()
         self.finalized = False
         self._touched = set()
         self.accumulate_all = False
+        self._transposed = []     # (param, handle): bf16 copies stored transposed (the fused feed-forward's forward operands)
 
     def add(self, name, shape, init):
         """init: CPU float tensor of `shape` (the reference's initializer already applied)."""
@@ -47,6 +56,16 @@ class ParamStore(object):
         p = Param(name, shape, init)
         self.params[name] = p
         return p
+
+    def add_transposed(self, param):
+        """Registers a transposed bf16 copy of a 2-D parameter; after finalize() `handle.t` is the [cols, rows] view, kept
+        in step with the weights by refresh_transposed() (called wherever the bf16 shadow is refreshed)."""
+        if self.finalized:
+            raise RuntimeError("ParamStore already finalized")
+        assert len(param.shape) == 2
+        handle = TransposedCopy(param)
+        self._transposed.append(handle)
+        return handle
 
     def finalize(self, device, compute_dtype):
         off = 0
@@ -69,9 +88,45 @@ class ParamStore(object):
             p.data = self.master[sl].view(p.shape)
             p.grad = self.grad[sl].view(p.shape)
             p.compute = (self.shadow if self.shadow is not None else self.master)[sl].view(p.shape)
+        self._build_transposed()
         self.finalized = True
         self.refresh_shadow()
         return self
+
+    def _build_transposed(self):
+        self.shadow_t = self._tr_table = None
+        self._tr_pairs, self._tr_tiles = [], 0
+        if self.shadow is None or not self._transposed:
+            return
+        off = 0
+        for hnd in self._transposed:
+            hnd.offset = off
+            off += (hnd.param.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.shadow_t = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        import numpy as np
+        rows = []
+        for hnd in self._transposed:
+            r, c = hnd.param.shape
+            hnd.t = self.shadow_t[hnd.offset:hnd.offset + r * c].view(c, r)
+            self._tr_pairs.append((hnd.param.compute, hnd.t))
+            tiles_c = (c + 63) // 64
+            rows.append((hnd.param.compute.data_ptr(), hnd.t.data_ptr(), r, c, tiles_c, self._tr_tiles))
+            self._tr_tiles += ((r + 63) // 64) * tiles_c
+        arr = np.array(rows, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                             ("tiles_c", "<i4"), ("tile0", "<i4")]))
+        if self.device.type == "cuda":
+            self._tr_table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+
+    def refresh_transposed(self):
+        """Re-derives the transposed bf16 copies from the bf16 shadow: one launch for all of them."""
+        if getattr(self, "shadow_t", None) is None:
+            return
+        if self.master.is_cuda:
+            from neurst_amd import kernels
+            kernels.transpose_bf16(self._tr_table, len(self._tr_pairs), self._tr_tiles)
+        else:  # host-side tests of the store / layer scheduling (like refresh_shadow's CPU branch)
+            for src, dst in self._tr_pairs:
+                dst.copy_(src.t())
 
     def refresh_shadow(self):
         if self.shadow is not None:
@@ -80,6 +135,7 @@ class ParamStore(object):
                 kernels.cast_f32_to_bf16(self.master, self.shadow)
             else:  # host-side unit tests of the store itself
                 self.shadow.copy_(self.master.to(torch.bfloat16))
+            self.refresh_transposed()
 
     # --- gradient bookkeeping: the first kernel that writes a parameter's gradient in a backward pass
     # overwrites, later writers (tied embedding, gradient accumulation micro-steps) accumulate.

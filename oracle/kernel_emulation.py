@@ -125,6 +125,49 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     return out
 
 
+def ffn_supported(d_model, filter_size, dtype):
+    return dtype == torch.bfloat16 and d_model == 256 and filter_size >= 128 and filter_size % 128 == 0 and filter_size <= 8192
+
+
+def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0, out_seed=0,
+            out_site=0):
+    rows, d = x.shape
+    f = w1t.shape[0]
+    assert x.is_contiguous() and w1t.is_contiguous() and w2t.is_contiguous() and w1t.shape == (f, d) and w2t.shape == (d, f)
+    assert x.dtype == torch.bfloat16 and w1t.dtype == x.dtype and w2t.dtype == x.dtype and d == 256 and f % 128 == 0
+    assert residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype)
+    h = (x.to(F64) @ w1t.to(F64).t() + (b1.to(F64) if b1 is not None else 0.0)).clamp_min(0)
+    if hidden_p > 0:
+        h = h * _keep(hidden_p, hidden_seed, hidden_site, (rows, f))
+    h = h.to(x.dtype)                                   # the hidden tile feeds the second product as bf16
+    y = h.to(F64) @ w2t.to(F64).t() + (b2.to(F64) if b2 is not None else 0.0)
+    if out_p > 0:
+        y = y * _keep(out_p, out_seed, out_site, (rows, d))
+    if residual is not None:
+        y = y + residual.to(F64)
+    return y.to(x.dtype), h
+
+
+def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None):
+    rows, d = dy.shape
+    f = w2.shape[0]
+    assert dy.is_contiguous() and hidden.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    assert w2.shape == (f, d) and w1.shape == (d, f) and hidden.shape == (rows, f) and dy.dtype == torch.bfloat16
+    from neurst_amd.kernels import dropout_inv_keep
+    gate = torch.where(hidden > 0, dropout_inv_keep(hidden_p) if hidden_p > 0 else 1.0, 0.0).to(F64)
+    dh = ((dy.to(F64) @ w2.to(F64).t()) * gate).to(dy.dtype)
+    dx = dh.to(F64) @ w1.to(F64).t()
+    if residual is not None:
+        dx = dx + residual.to(F64)
+    return dx.to(dy.dtype), dh
+
+
+def transpose_bf16(table, njobs, total_tiles):
+    """`table` on the CPU tier is the Python list of (src, dst) tensor pairs ParamStore keeps next to the device table."""
+    for src, dst in table:
+        dst.copy_(src.t())
+
+
 def colsum(x, out, accumulate=False):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
     s = x.to(F64).sum(0).float()
@@ -394,7 +437,7 @@ def cast_f32_to_bf16(src, dst):
 _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "attention_fwd", "attention_bwd",
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
-          "cast_f32_to_bf16"]
+          "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16"]
 
 
 def install(monkeypatch):

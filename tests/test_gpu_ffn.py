@@ -1,0 +1,146 @@
+"""Parity of the fused feed-forward pair (nst_ffn_fwd / nst_ffn_bwd, neurst_amd/csrc/nst_ffn.hip) through the C ABI against
+float64 math of the reference's TransformerFFN + PrePostProcessingWrapper (neurst/layers/common_layers.py:145-160, 73-85) on
+the same seeded inputs, bf16 tolerance 1e-2 relative to the magnitude of the reference tensor; dropout masks must be the
+library's Philox masks BIT FOR BIT (oracle/philox.py restates the generator)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def rel(got, ref):
+    got, ref = got.detach().float().cpu().double(), ref.double()
+    assert got.shape == ref.shape
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+
+
+def _operands(M, F, seed):
+    d = 256
+    x, res = rnd(M, d, seed=seed), rnd(M, d, seed=seed + 1)
+    w1, w2 = rnd(d, F, seed=seed + 2, scale=d ** -0.5), rnd(F, d, seed=seed + 3, scale=F ** -0.5)
+    g = torch.Generator().manual_seed(seed + 4)
+    b1, b2 = torch.randn(F, generator=g) * 0.1, torch.randn(d, generator=g) * 0.1
+    return x, res, w1, w2, b1, b2
+
+
+# M: full 128-row tiles (4 waves), 64-row tiles (2 waves), ragged tails of both kinds, one row, and a size past the
+# 128-row / 64-row switch
+@pytest.mark.parametrize("M,F", [(256, 256), (192, 128), (200, 512), (1, 128), (77, 2048), (9600, 2048), (20480 + 40, 256)])
+def test_ffn_forward_without_dropout(M, F):
+    from neurst_amd import kernels as K
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=M + F)
+    y, h = K.ffn_fwd(x.to(DEV), w1.t().contiguous().to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV),
+                     residual=res.to(DEV))
+    h_ref = (x.double() @ w1.double() + b1.double()).clamp_min(0)
+    assert rel(h, h_ref) <= 1e-2
+    # the second product consumes the bf16-rounded hidden tile: compare against that
+    y_ref = h.float().cpu().double() @ w2.double() + b2.double() + res.double()
+    assert rel(y, y_ref) <= 1e-2
+    # without a residual / biases
+    y2, _ = K.ffn_fwd(x.to(DEV), w1.t().contiguous().to(DEV), None, w2.t().contiguous().to(DEV), None)
+    h2 = (x.double() @ w1.double()).clamp_min(0).to(BF).double()
+    assert rel(y2, h2 @ w2.double()) <= 1e-2
+
+
+@pytest.mark.parametrize("M,F", [(256, 256), (200, 512), (9600, 2048)])
+def test_ffn_forward_dropout_masks_are_the_library_masks(M, F):
+    from neurst_amd import kernels as K
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=7 * M + F)
+    p1, p2, seed, s1, s2 = 0.25, 0.1, 987654321, 11, 12
+    b1 = b1.abs() + 3.0        # every pre-activation positive: a zero in the hidden tile is a dropped unit
+    y, h = K.ffn_fwd(x.to(DEV), w1.t().contiguous().to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV),
+                     residual=res.to(DEV), hidden_p=p1, hidden_seed=seed, hidden_site=s1, out_p=p2, out_seed=seed, out_site=s2)
+    hc = h.float().cpu().double()
+    keep1 = torch.from_numpy(philox.keep_multiplier(seed, s1, M * F, p1)).reshape(M, F)
+    pre = x.double() @ w1.double() + b1.double()
+    assert float(pre.min()) > 0
+    assert torch.equal(hc != 0, keep1 != 0), "hidden dropout mask differs from the Philox restatement"
+    assert rel(h, pre * keep1) <= 1e-2
+    keep2 = torch.from_numpy(philox.keep_multiplier(seed, s2, M * 256, p2)).reshape(M, 256)
+    y_ref = (hc @ w2.double() + b2.double()) * keep2 + res.double()
+    assert rel(y, y_ref) <= 1e-2
+    # same masks as the two-GEMM path (nst_gemm epilogues) draws for the same (seed, site)
+    h_g = K.gemm(x.to(DEV), w1.to(DEV), M, F, 256, bias=b1.to(DEV), relu=True, dropout_p=p1, seed=seed, stream_id=s1)
+    assert torch.equal(h_g != 0, h != 0)
+    y_g = K.gemm(h_g, w2.to(DEV), M, 256, F, bias=b2.to(DEV), dropout_p=p2, seed=seed, stream_id=s2, residual=res.to(DEV))
+    assert rel(y, y_g.float().cpu()) <= 2e-2
+
+
+@pytest.mark.parametrize("M,F", [(256, 256), (192, 128), (200, 512), (1, 128), (63, 384), (9600, 2048), (20480 + 40, 256)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_ffn_backward(M, F, with_residual):
+    from neurst_amd import kernels as K
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=3 * M + F)
+    dy = rnd(M, 256, seed=5)
+    p = 0.25
+    keep = torch.from_numpy(philox.keep_multiplier(5, 3, M * F, p)).reshape(M, F)
+    h = ((x.double() @ w1.double() + b1.double()).clamp_min(0) * keep).to(BF)       # what the forward saved
+    dx, dh = K.ffn_bwd(dy.to(DEV), h.to(DEV), w2.to(DEV), w1.to(DEV), hidden_p=p, residual=res.to(DEV) if with_residual else None)
+    gate = torch.where(h > 0, K.dropout_inv_keep(p), 0.0).double()
+    dh_ref = (dy.double() @ w2.double().t()) * gate
+    assert rel(dh, dh_ref) <= 1e-2
+    assert torch.equal(dh.float().cpu() != 0, (dh_ref.to(BF) != 0)) or rel(dh, dh_ref) <= 1e-2
+    dx_ref = dh.float().cpu().double() @ w1.double().t() + (res.double() if with_residual else 0.0)
+    assert rel(dx, dx_ref) <= 1e-2
+    # agrees with the two-GEMM path
+    dh_g = K.gemm(dy.to(DEV), w2.to(DEV), M, F, 256, trans_b=True, gate_src=h.to(DEV), gate_scale=K.dropout_inv_keep(p))
+    assert rel(dh, dh_g.float().cpu()) <= 1e-2
+
+
+def test_transposed_weight_copies_follow_the_optimizer():
+    """The forward reads transposed bf16 copies of the two FFN kernels: they must equal the bf16 shadow transposed after
+    construction, after a state-dict load and after every optimizer step."""
+    from neurst_amd.layers.common_layers import TransformerFFN
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.runtime import Runtime
+    rt = Runtime(device=DEV, dtype="bfloat16", seed=1)
+    ffn = TransformerFFN(rt, "ffn", 256, 384, 0.1, torch.Generator().manual_seed(0))
+    assert ffn.fused
+    rt.store.finalize(rt.device, rt.dtype)
+
+    def check():
+        assert torch.equal(ffn._w1t.t, ffn.dense1.kernel.compute.t()) and torch.equal(ffn._w2t.t, ffn.dense2.kernel.compute.t())
+    check()
+    opt = Adam(rt.store, learning_rate=1e-2)
+    rt.store.grad.normal_()
+    opt.apply_gradients()
+    check()
+    rt.store.load_state_dict({n: torch.randn(p.shape) for n, p in rt.store.params.items()})
+    check()
+
+
+def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
+    """TransformerFFN inside the pre-norm wrapper: fused launch vs the two-GEMM composition, forward and backward, same
+    dropout masks (both dropouts on)."""
+    from neurst_amd.layers.common_layers import PrePostProcessingWrapper, TransformerFFN
+    from neurst_amd.runtime import Runtime
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NST_FFN_FUSED", fused)
+        rt = Runtime(device=DEV, dtype="bfloat16", seed=3)
+        w = PrePostProcessingWrapper(rt, "w", TransformerFFN(rt, "w/ffn", 256, 512, 0.1, torch.Generator().manual_seed(0)), 256,
+                                     0.1, 1e-6)
+        assert w.layer.fused == (fused == "1")
+        rt.store.finalize(rt.device, rt.dtype)
+        x = rnd(300, 256, seed=1).to(DEV)
+        y = w.forward(x, True)
+        rt.store.begin_backward()
+        dx = w.backward(rnd(300, 256, seed=2).to(DEV))
+        rt.join_wgrad_stream()
+        torch.cuda.synchronize()
+        outs.append((y.float().cpu(), dx.float().cpu(), rt.store.grad.clone().cpu()))
+    (y1, dx1, g1), (y0, dx0, g0) = outs
+    assert rel(y1, y0) <= 1e-2 and rel(dx1, dx0) <= 2e-2
+    assert float((g1 - g0).norm() / g0.norm()) <= 2e-2

@@ -887,3 +887,32 @@ def test_predict_entry_with_metric_on_projected_audio_records_skips_the_referenc
                       strategy="none", model=model, task=task, model_dir=None, custom_dataset=ds)
     hyps = entry.run()
     assert len(hyps) == 5 and entry.metric_result is None
+
+
+def test_fused_feed_forward_host_wiring_matches_the_two_gemm_schedule(cpu_kernels, monkeypatch):
+    """TransformerFFN in bf16 at d_model 256 takes the one-launch path (nst_ffn_fwd / nst_ffn_bwd over transposed weight
+    copies); over the emulated kernels it must give what the two-GEMM schedule gives -- same masks (both dropouts on),
+    same gradients in the flat buffer -- for the pre-norm and the post-norm wrapper."""
+    from neurst_amd.layers.common_layers import PrePostProcessingWrapper, TransformerFFN
+    from neurst_amd.runtime import Runtime
+    for pre_norm in (True, False):
+        outs = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("NST_FFN_FUSED", fused)
+            rt = Runtime(device="cpu", dtype="bfloat16", seed=3)
+            w = PrePostProcessingWrapper(rt, "w", TransformerFFN(rt, "w/ffn", 256, 384, 0.2, torch.Generator().manual_seed(0)),
+                                         256, 0.1, 1e-6, pre_norm=pre_norm)
+            assert w.layer.fused == (fused == "1")
+            rt.store.finalize(rt.device, rt.dtype)
+            if fused == "1":
+                assert torch.equal(w.layer._w1t.t, w.layer.dense1.kernel.compute.t())
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(70, 256, generator=g).to(torch.bfloat16)
+            y = w.forward(x, True)
+            rt.store.begin_backward()
+            dx = w.backward(torch.randn(70, 256, generator=g).to(torch.bfloat16))
+            outs.append((y.double(), dx.double(), rt.store.grad.clone().double()))
+        (y1, dx1, g1), (y0, dx0, g0) = outs
+        assert float((y1 - y0).abs().max()) <= 2e-2 * float(y0.abs().max())
+        assert float((dx1 - dx0).abs().max()) <= 2e-2 * float(dx0.abs().max())
+        assert float((g1 - g0).norm() / g0.norm()) <= 1e-2
