@@ -148,13 +148,21 @@ struct Cfg {
   // a phase opens once the piece it consumes AND the next one have landed (fragment reads run half a phase ahead of the
   // MFMAs, so they reach into the next piece): DEPTH-2 younger pieces stay in flight
   static constexpr int WAITN = IPW * (DEPTH - 2);
-  static_assert(WAITN <= 63, "vmcnt is a 6-bit counter");
+  // ... plus the hidden-tile stores issued since (vmcnt retires loads and stores in issue order, so a store younger than
+  // the piece a phase needs must be COUNTED, or the wait also demands pieces that are not needed yet).  Two 16-byte stores
+  // per 32-column block, issued in the phase before the second product starts and in its first three phases; the window
+  // of younger operations at the opening of phase J spans every phase except J and J+1.
+  static constexpr int stores_in_phase(int j) { return (j >= 3 + NG && j <= 6 + NG) ? 2 : 0; }
+  static constexpr int waitn_exact(int j) { return WAITN + 8 - stores_in_phase(j) - stores_in_phase((j + 1) % PPC); }
+  static_assert(WAITN + 8 <= 63, "vmcnt is a 6-bit counter");
 };
 
 // DROP: bit 0 = hidden dropout on, bit 1 = output dropout on (forward); FULL: M is a multiple of the workgroup's rows.
 // Both are template parameters so that a phase is ONE basic block: the scheduler can then place the mid epilogue's
 // VALU work between the MFMAs of the second product.
-template <int MODE, int NW, int DROP, bool FULL>
+// DBG (ablation builds of the benchmark shape only, NST_FFN_DBG): 1 = no hidden-tile store, 2 = no DMA after the prologue
+// (stale LDS), 4 = no MFMA, 8 = no fragment reads.
+template <int MODE, int NW, int DROP, bool FULL, int DBG = 0>
 __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   typedef Cfg<MODE, NW> C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,7 +232,8 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   // bias of the first product: staged once into LDS behind the ring (forward only)
   float* bias_lds = reinterpret_cast<float*>(smem + C::RING);
   if (MODE == MODE_FWD) {
-    for (int i = tid; i < F; i += 64 * NW) bias_lds[i] = a.bias_a ? a.bias_a[i] : 0.f;
+    const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;   // relu(z) * inv_keep == relu(z * inv_keep)
+    for (int i = tid; i < F; i += 64 * NW) bias_lds[i] = a.bias_a ? a.bias_a[i] * sc : 0.f;
   }
 
   // ---------------------------------------------------------------- fragment read offsets (per lane, constant)
@@ -252,22 +261,27 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   auto open_phase = [&](int c, auto jtag) {
     constexpr int J = decltype(jtag)::value;
     if (c == nch - 1 && J > C::PPC - C::DEPTH) wait_vm<0>();   // fewer than DEPTH-1 younger pieces exist: drain
-    else wait_vm<C::WAITN>();
+    else if (c == 0 || !FULL || (DBG & 1)) wait_vm<C::WAITN>();   // no (or predicated) stores behind the pieces: conservative
+    else wait_vm<C::waitn_exact(J)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr int JN = (J + C::DEPTH) % C::PPC;
     const int cn = c + (J + C::DEPTH) / C::PPC;
-    if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
+    if constexpr ((DBG & 2) == 0) {
+      if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
+    }
   };
 
   // The MFMAs of a chunk form a stream of 128 positions: s < 64: first product, phase pa = s >> 4, k-block kbl = (s >> 2) & 3,
   // column block nb = s & 3; s >= 64: second product, phase pb = (s - 64) >> 4, k-block t = (s >> 3) & 1, row block db = s & 7.
   // The weight fragment of position s is read PD positions early into a ring of PD registers quads.
-  constexpr int PD = 8;
+  constexpr int PD = 16;
   bf16x8_t wq[PD];
   auto read_frag = [&](auto stag) {
     constexpr int S = decltype(stag)::value & 127;
-    if constexpr (S < 64) {
+    if constexpr ((DBG & 8) != 0) {
+      return;
+    } else if constexpr (S < 64) {
       constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
       wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + pa * PIECE + nb * (32 * 128) + offA[kbl]);
     } else {
@@ -277,7 +291,10 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   };
   auto mfma_at = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
-    if constexpr (S < 64) {
+    if constexpr ((DBG & 4) != 0) {
+      const bf16x8_t keep_alive = wq[S % PD];   // keeps the fragment read alive
+      asm volatile("" ::"v"(keep_alive));
+    } else if constexpr (S < 64) {
       constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
       if constexpr (pa == 0 && kbl == 0) {
         const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -301,21 +318,25 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     for (int e = 0; e < 16; ++e) v[e] = accH[nb][e];
     if (MODE == MODE_FWD) {
       const float4* bp = reinterpret_cast<const float4*>(bias_lds + col0);
+      const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 b = bp[q];
-        v[4 * q + 0] = fmaxf(v[4 * q + 0] + b.x, 0.f);
-        v[4 * q + 1] = fmaxf(v[4 * q + 1] + b.y, 0.f);
-        v[4 * q + 2] = fmaxf(v[4 * q + 2] + b.z, 0.f);
-        v[4 * q + 3] = fmaxf(v[4 * q + 3] + b.w, 0.f);
+        v[4 * q + 0] = fmaxf(fmaf(v[4 * q + 0], sc, b.x), 0.f);
+        v[4 * q + 1] = fmaxf(fmaf(v[4 * q + 1], sc, b.y), 0.f);
+        v[4 * q + 2] = fmaxf(fmaf(v[4 * q + 2], sc, b.z), 0.f);
+        v[4 * q + 3] = fmaxf(fmaf(v[4 * q + 3], sc, b.w), 0.f);
       }
       if constexpr ((DROP & 1) != 0) {
         const uint64_t idx = (uint64_t)row * (uint64_t)F + (uint64_t)col0;   // multiple of 8
-        float k0[8], k1[8];
-        dropout_keep8(a.seed1 + seed_off, a.stream1, idx, a.drop1_thresh, a.drop1_inv_keep, k0);
-        dropout_keep8(a.seed1 + seed_off, a.stream1, idx + 8, a.drop1_thresh, a.drop1_inv_keep, k1);
+        const Philox4 r0 = philox4x32_10(a.seed1 + seed_off, a.stream1, idx >> 3);
+        const Philox4 r1 = philox4x32_10(a.seed1 + seed_off, a.stream1, (idx >> 3) + 1);
+        const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] *= k0[e]; v[8 + e] *= k1[e]; }
+        for (int e = 0; e < 16; ++e) {   // 16-bit field e of the two calls: keep iff field >= threshold (drop_field)
+          const uint32_t f = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+          v[e] = f >= a.drop1_thresh ? v[e] : 0.f;
+        }
       }
     } else {
       union { uint4 u[2]; short s[16]; } g;
@@ -326,7 +347,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) P[nb][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-    if (row_ok) {
+    if (row_ok && (DBG & 1) == 0) {
       uint4* o = reinterpret_cast<uint4*>(a.mid_out + (int64_t)row * F + col0);
       o[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
       o[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
@@ -356,15 +377,23 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     if constexpr (MODE == MODE_BWD) {
       // the gate pieces (no MFMA work): the lane's 4 x 32 bytes go to registers -- their slots are refilled while the
       // second product still runs
-      open_phase(c, std::integral_constant<int, 4>());
-      if constexpr (C::NG == 2) open_phase(c, std::integral_constant<int, 5>());
+      // slot 4 (rows 0..63 of the workgroup) is refilled when phase 5 opens, slot 5 when phase 6 opens: each half of
+      // the workgroup reads its gate rows right after the phase that made them visible
       const int rr = (NW == 4 ? (wave & 1) : wave) * 32 + m_l;
-      const char* gslot = smem + (4 + (NW == 4 ? (wave >> 1) : 0)) * PIECE + rr * 256;
+      auto read_gate = [&](int slot_index) {
+        const char* gslot = smem + slot_index * PIECE + rr * 256;
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-          gq[nb][s2] = *reinterpret_cast<const uint4*>(gslot + (((nb * 4 + 2 * h + s2) ^ (rr & 15)) << 4));
+          for (int s2 = 0; s2 < 2; ++s2)
+            gq[nb][s2] = *reinterpret_cast<const uint4*>(gslot + (((nb * 4 + 2 * h + s2) ^ (rr & 15)) << 4));
+      };
+      open_phase(c, std::integral_constant<int, 4>());
+      if (NW != 4 || (wave >> 1) == 0) read_gate(4);
+      if constexpr (C::NG == 2) {
+        open_phase(c, std::integral_constant<int, 5>());
+        if ((wave >> 1) == 1) read_gate(5);
+      }
       [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, 64 + I>()), ...); }(std::make_integer_sequence<int, PD>());
     }
     mid_epilogue(c, 0);
@@ -435,7 +464,7 @@ void allow_lds(KernelT kernel, int bytes) {
   if (ndone < 16) done[ndone++] = (const void*)kernel;
 }
 
-template <int MODE, int NW, int DROP, bool FULL>
+template <int MODE, int NW, int DROP, bool FULL, int DBG = 0>
 int launch_one(const FfnArgs& a, hipStream_t st) {
   typedef Cfg<MODE, NW> C;
   const int lds = C::RING + (MODE == MODE_FWD ? a.F * 4 : 0);
@@ -443,7 +472,7 @@ int launch_one(const FfnArgs& a, hipStream_t st) {
     nst_set_error("ffn: filter size %d needs %d bytes of LDS", a.F, lds);
     return NST_ERR_UNSUPPORTED;
   }
-  auto k = ffn_pair_kernel<MODE, NW, DROP, FULL>;
+  auto k = ffn_pair_kernel<MODE, NW, DROP, FULL, DBG>;
   allow_lds(k, lds);
   const int rows = 32 * NW;
   k<<<(a.M + rows - 1) / rows, 64 * NW, lds, st>>>(a);
@@ -459,6 +488,22 @@ int launch_pair(const FfnArgs& a, hipStream_t st) {
     return full ? launch_one<MODE, NW, 0, true>(a, st) : launch_one<MODE, NW, 0, false>(a, st);
   } else {
     const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
+    if constexpr (NW == 4) {
+      const char* e = getenv("NST_FFN_DBG");
+      const int dbg = e ? atoi(e) : 0;
+      if (dbg && full) {
+        switch (dbg) {
+          case 1: return launch_one<MODE, NW, 0, true, 1>(a, st);
+          case 2: return launch_one<MODE, NW, 0, true, 2>(a, st);
+          case 3: return launch_one<MODE, NW, 0, true, 3>(a, st);
+          case 4: return launch_one<MODE, NW, 0, true, 4>(a, st);
+          case 7: return launch_one<MODE, NW, 0, true, 7>(a, st);
+          case 8: return launch_one<MODE, NW, 0, true, 8>(a, st);
+          case 12: return launch_one<MODE, NW, 0, true, 12>(a, st);
+          default: break;
+        }
+      }
+    }
     if (full && drop == 3) return launch_one<MODE, NW, 3, true>(a, st);
     if (full && drop == 0) return launch_one<MODE, NW, 0, true>(a, st);
     return launch_one<MODE, NW, 3, false>(a, st);

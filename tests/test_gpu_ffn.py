@@ -59,7 +59,7 @@ def test_ffn_forward_dropout_masks_are_the_library_masks(M, F):
     from neurst_amd import kernels as K
     x, res, w1, w2, b1, b2 = _operands(M, F, seed=7 * M + F)
     p1, p2, seed, s1, s2 = 0.25, 0.1, 987654321, 11, 12
-    b1 = b1.abs() + 3.0        # every pre-activation positive: a zero in the hidden tile is a dropped unit
+    b1 = b1.abs() + 12.0       # every pre-activation positive: a zero in the hidden tile is a dropped unit
     y, h = K.ffn_fwd(x.to(DEV), w1.t().contiguous().to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV),
                      residual=res.to(DEV), hidden_p=p1, hidden_seed=seed, hidden_site=s1, out_p=p2, out_seed=seed, out_site=s2)
     hc = h.float().cpu().double()
