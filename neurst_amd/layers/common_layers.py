@@ -33,6 +33,9 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
 
 
 _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
+# the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
+# below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
+_FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
 
 
 def _wgrad_split(rows, k_in, n_out, dtype):
@@ -163,7 +166,9 @@ class TransformerFFN(Layer):
     def forward(self, x, is_training, epilogue=None):
         p = self.rate if is_training else 0.0
         epi = epilogue or {}
-        if self.fused and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"}) and x.is_contiguous():
+        use_fused = self.fused and x.shape[0] >= _FFN_FUSED_MIN_ROWS and x.is_contiguous() \
+            and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"})
+        if use_fused:
             y, h = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
                              residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed, hidden_site=self.site,
                              out_p=epi.get("dropout_p", 0.0), out_seed=epi.get("seed", 0), out_site=epi.get("stream_id", 0))
@@ -179,7 +184,7 @@ class TransformerFFN(Layer):
         x, h, p = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
-        if self.fused and dz.is_contiguous():
+        if self.fused and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
             dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual)
             self.dense1.backward_params(x, dh)
             return dx
