@@ -47,6 +47,17 @@ enum {
 int nst_abi_version(void);
 const char* nst_last_error_string(void);
 
+/* Dropout seed offset.  Every entry point that draws a dropout mask (nst_gemm, nst_attention_fwd, nst_ffn_fwd,
+ * nst_layernorm_bwd_dropout, nst_embedding_*, nst_scale_*_dropout_*) keys its Philox generator with
+ * (seed + OFFSET, stream_id, element index), where OFFSET is one device-resident 64-bit scalar owned by the library
+ * (0 until set) that the kernels read WHEN THEY RUN.  A host that replays a captured HIP graph of a training step keeps
+ * its seed arguments constant and enqueues nst_dropout_seed_offset_add(1) once per step (inside the graph): every replay
+ * then draws fresh masks, and forward / backward kernels of one step still see the same value.  A host that passes a
+ * new seed per step (the reference passes none: tf.nn.dropout draws from TF's global generator,
+ * neurst/layers/common_layers.py:82,157) leaves the offset at 0.  Both calls are asynchronous on `stream`. */
+int nst_dropout_seed_offset_set(uint64_t value, void* stream);
+int nst_dropout_seed_offset_add(uint64_t delta, void* stream);
+
 /* ------------------------------------------------------------------ LayerNorm
  * tf.keras.layers.LayerNormalization(epsilon, dtype=float32) over the last axis:
  *   neurst/layers/common_layers.py:64-65,77 (pre-norm), transformer_encoder.py:98-100,135,
@@ -250,6 +261,10 @@ int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weig
  * p,m,v,g f32 [n]; shadow (bf16 copy of p for the compute path) may be NULL. */
 int nst_adam_update(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n, float lr_t,
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* Same update with the bias-corrected step size lr_t read from DEVICE memory when the kernel runs: a captured HIP graph of
+ * the training step is replayed with a new lr_t per step (the host writes the scalar before each replay). */
+int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
+                        const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* Gradient clipping of the flat gradient buffer after the data-parallel average (GradAccumKerasModel.train_step,
  * neurst/training/gradaccum_keras_model.py:228-233):  g *= pre_scale (the 1/world_size average), then

@@ -100,9 +100,12 @@ SIGNATURES = {
     "nst_ls_xent_fwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _I, _P],
     "nst_ls_xent_bwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _F, _P, _I, _P],
     "nst_adam_update": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
+    "nst_adam_update_dev": [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
     "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
     "nst_cast_bf16_to_f32": [_P, _P, _L, _P],
     "nst_probe_mfma": [_P, _P, _P, _P],
+    "nst_dropout_seed_offset_set": [_U64, _P],
+    "nst_dropout_seed_offset_add": [_U64, _P],
     "nst_ffn_supported": [_I, _I, _I],
     "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],

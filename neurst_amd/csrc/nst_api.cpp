@@ -13,6 +13,37 @@ void nst_set_error(const char* fmt, ...) {
 }
 
 extern "C" int nst_abi_version(void) { return NST_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// dropout seed offset: one device scalar per process (one process drives one GPU)
+// ---------------------------------------------------------------------------------------------
+static uint64_t* g_seed_offset = nullptr;
+
+const uint64_t* nst_seed_offset_devptr() {
+  if (!g_seed_offset) {
+    uint64_t* p = nullptr;
+    if (hipMalloc((void**)&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) {
+      nst_set_error("dropout seed offset: device allocation failed");
+      return nullptr;
+    }
+    g_seed_offset = p;
+  }
+  return g_seed_offset;
+}
+
+namespace {
+__global__ void seed_offset_kernel(uint64_t* p, uint64_t v, int add) { *p = add ? *p + v : v; }
+}  // namespace
+
+static int seed_offset_update(uint64_t v, int add, void* stream) {
+  uint64_t* p = const_cast<uint64_t*>(nst_seed_offset_devptr());
+  if (!p) return NST_ERR_LAUNCH;
+  seed_offset_kernel<<<1, 1, 0, (hipStream_t)stream>>>(p, v, add);
+  NST_CHECK_LAUNCH("dropout_seed_offset");
+  return NST_OK;
+}
+extern "C" int nst_dropout_seed_offset_set(uint64_t value, void* stream) { return seed_offset_update(value, 0, stream); }
+extern "C" int nst_dropout_seed_offset_add(uint64_t delta, void* stream) { return seed_offset_update(delta, 1, stream); }
 extern "C" const char* nst_last_error_string(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------

@@ -193,6 +193,7 @@ struct AttnParams {
   uint32_t drop_thresh;  // 16-bit threshold, 0 = no dropout
   float drop_inv_keep;
   uint64_t seed, stream_id;
+  const uint64_t* seed_dev;   // device scalar added to `seed` when the forward kernel runs (nst_dropout_seed_offset_*)
 };
 
 // additive key term of the logits in the log2 domain; keys beyond Tk are excluded
@@ -331,7 +332,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
       if (p.drop_thresh) {
         // 16 fields of 16 bits for the lane's 16 probabilities: two Philox calls
         const uint64_t ctr = ((uint64_t)((bh * p.Tq + qg) * p.nkt + kt) * 4 + g) * 2;
-        const Philox4 w0 = philox4x32_10(p.seed, p.stream_id, ctr), w1 = philox4x32_10(p.seed, p.stream_id, ctr + 1);
+        const uint64_t seed_eff = seed_with_offset(p.seed, p.seed_dev);
+        const Philox4 w0 = philox4x32_10(seed_eff, p.stream_id, ctr), w1 = philox4x32_10(seed_eff, p.stream_id, ctr + 1);
         const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         uint32_t bits = 0;
 #pragma unroll
@@ -736,6 +738,8 @@ int fill_params(const NstAttnDesc* d, AttnParams& p) {
     p.mask = reinterpret_cast<uint16_t*>(d->dropout_mask);
   }
   p.seed = d->seed; p.stream_id = d->stream_id;
+  p.seed_dev = nst_seed_offset_devptr();
+  if (!p.seed_dev) return NST_ERR_LAUNCH;
   return NST_OK;
 }
 

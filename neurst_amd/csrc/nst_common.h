@@ -46,6 +46,10 @@ void nst_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// Device scalar every dropout-drawing kernel ADDS to its seed argument when it runs (nst_dropout_seed_offset_set / _add):
+// a captured HIP graph then draws new masks at every replay.  Allocated once per process (8 bytes), zero by default.
+const uint64_t* nst_seed_offset_devptr();
+
 static inline int nst_dtype_size(int dt) { return dt == NST_BF16 ? 2 : 4; }
 static inline bool nst_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -110,6 +114,14 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// seed + *offset read through the scalar cache (never a vector load: a pending VMEM load would make the compiler drain
+// the LDS-DMA prefetch of the GEMM kernels in front of it)
+__device__ __forceinline__ uint64_t seed_with_offset(uint64_t seed, const uint64_t* offset_dev) {
+  uint64_t off;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(off) : "s"(offset_dev) : "memory");
+  return seed + off;
 }
 
 // ---------------------------------------------------------------------------

@@ -57,7 +57,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 template <typename T>
 __global__ void embedding_fwd_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids,
                                      const float* __restrict__ posenc, T* __restrict__ out, int64_t rows, int L, int d,
-                                     int V, float scale, uint32_t thresh, float inv_keep, uint64_t seed, uint64_t sid) {
+                                     int V, float scale, uint32_t thresh, float inv_keep, uint64_t seed, uint64_t sid,
+                                     const uint64_t* __restrict__ seed_dev) {
+  if (thresh) seed = seed_with_offset(seed, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * nw + wave; row < rows; row += (int64_t)gridDim.x * nw) {
     int64_t id = ids[row];
@@ -75,7 +77,8 @@ __global__ void embedding_fwd_kernel(const T* __restrict__ table, const int64_t*
 template <typename T>
 __global__ void embedding_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dtable,
                                      int64_t rows, int d, int V, float scale, uint32_t thresh, float inv_keep,
-                                     uint64_t seed, uint64_t sid) {
+                                     uint64_t seed, uint64_t sid, const uint64_t* __restrict__ seed_dev) {
+  if (thresh) seed = seed_with_offset(seed, seed_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * nw + wave; row < rows; row += (int64_t)gridDim.x * nw) {
     int64_t id = ids[row];
@@ -94,7 +97,8 @@ __global__ void embedding_bwd_kernel(const T* __restrict__ dout, const int64_t* 
 template <typename T, int VEC>
 __global__ void scale_posenc_dropout_kernel(const T* __restrict__ x, const float* __restrict__ posenc, T* __restrict__ y,
                                             int64_t n, int d, int period, float scale, uint32_t thresh, float inv_keep,
-                                            uint64_t seed, uint64_t sid) {
+                                            uint64_t seed, uint64_t sid, const uint64_t* __restrict__ seed_dev) {
+  if (thresh) seed = seed_with_offset(seed, seed_dev);
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n;
        i += (int64_t)gridDim.x * blockDim.x * VEC) {
     float v[4];
@@ -240,8 +244,9 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
 // Keras Adam over a flat buffer (+ optional bf16 shadow of the updated parameter)
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                            bf16_t* __restrict__ shadow, int64_t n, float lr_t, float b1, float b2, float eps,
-                            float gscale) {
+                            bf16_t* __restrict__ shadow, int64_t n, float lr_t, const float* __restrict__ lr_t_dev, float b1,
+                            float b2, float eps, float gscale) {
+  if (lr_t_dev) lr_t = *lr_t_dev;   // graph replay: the step size of THIS replay lives in device memory
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -282,9 +287,9 @@ extern "C" int nst_embedding_fwd(const void* table, const int64_t* ids, const fl
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(rows, 4, 4096);
   if (dtype == NST_F32)
-    embedding_fwd_kernel<float><<<g, 256, 0, st>>>((const float*)table, ids, posenc, (float*)out, rows, L, d, V, emb_scale, th, ik, seed, stream_id);
+    embedding_fwd_kernel<float><<<g, 256, 0, st>>>((const float*)table, ids, posenc, (float*)out, rows, L, d, V, emb_scale, th, ik, seed, stream_id, nst_seed_offset_devptr());
   else if (dtype == NST_BF16)
-    embedding_fwd_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)table, ids, posenc, (bf16_t*)out, rows, L, d, V, emb_scale, th, ik, seed, stream_id);
+    embedding_fwd_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)table, ids, posenc, (bf16_t*)out, rows, L, d, V, emb_scale, th, ik, seed, stream_id, nst_seed_offset_devptr());
   else { nst_set_error("embedding_fwd: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("embedding_fwd");
   return NST_OK;
@@ -301,9 +306,9 @@ extern "C" int nst_embedding_bwd(const void* dout, const int64_t* ids, float* dt
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(rows, 4, 4096);
   if (dtype == NST_F32)
-    embedding_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)dout, ids, dtable, rows, d, V, emb_scale, th, ik, seed, stream_id);
+    embedding_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)dout, ids, dtable, rows, d, V, emb_scale, th, ik, seed, stream_id, nst_seed_offset_devptr());
   else if (dtype == NST_BF16)
-    embedding_bwd_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)dout, ids, dtable, rows, d, V, emb_scale, th, ik, seed, stream_id);
+    embedding_bwd_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)dout, ids, dtable, rows, d, V, emb_scale, th, ik, seed, stream_id, nst_seed_offset_devptr());
   else { nst_set_error("embedding_bwd: bad dtype %d", dtype); return NST_ERR_INVALID_ARG; }
   NST_CHECK_LAUNCH("embedding_bwd");
   return NST_OK;
@@ -313,9 +318,9 @@ template <typename T>
 static void launch_spd(const void* x, const float* posenc, void* y, int64_t n, int d, int period, float scale, uint32_t th,
                        float ik, uint64_t seed, uint64_t sid, hipStream_t st) {
   if (n % 4 == 0 && aligned4<T>(x) && aligned4<T>(y) && (d % 4 == 0))
-    scale_posenc_dropout_kernel<T, 4><<<grid_for(n / 4, 256, 8192), 256, 0, st>>>((const T*)x, posenc, (T*)y, n, d, period, scale, th, ik, seed, sid);
+    scale_posenc_dropout_kernel<T, 4><<<grid_for(n / 4, 256, 8192), 256, 0, st>>>((const T*)x, posenc, (T*)y, n, d, period, scale, th, ik, seed, sid, nst_seed_offset_devptr());
   else
-    scale_posenc_dropout_kernel<T, 1><<<grid_for(n, 256, 8192), 256, 0, st>>>((const T*)x, posenc, (T*)y, n, d, period, scale, th, ik, seed, sid);
+    scale_posenc_dropout_kernel<T, 1><<<grid_for(n, 256, 8192), 256, 0, st>>>((const T*)x, posenc, (T*)y, n, d, period, scale, th, ik, seed, sid, nst_seed_offset_devptr());
 }
 
 extern "C" int nst_scale_posenc_dropout_fwd(const void* x, const float* posenc, void* y, int64_t rows, int d, int period,
@@ -428,8 +433,17 @@ extern "C" int nst_adam_update(float* p, float* m, float* v, const float* g, uin
                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
   NST_CHECK_ARG(p && m && v && g, "adam_update: null pointer");
   if (n <= 0) return NST_OK;
-  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale);
+  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, lr_t, nullptr, beta1, beta2, eps, grad_scale);
   NST_CHECK_LAUNCH("adam_update");
+  return NST_OK;
+}
+
+extern "C" int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
+                                   const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  NST_CHECK_ARG(p && m && v && g && lr_t_dev, "adam_update_dev: null pointer");
+  if (n <= 0) return NST_OK;
+  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, 0.f, lr_t_dev, beta1, beta2, eps, grad_scale);
+  NST_CHECK_LAUNCH("adam_update_dev");
   return NST_OK;
 }
 

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   const int row_c = row_ok ? row : M - 1;
 
   uint64_t seed_off = 0;
-  if (a.seed_dev) seed_off = *a.seed_dev;
+  if (MODE == MODE_FWD && DROP != 0) seed_off = seed_with_offset(0, a.seed_dev);
 
   // ---------------------------------------------------------------- DMA source offsets (per lane, constant)
   // A piece (chunk c, pa): rows 128c + r, bytes [128 pa, +128) of the 512-byte WA rows
@@ -562,7 +562,8 @@ extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, 
   a.xin = (const bf16_t*)x; a.wa = (const bf16_t*)w1t; a.wb = (const bf16_t*)w2t;
   a.bias_a = b1; a.bias_b = b2; a.residual = (const bf16_t*)residual;
   a.mid_out = (bf16_t*)hidden; a.out = (bf16_t*)y;
-  a.seed_dev = d->seed_offset;
+  a.seed_dev = d->seed_offset ? d->seed_offset : nst_seed_offset_devptr();   // explicit scalar, else the library's
+  if (!a.seed_dev) return NST_ERR_LAUNCH;
   a.M = (int)d->rows; a.F = d->filter_size;
   nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
   nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);

@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, 
   int kt_count = kt_total - kt_first;
   if (kt_count > kt_per_split) kt_count = kt_per_split;
   if (kt_count <= 0) return;
+  if (ep.drop_thresh) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);
   gemm_block<T, OutT, AMODE, BMODE, USE_TR>(la, lb, C + (int64_t)blockIdx.z * ep.slab_stride, ldc, M, N, tm * BM, tn * BN,
                                             kt_first, kt_count, ep, smem);
 }
@@ -192,6 +193,8 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   nst_dropout_params16(d->dropout_p, &ep.drop_thresh, &ep.drop_inv_keep);
   ep.seed = d->seed;
   ep.stream_id = d->stream_id;
+  ep.seed_dev = nst_seed_offset_devptr();
+  if (!ep.seed_dev) return NST_ERR_LAUNCH;
   ep.residual = d->residual;
   ep.ldr = d->ldr;
   ep.gate_src = d->gate_src;

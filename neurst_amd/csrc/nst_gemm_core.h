@@ -66,6 +66,7 @@ struct Epilogue {
   uint32_t drop_thresh;
   float drop_inv_keep;
   uint64_t seed, stream_id;
+  const uint64_t* seed_dev;  // device scalar added to `seed` when the kernel runs (nst_dropout_seed_offset_*)
   const void* residual;
   int64_t ldr;
   const void* gate_src;
@@ -1190,7 +1191,8 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
     stage ^= 1;
     if (++ckt == cq.kt_count) {
       const NST_AS4 Args* k2 = launder(ka);
-      const Epilogue ep = kload(&k2->ep);
+      Epilogue ep = kload(&k2->ep);
+      if (ep.drop_thresh) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
       const RowMap rowmap = kload(&k2->rowmap);
       const int M = k2->M, N = k2->N;
       if (CS && do_cs && lane < 16) {  // every row of cs holds the column sums; lane = column within the 16-block

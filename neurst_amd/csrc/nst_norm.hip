@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const T* __restrict__ dres, T* __restrict__ dx, int64_t rows, int d,
                                                          float* __restrict__ partial, T* __restrict__ dz, uint32_t dz_thresh,
-                                                         float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid) {
+                                                         float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid,
+                                                         const uint64_t* __restrict__ seed_dev) {
+  if (dz) dz_seed = seed_with_offset(dz_seed, seed_dev);   // wave-uniform
   constexpr int RPW = 64 / LPR;
   constexpr int W = LPR * S * 8;  // padded row width
   __shared__ float red[4][2][W];
@@ -515,7 +517,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     int64_t wb = (rows + 4 * (64 / lpr) * U - 1) / (4 * (64 / lpr) * U);
     if (wb > 512) wb = 512;
     *nblocks = (int)wb;
-#define NST_LN_BWDW(L, S) ln_bwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid)
+#define NST_LN_BWDW(L, S) ln_bwd_wide_kernel<T, L, S, RELU, U><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr())
     *dz_done = true;
     if (lpr == 16) NST_LN_BWDW(16, 1); else if (lpr == 32) NST_LN_BWDW(32, 1); else if (d <= 512) NST_LN_BWDW(64, 1); else NST_LN_BWDW(64, 2);
 #undef NST_LN_BWDW

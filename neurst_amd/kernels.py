@@ -91,6 +91,16 @@ class _KernelProbe(object):
 PROBE = _KernelProbe()
 
 
+# ------------------------------------------------------------------------------------------------ dropout seed offset
+def dropout_seed_offset_set(value):
+    """The library's device scalar that every dropout kernel adds to its seed when it runs (0 by default)."""
+    check(lib.nst_dropout_seed_offset_set(int(value), _stream()), "dropout_seed_offset_set")
+
+
+def dropout_seed_offset_add(delta=1):
+    check(lib.nst_dropout_seed_offset_add(int(delta), _stream()), "dropout_seed_offset_add")
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, gamma, beta, eps, relu=False):
     assert x.is_contiguous()
@@ -424,7 +434,13 @@ def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None,
 
 
 def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    """lr_t: float, or a 1-element float32 DEVICE tensor read when the kernel runs (graph replay)."""
     n = p.numel()
+    if torch.is_tensor(lr_t):
+        assert lr_t.dtype == torch.float32 and lr_t.numel() == 1
+        check(lib.nst_adam_update_dev(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, _p(lr_t), beta1, beta2, eps, grad_scale,
+                                      _stream()), "adam_update_dev")
+        return
     check(lib.nst_adam_update(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, lr_t, beta1, beta2, eps, grad_scale,
                               _stream()), "adam_update")
 

@@ -36,6 +36,9 @@ _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
+# the backward pair holds all 160 KB of a CU's LDS, so no weight-gradient workgroup (second stream) can share its CUs: in the
+# step it is not faster than the two persistent GEMMs it replaces (profiles/r02_*): off unless NST_FFN_FUSED_BWD=1
+_FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "0") != "0"
 
 
 def _wgrad_split(rows, k_in, n_out, dtype):
@@ -184,7 +187,7 @@ class TransformerFFN(Layer):
         x, h, p = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
-        if self.fused and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
+        if self.fused and _FFN_FUSED_BWD and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
             dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual)
             self.dense1.backward_params(x, dh)
             return dx

@@ -33,14 +33,23 @@ class Adam(object):
         lr = self.learning_rate
         return float(lr(self.iterations)) if callable(lr) else float(lr)
 
-    def apply_gradients(self, grad_scale=1.0):
+    def step_size(self):
+        """lr_t of the NEXT update: lr * sqrt(1 - beta_2^t) / (1 - beta_1^t)."""
         t = self.iterations + 1
-        lr_t = self.current_lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        return self.current_lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply_gradients(self, grad_scale=1.0, lr_t_dev=None):
+        """lr_t_dev: 1-element float32 device tensor holding step_size() -- the kernel reads it when it runs, so the launch
+        can sit in a captured graph (the caller refreshes the scalar and calls advance() per replay)."""
         st = self.store
-        K.adam_update(st.master, self.m, self.v, st.grad, st.shadow, lr_t, self.beta_1, self.beta_2, self.epsilon,
-                      grad_scale)
+        K.adam_update(st.master, self.m, self.v, st.grad, st.shadow, lr_t_dev if lr_t_dev is not None else self.step_size(),
+                      self.beta_1, self.beta_2, self.epsilon, grad_scale)
         st.refresh_transposed()   # the fused feed-forward reads transposed copies of its two kernels
-        self.iterations = t
+        if lr_t_dev is None:
+            self.advance()
+
+    def advance(self):
+        self.iterations += 1
 
     def state(self):
         """Resume state (checkpoints.py keeps it next to the weights): step count and both moment buffers."""

@@ -199,7 +199,10 @@ class Runtime(object):
         self.dtype = dtype
         self.store = ParamStore()
         self.base_seed = int(seed)
-        self.step = 0
+        self._step = 0
+        # device_step: the step counter that varies the dropout masks lives in the library's device scalar (read by the
+        # kernels when they run) instead of in the seed argument -- what a captured HIP graph of the step needs
+        self.device_step = False
         self._sites = 0
         self._posenc_cache = {}
         # Weight-gradient GEMMs do not feed the backward chain: they run on a second HIP stream so that their
@@ -232,8 +235,37 @@ class Runtime(object):
         return self._sites
 
     @property
+    def step(self):
+        return self._step
+
+    @step.setter
+    def step(self, value):
+        self._step = int(value)
+        if self.device_step:
+            from neurst_amd import kernels
+            kernels.dropout_seed_offset_set(self._step)
+
+    def enable_device_step(self):
+        if not self.device_step:
+            self.device_step = True
+            self.step = self._step   # uploads the counter
+
+    def advance_step(self, enqueue=True):
+        """End of an optimizer step.  enqueue=False: the device-side increment is part of a graph that was just replayed."""
+        self._step += 1
+        if self.device_step and enqueue:
+            from neurst_amd import kernels
+            kernels.dropout_seed_offset_add(1)
+
+    @property
     def step_seed(self):
-        return self.base_seed * 1000003 + self.step
+        """The seed ARGUMENT of this step's dropout kernels: with device_step the kernels add the step themselves."""
+        return self.base_seed * 1000003 + (0 if self.device_step else self._step)
+
+    @property
+    def effective_seed(self):
+        """The Philox key the kernels end up using in this step, whichever side adds the step."""
+        return self.base_seed * 1000003 + self._step
 
     def posenc(self, length, channels):
         """Sinusoid timing table [length, channels] f32 (neurst/layers/common_layers.py:356-413), built on

@@ -71,6 +71,10 @@ class GradientReducer(object):
         self._covered = []
         self._open = None        # coalescing range [start, end) not yet issued
         self.messages = 0        # collectives issued since the last finish() (introspection / tests)
+        self.last_messages = 0
+        # graph capture of the train step (training/train_step.py): instead of issuing a bucket, the reducer hands its
+        # range to this callback, which cuts the capture there and replays the exchange eagerly between two graph launches
+        self.capture_cut = None
 
     # ---- parameter ranges -------------------------------------------------------------------------------------
     def range_of(self, prefixes):
@@ -109,6 +113,13 @@ class GradientReducer(object):
     def _issue(self, start, end):
         if self.world <= 1 or end <= start:
             return
+        if self.capture_cut is not None:
+            self.capture_cut(start, end)
+            return
+        self.issue(start, end)
+
+    def issue(self, start, end):
+        """The exchange of grad[start:end] itself (asynchronous on the communication stream when there is one)."""
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for s in self.extra_streams:
@@ -150,13 +161,18 @@ class GradientReducer(object):
         self.reduce_range(0, self.store.total)
         self.flush()
         self._covered = []
+        if self.capture_cut is None:   # while capturing, the waits belong to the replay (wait_issued)
+            self.wait_issued()
+        self.last_messages, self.messages = self.messages, 0
+        return 1.0 / self.world
+
+    def wait_issued(self):
+        """The current stream waits for every exchange issued so far."""
         for h in self._pending:
             h.wait()
         self._pending = []
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self.last_messages, self.messages = self.messages, 0
-        return 1.0 / self.world
 
     def broadcast_parameters(self, src=0):
         """BroadcastGlobalVariablesCallback(0) (exps/trainer.py:285)."""

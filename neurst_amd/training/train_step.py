@@ -5,12 +5,29 @@ neurst/training/gradaccum_keras_model.py:162-260, 437-477; hvd optimizer hook hv
             -> [update_cycle-1 more micro batches accumulated] -> average [-> clip by value / per-tensor norm] -> fused Adam
 
 No host<->device synchronisation happens inside a step; the loss is returned as a device scalar.
+
+Graph mode (use_graph=True / NST_TRAIN_GRAPH=1; the reference's counterpart is tf.function tracing of the train step,
+gradaccum_keras_model.py:262-352): the step issues ~450 library calls, ~10 ms of Python / ctypes work against 13-18 ms of
+GPU time, so per input signature (shapes + dtypes of the batch) the whole step is captured ONCE into HIP graphs over static
+input buffers and replayed afterwards.  What changes per step is read from device memory when the kernels run: the
+dropout step counter (nst_dropout_seed_offset_*: `add 1` is the last node of the graph) and Adam's step size lr_t (a
+device scalar the host refreshes before each replay).  With more than one rank the capture is CUT wherever the reducer
+issues a bucket: the all-reduce stays an eager RCCL call on the communication stream between two graph launches, so the
+exchange still overlaps the rest of the backward pass (no collective is captured).  The first call with a new signature
+runs eagerly (allocations, lazy tables), the second captures and replays, later ones only replay.
 """
+import os
+
 import torch
 
 
+class _CapturedStep(object):
+    __slots__ = ("static_inputs", "segments", "plan", "loss", "pool")
+
+
 class TrainStep(object):
-    def __init__(self, model, criterion, optimizer, reducer=None, update_cycle=1, clip_value=None, clip_norm=None):
+    def __init__(self, model, criterion, optimizer, reducer=None, update_cycle=1, clip_value=None, clip_norm=None,
+                 use_graph=None):
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         # gradaccum_keras_model.py:228-233: clip_value takes precedence over clip_norm; both act on the averaged gradients
         self.clip_value = clip_value if clip_value else None
@@ -22,16 +39,24 @@ class TrainStep(object):
             if ws is not None and ws not in reducer.extra_streams:
                 reducer.extra_streams.append(ws)
         self._last_micro = True
+        if use_graph is None:
+            use_graph = os.environ.get("NST_TRAIN_GRAPH", "0") == "1"
+        self.use_graph = bool(use_graph) and model.rt.device.type == "cuda"
+        self._seen, self._captured = set(), {}
+        self._lr_dev = self._cap_stream = None
+        self.replays = 0
+        if self.use_graph:
+            model.rt.enable_device_step()
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=model.rt.device)
+            self._cap_stream = torch.cuda.Stream(model.rt.device)
 
     def _hook(self, prefixes):
         if self._last_micro and self.reducer is not None:
             self.reducer.component_ready(prefixes)
 
-    def __call__(self, batches):
-        """batches: one model-input dict, or a list of `update_cycle` dicts (gradient accumulation: the mean of
-        the micro-batch gradients, GradientAccumulator semantics gradaccum_keras_model.py:62-109)."""
-        if isinstance(batches, dict):
-            batches = [batches]
+    # ------------------------------------------------------------------------------------------------ the step body
+    def _body(self, batches, lr_t_dev=None):
+        """Queues one optimizer step on the current stream (eagerly, or into an ongoing capture)."""
         n = len(batches)
         loss_sum = None
         for i, inputs in enumerate(batches):
@@ -49,6 +74,99 @@ class TrainStep(object):
             K.grad_clip(self.model.store.grad, table, nentries, seg_first, nseg, pre_scale=scale,
                         clip_value=self.clip_value, clip_norm=self.clip_norm)
             scale = 1.0   # the average is already applied
-        self.optimizer.apply_gradients(grad_scale=scale)
-        self.model.rt.step += 1
+        self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev)
         return loss_sum / n
+
+    def __call__(self, batches):
+        """batches: one model-input dict, or a list of `update_cycle` dicts (gradient accumulation: the mean of
+        the micro-batch gradients, GradientAccumulator semantics gradaccum_keras_model.py:62-109)."""
+        if isinstance(batches, dict):
+            batches = [batches]
+        if self.use_graph:
+            return self._graph_call(batches)
+        loss = self._body(batches)
+        self.model.rt.advance_step()
+        return loss
+
+    # ------------------------------------------------------------------------------------------------ graph mode
+    @staticmethod
+    def _signature(batches):
+        return tuple(tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(b.items()) if torch.is_tensor(v))
+                     for b in batches)
+
+    def _graph_call(self, batches):
+        key = self._signature(batches)
+        cap = self._captured.get(key)
+        if cap is None:
+            if key not in self._seen:          # first sight of this shape: a plain eager step (also the warm-up)
+                self._seen.add(key)
+                loss = self._body(batches)
+                self.model.rt.advance_step()
+                return loss
+            cap = self._captured[key] = self._capture(batches)
+        for sb, b in zip(cap.static_inputs, batches):
+            for k, v in sb.items():
+                if b[k] is not v and b[k].data_ptr() != v.data_ptr():
+                    v.copy_(b[k], non_blocking=True)
+        self._lr_dev.fill_(self.optimizer.step_size())
+        red = self.reducer
+        last = len(cap.segments) - 1
+        for i, g in enumerate(cap.segments):
+            if i == last and cap.plan:
+                red.wait_issued()              # every bucket has been exchanged before clip / Adam
+            g.replay()
+            if i < len(cap.plan):
+                red.issue(*cap.plan[i])
+        if red is not None:
+            red.last_messages = len(cap.plan)
+        self.optimizer.advance()
+        self.model.rt.advance_step(enqueue=False)   # the increment of the device counter is the graph's last node
+        self.replays += 1
+        return cap.loss
+
+    def _capture(self, batches):
+        from neurst_amd import kernels as K
+        rt, red = self.model.rt, self.reducer
+        cap = _CapturedStep()
+        cap.static_inputs = [{k: v.clone() for k, v in b.items() if torch.is_tensor(v)} for b in batches]
+        full = [dict(b, **sb) for b, sb in zip(batches, cap.static_inputs)]
+        cap.segments, cap.plan = [], []
+        cap.pool = torch.cuda.graph_pool_handle()
+        stream = self._cap_stream
+        stream.wait_stream(torch.cuda.current_stream(rt.device))
+        state = {"g": None}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=cap.pool)
+
+        def end():
+            state["g"].capture_end()
+            cap.segments.append(state["g"])
+            state["g"] = None
+
+        def cut(start, stop):       # the reducer wants grad[start:stop] exchanged now: close the segment, plan the call
+            rt.join_wgrad_stream()
+            end()
+            cap.plan.append((start, stop))
+            begin()
+
+        if red is not None:
+            red.capture_cut = cut
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                loss = self._body(full, lr_t_dev=self._lr_dev)
+                K.dropout_seed_offset_add(1)
+                cap.loss = loss
+                end()
+        finally:
+            if red is not None:
+                red.capture_cut = None
+            if state["g"] is not None:   # an exception inside the capture: leave capture mode
+                try:
+                    state["g"].capture_end()
+                except Exception:
+                    pass
+        torch.cuda.current_stream(rt.device).wait_stream(stream)
+        return cap

@@ -25,9 +25,10 @@ F64 = torch.float64
 
 
 def _keep(p, seed, site, shape):
-    """float64 keep multipliers (0 or 1/keep) of a tensor of `shape` whose elements are numbered in row-major order."""
+    """float64 keep multipliers (0 or 1/keep) of a tensor of `shape` whose elements are numbered in row-major order; the
+    library's seed offset (dropout_seed_offset_set / _add) is added to the seed like the kernels do."""
     n = int(np.prod(shape))
-    return torch.from_numpy(philox.keep_multiplier(seed, site, n, p)).reshape(tuple(shape))
+    return torch.from_numpy(philox.keep_multiplier(seed + _SEED_OFFSET[0], site, n, p)).reshape(tuple(shape))
 
 
 # ---------------------------------------------------------------------------------------------------- LayerNorm
@@ -123,6 +124,17 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
         else:
             colsum_out.copy_(cs)
     return out
+
+
+_SEED_OFFSET = [0]
+
+
+def dropout_seed_offset_set(value):
+    _SEED_OFFSET[0] = int(value)
+
+
+def dropout_seed_offset_add(delta=1):
+    _SEED_OFFSET[0] += int(delta)
 
 
 def ffn_supported(d_model, filter_size, dtype):
@@ -437,7 +449,8 @@ def cast_f32_to_bf16(src, dst):
 _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "attention_fwd", "attention_bwd",
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
-          "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16"]
+          "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16",
+          "dropout_seed_offset_set", "dropout_seed_offset_add"]
 
 
 def install(monkeypatch):

@@ -130,6 +130,7 @@ def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
     for fused in ("1", "0"):
         monkeypatch.setenv("NST_FFN_FUSED", fused)
         monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_MIN_ROWS", 1)
+        monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_BWD", True)
         rt = Runtime(device=DEV, dtype="bfloat16", seed=3)
         w = PrePostProcessingWrapper(rt, "w", TransformerFFN(rt, "w/ffn", 256, 512, 0.1, torch.Generator().manual_seed(0)), 256,
                                      0.1, 1e-6)

@@ -1,0 +1,109 @@
+"""HIP-graph replay of the training step (neurst_amd/training/train_step.py, graph mode) against the eager step: same
+losses and weights for the same seeds, new dropout masks at every replay (the step counter is read from device memory by
+the kernels), Adam's step size refreshed per replay, and the capture cut into segments where a data-parallel reducer
+issues its buckets."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(dtype, dropout, use_graph, reducer_factory=None, lr=1e-2, seed=11):
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.models import build_model
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.train_step import TrainStep
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    p = dict(get_hyper_parameters("speech_transformer_toy")["model.params"])
+    p.update({"modality.dim": 64, "modality.source.channels": 32, "encoder.num_layers": 2, "decoder.num_layers": 2,
+              "encoder.hidden_size": 64, "decoder.hidden_size": 64, "encoder.num_attention_heads": 2,
+              "decoder.num_attention_heads": 2, "encoder.filter_size": 128, "decoder.filter_size": 128})
+    for k in list(p):
+        if k.endswith("dropout_rate"):
+            p[k] = dropout
+    V = 50
+    model = build_model({"model.class": "SpeechTransformer", "model.params": p},
+                        {"audio_feature_dim": 16, "audio_feature_channels": 1},
+                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=DEV, dtype=dtype,
+                        init_seed=3, seed=seed)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = Adam(model.store, learning_rate=(lambda it: lr * (1.0 + 0.1 * it)), beta_1=0.9, beta_2=0.98, epsilon=1e-9)
+    red = reducer_factory(model.store) if reducer_factory else None
+    return model, TrainStep(model, crit, opt, red, use_graph=use_graph), opt
+
+
+def _batch(seed, B=3, T=70, F=16, L=9, V=50):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, T, F, 1, generator=g)
+    trg = torch.randint(0, V - 3, (B, L), generator=g)
+    trg[:, -1] = V - 1
+    b = {"src": src, "src_length": torch.tensor([T, T - 9, T - 20]), "trg": trg, "trg_length": torch.tensor([L, L, L]),
+         "trg_input": torch.cat([torch.full((B, 1), V - 2), trg[:, :-1]], 1)}
+    return {k: v.to(DEV) for k, v in b.items()}
+
+
+@pytest.mark.parametrize("dtype,dropout", [("float32", 0.0), ("float32", 0.1), ("bfloat16", 0.1)])
+def test_graph_replay_equals_eager_steps(dtype, dropout):
+    batches = [_batch(100 + i) for i in range(6)]
+    res = {}
+    for use_graph in (False, True):
+        model, step, opt = _setup(dtype, dropout, use_graph)
+        losses = [float(step(b)) for b in batches]
+        torch.cuda.synchronize()
+        res[use_graph] = (losses, model.store.master.clone(), opt.iterations, model.rt.step, step.replays)
+    (le, we, ie, se, _), (lg, wg, ig, sg, replays) = res[False], res[True]
+    assert replays == len(batches) - 1 and ie == ig == len(batches) and se == sg == len(batches)
+    tol = 1e-5 if dtype == "float32" else 2e-3     # embedding gradients use float atomics: last-bit differences
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (le, lg)
+    assert float((we - wg).abs().max()) <= (1e-5 if dtype == "float32" else 1e-3)
+
+
+def test_graph_replay_draws_new_dropout_masks_and_new_step_sizes():
+    """The same batch replayed with a zero learning rate: the loss changes from step to step only through the masks."""
+    model, step, opt = _setup("float32", 0.3, True, lr=0.0)
+    b = _batch(5)
+    losses = [float(step(b)) for _ in range(5)]
+    assert step.replays == 4 and len(set(round(l, 6) for l in losses)) == 5, losses
+    # eager steps of a fresh model with the same seeds see the same masks
+    model2, step2, _ = _setup("float32", 0.3, False, lr=0.0)
+    losses2 = [float(step2(b)) for _ in range(5)]
+    assert max(abs(a - c) for a, c in zip(losses, losses2)) < 1e-5
+    # and with a learning rate the replays follow the schedule (the step size lives in device memory)
+    m3, s3, o3 = _setup("float32", 0.0, True, lr=1e-2)
+    m4, s4, o4 = _setup("float32", 0.0, False, lr=1e-2)
+    for i in range(4):
+        s3(b), s4(b)
+    torch.cuda.synchronize()
+    assert float((m3.store.master - m4.store.master).abs().max()) < 1e-5
+
+
+def test_graph_capture_is_cut_where_the_reducer_issues_buckets():
+    """A reducer that behaves like world_size 2 (its exchange replaced by a recorder): the capture must be cut at every
+    bucket, the buckets must be issued in the same order and ranges as in the eager step, and the result must be the eager
+    result (gradients scaled by 1/2)."""
+    from neurst_amd.training.distributed import GradientReducer
+
+    def factory(log):
+        def make(store):
+            red = GradientReducer(store, bucket_bytes=1 << 16, min_bucket_bytes=1 << 14)
+            red.world, red.overlap = 2, False
+            red.issue = lambda s, e: log.append((s, e))
+            return red
+        return make
+    batches = [_batch(200 + i) for i in range(4)]
+    logs, out = {}, {}
+    for use_graph in (False, True):
+        logs[use_graph] = []
+        model, step, opt = _setup("float32", 0.1, use_graph, reducer_factory=factory(logs[use_graph]))
+        losses = [float(step(b)) for b in batches]
+        torch.cuda.synchronize()
+        out[use_graph] = (losses, model.store.master.clone(), step)
+    per_step = len(logs[False]) // len(batches)
+    assert per_step >= 3 and logs[True] == logs[False]
+    assert len(out[True][2]._captured) == 1
+    cap = next(iter(out[True][2]._captured.values()))
+    assert len(cap.segments) == per_step + 1 and cap.plan == logs[False][:per_step]
+    assert max(abs(a - b) for a, b in zip(out[False][0], out[True][0])) < 1e-5
+    assert float((out[False][1] - out[True][1]).abs().max()) < 1e-5
