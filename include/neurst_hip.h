@@ -55,6 +55,11 @@ const char* nst_last_error_string(void);
  * then draws fresh masks, and forward / backward kernels of one step still see the same value.  A host that passes a
  * new seed per step (the reference passes none: tf.nn.dropout draws from TF's global generator,
  * neurst/layers/common_layers.py:82,157) leaves the offset at 0.  Both calls are asynchronous on `stream`. */
+/* nst_dropout_seed_offset_bind(scalar_dev): from now on (this host thread) launches use the caller's 8-byte device scalar as
+ * OFFSET instead of the library's own (NULL: back to the library's).  The pointer is passed to each kernel at launch, so
+ * several model instances in one process keep separate counters, and a captured graph keeps the scalar it was captured
+ * with.  _set / _add act on the scalar currently bound. */
+int nst_dropout_seed_offset_bind(uint64_t* scalar_dev);
 int nst_dropout_seed_offset_set(uint64_t value, void* stream);
 int nst_dropout_seed_offset_add(uint64_t delta, void* stream);
 

@@ -17,9 +17,11 @@ extern "C" int nst_abi_version(void) { return NST_ABI_VERSION; }
 // ---------------------------------------------------------------------------------------------
 // dropout seed offset: one device scalar per process (one process drives one GPU)
 // ---------------------------------------------------------------------------------------------
-static uint64_t* g_seed_offset = nullptr;
+static uint64_t* g_seed_offset = nullptr;        // the library's own scalar (default)
+static thread_local uint64_t* g_seed_bound = nullptr;   // the scalar the host bound for its next launches, if any
 
 const uint64_t* nst_seed_offset_devptr() {
+  if (g_seed_bound) return g_seed_bound;
   if (!g_seed_offset) {
     uint64_t* p = nullptr;
     if (hipMalloc((void**)&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) {
@@ -40,6 +42,10 @@ static int seed_offset_update(uint64_t v, int add, void* stream) {
   if (!p) return NST_ERR_LAUNCH;
   seed_offset_kernel<<<1, 1, 0, (hipStream_t)stream>>>(p, v, add);
   NST_CHECK_LAUNCH("dropout_seed_offset");
+  return NST_OK;
+}
+extern "C" int nst_dropout_seed_offset_bind(uint64_t* scalar_dev) {
+  g_seed_bound = scalar_dev;
   return NST_OK;
 }
 extern "C" int nst_dropout_seed_offset_set(uint64_t value, void* stream) { return seed_offset_update(value, 0, stream); }

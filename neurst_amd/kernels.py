@@ -92,6 +92,11 @@ PROBE = _KernelProbe()
 
 
 # ------------------------------------------------------------------------------------------------ dropout seed offset
+def dropout_seed_offset_bind(scalar):
+    """scalar: 1-element int64 device tensor that the following launches use as the dropout seed offset (None: the library's)."""
+    check(lib.nst_dropout_seed_offset_bind(_p(scalar)), "dropout_seed_offset_bind")
+
+
 def dropout_seed_offset_set(value):
     """The library's device scalar that every dropout kernel adds to its seed when it runs (0 by default)."""
     check(lib.nst_dropout_seed_offset_set(int(value), _stream()), "dropout_seed_offset_set")

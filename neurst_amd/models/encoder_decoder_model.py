@@ -161,6 +161,7 @@ class EncoderDecoderModel(BaseModel):
     def forward(self, inputs, is_training=True):
         """inputs: dict(src, src_length|src_padding, trg_input) of device tensors -> logits [B, L, V]
         (encoder_decoder_model.py:211-279)."""
+        self.rt.bind()
         embedded_inputs = self._src_modality.forward(inputs["src"], is_training=is_training)
         src_padding = self._src_padding(inputs, embedded_inputs)
         encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=is_training)
@@ -219,6 +220,7 @@ class EncoderDecoderModel(BaseModel):
     def backward(self, dlogits, accumulate=False):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
+        self.rt.bind()
         self.rt.store.begin_backward(accumulate)
         hook = self.grad_ready_hook or (lambda prefixes: None)
         # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the

@@ -203,6 +203,9 @@ class Runtime(object):
         # device_step: the step counter that varies the dropout masks lives in the library's device scalar (read by the
         # kernels when they run) instead of in the seed argument -- what a captured HIP graph of the step needs
         self.device_step = False
+        # this runtime's own seed-offset scalar: bound before its kernels are launched (bind()), so several models in one
+        # process -- and captured graphs -- never see each other's counters
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._sites = 0
         self._posenc_cache = {}
         # Weight-gradient GEMMs do not feed the backward chain: they run on a second HIP stream so that their
@@ -243,7 +246,13 @@ class Runtime(object):
         self._step = int(value)
         if self.device_step:
             from neurst_amd import kernels
+            self.bind()
             kernels.dropout_seed_offset_set(self._step)
+
+    def bind(self):
+        """Makes this runtime's seed-offset scalar the one the following kernel launches read."""
+        from neurst_amd import kernels
+        kernels.dropout_seed_offset_bind(self._step_dev)
 
     def enable_device_step(self):
         if not self.device_step:
@@ -255,6 +264,7 @@ class Runtime(object):
         self._step += 1
         if self.device_step and enqueue:
             from neurst_amd import kernels
+            self.bind()
             kernels.dropout_seed_offset_add(1)
 
     @property

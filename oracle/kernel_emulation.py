@@ -28,7 +28,7 @@ def _keep(p, seed, site, shape):
     """float64 keep multipliers (0 or 1/keep) of a tensor of `shape` whose elements are numbered in row-major order; the
     library's seed offset (dropout_seed_offset_set / _add) is added to the seed like the kernels do."""
     n = int(np.prod(shape))
-    return torch.from_numpy(philox.keep_multiplier(seed + _SEED_OFFSET[0], site, n, p)).reshape(tuple(shape))
+    return torch.from_numpy(philox.keep_multiplier(seed + int(_SEED_OFFSET[0]), site, n, p)).reshape(tuple(shape))
 
 
 # ---------------------------------------------------------------------------------------------------- LayerNorm
@@ -126,7 +126,14 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     return out
 
 
-_SEED_OFFSET = [0]
+_SEED_OFFSET = [0]      # the scalar in use: a one-element list, rebound by dropout_seed_offset_bind
+_SEED_OWN = _SEED_OFFSET
+
+
+def dropout_seed_offset_bind(scalar):
+    """On the CPU tier the bound scalar is the runtime's 1-element int64 tensor (or None for the library's own)."""
+    global _SEED_OFFSET
+    _SEED_OFFSET = scalar if scalar is not None else _SEED_OWN
 
 
 def dropout_seed_offset_set(value):
@@ -450,7 +457,7 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16",
-          "dropout_seed_offset_set", "dropout_seed_offset_add"]
+          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add"]
 
 
 def install(monkeypatch):

@@ -33,6 +33,13 @@ def _setup(dtype, dropout, use_graph, reducer_factory=None, lr=1e-2, seed=11):
     return model, TrainStep(model, crit, opt, red, use_graph=use_graph), opt
 
 
+def _solid(v):
+    """Adam divides by sqrt(v): where the true gradient is zero (key biases: softmax is shift invariant) the update is
+    lr * sign(rounding noise), and the float atomics of the embedding gradient make that noise run-dependent.  Those
+    elements are excluded from weight comparisons."""
+    return (v > 1e-8 * v.max()).float()
+
+
 def _batch(seed, B=3, T=70, F=16, L=9, V=50):
     g = torch.Generator().manual_seed(seed)
     src = torch.randn(B, T, F, 1, generator=g)
@@ -51,13 +58,13 @@ def test_graph_replay_equals_eager_steps(dtype, dropout):
         model, step, opt = _setup(dtype, dropout, use_graph)
         losses = [float(step(b)) for b in batches]
         torch.cuda.synchronize()
-        res[use_graph] = (losses, model.store.master.clone(), opt.iterations, model.rt.step, step.replays)
-    (le, we, ie, se, _), (lg, wg, ig, sg, replays) = res[False], res[True]
+        res[use_graph] = (losses, model.store.master.clone(), opt.iterations, model.rt.step, step.replays, opt.v.clone())
+    (le, we, ie, se, _, ve), (lg, wg, ig, sg, replays, _) = res[False], res[True]
     assert replays == len(batches) - 1 and ie == ig == len(batches) and se == sg == len(batches)
     tol = 1e-5 if dtype == "float32" else 2e-3     # embedding gradients use float atomics: last-bit differences
     for a, b in zip(le, lg):
         assert abs(a - b) <= tol * max(1.0, abs(a)), (le, lg)
-    assert float((we - wg).abs().max()) <= (1e-5 if dtype == "float32" else 1e-3)
+    assert float(((we - wg).abs() * _solid(ve)).max()) <= (2e-5 if dtype == "float32" else 1e-3)
 
 
 def test_graph_replay_draws_new_dropout_masks_and_new_step_sizes():
@@ -76,7 +83,7 @@ def test_graph_replay_draws_new_dropout_masks_and_new_step_sizes():
     for i in range(4):
         s3(b), s4(b)
     torch.cuda.synchronize()
-    assert float((m3.store.master - m4.store.master).abs().max()) < 1e-5
+    assert float(((m3.store.master - m4.store.master).abs() * _solid(o4.v)).max()) < 2e-5
 
 
 def test_graph_capture_is_cut_where_the_reducer_issues_buckets():
@@ -99,11 +106,11 @@ def test_graph_capture_is_cut_where_the_reducer_issues_buckets():
         model, step, opt = _setup("float32", 0.1, use_graph, reducer_factory=factory(logs[use_graph]))
         losses = [float(step(b)) for b in batches]
         torch.cuda.synchronize()
-        out[use_graph] = (losses, model.store.master.clone(), step)
+        out[use_graph] = (losses, model.store.master.clone(), step, opt.v.clone())
     per_step = len(logs[False]) // len(batches)
     assert per_step >= 3 and logs[True] == logs[False]
     assert len(out[True][2]._captured) == 1
     cap = next(iter(out[True][2]._captured.values()))
     assert len(cap.segments) == per_step + 1 and cap.plan == logs[False][:per_step]
     assert max(abs(a - b) for a, b in zip(out[False][0], out[True][0])) < 1e-5
-    assert float((out[False][1] - out[True][1]).abs().max()) < 1e-5
+    assert float(((out[False][1] - out[True][1]).abs() * _solid(out[False][3])).max()) < 2e-5
