@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split over the ranks (default: per-GPU batch, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from captured HIP graphs (training/train_step.py graph mode) instead of eager launches; "
+                         "on ROCm 7.2 the graph executor overlaps the weight-gradient branch poorly (19.9 vs 17.9 ms/step on one "
+                         "MI355X, profiles/r02_graph_vs_eager.json), so eager is the default")
     ap.add_argument("--roofline-steps", type=int, default=3, help="extra un-timed steps with per-launch HIP events (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -196,7 +199,7 @@ def main():
                                            "lr_schedule.params": hp["lr_schedule.params"]})
     reducer = GradientReducer(model.store)
     reducer.broadcast_parameters(0)
-    step_fn = TrainStep(model, crit, opt, reducer, use_graph=not args.no_graph)
+    step_fn = TrainStep(model, crit, opt, reducer, use_graph=args.graph)
     ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
                                  "ragged": args.ragged, "seed": 1234})
     it = ds.build_iterator(map_func=lambda b: task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
@@ -288,7 +291,7 @@ def main():
         "roofline": roofline,
         "roofline_families": families,
         "ffn_gemm_mfma_utilisation": ffn_util,
-        "hip_graph": bool(not args.no_graph), "graph_replays": getattr(step_fn, "replays", 0),
+        "hip_graph": bool(args.graph), "graph_replays": getattr(step_fn, "replays", 0),
         "rccl_world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
         "reducer_messages_per_step": getattr(reducer, "last_messages", None),
     }
