@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split over the ranks (default: per-GPU batch, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-stream-priority", type=int, default=int(os.environ.get("NST_MAIN_PRIORITY", "0")),
+                    help="-1: run the step on a high-priority HIP stream (the weight-gradient stream keeps the default priority)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from captured HIP graphs (training/train_step.py graph mode) instead of eager launches; "
                          "on ROCm 7.2 the graph executor overlaps the weight-gradient branch poorly (19.9 vs 17.9 ms/step on one "
@@ -210,6 +212,11 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+
+    if args.main_stream_priority != 0:
+        main_stream = torch.cuda.Stream(device=dev, priority=args.main_stream_priority)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
 
     for i in range(args.warmup):
         step_fn(batches[i % len(batches)])

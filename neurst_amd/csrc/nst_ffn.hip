@@ -80,10 +80,29 @@ __device__ __forceinline__ void wait_vm() {
 // One piece share of a wave: IPW LDS-DMA instructions (64 lanes x 16 bytes each -> LDS [dst + i*1024 + lane*16]) from
 // sbase + voff[i] (per lane), issued back to back from one asm block (M0 carries the LDS address; the s_nop 4 covers an
 // SGPR base the compiler may have produced with v_readfirstlane right in front of the statement).
-template <int IPW>
+template <int IPW, bool NT = false>
 __device__ __forceinline__ void glds_piece(const void* sbase, const uint32_t (&voff)[IPW], uint32_t lds_addr_uniform) {
   uint32_t keep;
-  if constexpr (IPW == 4) {
+  if constexpr (NT && IPW == 4) {   // streamed-once data (the backward's gate rows): non-temporal, keeps the weights in L2
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %5 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds_addr_uniform)
+        : "memory", "scc");
+  } else if constexpr (IPW == 4) {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %6\n\t"
@@ -150,9 +169,9 @@ struct Cfg {
   static constexpr int WAITN = IPW * (DEPTH - 2);
   // ... plus the hidden-tile stores issued since (vmcnt retires loads and stores in issue order, so a store younger than
   // the piece a phase needs must be COUNTED, or the wait also demands pieces that are not needed yet).  Two 16-byte stores
-  // per 32-column block, issued in the phase before the second product starts and in its first three phases; the window
-  // of younger operations at the opening of phase J spans every phase except J and J+1.
-  static constexpr int stores_in_phase(int j) { return (j >= 3 + NG && j <= 6 + NG) ? 2 : 0; }
+  // per 32-column block: blocks 0 and 1 in the first phase of the second product, 2 and 3 in the next two; the window of
+  // younger operations at the opening of phase J spans every phase except J and J+1.
+  static constexpr int stores_in_phase(int j) { return j == 4 + NG ? 4 : ((j == 5 + NG || j == 6 + NG) ? 2 : 0); }
   static constexpr int waitn_exact(int j) { return WAITN + 8 - stores_in_phase(j) - stores_in_phase((j + 1) % PPC); }
   static_assert(WAITN + 8 <= 63, "vmcnt is a 6-bit counter");
 };
@@ -174,6 +193,12 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   const int F = a.F, M = a.M;
   const int nch = F / CH;
   const int m0 = blockIdx.x * (32 * NW);
+  // Workgroups walk the hidden chunks in ROTATED order (the sum over chunks does not care): at any moment the chip then
+  // writes all column positions of the [M, F] hidden tensor instead of one 256-byte column of every 2F-byte row -- with
+  // every workgroup on the same chunk, all hidden-tile stores of the chip hit the few memory channels that column maps to
+  // (measured: the stores cost 25-30 % of the kernel).
+  const int rot = blockIdx.x % nch;
+  auto phys = [&](int c) { const int q = c + rot; return q >= nch ? q - nch : q; };
   const int row = m0 + wave * 32 + m_l;           // this lane's row of Xin / outputs
   const bool row_ok = FULL || row < M;
   const int row_c = row_ok ? row : M - 1;
@@ -206,13 +231,14 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     }
   }
   // issue the piece with static in-chunk index J of chunk c into ring slot J
-  auto issue_piece = [&](int c, auto jtag) {
+  auto issue_piece = [&](int c_logical, auto jtag) {
     constexpr int J = decltype(jtag)::value;
+    const int c = phys(c_logical);
     const uint32_t dst = smem_addr + (uint32_t)J * PIECE + (uint32_t)(wave * C::IPW) * 1024u;
     if constexpr (J < 4) {
       glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wa) + ((int64_t)c * CH * D + J * 64) * 2, voff_a, dst);
     } else if constexpr (J < 4 + C::NG) {
-      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.gate) + (int64_t)c * CH * 2, voff_g[J - 4], dst);
+      glds_piece<C::IPW, true>(reinterpret_cast<const char*>(a.gate) + (int64_t)c * CH * 2, voff_g[J - 4], dst);
     } else {
       glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wb) + ((int64_t)c * CH + (J - 4 - C::NG) * 32) * 2, voff_b, dst);
     }
@@ -275,7 +301,11 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   // The MFMAs of a chunk form a stream of 128 positions: s < 64: first product, phase pa = s >> 4, k-block kbl = (s >> 2) & 3,
   // column block nb = s & 3; s >= 64: second product, phase pb = (s - 64) >> 4, k-block t = (s >> 3) & 1, row block db = s & 7.
   // The weight fragment of position s is read PD positions early into a ring of PD registers quads.
-  constexpr int PD = 16;
+  // Ring of PD register quads, filled LOOK = PD - 2 positions ahead: the quad a read overwrites was last used by the MFMA
+  // issued TWO positions earlier.  (Refilling the quad of the MFMA that has just been issued makes the read wait until
+  // that MFMA has fetched its operands, and the in-order wave then issues MFMA and read strictly one after the other:
+  // measured, the fragment reads and the MFMAs did not overlap at all.)
+  constexpr int PD = 16, LOOK = PD - 2;
   bf16x8_t wq[PD];
   auto read_frag = [&](auto stag) {
     constexpr int S = decltype(stag)::value & 127;
@@ -288,6 +318,13 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
       constexpr int pb = (S - 64) >> 4, t = (S >> 3) & 1, db = S & 7;
       wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + (B0 + pb) * PIECE + db * (32 * 64) + offB[t]);
     }
+  };
+  // keeps the fragments of positions S and S-1 allocated across the read issued at position S, so that the register
+  // allocator cannot hand that read the quad of an MFMA still fetching its operands
+  auto pin_recent = [&](auto stag) {
+    constexpr int S = decltype(stag)::value;
+    const bf16x8_t f0 = wq[S % PD], f1 = wq[(S + PD - 1) % PD];
+    asm volatile("" ::"v"(f0), "v"(f1));
   };
   auto mfma_at = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
@@ -311,7 +348,14 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   };
 
   // mid epilogue of one 32-column block nb of chunk c: accumulators -> P[nb] (+ store)
-  auto mid_epilogue = [&](int c, int nb) {
+  // `stage`: 2 KB of wave-private LDS inside the ring slot of the CURRENT phase (its fragments were read a phase ago and
+  // its refill is only issued when the next phase opens): the 32 x 32 block goes through it so that a store instruction
+  // writes 16 rows x 64 contiguous bytes instead of 64 scattered 16-byte pieces (those cost ~20 % of the kernel: 64
+  // write requests per instruction on the path the LDS-DMA reads share)
+  const int st_row = lane >> 2, st_slot = lane & 3;
+  const bool st_ok0 = FULL || (m0 + wave * 32 + st_row) < M, st_ok1 = FULL || (m0 + wave * 32 + st_row + 16) < M;
+  auto mid_epilogue = [&](int c_logical, int nb, char* stage) {
+    const int c = phys(c_logical);
     const int col0 = c * CH + nb * 32 + 16 * h;   // this lane's 16 consecutive hidden units
     float v[16];
 #pragma unroll
@@ -347,10 +391,24 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) P[nb][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-    if (row_ok && (DBG & 1) == 0) {
-      uint4* o = reinterpret_cast<uint4*>(a.mid_out + (int64_t)row * F + col0);
-      o[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
-      o[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
+    if constexpr ((DBG & 1) == 0) {
+      uint4* w = reinterpret_cast<uint4*>(stage + m_l * 64 + h * 32);
+      w[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
+      w[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
+      // same wave, LDS operations complete in issue order: the reads below see the block
+      const uint4 r0 = *reinterpret_cast<const uint4*>(stage + st_row * 64 + st_slot * 16);
+      const uint4 r1 = *reinterpret_cast<const uint4*>(stage + (st_row + 16) * 64 + st_slot * 16);
+      bf16_t* o = a.mid_out + (int64_t)(m0 + wave * 32 + st_row) * F + (c * CH + nb * 32 + st_slot * 8);
+      // non-temporal: the hidden tensor streams out (118 MB per launch at the benchmark shape) and must not push the 2 MB of
+      // weights every CU re-reads out of the XCD's L2 (measured: -12 % kernel time against plain stores)
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+      if constexpr ((DBG & 16) != 0) {   // ablation: plain stores
+        if (st_ok0) *reinterpret_cast<uint4*>(o) = r0;
+        if (st_ok1) *reinterpret_cast<uint4*>(o + (int64_t)16 * F) = r1;
+      } else {
+        if (st_ok0) __builtin_nontemporal_store(u32x4_t{r0.x, r0.y, r0.z, r0.w}, reinterpret_cast<u32x4_t*>(o));
+        if (st_ok1) __builtin_nontemporal_store(u32x4_t{r1.x, r1.y, r1.z, r1.w}, reinterpret_cast<u32x4_t*>(o + (int64_t)16 * F));
+      }
     }
   };
 
@@ -358,7 +416,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   wait_vm<C::WAITN>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, I>()), ...); }(std::make_integer_sequence<int, PD>());
+  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, I>()), ...); }(std::make_integer_sequence<int, LOOK>());
 
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
@@ -368,8 +426,9 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
         constexpr int S = SS;
         if constexpr ((S & 15) == 0) open_phase(c, std::integral_constant<int, (S >> 4)>());
         mfma_at(std::integral_constant<int, S>());
-        // the fragment PD positions ahead; in the backward the first fragments of the second product wait for the gate phases
-        if constexpr (S + PD < 64 || MODE == MODE_FWD) read_frag(std::integral_constant<int, S + PD>());
+        // the fragment LOOK positions ahead; in the backward the first fragments of the second product wait for the gate phases
+        if constexpr (S + LOOK < 64 || MODE == MODE_FWD) read_frag(std::integral_constant<int, S + LOOK>());
+        pin_recent(std::integral_constant<int, S>());
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }(), ...);
@@ -394,20 +453,23 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
         open_phase(c, std::integral_constant<int, 5>());
         if ((wave >> 1) == 1) read_gate(5);
       }
-      [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, 64 + I>()), ...); }(std::make_integer_sequence<int, PD>());
+      [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, 64 + I>()), ...); }(std::make_integer_sequence<int, LOOK>());
     }
-    mid_epilogue(c, 0);
     // ---- second product: 4 phases (one per 32-unit block) of 2 k-blocks x 8 output row blocks; the mid epilogue of the
     //      NEXT block sits in the same scheduling region as this block's MFMAs
     [&]<int... SS>(std::integer_sequence<int, SS...>) {
       ([&] {
         constexpr int S = 64 + SS;
         if constexpr ((S & 15) == 0) {
-          open_phase(c, std::integral_constant<int, B0 + ((S - 64) >> 4)>());
-          if constexpr (S < 112) mid_epilogue(c, ((S - 64) >> 4) + 1);
+          constexpr int J = B0 + ((S - 64) >> 4);
+          open_phase(c, std::integral_constant<int, J>());
+          char* stage = smem + J * PIECE + wave * 2048;
+          if constexpr (S == 64) mid_epilogue(c, 0, stage);
+          if constexpr (S < 112) mid_epilogue(c, ((S - 64) >> 4) + 1, stage);
         }
         mfma_at(std::integral_constant<int, S>());
-        read_frag(std::integral_constant<int, S + PD>());   // positions >= 128: the next chunk's first fragments (slot 0)
+        read_frag(std::integral_constant<int, S + LOOK>());   // positions >= 128: the next chunk's first fragments (slot 0)
+        pin_recent(std::integral_constant<int, S>());
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }(), ...);
@@ -447,9 +509,10 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
       for (int e = 0; e < 16; ++e) v[e] += bf16_to_f32(r.s[e]);
     }
     if (row_ok) {
-      uint4* o = reinterpret_cast<uint4*>(a.out + (int64_t)row * D + col0);
-      o[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      o[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+      u32x4_t* o = reinterpret_cast<u32x4_t*>(a.out + (int64_t)row * D + col0);
+      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, o);
+      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])}, o + 1);
     }
   }
 }
@@ -500,6 +563,7 @@ int launch_pair(const FfnArgs& a, hipStream_t st) {
           case 7: return launch_one<MODE, NW, 0, true, 7>(a, st);
           case 8: return launch_one<MODE, NW, 0, true, 8>(a, st);
           case 12: return launch_one<MODE, NW, 0, true, 12>(a, st);
+          case 16: return launch_one<MODE, NW, 0, true, 16>(a, st);
           default: break;
         }
       }

@@ -36,9 +36,10 @@ _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
-# the backward pair holds all 160 KB of a CU's LDS, so no weight-gradient workgroup (second stream) can share its CUs: in the
-# step it is not faster than the two persistent GEMMs it replaces (profiles/r02_*): off unless NST_FFN_FUSED_BWD=1
-_FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "0") != "0"
+# the backward pair (NST_FFN_FUSED_BWD=0: two persistent GEMMs instead).  It holds all 160 KB of a CU's LDS, so no
+# weight-gradient workgroup shares its CUs, but at 97 us against 124 us for the two GEMMs it still wins in the step
+# (17.03 vs 17.31 ms, profiles/r02_ffn_*.json)
+_FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "1") != "0"
 
 
 def _wgrad_split(rows, k_in, n_out, dtype):
