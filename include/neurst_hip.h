@@ -268,8 +268,21 @@ int nst_adam_update(float* p, float* m, float* v, const float* g, uint16_t* shad
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* Same update with the bias-corrected step size lr_t read from DEVICE memory when the kernel runs: a captured HIP graph of
  * the training step is replayed with a new lr_t per step (the host writes the scalar before each replay). */
-int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
-                        const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n, float lr_t,
+                        const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale,
+                        const float* loss_scale_state, void* stream);
+/* lr_t_dev (nullable): overrides lr_t.  loss_scale_state (nullable): the 4-float state of nst_loss_scale_update -- the update is
+ * skipped when its finite flag is 0 and the gradients are divided by the scale they carry otherwise
+ * (tf.keras LossScaleOptimizer.apply_gradients under the reference's RevisedDynamicLossScale).
+ *
+ * Dynamic loss scale, neurst/training/revised_dynamic_loss_scale.py:48-107 (wrapped around the optimizer by
+ * training_utils.handle_fp16_and_distributed_optimizer :373-419 when the compute dtype is float16; initial scale 2^15,
+ * growth_steps 2000, multiplier 2).  state[4] f32 = {current scale, good-step counter, finite flag, scale of the checked
+ * gradients}.  One call per optimizer step, AFTER the gradient exchange: checks grad[0..n) for inf / nan, records the flag and
+ * the scale the gradients carry, then halves the scale (floor 1) and clears the counter on overflow, or counts a good step and
+ * doubles the scale every growth_steps good steps.  workspace: >= 4 bytes, zero on first use (left zero). */
+int nst_loss_scale_update(const float* grad, int64_t n, float* state, float growth_steps, float multiplier, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* Gradient clipping of the flat gradient buffer after the data-parallel average (GradAccumKerasModel.train_step,
  * neurst/training/gradaccum_keras_model.py:228-233):  g *= pre_scale (the 1/world_size average), then

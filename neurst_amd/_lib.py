@@ -100,7 +100,8 @@ SIGNATURES = {
     "nst_ls_xent_fwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _I, _P],
     "nst_ls_xent_bwd": [_P, _P, _P, _P, _P, _L, _I, _L, _F, _F, _P, _I, _P],
     "nst_adam_update": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P],
-    "nst_adam_update_dev": [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
+    "nst_adam_update_dev": [_P, _P, _P, _P, _P, _L, _F, _P, _F, _F, _F, _F, _P, _P],
+    "nst_loss_scale_update": [_P, _L, _P, _F, _F, _P, _L, _P],
     "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
     "nst_cast_bf16_to_f32": [_P, _P, _L, _P],
     "nst_probe_mfma": [_P, _P, _P, _P],

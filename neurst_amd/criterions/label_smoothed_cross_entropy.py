@@ -64,11 +64,15 @@ class LabelSmoothedCrossEntropy(Criterion):
         nll_sum, _, n_tokens = self(model_inp, model_out)
         return nll_sum.sum() / n_tokens.sum()
 
-    def backward(self, loss_scale=1.0):
-        """d(reduce_loss * loss_scale)/d(logits) for the logits of the last __call__; [B, L, V] in the logits dtype."""
+    def backward(self, loss_scale=1.0, loss_scale_dev=None):
+        """d(reduce_loss * loss_scale)/d(logits) for the logits of the last __call__; [B, L, V] in the logits dtype.
+        loss_scale_dev: an additional factor held in a device scalar (the dynamic loss scale)."""
         l2, labels, weights, lse, n_tokens, (B, L, V) = self._saved
         self._saved = None
-        inv = (1.0 / n_tokens.sum()).reshape(1).contiguous()
+        inv = (1.0 / n_tokens.sum()).reshape(1)
+        if loss_scale_dev is not None:
+            inv = inv * loss_scale_dev.reshape(1)
+        inv = inv.contiguous()
         return K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), gscale_dev=inv).view(B, L, V)
 
     def reduce_metrics(self, eval_res_list):

@@ -245,8 +245,12 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                             bf16_t* __restrict__ shadow, int64_t n, float lr_t, const float* __restrict__ lr_t_dev, float b1,
-                            float b2, float eps, float gscale) {
+                            float b2, float eps, float gscale, const float* __restrict__ ls_state) {
   if (lr_t_dev) lr_t = *lr_t_dev;   // graph replay: the step size of THIS replay lives in device memory
+  if (ls_state) {                   // dynamic loss scale: skip the step on non-finite gradients, else unscale
+    if (ls_state[2] == 0.f) return;
+    gscale /= ls_state[3];
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -254,6 +258,36 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
     m[i] = mi; v[i] = vi; p[i] = pi;
     if (shadow) shadow[i] = f32_to_bf16(pi);
+  }
+}
+
+// dynamic loss scale (neurst/training/revised_dynamic_loss_scale.py:48-107): state = {scale, good steps, finite flag of the
+// gradients just checked, scale those gradients carry}
+__global__ void __launch_bounds__(256) nonfinite_count_kernel(const float* __restrict__ g, int64_t n, unsigned int* __restrict__ count) {
+  unsigned int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t bits = __float_as_uint(g[i]);
+    bad += ((bits & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;   // exponent all ones: inf or nan
+  }
+  bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0 ? 1u : 0u;
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, 1u);
+}
+__global__ void loss_scale_update_kernel(float* __restrict__ st, unsigned int* __restrict__ count, float growth_steps, float multiplier) {
+  const bool finite = *count == 0u;
+  *count = 0u;
+  st[3] = st[0];
+  st[2] = finite ? 1.f : 0.f;
+  if (finite) {
+    if (st[1] + 1.f >= growth_steps) {
+      const float grown = st[0] * multiplier;
+      if ((__float_as_uint(grown) & 0x7f800000u) != 0x7f800000u) st[0] = grown;   // _assign_if_finite
+      st[1] = 0.f;
+    } else {
+      st[1] += 1.f;
+    }
+  } else {
+    st[0] = fmaxf(st[0] / multiplier, 1.f);
+    st[1] = 0.f;
   }
 }
 
@@ -433,17 +467,29 @@ extern "C" int nst_adam_update(float* p, float* m, float* v, const float* g, uin
                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
   NST_CHECK_ARG(p && m && v && g, "adam_update: null pointer");
   if (n <= 0) return NST_OK;
-  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, lr_t, nullptr, beta1, beta2, eps, grad_scale);
+  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, lr_t, nullptr, beta1, beta2, eps, grad_scale, nullptr);
   NST_CHECK_LAUNCH("adam_update");
   return NST_OK;
 }
 
-extern "C" int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
-                                   const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, void* stream) {
-  NST_CHECK_ARG(p && m && v && g && lr_t_dev, "adam_update_dev: null pointer");
+extern "C" int nst_adam_update_dev(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n, float lr_t,
+                                   const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale,
+                                   const float* loss_scale_state, void* stream) {
+  NST_CHECK_ARG(p && m && v && g, "adam_update_dev: null pointer");
   if (n <= 0) return NST_OK;
-  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, 0.f, lr_t_dev, beta1, beta2, eps, grad_scale);
+  adam_kernel<<<grid_for(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, m, v, g, shadow_bf16, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, loss_scale_state);
   NST_CHECK_LAUNCH("adam_update_dev");
+  return NST_OK;
+}
+
+extern "C" int nst_loss_scale_update(const float* grad, int64_t n, float* state, float growth_steps, float multiplier,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  NST_CHECK_ARG(grad && state && workspace && workspace_bytes >= 4, "loss_scale_update: null pointer / workspace of >= 4 zeroed bytes");
+  NST_CHECK_ARG(growth_steps >= 1.f && multiplier > 1.f, "loss_scale_update: growth_steps=%f multiplier=%f", growth_steps, multiplier);
+  unsigned int* count = (unsigned int*)workspace;   // must be zero on entry; the update kernel leaves it zero
+  if (n > 0) nonfinite_count_kernel<<<grid_for(n, 256 * 8, 2048), 256, 0, (hipStream_t)stream>>>(grad, n, count);
+  loss_scale_update_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, count, growth_steps, multiplier);
+  NST_CHECK_LAUNCH("loss_scale_update");
   return NST_OK;
 }
 

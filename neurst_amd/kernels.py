@@ -438,16 +438,25 @@ def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None,
     return dlogits
 
 
-def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0):
-    """lr_t: float, or a 1-element float32 DEVICE tensor read when the kernel runs (graph replay)."""
+def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0, loss_scale_state=None):
+    """lr_t: float, or a 1-element float32 DEVICE tensor read when the kernel runs (graph replay).  loss_scale_state: the
+    4-float device state of loss_scale_update (skip on overflow, unscale otherwise)."""
     n = p.numel()
-    if torch.is_tensor(lr_t):
-        assert lr_t.dtype == torch.float32 and lr_t.numel() == 1
-        check(lib.nst_adam_update_dev(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, _p(lr_t), beta1, beta2, eps, grad_scale,
-                                      _stream()), "adam_update_dev")
+    if torch.is_tensor(lr_t) or loss_scale_state is not None:
+        lr_dev = lr_t if torch.is_tensor(lr_t) else None
+        assert lr_dev is None or (lr_dev.dtype == torch.float32 and lr_dev.numel() == 1)
+        check(lib.nst_adam_update_dev(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, 0.0 if lr_dev is not None else lr_t, _p(lr_dev),
+                                      beta1, beta2, eps, grad_scale, _p(loss_scale_state), _stream()), "adam_update_dev")
         return
     check(lib.nst_adam_update(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, lr_t, beta1, beta2, eps, grad_scale,
                               _stream()), "adam_update")
+
+
+def loss_scale_update(grad, state, growth_steps, multiplier, counter):
+    """RevisedDynamicLossScale.update over the flat (already exchanged) gradient buffer; `counter` is a zeroed int32[1]."""
+    assert grad.dtype == torch.float32 and state.dtype == torch.float32 and state.numel() == 4 and counter.numel() >= 1
+    check(lib.nst_loss_scale_update(_p(grad), grad.numel(), _p(state), float(growth_steps), float(multiplier), _p(counter),
+                                    counter.numel() * counter.element_size(), _stream()), "loss_scale_update")
 
 
 def cast_f32_to_bf16(src, dst):

@@ -38,12 +38,12 @@ class Adam(object):
         t = self.iterations + 1
         return self.current_lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def apply_gradients(self, grad_scale=1.0, lr_t_dev=None):
+    def apply_gradients(self, grad_scale=1.0, lr_t_dev=None, loss_scale_state=None):
         """lr_t_dev: 1-element float32 device tensor holding step_size() -- the kernel reads it when it runs, so the launch
         can sit in a captured graph (the caller refreshes the scalar and calls advance() per replay)."""
         st = self.store
         K.adam_update(st.master, self.m, self.v, st.grad, st.shadow, lr_t_dev if lr_t_dev is not None else self.step_size(),
-                      self.beta_1, self.beta_2, self.epsilon, grad_scale)
+                      self.beta_1, self.beta_2, self.epsilon, grad_scale, loss_scale_state=loss_scale_state)
         st.refresh_transposed()   # the fused feed-forward reads transposed copies of its two kernels
         if lr_t_dev is None:
             self.advance()

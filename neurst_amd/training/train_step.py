@@ -27,7 +27,7 @@ class _CapturedStep(object):
 
 class TrainStep(object):
     def __init__(self, model, criterion, optimizer, reducer=None, update_cycle=1, clip_value=None, clip_norm=None,
-                 use_graph=None):
+                 use_graph=None, loss_scale=None):
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         # gradaccum_keras_model.py:228-233: clip_value takes precedence over clip_norm; both act on the averaged gradients
         self.clip_value = clip_value if clip_value else None
@@ -39,6 +39,20 @@ class TrainStep(object):
             if ws is not None and ws not in reducer.extra_streams:
                 reducer.extra_streams.append(ws)
         self._last_micro = True
+        # dynamic loss scale (training_utils.py:373-419 wraps the optimizer with it for float16; RevisedDynamicLossScale:
+        # initial 2^15, x2 every 2000 good steps, /2 on overflow with the step skipped).  bf16 keeps fp32's exponent range and
+        # does not need it; it is available for every dtype: loss_scale="dynamic" or a dict of its three constants.
+        self.loss_scale = None
+        if loss_scale:
+            if self.clip_value or self.clip_norm:
+                raise NotImplementedError("loss scaling together with gradient clipping")
+            cfg = dict(initial_loss_scale=2.0 ** 15, growth_steps=2000, multiplier=2.0)
+            if isinstance(loss_scale, dict):
+                cfg.update(loss_scale)
+            dev = model.rt.device
+            self.loss_scale = cfg
+            self._ls_state = torch.tensor([cfg["initial_loss_scale"], 0.0, 1.0, cfg["initial_loss_scale"]], dtype=torch.float32).to(dev)
+            self._ls_counter = torch.zeros(4, dtype=torch.int32, device=dev)
         if use_graph is None:
             use_graph = os.environ.get("NST_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and model.rt.device.type == "cuda"
@@ -63,7 +77,10 @@ class TrainStep(object):
             self._last_micro = (i == n - 1)
             logits = self.model(inputs, is_training=True)
             loss = self.criterion.reduce_loss(inputs, logits)
-            dlogits = self.criterion.backward(loss_scale=1.0 / n)
+            if self.loss_scale:
+                dlogits = self.criterion.backward(loss_scale=1.0 / n, loss_scale_dev=self._ls_state[0:1])
+            else:
+                dlogits = self.criterion.backward(loss_scale=1.0 / n)
             del logits
             self.model.backward(dlogits, accumulate=(i > 0))
             loss_sum = loss if loss_sum is None else loss_sum + loss
@@ -74,7 +91,13 @@ class TrainStep(object):
             K.grad_clip(self.model.store.grad, table, nentries, seg_first, nseg, pre_scale=scale,
                         clip_value=self.clip_value, clip_norm=self.clip_norm)
             scale = 1.0   # the average is already applied
-        self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev)
+        if self.loss_scale:
+            from neurst_amd import kernels as K
+            K.loss_scale_update(self.model.store.grad, self._ls_state, self.loss_scale["growth_steps"], self.loss_scale["multiplier"],
+                                self._ls_counter)
+            self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev, loss_scale_state=self._ls_state)
+        else:
+            self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev)
         return loss_sum / n
 
     def __call__(self, batches):

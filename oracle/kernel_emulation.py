@@ -440,7 +440,28 @@ def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None,
     return g
 
 
-def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0):
+def loss_scale_update(grad, state, growth_steps, multiplier, counter):
+    finite = bool(torch.isfinite(grad).all())
+    state[3] = state[0]
+    state[2] = 1.0 if finite else 0.0
+    if finite:
+        if float(state[1]) + 1.0 >= growth_steps:
+            grown = state[0] * multiplier
+            if bool(torch.isfinite(grown)):
+                state[0] = grown
+            state[1] = 0.0
+        else:
+            state[1] += 1.0
+    else:
+        state[0] = max(float(state[0]) / multiplier, 1.0)
+        state[1] = 0.0
+
+
+def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0, loss_scale_state=None):
+    if loss_scale_state is not None:
+        if float(loss_scale_state[2]) == 0.0:
+            return
+        grad_scale = grad_scale / float(loss_scale_state[3])
     gs = g * grad_scale
     m.mul_(beta1).add_(gs, alpha=1.0 - beta1)
     v.mul_(beta2).add_(gs * gs, alpha=1.0 - beta2)
@@ -457,7 +478,7 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16",
-          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add"]
+          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update"]
 
 
 def install(monkeypatch):

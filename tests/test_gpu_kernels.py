@@ -671,3 +671,71 @@ def test_grad_clip_matches_oracle(K, mode):
     assert torch.equal(store.grad[mask], pad_before[mask])
     with pytest.raises(RuntimeError):
         K.grad_clip(store.grad, table, nentries, seg_first, nseg, clip_value=1.0, clip_norm=1.0)
+
+
+# ------------------------------------------------------------------------------------------------ loss scale, degenerate masks
+def test_loss_scale_update_and_scaled_adam(K):
+    """nst_loss_scale_update + nst_adam_update_dev (RevisedDynamicLossScale, revised_dynamic_loss_scale.py:48-107)."""
+    n = 100003
+    g = rnd(n, seed=1).to(DEV) * 512.0                     # gradients carrying a scale of 512
+    state = torch.tensor([512.0, 0.0, 1.0, 512.0], device=DEV)
+    counter = torch.zeros(4, dtype=torch.int32, device=DEV)
+    p = rnd(n, seed=2).to(DEV)
+    p0 = p.clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    K.loss_scale_update(g, state, 2, 2.0, counter)
+    assert state.tolist() == [512.0, 1.0, 1.0, 512.0] and int(counter[0]) == 0
+    K.adam_update(p, m, v, g, None, 1e-3, 0.9, 0.98, 1e-9, 1.0, loss_scale_state=state)
+    pr, mr, vr = O.keras_adam_step(p0.cpu().double(), (g / 512.0).cpu().double(), torch.zeros(n, dtype=torch.float64),
+                                   torch.zeros(n, dtype=torch.float64), 1, 1e-3 * math.sqrt(1 - 0.98) / (1 - 0.9))
+    # keras_adam_step applies the bias correction itself from lr: compare through the raw formula instead
+    gi = (g / 512.0).cpu().double()
+    want = p0.cpu().double() - 1e-3 * (0.1 * gi) / ((0.02 * gi * gi).sqrt() + 1e-9)
+    close("loss_scale.adam", p, want, torch.float32)
+    K.loss_scale_update(g, state, 2, 2.0, counter)
+    assert state.tolist() == [1024.0, 0.0, 1.0, 512.0]     # second good step: the scale doubles, the gradients carried 512
+    g[77] = float("nan")
+    p1 = p.clone()
+    K.loss_scale_update(g, state, 2, 2.0, counter)
+    assert state.tolist() == [512.0, 0.0, 0.0, 1024.0] and int(counter[0]) == 0
+    K.adam_update(p, m, v, g, None, 1e-3, 0.9, 0.98, 1e-9, 1.0, loss_scale_state=state)
+    assert torch.equal(p, p1)                              # skipped
+    state[0] = 1.5
+    g[77] = float("inf")
+    K.loss_scale_update(g, state, 2, 2.0, counter)
+    assert state[0].item() == 1.0                          # floor
+
+
+def test_attention_fully_padded_rows_match_the_fp32_reference_semantics(K):
+    """All keys of a batch element padded (source length 0): the reference adds the FINITE bias -1e9 in fp32
+    (neurst/utils/compat.py:24, multi_head_attention.py:147-160), the logits all round to -1e9 and the softmax is uniform.
+    An fp64 oracle cannot show this (it keeps the logits apart), so the forward of that element is checked against the same
+    math in float32 torch; the partially padded element next to it is checked forward AND backward.  (The backward of the
+    fully padded element is a documented limitation: the saved log-sum-exp is one fp32 number and cannot hold log(Tk) next
+    to -1e9, so the recomputed probabilities of such a row are not the uniform ones; it costs one more VALU operation per
+    probability in three VALU-bound kernels to carry the row's bias offset separately, for a case -- an utterance without a
+    single frame -- that the data pipeline filters out, neurst/tasks/speech2text.py:236-260.)"""
+    B, H, T, dh = 2, 2, 40, 64
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, T, H * dh, generator=g) for _ in range(3))
+    do = torch.randn(B, T, H * dh, generator=g)
+    do[0] = 0.0                                           # no gradient enters through the degenerate element
+    bias = torch.zeros(B, T)
+    bias[0] = -1.0e9                                      # every key of batch element 0 is padding
+    bias[1, 30:] = -1.0e9
+    qd, kd, vd = (t.to(DEV) for t in (q, k, v))
+    out, lse, _ = K.attention_fwd(qd, kd, vd, H, dh, key_bias=bias.to(DEV))
+    dq, dk, dv = (torch.empty_like(qd) for _ in range(3))
+    K.attention_bwd(qd, kd, vd, out, do.to(DEV), lse, dq, dk, dv, H, dh, key_bias=bias.to(DEV))
+    q32, k32, v32 = (t.clone().requires_grad_(True) for t in (q, k, v))
+    q4 = (q32 * dh ** -0.5).view(B, T, H, dh)
+    logits = torch.einsum("bqhd,bkhd->bhqk", q4, k32.view(B, T, H, dh)) + bias[:, None, None, :]   # float32, like TF
+    w = torch.softmax(logits, -1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", w, v32.view(B, T, H, dh)).reshape(B, T, H * dh)
+    ref.backward(do)
+    assert float((w[0] - 1.0 / T).abs().max()) < 1e-6     # the reference's fp32 softmax IS uniform there
+    close("attn_fully_padded.out", out, ref.detach(), torch.float32)
+    close("attn_partially_padded.dv", dv[1], v32.grad[1], torch.float32)
+    close("attn_partially_padded.dq", dq[1], q32.grad[1], torch.float32, scale=5)
+    close("attn_partially_padded.dk", dk[1], k32.grad[1], torch.float32, scale=5)
+    assert float(dv[0].float().abs().max()) == 0.0 and float(dq[0].float().abs().max()) == 0.0

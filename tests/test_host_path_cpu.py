@@ -918,3 +918,41 @@ def test_fused_feed_forward_host_wiring_matches_the_two_gemm_schedule(cpu_kernel
         assert float((y1 - y0).abs().max()) <= 2e-2 * float(y0.abs().max())
         assert float((dx1 - dx0).abs().max()) <= 2e-2 * float(dx0.abs().max())
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-2
+
+
+def test_dynamic_loss_scale_skips_overflow_steps_and_follows_the_reference_schedule(cpu_kernels):
+    """RevisedDynamicLossScale (neurst/training/revised_dynamic_loss_scale.py:48-107) around the train step: gradients carry the
+    scale, a finite step applies them unscaled (same weights as the unscaled step), every `growth_steps` good steps the scale
+    doubles, an overflow halves it (floor 1), clears the counter and leaves weights and moments untouched."""
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.train_step import TrainStep
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    model, cfg, shape = _speech_model("toy")
+    ref_model, _, _ = _speech_model("toy")
+    opt, ref_opt = Adam(model.store, learning_rate=1e-2), Adam(ref_model.store, learning_rate=1e-2)
+    step = TrainStep(model, crit, opt, loss_scale={"initial_loss_scale": 1024.0, "growth_steps": 2, "multiplier": 2.0})
+    ref_step = TrainStep(ref_model, build_criterion({"criterion.class": "label_smoothed_cross_entropy",
+                                                     "criterion.params": {"label_smoothing": 0.1}}), ref_opt)
+    scales = []
+    for i in range(3):
+        b = _speech_inputs(shape, 50 + i)
+        step(b), ref_step(b)
+        scales.append(float(step._ls_state[0]))
+    assert scales == [1024.0, 2048.0, 2048.0]                       # good steps 1, 2 (-> x2, counter 0), 1
+    assert rel_err(model.store.master, ref_model.store.master) < 1e-4   # scaled-then-unscaled == unscaled
+    # an overflow: poison one gradient element through a hook that runs after the backward pass
+    before = model.store.master.clone()
+    m_before = opt.m.clone()
+    orig = model.backward
+
+    def poisoned(dlogits, accumulate=False):
+        orig(dlogits, accumulate=accumulate)
+        model.store.grad[5] = float("inf")
+    model.backward = poisoned
+    step(_speech_inputs(shape, 99))
+    model.backward = orig
+    assert float(step._ls_state[0]) == 1024.0 and float(step._ls_state[1]) == 0.0 and float(step._ls_state[2]) == 0.0
+    assert torch.equal(model.store.master, before) and torch.equal(opt.m, m_before)      # the step was skipped
+    step(_speech_inputs(shape, 100))
+    assert float(step._ls_state[2]) == 1.0 and not torch.equal(model.store.master, before)
