@@ -167,6 +167,11 @@ typedef struct {
    * wait-k bias of layer_utils.py:56-78 for cross attention, band_part(ones, -1, k - 1)).  Must be >= 0. */
   int causal_offset;
   int reserved0;
+  /* nst_attention_bwd, bf16: optional scratch of at least B*H*ceil(Tk/128)*128*ceil(Tq/64)*64*2 bytes (16-byte aligned).
+   * With it the dK/dV kernel leaves the scaled dS^T there and dQ is one small product over it instead of a second pass that
+   * recomputes both score products and all the element-wise work (the backward is VALU-issue bound).  NULL: two-pass form. */
+  void* ds_workspace;
+  int64_t ds_workspace_bytes;
 } NstAttnDesc;
 
 /* B*H*ceil(Tq/16)*ceil(Tk/64)*128 bytes */

@@ -50,6 +50,7 @@ class NstAttnDesc(C.Structure):
         ("dropout_mask", C.c_void_p), ("dropout_mask_bytes", C.c_int64),
         ("bsk", C.c_int64), ("bsv", C.c_int64),
         ("causal_offset", C.c_int), ("reserved0", C.c_int),
+        ("ds_workspace", C.c_void_p), ("ds_workspace_bytes", C.c_int64),
     ]
 
 

@@ -176,6 +176,10 @@ __device__ __forceinline__ float xgroup_sum(float v) {
 
 // raw v_exp_f32 (no denormal range fix-up: arguments are <= 0 up to rounding, tiny results may flush to 0)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// a recomputed probability: exp2 with the result clamped to [0, 1] (the VOP3 clamp bit of v_exp_f32, no extra instruction).
+// Mathematically a no-op; it keeps a row whose saved log-sum-exp lost its low bits next to the -1e9 padding bias (every
+// key padded) from turning into inf, and inf * 0 into NaN gradients for the whole (batch, head).
+__device__ __forceinline__ float prob_exp2(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.f, 1.f); }
 
 struct AttnParams {
   const void *q, *k, *v, *out, *dout;
@@ -194,6 +198,8 @@ struct AttnParams {
   float drop_inv_keep;
   uint64_t seed, stream_id;
   const uint64_t* seed_dev;   // device scalar added to `seed` when the forward kernel runs (nst_dropout_seed_offset_*)
+  bf16_t* dst;     // backward workspace: dS^T [B*H][tkp keys][tqp queries] bf16 (scaled), written by the dK/dV kernel
+  int tqp, tkp, ds_kblock;   // padded extents; keys per dK/dV workgroup (the causal skip rule of that kernel)
 };
 
 // additive key term of the logits in the log2 domain; keys beyond Tk are excluded
@@ -429,7 +435,7 @@ __device__ __forceinline__ float keep_mul(uint32_t bits, int e, float inv_keep) 
 //   S[q][key] = Q.K^T ; P = exp(S*scale + bias - lse[q]) ; dV^T += dO^T.Pdrop
 //   dP[q][key] = dO.V^T ; dS = P o (keep*dP - delta[q]) ; dK^T += scale * Q^T.dS
 // =============================================================================================
-template <typename T, int MI, bool VEC>
+template <typename T, int MI, bool VEC, bool WDS = false>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
   typedef typename FragT<T>::type Frag;
   __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES + 2 * TR * 4];
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
                 p.mask + ((bh * p.nqb + ((q0 >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pv = fast_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
+            float pv = prob_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
             if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r + p.coff)) pv = 0.f;
             float keep = 1.f;
             if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
@@ -552,6 +558,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
       };
       if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
       else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
+      if constexpr (WDS && sizeof(T) == 2) {
+        // dS^T[key][q] for the dQ kernel: this lane's key row, 4 consecutive queries per 16-query block (8-byte stores;
+        // the four lane groups of a key cover 32 contiguous bytes).  Rows / columns beyond Tk / Tq hold exact zeros.
+        bf16_t* row = p.dst + ((int64_t)bh * p.tkp + kg) * p.tqp + q0 + g * 4;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          *reinterpret_cast<uint2*>(row + f * 16) =
+              make_uint2(pack_bf16x2(dp[mi][f][0], dp[mi][f][1]), pack_bf16x2(dp[mi][f][2], dp[mi][f][3]));
+      }
     }
     tmul_acc<T, MI>(dv, st, Gs, lane);
     tmul_acc<T, MI>(dk, dp, Qs, lane);
@@ -570,6 +585,77 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
         store_row4<T, VEC>(dvb + (int64_t)kg * p.ldv, fd * 16 + g * 4, p.dh, dv[mi][fd], 1.f);
       }
     }
+  }
+}
+
+// =============================================================================================
+// backward, step 2 (bf16 with a dS workspace): dQ^T[d][q] = sum_key K^T[d][key] . dS^T[key][q] from the (already scaled)
+// dS^T the dK/dV kernel left in the workspace.  No score recomputation, no exp, no mask: the kernel that used to redo both
+// products and all the element-wise work of the first pass (VALU-issue bound) becomes 8 MFMAs per 64-key tile and wave fed by
+// transpose reads.  One workgroup = 64 queries (wave w: 16 of them), loops over the 64-key tiles; both operands are staged
+// [key][.] row-major and read with ds_read_b64_tr_b16 (the reduction index runs over LDS rows on both sides).
+// =============================================================================================
+template <bool VEC>
+__global__ void __launch_bounds__(256) attn_bwd_dq_from_ds_kernel(AttnParams p) {
+  typedef bf16_t T;
+  __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES];
+  char* Ks = smem;                       // [key][d]
+  char* Ds = smem + AT<T>::TILE_BYTES;   // dS^T [key][q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lc = lane & 15;
+  const int q0 = blockIdx.x * TR, h = blockIdx.y, b = blockIdx.z;
+  const T* kb = (const T*)p.k + (int64_t)b * p.bsk + h * p.dh;
+  const int64_t bh = (int64_t)b * p.H + h;
+  const T* db = p.dst + bh * p.tkp * (int64_t)p.tqp + q0;   // column block q0.. of every key row
+  floatx4_t dq[1][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) dq[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  const int qt = blockIdx.x;
+  // key tiles whose dK/dV workgroup processed this query tile (that kernel skips query tiles wholly above the causal
+  // diagonal of its key block: their dS is zero and was never written)
+  auto tile_written = [&](int kt) {
+    const int k0 = (kt * TR / p.ds_kblock) * p.ds_kblock;
+    return !(p.causal && k0 > p.coff) || qt >= (k0 - p.coff) / TR;
+  };
+  int nkt = p.nkt;
+  if (p.causal) { const int lim = (q0 + TR - 1 + p.coff) / TR + 1; if (lim < nkt) nkt = lim; }
+  TileRegs<T> kreg, dreg;
+  tile_load<T, VEC>(kreg, kb, p.ldk, 0, p.Tk, p.dh, tid);
+  tile_load<T, true>(dreg, db, p.tqp, 0, p.tkp, TR, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    tile_store<T>(Ks, kreg, tid);
+    tile_store<T>(Ds, dreg, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_load<T, VEC>(kreg, kb, p.ldk, (kt + 1) * TR, p.Tk, p.dh, tid);
+      tile_load<T, true>(dreg, db, p.tqp, (kt + 1) * TR, p.tkp, TR, tid);
+    }
+    if (tile_written(kt)) {   // workgroup-uniform
+      typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+      const int roff = (g * 4 + (lc >> 2)) * AT<T>::RS + (lc & 3) * 8;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        union { short4_t hh[2]; bf16x8_t f; } bfr;
+        const char* pb = Ds + roff + st * 32 * AT<T>::RS + wave * 32;
+        bfr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb));
+        bfr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb + 16 * AT<T>::RS));
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+          union { short4_t hh[2]; bf16x8_t f; } afr;
+          const char* pa = Ks + roff + st * 32 * AT<T>::RS + fd * 32;
+          afr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa));
+          afr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa + 16 * AT<T>::RS));
+          dq[0][fd] = Mma<T>::run(afr.f, bfr.f, dq[0][fd]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
+  const int qg = q0 + wave * 16 + lc;
+  if (qg < p.Tq) {
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) store_row4<T, VEC>(dqb + (int64_t)qg * p.ldq, fd * 16 + g * 4, p.dh, dq[0][fd], 1.f);
   }
 }
 
@@ -674,7 +760,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnParams p) {
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pv = fast_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
+            float pv = prob_exp2(fmaf(s[mi][f][r], p.scale2, kb4[f][r] - ls2[mi]));
             if (decltype(DIAG)::value && (k0 + f * 16 + g * 4 + r > qg + p.coff)) pv = 0.f;
             float keep = 1.f;
             if (decltype(DROP)::value) keep = keep_mul(bits, f * 4 + r, p.drop_inv_keep);
@@ -820,6 +906,21 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
   }
   const int mik = pick_mi("NST_ATTN_MI_DKDV", d->Tk, (int64_t)d->B * d->H, false);
   const int miq = pick_mi("NST_ATTN_MI_DQ", d->Tq, (int64_t)d->B * d->H, false);
+  // bf16 with a workspace: the dK/dV kernel leaves dS^T behind and dQ is one small product over it (no second pass)
+  const int kblock = TR * mik;
+  const int64_t tkp = ((int64_t)d->Tk + kblock - 1) / kblock * kblock, tqp = ((int64_t)d->Tq + TR - 1) / TR * TR;
+  const int64_t ds_need = (int64_t)d->B * d->H * tkp * tqp * 2;
+  const bool use_ds = d->dtype == NST_BF16 && vec && d->ds_workspace && d->ds_workspace_bytes >= ds_need &&
+                      nst_aligned16(d->ds_workspace) && env_int("NST_ATTN_DS", 1) != 0;
+  if (use_ds) {
+    p.dst = (bf16_t*)d->ds_workspace; p.tqp = (int)tqp; p.tkp = (int)tkp; p.ds_kblock = kblock;
+    dim3 gk((d->Tk + kblock - 1) / kblock, d->H, d->B), gq((d->Tq + TR - 1) / TR, d->H, d->B);
+    if (mik == 2) attn_bwd_dkdv_kernel<bf16_t, 2, true, true><<<gk, 256, 0, st>>>(p);
+    else attn_bwd_dkdv_kernel<bf16_t, 1, true, true><<<gk, 256, 0, st>>>(p);
+    attn_bwd_dq_from_ds_kernel<true><<<gq, 256, 0, st>>>(p);
+    NST_CHECK_LAUNCH("attention_bwd");
+    return NST_OK;
+  }
   NST_ATTN_DISPATCH(attn_bwd_dkdv_kernel, d->Tk, mik, vec);
   NST_ATTN_DISPATCH(attn_bwd_dq_kernel, d->Tq, miq, vec);
   NST_CHECK_LAUNCH("attention_bwd");

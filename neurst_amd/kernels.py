@@ -320,6 +320,10 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, cau
     if dropout_p > 0:
         assert drop_mask is not None, "attention_bwd: dropout needs the mask written by attention_fwd"
         d.dropout_mask, d.dropout_mask_bytes = drop_mask.data_ptr(), drop_mask.numel() * 8
+    if q.dtype == torch.bfloat16:   # scratch for dS^T: the dQ product then needs no second pass over the scores
+        B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+        ds = torch.empty(B * H * ((Tk + 127) // 128 * 128) * ((Tq + 63) // 64 * 64), dtype=torch.bfloat16, device=q.device)
+        d.ds_workspace, d.ds_workspace_bytes = ds.data_ptr(), ds.numel() * 2
     ev = PROBE.begin("attention_bwd")
     check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(dout), _p(lse), _p(delta),
                                 _p(dq), _p(dk), _p(dv), _stream()), "attention_bwd")

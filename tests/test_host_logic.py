@@ -37,7 +37,7 @@ def test_struct_layouts_match_header_sizes():
     from neurst_amd import _lib
     # field order/types mirror the header; sizes guard against silent drift (x86-64 SysV layout)
     assert ctypes.sizeof(_lib.NstGemmDesc) == 192
-    assert ctypes.sizeof(_lib.NstAttnDesc) == 136
+    assert ctypes.sizeof(_lib.NstAttnDesc) == 152
     assert ctypes.sizeof(_lib.NstFfnDesc) == 72 and ctypes.sizeof(_lib.NstTransposeJob) == 32
 
 
