@@ -161,15 +161,15 @@ class EncoderDecoderModel(BaseModel):
     def forward(self, inputs, is_training=True):
         """inputs: dict(src, src_length|src_padding, trg_input) of device tensors -> logits [B, L, V]
         (encoder_decoder_model.py:211-279)."""
-        self.rt.bind()
-        embedded_inputs = self._src_modality.forward(inputs["src"], is_training=is_training)
-        src_padding = self._src_padding(inputs, embedded_inputs)
-        encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=is_training)
-        cache = self._decoder.create_decoding_internal_cache(encoder_outputs, src_padding, is_inference=False)
-        dec_in = self._trg_modality.forward(inputs["trg_input"], is_training=is_training)
-        decoder_output = self._decoder.forward(dec_in, cache, is_training=is_training,
-                                               decode_lagging=self.decode_lagging(is_training, None))
-        return self.output_logits_layer(decoder_output, is_training=is_training)
+        with self.rt.bound():
+            embedded_inputs = self._src_modality.forward(inputs["src"], is_training=is_training)
+            src_padding = self._src_padding(inputs, embedded_inputs)
+            encoder_outputs = self._encoder.forward(embedded_inputs, src_padding, is_training=is_training)
+            cache = self._decoder.create_decoding_internal_cache(encoder_outputs, src_padding, is_inference=False)
+            dec_in = self._trg_modality.forward(inputs["trg_input"], is_training=is_training)
+            decoder_output = self._decoder.forward(dec_in, cache, is_training=is_training,
+                                                   decode_lagging=self.decode_lagging(is_training, None))
+            return self.output_logits_layer(decoder_output, is_training=is_training)
 
     def decode_lagging(self, is_training, time):
         """The wait-k lagging of this call (None = full attention); WaitkTransformer overrides."""
@@ -220,25 +220,25 @@ class EncoderDecoderModel(BaseModel):
     def backward(self, dlogits, accumulate=False):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
-        self.rt.bind()
-        self.rt.store.begin_backward(accumulate)
-        hook = self.grad_ready_hook or (lambda prefixes: None)
-        # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
-        # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
-        # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
-        shared = self._src_modality is self._trg_modality
-        ddec = self._output_logits_backward(dlogits)
-        ddec_in, dmemory = self._decoder.backward(ddec, layer_done=hook)
-        # softmax_linear (untied logits) is registered right after the decoder: one contiguous slice with it
-        hook([self._decoder.name + "/"] + (["softmax_linear/"] if self._output_linear_layer is not None else []))
-        self._trg_modality.backward(ddec_in, mode="embedding")
-        if not shared:
-            hook([self._modality_scope(self._trg_modality) + "/"])
-        denc_in = self._encoder.backward(dmemory, layer_done=hook)
-        hook([self._encoder.name + "/"])
-        self._src_modality.backward(denc_in, mode="embedding")
-        hook([self._modality_scope(self._src_modality) + "/"])
-        self.rt.join_wgrad_stream()
+        with self.rt.bound():
+            self.rt.store.begin_backward(accumulate)
+            hook = self.grad_ready_hook or (lambda prefixes: None)
+            # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
+            # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
+            # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
+            shared = self._src_modality is self._trg_modality
+            ddec = self._output_logits_backward(dlogits)
+            ddec_in, dmemory = self._decoder.backward(ddec, layer_done=hook)
+            # softmax_linear (untied logits) is registered right after the decoder: one contiguous slice with it
+            hook([self._decoder.name + "/"] + (["softmax_linear/"] if self._output_linear_layer is not None else []))
+            self._trg_modality.backward(ddec_in, mode="embedding")
+            if not shared:
+                hook([self._modality_scope(self._trg_modality) + "/"])
+            denc_in = self._encoder.backward(dmemory, layer_done=hook)
+            hook([self._encoder.name + "/"])
+            self._src_modality.backward(denc_in, mode="embedding")
+            hook([self._modality_scope(self._src_modality) + "/"])
+            self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here
 

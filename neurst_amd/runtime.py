@@ -246,13 +246,25 @@ class Runtime(object):
         self._step = int(value)
         if self.device_step:
             from neurst_amd import kernels
-            self.bind()
-            kernels.dropout_seed_offset_set(self._step)
+            with self.bound():
+                kernels.dropout_seed_offset_set(self._step)
 
-    def bind(self):
-        """Makes this runtime's seed-offset scalar the one the following kernel launches read."""
+    @contextlib.contextmanager
+    def bound(self):
+        """Inside: this runtime's seed-offset scalar is the one kernel launches read (the pointer travels with each launch,
+        so it also ends up in captured graphs).  Outside nothing stays bound: direct kernel calls see the library's own zero
+        scalar, and no binding outlives the runtime's memory.  Re-entrant."""
         from neurst_amd import kernels
-        kernels.dropout_seed_offset_bind(self._step_dev)
+        depth = getattr(self, "_bind_depth", 0)
+        if depth == 0:
+            kernels.dropout_seed_offset_bind(self._step_dev)
+        self._bind_depth = depth + 1
+        try:
+            yield
+        finally:
+            self._bind_depth -= 1
+            if self._bind_depth == 0:
+                kernels.dropout_seed_offset_bind(None)
 
     def enable_device_step(self):
         if not self.device_step:
@@ -264,8 +276,8 @@ class Runtime(object):
         self._step += 1
         if self.device_step and enqueue:
             from neurst_amd import kernels
-            self.bind()
-            kernels.dropout_seed_offset_add(1)
+            with self.bound():
+                kernels.dropout_seed_offset_add(1)
 
     @property
     def step_seed(self):

@@ -180,8 +180,8 @@ class TrainStep(object):
             with torch.cuda.stream(stream):
                 begin()
                 loss = self._body(full, lr_t_dev=self._lr_dev)
-                rt.bind()
-                K.dropout_seed_offset_add(1)
+                with rt.bound():
+                    K.dropout_seed_offset_add(1)
                 cap.loss = loss
                 end()
         finally:
