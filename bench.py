@@ -225,6 +225,7 @@ def main():
     loss = None
     for i in range(args.steps):
         loss = step_fn(batches[i % len(batches)])
+    t_issued = time.perf_counter() - t0      # the host has queued every launch of the K steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
     # roofline pass (un-timed, after the measurement): the same steps with HIP events around every launch of the MFMA kernel
@@ -298,6 +299,7 @@ def main():
         "roofline": roofline,
         "roofline_families": families,
         "ffn_gemm_mfma_utilisation": ffn_util,
+        "host_issue_ms_per_step": t_issued / args.steps * 1e3,   # ~ ms_per_step means the host, not the GPU, paces the step
         "hip_graph": bool(args.graph), "graph_replays": getattr(step_fn, "replays", 0),
         "rccl_world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
         "reducer_messages_per_step": getattr(reducer, "last_messages", None),

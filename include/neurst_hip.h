@@ -129,9 +129,26 @@ typedef struct {
    * split_k > 1 the workspace must hold split_k*(M+1)*N floats. */
   float* colsum;
   int colsum_accumulate;
+  /* split_k > 1 with a workspace: reduce_job_out != NULL defers the second stage -- nst_gemm only writes the partial
+   * slabs (which must then stay untouched in `workspace`) and fills *reduce_job_out (HOST memory); the caller later hands up
+   * to 8 such jobs to ONE nst_splitk_reduce_multi launch.  The 92 weight gradients of a step otherwise pay 92 separate
+   * reduce launches of 7-20 us each on the weight-gradient stream. */
+  struct NstSplitkJob* reduce_job_out;
 } NstGemmDesc;
 
+typedef struct NstSplitkJob {
+  const float* slabs;      /* [split][M][N] f32 */
+  float* C;                /* [M][N] f32, leading dimension ldc */
+  int64_t ldc;
+  int M, N, split, accumulate;
+  const float* cs_parts;   /* [split][N] partial column sums or NULL */
+  float* cs_out;           /* [N] */
+  int cs_accumulate, reserved;
+} NstSplitkJob;
+
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
+/* C (+)= sum of the slabs (and the column sums) of up to 8 deferred split-K products, one launch. */
+int nst_splitk_reduce_multi(const NstSplitkJob* jobs_host, int njobs, void* stream);
 
 /* Column sums: out[N] (f32) (+)= sum_rows x[rows,N] -- bias gradients.  workspace (nullable, >= 256*N*4 bytes):
  * two-stage reduction without atomics, as for nst_layernorm_bwd. */

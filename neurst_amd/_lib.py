@@ -34,7 +34,14 @@ class NstGemmDesc(C.Structure):
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
         ("colsum", C.c_void_p), ("colsum_accumulate", C.c_int),
+        ("reduce_job_out", C.c_void_p),
     ]
+
+
+class NstSplitkJob(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("C", C.c_void_p), ("ldc", C.c_int64), ("M", C.c_int), ("N", C.c_int),
+                ("split", C.c_int), ("accumulate", C.c_int), ("cs_parts", C.c_void_p), ("cs_out", C.c_void_p),
+                ("cs_accumulate", C.c_int), ("reserved", C.c_int)]
 
 
 class NstAttnDesc(C.Structure):
@@ -85,6 +92,7 @@ SIGNATURES = {
     "nst_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
+    "nst_splitk_reduce_multi": [_P, _I, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],
     "nst_attention_dropout_mask_bytes": [C.POINTER(NstAttnDesc)],
     "nst_attention_fwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P],

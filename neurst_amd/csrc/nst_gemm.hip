@@ -95,6 +95,36 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
+// up to 8 deferred split-K second stages in one launch: blockIdx.y = job
+struct SplitkJobs { NstSplitkJob j[8]; };
+__global__ void __launch_bounds__(256) splitk_reduce_multi_kernel(SplitkJobs jobs) {
+  const NstSplitkJob& q = jobs.j[blockIdx.y];
+  const int M = q.M, N = q.N, split = q.split;
+  const int64_t total4 = (int64_t)M * N / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < split; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(q.slabs + ((int64_t)z * M * N + i * 4));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int64_t e = i * 4;
+    const int row = (int)(e / N), col = (int)(e - (int64_t)row * N);
+    float* o = q.C + (int64_t)row * q.ldc + col;
+    if (q.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    *reinterpret_cast<float4*>(o) = acc;
+  }
+  if (q.cs_parts) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int z = 0; z < split; ++z) acc += q.cs_parts[(int64_t)z * N + j];
+      q.cs_out[j] = q.cs_accumulate ? q.cs_out[j] + acc : acc;
+    }
+  }
+}
+
 template <typename T>
 DenseLoader<T> make_loader(const void* base, int64_t ld, int mode, int out_extent, int k_extent) {
   DenseLoader<T> l;
@@ -162,6 +192,24 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
 }
 
 }  // namespace
+
+extern "C" int nst_splitk_reduce_multi(const NstSplitkJob* jobs, int njobs, void* stream) {
+  NST_CHECK_ARG(njobs >= 0 && njobs <= 8 && (njobs == 0 || jobs), "splitk_reduce_multi: 0..8 jobs");
+  if (njobs == 0) return NST_OK;
+  SplitkJobs packed;
+  int64_t most = 0;
+  for (int i = 0; i < njobs; ++i) {
+    NST_CHECK_ARG(jobs[i].slabs && jobs[i].C && jobs[i].M > 0 && jobs[i].N > 0 && jobs[i].N % 4 == 0 && jobs[i].split > 0,
+                  "splitk_reduce_multi: bad job %d", i);
+    packed.j[i] = jobs[i];
+    const int64_t t4 = (int64_t)jobs[i].M * jobs[i].N / 4;
+    most = t4 > most ? t4 : most;
+  }
+  int blocks = (int)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
+  splitk_reduce_multi_kernel<<<dim3(blocks, njobs), 256, 0, (hipStream_t)stream>>>(packed);
+  NST_CHECK_LAUNCH("splitk_reduce_multi");
+  return NST_OK;
+}
 
 extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void* C, void* stream) {
   NST_CHECK_ARG(d && A && B && C, "gemm: null pointer");
@@ -244,6 +292,13 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
       if (d->in_dtype == NST_F32) launch<float, float>(&ds, A, B, d->workspace, eps, split, st);
       else launch<bf16_t, float>(&ds, A, B, d->workspace, eps, split, st);
       NST_CHECK_LAUNCH("gemm(split-K partials)");
+      if (d->reduce_job_out && (!d->colsum || cs_fused)) {   // deferred second stage: describe it, the caller batches it
+        NstSplitkJob* j = d->reduce_job_out;
+        j->slabs = (const float*)d->workspace; j->C = (float*)C; j->ldc = d->ldc; j->M = d->M; j->N = d->N; j->split = split;
+        j->accumulate = d->accumulate; j->cs_parts = cs_parts; j->cs_out = d->colsum; j->cs_accumulate = d->colsum_accumulate;
+        j->reserved = 0;
+        return NST_OK;
+      }
       const int64_t total4 = (int64_t)d->M * d->N / 4;
       int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
       splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)d->workspace, (float*)C, d->M, d->N, d->ldc, split,

@@ -128,7 +128,7 @@ class Dense(Layer):
             bias_kw = dict(colsum_out=self.bias.grad, colsum_accumulate=st.acc_flag(self.bias))
         with self.rt.on_wgrad_stream(x, dz):
             K.gemm(x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad, accumulate=acc_k,
-                   split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), **bias_kw)
+                   split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), batch=self.rt.wgrad_batch(), **bias_kw)
 
     def backward_input(self, dz, **epi):
         """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""

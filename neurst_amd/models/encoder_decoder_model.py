@@ -222,7 +222,11 @@ class EncoderDecoderModel(BaseModel):
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
         with self.rt.bound():
             self.rt.store.begin_backward(accumulate)
-            hook = self.grad_ready_hook or (lambda prefixes: None)
+            user_hook = self.grad_ready_hook or (lambda prefixes: None)
+
+            def hook(prefixes):   # a report promises that everything writing these gradients is QUEUED: incl. deferred reduces
+                self.rt.flush_wgrads()
+                user_hook(prefixes)
             # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
             # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
             # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.

@@ -228,8 +228,26 @@ class Runtime(object):
         for t in tensors:
             t.record_stream(s)
 
+    def wgrad_batch(self):
+        """The split-K batch of the weight-gradient stream (kernels.SplitkBatch), created on first use; None on the CPU tier
+        or with NST_WGRAD_BATCH=0."""
+        if self.device.type != "cuda" or os.environ.get("NST_WGRAD_BATCH", "1") == "0":
+            return None
+        if getattr(self, "_wgrad_batch", None) is None:
+            from neurst_amd import kernels
+            self._wgrad_batch = kernels.SplitkBatch(self.device)
+        return self._wgrad_batch
+
+    def flush_wgrads(self):
+        """Launches the pending (deferred) second stages of the weight gradients queued so far, on their stream."""
+        b = getattr(self, "_wgrad_batch", None)
+        if b is not None and b.n:
+            with self.on_wgrad_stream():
+                b.flush()
+
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""
+        self.flush_wgrads()
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
 

@@ -78,7 +78,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
 # ---------------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
-         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False):
+         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False, batch=None):
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype and A.stride(1) == 1 and B.stride(1) == 1
     assert out is None or (out.dim() == 2 and out.stride(1) == 1)
     assert residual is None or residual.stride(1) == 1
@@ -142,6 +142,11 @@ def dropout_seed_offset_set(value):
 
 def dropout_seed_offset_add(delta=1):
     _SEED_OFFSET[0] += int(delta)
+
+
+def splitk_reduce_multi(jobs, n):
+    """The emulated gemm completes a split-K product at once: nothing is ever deferred on the CPU tier."""
+    assert n == 0
 
 
 def ffn_supported(d_model, filter_size, dtype):
@@ -478,7 +483,7 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16",
-          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update"]
+          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi"]
 
 
 def install(monkeypatch):

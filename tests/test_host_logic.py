@@ -36,9 +36,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     from neurst_amd import _lib
     # field order/types mirror the header; sizes guard against silent drift (x86-64 SysV layout)
-    assert ctypes.sizeof(_lib.NstGemmDesc) == 192
+    assert ctypes.sizeof(_lib.NstGemmDesc) == 200
     assert ctypes.sizeof(_lib.NstAttnDesc) == 152
-    assert ctypes.sizeof(_lib.NstFfnDesc) == 72 and ctypes.sizeof(_lib.NstTransposeJob) == 32
+    assert ctypes.sizeof(_lib.NstFfnDesc) == 72 and ctypes.sizeof(_lib.NstTransposeJob) == 32 and ctypes.sizeof(_lib.NstSplitkJob) == 64
 
 
 def test_kernels_refuse_cpu_tensors():
