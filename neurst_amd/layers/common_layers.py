@@ -33,6 +33,7 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
 
 
 _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
+_SKIP_WGRAD = os.environ.get("NST_SKIP_WGRAD", "0") == "1"
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
@@ -122,13 +123,15 @@ class Dense(Layer):
         """dkernel (+)= x^T dz ; dbias (+)= colsum(dz)."""
         st = self.rt.store
         rows = x.shape[0]
+        if _SKIP_WGRAD:      # timing experiment only (NST_SKIP_WGRAD=1): the dgrad chain without the weight-gradient stream
+            return
         acc_k = st.acc_flag(self.kernel)
         bias_kw = {}
         if self.bias is not None:  # dbias rides on the same pass over dz (ones^T.dz inside the MFMA loop)
             bias_kw = dict(colsum_out=self.bias.grad, colsum_accumulate=st.acc_flag(self.bias))
-        with self.rt.on_wgrad_stream(x, dz):
-            K.gemm(x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad, accumulate=acc_k,
-                   split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), batch=self.rt.wgrad_batch(), **bias_kw)
+        self.rt.run_wgrad(lambda: K.gemm(
+            x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad, accumulate=acc_k,
+            split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), batch=self.rt.wgrad_batch(), **bias_kw), x, dz)
 
     def backward_input(self, dz, **epi):
         """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""

@@ -82,8 +82,10 @@ class AudioConv2dSubsamplingLayer(Layer):
             dy2 = self._dense_layer.backward_input(dz, gate_src=a2_2d, gate_scale=1.0).view(B, T2, F2, C)
         acc2 = st.acc_flag(self.w2)
         assert st.acc_flag(self.b2) == acc2
-        with self.rt.on_wgrad_stream(a1, dy2):  # overlaps the dgrad below and the conv1 backward
-            K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
+        import os
+        if os.environ.get("NST_SKIP_WGRAD", "0") != "1":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
+            # overlaps the dgrad below and the conv1 backward
+            self.rt.run_wgrad(lambda: K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2), a1, dy2)
         da1 = K.conv2_dgrad(dy2, self.w2.compute, a1.shape[1], a1.shape[2])
         acc = st.acc_flag(self.w1)
         st.acc_flag(self.b1)

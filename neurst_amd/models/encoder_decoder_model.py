@@ -225,7 +225,7 @@ class EncoderDecoderModel(BaseModel):
             user_hook = self.grad_ready_hook or (lambda prefixes: None)
 
             def hook(prefixes):   # a report promises that everything writing these gradients is QUEUED: incl. deferred reduces
-                self.rt.flush_wgrads()
+                self.rt.wgrad_boundary()
                 user_hook(prefixes)
             # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
             # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only

@@ -211,6 +211,7 @@ class Runtime(object):
         # Weight-gradient GEMMs do not feed the backward chain: they run on a second HIP stream so that their
         # workgroups fill the ramp-up / tail gaps of the dgrad-path kernels (NST_WGRAD_STREAM=0 keeps one stream).
         self.wgrad_stream = None
+        self.capture = None   # set by TrainStep while it captures a step (see run_wgrad)
         if self.device.type == "cuda" and os.environ.get("NST_WGRAD_STREAM", "1") != "0":
             self.wgrad_stream = torch.cuda.Stream(self.device)
 
@@ -228,6 +229,18 @@ class Runtime(object):
         for t in tensors:
             t.record_stream(s)
 
+    def run_wgrad(self, fn, *tensors):
+        """Runs fn() -- weight-gradient launches that do not feed the backward chain -- on the weight-gradient stream, after
+        everything queued so far on the current stream; `tensors` are the operands it reads.  While a train step is being
+        CAPTURED (training/train_step.py) the call is only recorded: the capture replays the recorded calls of a layer into
+        a graph of their own, which the replay launches on the weight-gradient stream next to the following layers."""
+        cap = self.capture
+        if cap is not None:
+            cap.defer(fn, tensors)
+            return
+        with self.on_wgrad_stream(*tensors):
+            fn()
+
     def wgrad_batch(self):
         """The split-K batch of the weight-gradient stream (kernels.SplitkBatch), created on first use; None on the CPU tier
         or with NST_WGRAD_BATCH=0."""
@@ -241,13 +254,22 @@ class Runtime(object):
     def flush_wgrads(self):
         """Launches the pending (deferred) second stages of the weight gradients queued so far, on their stream."""
         b = getattr(self, "_wgrad_batch", None)
-        if b is not None and b.n:
-            with self.on_wgrad_stream():
-                b.flush()
+        if b is not None and (b.n or self.capture is not None):
+            self.run_wgrad(b.flush)
+
+    def wgrad_boundary(self):
+        """End of a layer's backward: every launch that writes its gradients is queued (eager) / belongs to the segment being
+        closed (capture)."""
+        self.flush_wgrads()
+        if self.capture is not None:
+            self.capture.layer_boundary()
 
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""
         self.flush_wgrads()
+        if self.capture is not None:
+            self.capture.join()
+            return
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
 

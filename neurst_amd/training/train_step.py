@@ -21,8 +21,87 @@ import os
 import torch
 
 
+class _Segment(object):
+    """One slice of a captured step: a graph of compute-stream work, optionally followed by a graph of the weight-gradient
+    launches recorded while it was captured (replayed on the weight-gradient stream), a join of that stream, and a
+    gradient bucket to exchange."""
+    __slots__ = ("main", "wgrad", "join", "buckets")
+
+    def __init__(self):
+        self.main = self.wgrad = None
+        self.join, self.buckets = False, []
+
+
 class _CapturedStep(object):
-    __slots__ = ("static_inputs", "segments", "plan", "loss", "pool")
+    __slots__ = ("static_inputs", "segments", "loss", "pool", "keep")
+
+
+class _StepCapture(object):
+    """The object Runtime.capture points at while a step is captured: collects the deferred weight-gradient calls and cuts
+    the capture into segments (see TrainStep._capture)."""
+
+    def __init__(self, rt, pool, main_stream, side_stream):
+        self.rt, self.pool, self.main_stream, self.side_stream = rt, pool, main_stream, side_stream
+        self.segments, self.deferred, self.keep = [], [], []
+        self.cur = None
+        self._fresh = False      # nothing has been queued since the current segment was opened by a layer boundary
+
+    def begin(self):
+        self.cur = _Segment()
+        self.cur.main = torch.cuda.CUDAGraph()
+        self.cur.main.capture_begin(pool=self.pool)
+
+    def _close(self):
+        """Ends the compute graph of the current segment and captures its weight-gradient graph from the recorded calls."""
+        seg = self.cur
+        seg.main.capture_end()
+        if self.deferred:
+            calls, self.deferred = self.deferred, []
+            self.side_stream.wait_stream(self.main_stream)
+            with torch.cuda.stream(self.side_stream):
+                cap, self.rt.capture = self.rt.capture, None      # the calls run for real inside this capture
+                try:
+                    seg.wgrad = torch.cuda.CUDAGraph()
+                    seg.wgrad.capture_begin(pool=self.pool)
+                    for fn in calls:
+                        fn()
+                    seg.wgrad.capture_end()
+                finally:
+                    self.rt.capture = cap
+            self.main_stream.wait_stream(self.side_stream)
+        self.segments.append(seg)
+        self.cur = None
+        return seg
+
+    # --- called through Runtime while the step body runs
+    def defer(self, fn, tensors):
+        self._fresh = False
+        self.deferred.append(fn)
+        self.keep.extend(tensors)      # their memory must not be handed out again inside this capture (the graphs run concurrently)
+
+    def layer_boundary(self):
+        if self.deferred:
+            self._close()
+            self.begin()
+            self._fresh = True
+
+    def join(self):
+        seg = self._close()
+        seg.join = True
+        self.begin()
+
+    def cut_for_bucket(self, start, stop):
+        # the model reports a layer right after its boundary: the bucket then belongs to the segment just closed (every writer
+        # of these gradients is in it or before it) and no empty segment is opened for it
+        seg = self.segments[-1] if (self._fresh and self.segments) else None
+        if seg is None:
+            seg = self._close()
+            self.begin()
+            self._fresh = True
+        seg.buckets.append((start, stop))
+
+    def finish(self):
+        self._close()
 
 
 class TrainStep(object):
@@ -57,7 +136,7 @@ class TrainStep(object):
             use_graph = os.environ.get("NST_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and model.rt.device.type == "cuda"
         self._seen, self._captured = set(), {}
-        self._lr_dev = self._cap_stream = None
+        self._lr_dev = self._cap_stream = self._side_stream = None
         self.replays = 0
         if self.use_graph:
             model.rt.enable_device_step()
@@ -132,65 +211,67 @@ class TrainStep(object):
                 if b[k] is not v and b[k].data_ptr() != v.data_ptr():
                     v.copy_(b[k], non_blocking=True)
         self._lr_dev.fill_(self.optimizer.step_size())
-        red = self.reducer
+        red, rt = self.reducer, self.model.rt
+        cur = torch.cuda.current_stream(rt.device)
+        nb = sum(len(sg.buckets) for sg in cap.segments)
         last = len(cap.segments) - 1
-        for i, g in enumerate(cap.segments):
-            if i == last and cap.plan:
+        for i, sg in enumerate(cap.segments):
+            if i == last and nb:
                 red.wait_issued()              # every bucket has been exchanged before clip / Adam
-            g.replay()
-            if i < len(cap.plan):
-                red.issue(*cap.plan[i])
+            sg.main.replay()
+            if sg.wgrad is not None:           # the layer's weight gradients, next to the following layers' backward
+                rt.wgrad_stream.wait_stream(cur)
+                with torch.cuda.stream(rt.wgrad_stream):
+                    sg.wgrad.replay()
+            if sg.join:
+                cur.wait_stream(rt.wgrad_stream)
+            for bucket in sg.buckets:
+                red.issue(*bucket)
         if red is not None:
-            red.last_messages = len(cap.plan)
+            red.last_messages = nb
         self.optimizer.advance()
-        self.model.rt.advance_step(enqueue=False)   # the increment of the device counter is the graph's last node
+        rt.advance_step(enqueue=False)   # the increment of the device counter is the graph's last node
         self.replays += 1
         return cap.loss
 
     def _capture(self, batches):
+        """Captures one step as a list of segments.  Compute-stream work goes into `main` graphs; the weight-gradient calls
+        (Runtime.run_wgrad) are only recorded while a segment is open and, at the next layer boundary, captured into a
+        graph of their own that the replay launches on the weight-gradient stream -- two plain graph launches per layer
+        instead of a fork / join inside one graph, which the ROCm 7.2 graph executor serialises (19.9 vs 17.9 ms / step)."""
         from neurst_amd import kernels as K
         rt, red = self.model.rt, self.reducer
+        if rt.wgrad_stream is None:
+            raise RuntimeError("graph mode needs the weight-gradient stream (NST_WGRAD_STREAM=1)")
         cap = _CapturedStep()
         cap.static_inputs = [{k: v.clone() for k, v in b.items() if torch.is_tensor(v)} for b in batches]
         full = [dict(b, **sb) for b, sb in zip(batches, cap.static_inputs)]
-        cap.segments, cap.plan = [], []
         cap.pool = torch.cuda.graph_pool_handle()
         stream = self._cap_stream
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(rt.device)
         stream.wait_stream(torch.cuda.current_stream(rt.device))
-        state = {"g": None}
-
-        def begin():
-            state["g"] = torch.cuda.CUDAGraph()
-            state["g"].capture_begin(pool=cap.pool)
-
-        def end():
-            state["g"].capture_end()
-            cap.segments.append(state["g"])
-            state["g"] = None
-
-        def cut(start, stop):       # the reducer wants grad[start:stop] exchanged now: close the segment, plan the call
-            rt.join_wgrad_stream()
-            end()
-            cap.plan.append((start, stop))
-            begin()
-
+        sc = _StepCapture(rt, cap.pool, stream, self._side_stream)
         if red is not None:
-            red.capture_cut = cut
+            red.capture_cut = sc.cut_for_bucket
+        rt.capture = sc
         try:
             with torch.cuda.stream(stream):
-                begin()
+                sc.begin()
                 loss = self._body(full, lr_t_dev=self._lr_dev)
                 with rt.bound():
                     K.dropout_seed_offset_add(1)
                 cap.loss = loss
-                end()
+                sc.finish()
         finally:
+            rt.capture = None
             if red is not None:
                 red.capture_cut = None
-            if state["g"] is not None:   # an exception inside the capture: leave capture mode
+            if sc.cur is not None:   # an exception inside the capture: leave capture mode
                 try:
-                    state["g"].capture_end()
+                    sc.cur.main.capture_end()
                 except Exception:
                     pass
         torch.cuda.current_stream(rt.device).wait_stream(stream)
+        cap.segments, cap.keep = sc.segments, sc.keep
         return cap
