@@ -235,9 +235,12 @@ class PrePostProcessingWrapper(Layer):
         if not self.pre_norm:
             ds = self.norm.backward(dy, consumer=self)     # d(inputs + dropout(layer)); its masked copy rides along
             dz = dropped_grad(self.rt, ds, self._p, self.site)
-            return self.layer.backward(dz, residual=ds)    # layer'(dz) + ds in the last dgrad epilogue
+            out = self.layer.backward(dz, residual=ds)     # layer'(dz) + ds in the last dgrad epilogue
+            self.rt.sublayer_boundary()
+            return out
         dz = dropped_grad(self.rt, dy, self._p, self.site)
         dn = self.layer.backward(dz)
+        self.rt.sublayer_boundary()
         return self.norm.backward(dn, dres=dy, consumer=consumer)
 
 

@@ -86,6 +86,7 @@ class AudioConv2dSubsamplingLayer(Layer):
         if os.environ.get("NST_SKIP_WGRAD", "0") != "1":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
             # overlaps the dgrad below and the conv1 backward
             self.rt.run_wgrad(lambda: K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2), a1, dy2)
+            self.rt.sublayer_boundary()
         da1 = K.conv2_dgrad(dy2, self.w2.compute, a1.shape[1], a1.shape[2])
         acc = st.acc_flag(self.w1)
         st.acc_flag(self.b1)

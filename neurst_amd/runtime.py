@@ -264,6 +264,12 @@ class Runtime(object):
         if self.capture is not None:
             self.capture.layer_boundary()
 
+    def sublayer_boundary(self):
+        """Capture only: the weight-gradient calls recorded so far may start now (their graph is launched on the
+        weight-gradient stream next to what follows).  Eager launches start on their own."""
+        if self.capture is not None:
+            self.capture.layer_boundary()
+
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""
         self.flush_wgrads()

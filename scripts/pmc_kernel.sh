@@ -35,7 +35,7 @@ for i in range(int(os.environ["PMC_NPASS"])):
                 k.setdefault(f"_us_pass{i}", []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 summary = {}
 for name, k in out["kernels"].items():
-    summary[name] = {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in k.items()}
+    summary[name] = {c: {"n": len(v), "mean": sum(v) / len(v), "sum": sum(v)} for c, v in k.items()}
 out["summary"] = summary
 out.pop("kernels")
 json.dump(out, open(os.environ["PMC_OUT"], "w"), indent=1)

@@ -59,6 +59,30 @@ def main():
         for g in gaps[:25]:
             big.append({"gap_us": g[0] / 1e3, "before": starts.get(g[2], "?")[:70]})
         res["largest_gaps"] = big
+        # when only the side stream runs (the compute stream waits): which side kernels, and what the compute stream resumes with
+        if key:
+            idx0 = 3
+            streams = sorted(set(r[idx0] for r in win))
+            if len(streams) >= 2:
+                main_id = max(streams, key=lambda q: sum(r[2] - r[1] for r in win if r[idx0] == q))
+                main_iv = sorted((r[1], r[2]) for r in win if r[idx0] == main_id)
+                _, main_gaps = union(main_iv)
+                side = [r for r in win if r[idx0] != main_id]
+                starts_main = {r[1]: r[0] for r in win if r[idx0] == main_id}
+                waits = []
+                for glen, gs, ge in main_gaps:
+                    if glen < 20000:
+                        continue
+                    active = {}
+                    for r in side:
+                        ov = min(ge, r[2]) - max(gs, r[1])
+                        if ov > 0:
+                            active[r[0][:60]] = active.get(r[0][:60], 0) + ov
+                    waits.append({"main_idle_us": glen / 1e3, "resumes_with": starts_main.get(ge, "?")[:60],
+                                  "side_busy_us": {k: round(v / 1e3, 1) for k, v in sorted(active.items(), key=lambda kv: -kv[1])[:3]}})
+                waits.sort(key=lambda w: -w["main_idle_us"])
+                res["main_stream_idle_over_20us_ms_per_step"] = sum(w["main_idle_us"] for w in waits) / 1e3 / steps
+                res["main_stream_waits"] = waits[:14]
         for k in key:
             idx = 3 + key.index(k)
             per = {}
@@ -66,7 +90,9 @@ def main():
                 per.setdefault(str(r[idx]), []).append((r[1], r[2]))
             res[f"busy_ms_per_step_by_{k}"] = {q: union(iv)[0] / 1e6 / steps for q, iv in per.items()}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: v for k, v in res.items() if k not in ("largest_gaps", "columns")}, indent=1))
+    print(json.dumps({k: v for k, v in res.items() if k not in ("largest_gaps", "columns", "main_stream_waits")}, indent=1))
+    for w in res.get("main_stream_waits", [])[:10]:
+        print(w)
     for g in res.get("largest_gaps", [])[:12]:
         print(g)
 
