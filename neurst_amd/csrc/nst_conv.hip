@@ -737,6 +737,83 @@ struct TileDma<T, MODE_RC, Im2colLoader<T>> {
   __device__ __forceinline__ void begin(int) { t_next = 0; }
   __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
 };
+
+// DMA cursor of the im2col operand when the PIXEL is the reduction index (OC: conv2 weight gradient, tile = 64 pixels x
+// 128 consecutive kk).  The four chunks of a lane share their kk column (hence tap and channel offset, fixed for the
+// whole unit); their pixels are p, p+16, p+32, p+48 and every K step moves all of them 64 pixels on.  The (b, to, fo)
+// decomposition is therefore done once and then ADVANCED: fo += 64 % F2, to += 64 / F2 (+ carry), image wrap by one
+// compare.  The generic path re-derives three integer divisions, a tap split and a 64-bit address per chunk per K step
+// (~300 VALU instructions per step per lane against 32 MFMAs: the kernel was bound by address arithmetic).
+template <typename T>
+struct TileDma<T, MODE_OC, Im2colLoader<T>> {
+  const Im2colLoader<T>* ld;
+  int o0, r0, lane;
+  bool fast;
+  int fo[4], to[4], grow[4], pix[4];  // grow = b*T1 + 2*to (global input row of tap kh == 1)
+  int kh, kw, dq, df, t_cur;
+  uint32_t coff;                      // byte offset of the lane's 16-byte channel chunk inside a pixel
+  bool cvalid;
+  __device__ __forceinline__ void init(const Im2colLoader<T>& l, int o0_, int r0_, int wave, int lane_) {
+    ld = &l; o0 = o0_; r0 = r0_; lane = lane_; t_cur = 0;
+    dq = Tile<T>::BK / l.F2;
+    df = Tile<T>::BK - dq * l.F2;
+    fast = sizeof(T) == 2 && l.vec && (l.C % BM) == 0 && l.T2 >= dq + 2;
+    if (!fast) return;
+    constexpr int CPR = Tile<T>::OC_CPR;
+    const int r_in = (lane / CPR) + wave * (64 / CPR);         // row of chunk s = 0; chunk s adds 4 * 64 / CPR rows
+    const int c16 = lane % CPR;
+    const int g = (r_in & 3) | (((r_in >> 3) & 1) << 2);       // unchanged by + multiples of 16 rows
+    const int kk = o0 + (c16 ^ (g << 1)) * Tile<T>::E;
+    const int tap = (int)l.dC.div((uint32_t)o0);               // the tile lies inside one tap (C % BM == 0)
+    kh = tap / 3; kw = tap - kh * 3;
+    cvalid = kk < l.contig_limit;
+    coff = (uint32_t)((kk - tap * l.C) * (int)sizeof(T));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int p = r0 + r_in + s * (4 * 64 / CPR);
+      uint32_t q, f, b, t;
+      l.dF2.divmod((uint32_t)p, q, f);
+      l.dT2.divmod(q, b, t);
+      pix[s] = p; fo[s] = (int)f; to[s] = (int)t; grow[s] = (int)b * l.T1 + 2 * (int)t;
+    }
+  }
+  __device__ __forceinline__ void advance() {
+    const int F2 = ld->F2, T2 = ld->T2, wrap = ld->T1 - 2 * T2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int f = fo[s] + df, inc = dq;
+      if (f >= F2) { f -= F2; ++inc; }
+      int t = to[s] + inc, gr = grow[s] + 2 * inc;
+      if (t >= T2) { t -= T2; gr += wrap; }
+      fo[s] = f; to[s] = t; grow[s] = gr; pix[s] += Tile<T>::BK;
+    }
+    ++t_cur;
+  }
+  __device__ __forceinline__ void put(uint32_t tile_lds_addr, int wave) const {
+    const int T1 = ld->T1, F1 = ld->F1;
+    const int64_t pix_bytes = (int64_t)ld->C * (int64_t)sizeof(T);
+    const char* xb = reinterpret_cast<const char*>(ld->x) + coff;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ti = 2 * to[s] + kh - 1, fi = 2 * fo[s] + kw - 1;
+      const bool ok = cvalid && pix[s] < ld->outer_limit && (unsigned)ti < (unsigned)T1 && (unsigned)fi < (unsigned)F1;
+      const void* src = ok ? (const void*)(xb + ((int64_t)(grow[s] + kh - 1) * F1 + fi) * pix_bytes) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
+    }
+  }
+  // K steps are requested in order (t == t_cur, or t_cur + a few in a prologue)
+  __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) {
+    if (!fast) {
+      dma_tile<T, MODE_OC, Im2colLoader<T>>(*ld, o0, r0 + t * Tile<T>::BK, tile_lds_addr, wave, lane);
+      return;
+    }
+    while (t_cur < t) advance();
+    put(tile_lds_addr, wave);
+  }
+  int t_next;
+  __device__ __forceinline__ void begin(int) { t_next = 0; }
+  __device__ __forceinline__ void next(uint32_t, uint32_t tile_lds_addr, int wave) { issue(t_next++, tile_lds_addr, wave); }
+};
 }  // namespace nstgemm
 
 namespace {
@@ -999,14 +1076,35 @@ bool conv_use_wide() {
 }
 
 // dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output);  db2[j] (+)= sum_z cs_parts[z][j] when cs_parts != NULL
+// conv2 weight gradient on the persistent v3 stream (same main loop, register-resident epilogue and unit walk as the
+// dense weight gradients; A = im2col gather with the incremental OC cursor above, B = dy, fused column sums = db2)
+template <typename T>
+__global__ void __launch_bounds__(THREADS, 2)
+conv2_wgrad_kernel_v3(GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;  // read through the kernarg segment, see gemm_stream_v3
+  gemm_stream_v3<T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>(smem_dyn);
+}
+
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int64_t total4, int split, int accumulate,
                                                                 const float* __restrict__ cs_parts, float* __restrict__ cs_out,
                                                                 int n, int cs_accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    // 8 slab loads in flight per round (one dependent round trip per slab otherwise); adds stay in slab order
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < split; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + ((int64_t)z * total4 + i) * 4);
+    const float* src = slabs + i * 4;
+    const int64_t zs = total4 * 4;
+    int z = 0;
+    for (; z + 8 <= split; z += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (z + u) * zs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; z < split; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(src + z * zs);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float* o = out + i * 4;
@@ -1567,6 +1665,18 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
   return 0;
 }
 
+bool conv2_wgrad_v3() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV2_WGRAD_V3"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+bool conv2_wgrad_zxcd() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_ZXCD"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 template <typename T>
 int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int accumulate, void* ws,
                   int64_t ws_bytes, hipStream_t st, bool* db2_done) {
@@ -1586,13 +1696,30 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   int split = (512 + ntiles - 1) / ntiles;  // ~2 workgroups per CU
+  const bool dma = conv_use_v2() && conv_use_tr() && la.vec && lb.vec;
+  // stream kernel: K slices pinned to XCDs (split = 8 S).  An XCD then owns ntiles * S units for its 64 resident
+  // workgroups; take the S (slices of >= 32 K steps, slabs inside the workspace) that wastes the fewest workgroup rounds.
+  bool zx = false;
+  if (dma && conv2_wgrad_v3() && conv2_wgrad_zxcd() && ws) {
+    int best = 0;
+    double best_eff = 0.0;
+    for (int S = 1; S <= 16; ++S) {
+      if (kt_total / (8 * S) < 32 || (int64_t)8 * S * (M + 1) * N * 4 > ws_bytes) break;
+      const int kps = (kt_total + 8 * S - 1) / (8 * S);
+      if ((kt_total + kps - 1) / kps != 8 * S) continue;  // the slice count has to survive the rounding below
+      const int per_xcd = ntiles * S, rounds = (per_xcd + 63) / 64;
+      const double eff = (double)per_xcd / (64.0 * rounds);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
+    }
+    if (best) { split = 8 * best; zx = true; }
+  }
   if (split > kt_total) split = kt_total;
   if (split < 1) split = 1;
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
+  zx = zx && split % 8 == 0;
   dim3 grid(ntiles, 1, split);
   const bool slab = ws && nst_aligned16(ws) && ws_bytes >= (int64_t)split * (M + 1) * N * 4 && (N % 8 == 0) && nst_aligned16(dw2);
-  const bool dma = conv_use_v2() && conv_use_tr() && la.vec && lb.vec;
   float* out = dw2;
   float* cs_parts = nullptr;
   if (slab) {
@@ -1610,7 +1737,19 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
       if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
     }
   }
-  if (cs_parts) {
+  if (slab && dma && conv2_wgrad_v3()) {
+    // persistent workgroups, two resident per CU; every workgroup walks the same number of (tile, K slice) units
+    GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
+    ga.la = la; ga.lb = lb; ga.C = out; ga.ldc = N; ga.M = M; ga.N = N; ga.K = K;
+    ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
+    ga.rowmap = IdentityRowMap();
+    ga.z_per_xcd = zx ? 1 : 0;
+    const int units = ntiles * split;
+    auto kfn = conv2_wgrad_kernel_v3<T>;
+    conv_allow_big_lds(kfn, V3_LDS_BYTES);
+    kfn<<<units < 512 ? units : 512, THREADS, V3_LDS_BYTES, st>>>(ga);
+    if (cs_parts) *db2_done = true;
+  } else if (cs_parts) {
     auto kfn = conv_gemm_kernel_v2<T, float, MODE_OC, MODE_OC, 2, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>;
     conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);
     kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(la, lb, out, (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());

@@ -64,6 +64,26 @@ bool use_v2() {
   return v == 1;
 }
 
+// sum_z src[z * zs .. +4): 8 slabs per round, all 8 loads in flight before the first add (a runtime-bound loop of single
+// loads is one dependent memory round trip per slab: the 64 slabs of a 256x256 gradient took ~60 us that way).  The adds
+// stay in slab order, so the result does not depend on the unroll.
+__device__ __forceinline__ float4 sum_slabs(const float* __restrict__ src, int64_t zs, int split) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int z = 0;
+  for (; z + 8 <= split; z += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (z + u) * zs);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; z < split; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(src + z * zs);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  return acc;
+}
+
 // C[i] (+)= sum_z slabs[z][i]   (split-K second stage; slabs are [split][M][N] f32, C has leading dimension ldc)
 // and, when cs_parts != NULL, cs_out[j] (+)= sum_z cs_parts[z][j]  (the fused column sums)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
@@ -72,11 +92,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                            int cs_accumulate) {
   const int64_t total4 = (int64_t)M * N / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < split; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + ((int64_t)z * M * N + i * 4));
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+    float4 acc = sum_slabs(slabs + i * 4, (int64_t)M * N, split);
     const int64_t e = i * 4;
     const int row = (int)(e / N), col = (int)(e - (int64_t)row * N);
     float* o = C + (int64_t)row * ldc + col;
@@ -102,11 +118,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_multi_kernel(SplitkJobs job
   const int M = q.M, N = q.N, split = q.split;
   const int64_t total4 = (int64_t)M * N / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < split; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(q.slabs + ((int64_t)z * M * N + i * 4));
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+    float4 acc = sum_slabs(q.slabs + i * 4, (int64_t)M * N, split);
     const int64_t e = i * 4;
     const int row = (int)(e / N), col = (int)(e - (int64_t)row * N);
     float* o = q.C + (int64_t)row * q.ldc + col;
@@ -134,6 +146,12 @@ DenseLoader<T> make_loader(const void* base, int64_t ld, int mode, int out_exten
   else { l.outer_limit = k_extent; l.contig_limit = out_extent; }
   l.vec = nst_aligned16(base) && ((ld * (int64_t)sizeof(T)) % 16 == 0) && (l.contig_limit % Tile<T>::E == 0);
   return l;
+}
+
+bool zxcd_enabled() {  // split-K slices pinned to XCDs (gemm_stream_v3 unit_of)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_ZXCD"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
 }
 
 bool use_tr() {
@@ -164,6 +182,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
     ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
     ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
+    ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0 && g3.x % 8 == 0) ? 1 : 0;
 #define NST_GEMM_LAUNCH3(AM, BMO, CS_)                                                                                \
   do {                                                                                                               \
     auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_>;                                                           \

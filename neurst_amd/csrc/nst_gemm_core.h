@@ -1037,6 +1037,7 @@ struct GemmArgs {
   OutT* C;
   int64_t ldc;
   int M, N, K, tiles_n, ntiles, split, kt_per_split;
+  int z_per_xcd;   // != 0 (needs split % 8 == 0, grid % 8 == 0): K slice z lives on XCD z % 8, see unit_of
   Epilogue ep;
   RowMap rowmap;
 };
@@ -1073,11 +1074,23 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
   const bool has_cs = CS && ka->ep.colsum_dst != nullptr;
 
   // unit -> tile origin and K range
+  // Split-K units of one K slice read the same rows of both operands.  Workgroup ids go round-robin over the 8 XCDs, so
+  // with z_per_xcd the slice index is tied to id % 8: all tiles of a slice run on ONE XCD and the re-reads of the
+  // shared rows hit that XCD's L2 (otherwise every XCD fetches every row across the fabric: the conv2 weight gradient
+  // moved 10.6 GB per launch that way, 7x its operands).
+  const int zx = ka->z_per_xcd;
   struct Unit { int m0, n0, z, kt_first, kt_count; };
   auto unit_of = [&](int u) {
     Unit q;
-    q.z = u / ntiles;
-    const int tile = xcd_remap(u - q.z * ntiles, ntiles);
+    int tile;
+    if (zx) {
+      const int idx = u >> 3, sl = idx / ntiles;
+      q.z = (u & 7) + 8 * sl;
+      tile = idx - sl * ntiles;
+    } else {
+      q.z = u / ntiles;
+      tile = xcd_remap(u - q.z * ntiles, ntiles);
+    }
     const int tm = tile / tiles_n;
     q.m0 = tm * BM;
     q.n0 = (tile - tm * tiles_n) * BN;

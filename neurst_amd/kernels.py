@@ -421,7 +421,7 @@ def conv2_wgrad(x, dy, dw2, db2=None, accumulate=False):
     B, T1, F1, Cc = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dw2.dtype == torch.float32
     assert db2 is None or (db2.dtype == torch.float32 and db2.numel() == Cc and db2.is_contiguous())
-    ws = _workspace(64 << 20, x.device)
+    ws = _workspace(192 << 20, x.device)   # split-K slabs: up to 8 * 16 slices of [9C + 1, C] f32
     ev = PROBE.begin("conv2_wgrad")
     check(lib.nst_conv2_wgrad(_p(x), _p(dy), _p(dw2), _p(db2), B, T1, F1, Cc, _dt(x), int(accumulate), ws.data_ptr(),
                               ws.numel(), _stream()), "conv2_wgrad")

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Stand-alone timings of the conv front-end kernels at the benchmark shape (B=128, T1=450, F1=40, C=256, bf16).
+
+    python scripts/conv_bench.py [--iters 20] [--out gpurun_out/conv_bench.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neurst_amd import kernels as K  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, T1, F1, C = a.batch, 450, 40, 256
+    T2, F2 = T1 // 2, F1 // 2
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(B, T1, F1, C, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.randn(B, T2, F2, C, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w2 = (torch.randn(3, 3, C, C, generator=g) / 48.0).to(torch.bfloat16).to(dev)
+    b2 = torch.zeros(C, device=dev)
+    dw2, db2 = torch.zeros(3, 3, C, C, device=dev), torch.zeros(C, device=dev)
+    flops = 2.0 * B * T2 * F2 * C * 9 * C
+    res = {}
+    for name, fn in (("conv2_fwd", lambda: K.conv2_fwd(x, w2, b2, relu=True)),
+                     ("conv2_dgrad", lambda: K.conv2_dgrad(dy, w2, T1, F1)),
+                     ("conv2_wgrad", lambda: K.conv2_wgrad(x, dy, dw2, db2=db2))):
+        us = timed(fn, a.iters)
+        res[name] = {"us": us, "tflops": flops / us / 1e6, "mfma_frac": flops / us / 1e6 / 2500.0}
+        print(name, res[name])
+    if a.out:
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -555,6 +555,15 @@ def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
         dx = K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1)
         close(f"conv2_patch[B{B}T{T1}F{F1}].dx", dx, xr.grad, dtype, scale=2.0)
         assert torch.equal(dx, K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1))
+        # weight gradient: the persistent stream kernel with the incremental im2col cursor (pixels advance 64 per K step:
+        # image wraps, the top padding row, ragged last K step, widths smaller than a K step)
+        wr = w2.double().requires_grad_(True)
+        torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), None, stride=2,
+                                   padding=1).permute(0, 2, 3, 1).backward(dy.double())
+        dw2, db2 = torch.full((3, 3, C, C), 2.0, device=DEV), torch.full((C,), 2.0, device=DEV)
+        K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, db2=db2)
+        close(f"conv2_patch[B{B}T{T1}F{F1}].dw2", dw2, wr.grad, dtype, scale=2.0)
+        close(f"conv2_patch[B{B}T{T1}F{F1}].db2", db2, dy.double().sum((0, 1, 2)), torch.float32)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / elementwise
