@@ -244,6 +244,26 @@ int nst_layernorm_relu_bwd(const void* dy, const void* x, const void* y, const f
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Deferred parameter-gradient stage of the LayerNorm backward.  dgamma / dbeta feed nothing in the backward chain, so
+ * their cross-workgroup reduction need not sit between dx and the next GEMM: nst_layernorm_bwd_deferred runs the dx
+ * kernel (all three variants: y != NULL -> ReLU gate, dz != NULL -> also emit the dropped gradient), leaves the partial
+ * sums in `workspace` (which must then stay untouched) and fills *job_out (HOST memory); up to 16 such jobs go to ONE
+ * nst_ln_finalize_multi launch, on any stream ordered after the dx kernels (the trainer uses its weight-gradient stream).
+ * job_out->nblocks == 0 means nothing is pending (rows == 0, or the workspace was too small and the gradients were
+ * accumulated directly). */
+typedef struct NstLnFinalizeJob {
+  const float* partial;    /* [nblocks][2][d] f32 */
+  float* dgamma;           /* [d] */
+  float* dbeta;            /* [d] */
+  int nblocks, d, accumulate, reserved;
+} NstLnFinalizeJob;
+int nst_layernorm_bwd_deferred(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                               const float* rstd, const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed,
+                               uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                               int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
+                               void* stream);
+int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs_host, int njobs, void* stream);
+
 /* ------------------------------------------------------------------ target embedding
  * WordEmbeddingSharedWeights._bottom + PositionEmbeddingWrapper.call
  *   neurst/layers/modalities/text_modalities.py:84-93, neurst/layers/common_layers.py:415-434:

@@ -44,6 +44,11 @@ class NstSplitkJob(C.Structure):
                 ("cs_accumulate", C.c_int), ("reserved", C.c_int)]
 
 
+class NstLnFinalizeJob(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("nblocks", C.c_int), ("d", C.c_int),
+                ("accumulate", C.c_int), ("reserved", C.c_int)]
+
+
 class NstAttnDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("dh", C.c_int),
@@ -91,6 +96,8 @@ SIGNATURES = {
     "nst_layernorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
+    "nst_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
+    "nst_ln_finalize_multi": [_P, _I, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
     "nst_splitk_reduce_multi": [_P, _I, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],

@@ -556,10 +556,44 @@ int ln_fwd_common(const void* x, const float* gamma, const float* beta, void* y,
   return NST_OK;
 }
 
+// up to 16 deferred finalize stages in one launch: blockIdx.y = job
+struct LnJobs { NstLnFinalizeJob j[16]; };
+__global__ void __launch_bounds__(256) ln_bwd_finalize_multi_kernel(LnJobs jobs) {
+  const NstLnFinalizeJob& q = jobs.j[blockIdx.y];
+  const int d = q.d, blocks = q.nblocks;
+  __shared__ float sh[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;
+  if (blockIdx.x * 16 >= 2 * d) return;  // (block-uniform) jobs narrower than the widest one
+  float t = 0.f;
+  if (e < 2 * d) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = rg;
+    for (; b + 48 < blocks; b += 64) {
+      t0 += q.partial[(int64_t)b * 2 * d + e];
+      t1 += q.partial[(int64_t)(b + 16) * 2 * d + e];
+      t2 += q.partial[(int64_t)(b + 32) * 2 * d + e];
+      t3 += q.partial[(int64_t)(b + 48) * 2 * d + e];
+    }
+    for (; b < blocks; b += 16) t0 += q.partial[(int64_t)b * 2 * d + e];
+    t = (t0 + t1) + (t2 + t3);
+  }
+  sh[rg][c] = t;
+  __syncthreads();
+  if (rg == 0 && e < 2 * d) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += sh[k][c];
+    float* o = e < d ? q.dgamma + e : q.dbeta + (e - d);
+    *o = q.accumulate ? *o + acc : acc;
+  }
+}
+
 int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
                   int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu, void* dz = nullptr, float dz_p = 0.f,
-                  uint64_t dz_seed = 0, uint64_t dz_sid = 0) {
+                  uint64_t dz_seed = 0, uint64_t dz_sid = 0, NstLnFinalizeJob* job_out = nullptr) {
+  if (job_out) memset(job_out, 0, sizeof(*job_out));
   NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
   NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
@@ -585,7 +619,10 @@ int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gam
     else launch_bwd<bf16_t, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
   }
   NST_CHECK_LAUNCH("layernorm_bwd");
-  if (partial) {
+  if (partial && job_out) {
+    job_out->partial = partial; job_out->dgamma = dgamma; job_out->dbeta = dbeta;
+    job_out->nblocks = nblocks; job_out->d = d; job_out->accumulate = accumulate;
+  } else if (partial) {
     ln_bwd_finalize_kernel<<<(2 * d + 15) / 16, 256, 0, st>>>(partial, dgamma, dbeta, nblocks, d, accumulate);
     NST_CHECK_LAUNCH("layernorm_bwd(finalize)");
   }
@@ -623,4 +660,29 @@ extern "C" int nst_layernorm_relu_bwd(const void* dy, const void* x, const void*
                                       int dtype, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   return ln_bwd_common(dy, x, y, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
                        workspace_bytes, stream, true);
+}
+extern "C" int nst_layernorm_bwd_deferred(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                                          const float* rstd, const void* dres, void* dx, void* dz, float dropout_p,
+                                          uint64_t seed, uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d,
+                                          int dtype, int accumulate, void* workspace, int64_t workspace_bytes,
+                                          NstLnFinalizeJob* job_out, void* stream) {
+  NST_CHECK_ARG(job_out, "layernorm_bwd_deferred: null job_out");
+  NST_CHECK_ARG(!(y && (dres || dz)), "layernorm_bwd_deferred: the ReLU variant takes neither dres nor dz");
+  return ln_bwd_common(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, y != nullptr, dz, dz ? dropout_p : 0.f, seed, stream_id, job_out);
+}
+extern "C" int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs, int njobs, void* stream) {
+  NST_CHECK_ARG(njobs >= 0 && njobs <= 16 && (njobs == 0 || jobs), "ln_finalize_multi: 0..16 jobs");
+  LnJobs packed;
+  int n = 0, dmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (jobs[i].nblocks <= 0) continue;  // nothing pending for this call
+    NST_CHECK_ARG(jobs[i].partial && jobs[i].dgamma && jobs[i].dbeta && jobs[i].d > 0, "ln_finalize_multi: bad job %d", i);
+    packed.j[n++] = jobs[i];
+    dmax = jobs[i].d > dmax ? jobs[i].d : dmax;
+  }
+  if (n == 0) return NST_OK;
+  ln_bwd_finalize_multi_kernel<<<dim3((2 * dmax + 15) / 16, n), 256, 0, (hipStream_t)stream>>>(packed);
+  NST_CHECK_LAUNCH("ln_finalize_multi");
+  return NST_OK;
 }

@@ -8,7 +8,8 @@ import ctypes as C
 
 import torch
 
-from neurst_amd._lib import NST_BF16, NST_F32, NstAttnDesc, NstFfnDesc, NstGemmDesc, NstSplitkJob, check, lib
+from neurst_amd._lib import (NST_BF16, NST_F32, NstAttnDesc, NstFfnDesc, NstGemmDesc, NstLnFinalizeJob, NstSplitkJob, check,
+                             lib)
 
 FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
 
@@ -120,13 +121,26 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
     """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x)).
-    emit_dropout=(p, seed, site): also returns dz = dropout_backward(dx) under that mask -> (dx, dz)."""
+    emit_dropout=(p, seed, site): also returns dz = dropout_backward(dx) under that mask -> (dx, dz).
+    batch (SplitkBatch): the dgamma / dbeta reduction is left to the batch's next flush (one launch for all pending
+    LayerNorms, on the stream that flushes -- the weight-gradient stream), see nst_layernorm_bwd_deferred."""
     assert dy.is_contiguous() and x.is_contiguous()
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
+    slot = batch.ln_slot(d) if batch is not None else None
+    if slot is not None:
+        assert dres is None or (dres.is_contiguous() and dres.dtype == x.dtype)
+        assert not (y is not None and (dres is not None or emit_dropout is not None))
+        p, seed, site = emit_dropout if emit_dropout is not None else (0.0, 0, 0)
+        dz = torch.empty_like(x) if emit_dropout is not None else None
+        ws_ptr, ws_bytes, job = slot
+        check(lib.nst_layernorm_bwd_deferred(_p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dz), p,
+                                             seed, site, _p(dgamma), _p(dbeta), rows, d, _dt(x), int(accumulate), ws_ptr,
+                                             ws_bytes, job, _stream()), "layernorm_bwd_deferred")
+        return (dx, dz) if emit_dropout is not None else dx
     ws = _workspace(64 << 20, x.device)
     if emit_dropout is not None:
         assert y is None
@@ -157,10 +171,35 @@ class SplitkBatch(object):
     """Collects the second stages of up to 8 split-K weight gradients (their slabs live side by side in one scratch buffer)
     and reduces them with ONE launch (nst_splitk_reduce_multi) instead of one 7-20 us launch each."""
 
+    LN_SLOTS, LN_MAX_D = 64, 512     # deferred LayerNorm finalize stages: ring of partial-sum slots (8 MB each)
+
     def __init__(self, device, nbytes=192 << 20):
         self.jobs = (NstSplitkJob * 8)()
         self.n, self.cursor = 0, 0
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.device = device
+        self.ln_jobs = (NstLnFinalizeJob * 16)()
+        self.ln_n, self.ln_cursor, self.ln_since_join, self.ln_ws = 0, 0, 0, None
+
+    def ln_slot(self, d):
+        """-> (device pointer, bytes, host job pointer) for one deferred LayerNorm finalize, or None (finalize right away).
+        The slot is written by the dx kernel on the CURRENT stream and read by the next flush on the flushing stream; a slot
+        comes round again LN_SLOTS calls later, so no more than LN_SLOTS are handed out between two joins of the streams
+        (joined(), called by Runtime.join_wgrad_stream at the end of every backward)."""
+        if d > self.LN_MAX_D or self.ln_n >= 16 or self.ln_since_join >= self.LN_SLOTS or not hasattr(lib, "nst_layernorm_bwd_deferred"):
+            return None
+        slot_bytes = 2048 * 2 * self.LN_MAX_D * 4   # what nst_layernorm_bwd* asks of a partial-sum workspace
+        if self.ln_ws is None:
+            self.ln_ws = torch.empty(self.LN_SLOTS * slot_bytes, dtype=torch.uint8, device=self.device)
+        ptr = self.ln_ws.data_ptr() + self.ln_cursor * slot_bytes
+        self.ln_cursor = (self.ln_cursor + 1) % self.LN_SLOTS
+        self.ln_since_join += 1
+        job = C.addressof(self.ln_jobs[self.ln_n])
+        self.ln_n += 1
+        return ptr, slot_bytes, job
+
+    def joined(self):
+        self.ln_since_join = 0
 
     def region(self, nbytes):
         """-> (device pointer, bytes) of a free 256-byte aligned region, or None when the batch must be flushed first."""
@@ -174,6 +213,9 @@ class SplitkBatch(object):
         if self.n:
             splitk_reduce_multi(self.jobs, self.n)
         self.n, self.cursor = 0, 0
+        if self.ln_n:
+            check(lib.nst_ln_finalize_multi(C.addressof(self.ln_jobs), self.ln_n, _stream()), "ln_finalize_multi")
+        self.ln_n = 0
 
 
 def splitk_reduce_multi(jobs, n):

@@ -44,12 +44,12 @@ _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
 _FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "1") != "0"
 
 
-def _wgrad_split(rows, k_in, n_out, dtype):
+def _wgrad_split(rows, k_in, n_out, dtype, units=None):
     """split-K factor for dW[k_in, n_out] = X^T dY reduced over `rows`: tiles*split ~ _WGRAD_UNITS workgroups."""
     tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
     bk = 64 if dtype == torch.bfloat16 else 32
     kt = (rows + bk - 1) // bk
-    split = max(1, min(_WGRAD_UNITS // max(tiles, 1), kt // 8))
+    split = max(1, min((units or _WGRAD_UNITS) // max(tiles, 1), kt // 8))
     if split >= 8 and tiles >= 8 and _WGRAD_SPLIT8:   # few tiles per slice: little to share, keep the finer split
         # multiples of 8: the stream kernel then pins every K slice to one XCD (its tiles share the slice's rows in that
         # L2).  The library re-derives the count from ceil(kt / ceil(kt / split)); take the nearest multiple that survives.
@@ -99,11 +99,11 @@ class LayerNorm(Layer):
         p = consumer.drop_rate() if consumer is not None else 0.0
         if p > 0:
             dx, dz = K.layernorm_bwd(dy, x, self.gamma.data, mean, rstd, self.gamma.grad, self.beta.grad, accumulate=acc,
-                                     dres=dres, emit_dropout=(p, self.rt.step_seed, consumer.site))
+                                     dres=dres, emit_dropout=(p, self.rt.step_seed, consumer.site), batch=self.rt.wgrad_batch())
             dx._nst_dropped = (consumer.site, dz)
             return dx
         return K.layernorm_bwd(dy, x, self.gamma.data, mean, rstd, self.gamma.grad, self.beta.grad, accumulate=acc,
-                               dres=dres)
+                               dres=dres, batch=self.rt.wgrad_batch())
 
 
 def dropped_grad(rt, dy, p, site):
@@ -126,6 +126,7 @@ class Dense(Layer):
         self.in_dim, self.out_dim = in_dim, out_dim
         self.kernel = rt.store.add(name + "/kernel", (in_dim, out_dim), glorot_uniform((in_dim, out_dim), gen))
         self.bias = rt.store.add(name + "/bias", (out_dim,), torch.zeros(out_dim)) if use_bias else None
+        self.wgrad_units = None   # workgroups the weight gradient is cut into (None: NST_WGRAD_UNITS)
 
     def forward(self, x, **epi):
         return K.gemm(x, self.kernel.compute, x.shape[0], self.out_dim, self.in_dim,
@@ -143,7 +144,8 @@ class Dense(Layer):
             bias_kw = dict(colsum_out=self.bias.grad, colsum_accumulate=st.acc_flag(self.bias))
         self.rt.run_wgrad(lambda: K.gemm(
             x, dz, self.in_dim, self.out_dim, rows, trans_a=True, out=self.kernel.grad, accumulate=acc_k,
-            split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype), batch=self.rt.wgrad_batch(), **bias_kw), x, dz)
+            split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype, self.wgrad_units), batch=self.rt.wgrad_batch(),
+            **bias_kw), x, dz)
 
     def backward_input(self, dz, **epi):
         """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""

@@ -6,6 +6,8 @@
            GEMM epilogue
 Variables (TF names/layouts): conv{1,2}/{kernel(HWIO),bias}, ln{1,2}/{gamma,beta}, output_dense/{kernel,bias}.
 """
+import os
+
 import torch
 
 from neurst_amd import kernels as K
@@ -33,6 +35,8 @@ class AudioConv2dSubsamplingLayer(Layer):
             self.be2 = st.add(name + "/ln2/beta", (C,), torch.zeros(C))
         f2 = ((input_dimension + 1) // 2 + 1) // 2
         self._dense_layer = Dense(rt, name + "/output_dense", f2 * C, embedding_dim, gen)
+        # (its weight gradient runs at the very end of the backward next to the conv kernels; 512 units measured no better)
+        self._dense_layer.wgrad_units = int(os.environ.get("NST_FRONT_WGRAD_UNITS", "256"))
 
     @property
     def embedding_dim(self):

@@ -254,7 +254,7 @@ class Runtime(object):
     def flush_wgrads(self):
         """Launches the pending (deferred) second stages of the weight gradients queued so far, on their stream."""
         b = getattr(self, "_wgrad_batch", None)
-        if b is not None and (b.n or self.capture is not None):
+        if b is not None and (b.n or b.ln_n or self.capture is not None):
             self.run_wgrad(b.flush)
 
     def wgrad_boundary(self):
@@ -273,6 +273,9 @@ class Runtime(object):
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""
         self.flush_wgrads()
+        b = getattr(self, "_wgrad_batch", None)
+        if b is not None:
+            b.joined()
         if self.capture is not None:
             self.capture.join()
             return

@@ -49,7 +49,7 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
     return y.to(x.dtype).reshape(x.shape), mean.float(), rstd.float()
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
     assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
     assert dres is None or (dres.is_contiguous() and dres.dtype == x.dtype and y is None)
     d = x.shape[-1]

@@ -89,6 +89,16 @@ def main():
             for r in win:
                 per.setdefault(str(r[idx]), []).append((r[1], r[2]))
             res[f"busy_ms_per_step_by_{k}"] = {q: union(iv)[0] / 1e6 / steps for q, iv in per.items()}
+    # per-launch trace of the LAST step of the window (start relative to the step's first launch)
+    if len(adam) > steps:
+        last = [r for r in rows if adam[-2] <= r[1] < adam[-1]]
+        if last:
+            base = last[0][1]
+            with open(out.replace(".json", "") + "_trace.csv", "w") as f:
+                f.write("start_us,dur_us,stream,kernel\n")
+                for r in last:
+                    nm = r[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60].replace(",", ";")
+                    f.write(f"{(r[1] - base) / 1e3:.1f},{(r[2] - r[1]) / 1e3:.1f},{r[3] if len(r) > 3 else 0},{nm}\n")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k not in ("largest_gaps", "columns", "main_stream_waits")}, indent=1))
     for w in res.get("main_stream_waits", [])[:10]:

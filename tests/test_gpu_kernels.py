@@ -135,6 +135,33 @@ def test_layernorm(K, dtype, rows, d, relu):
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, accumulate=True,
                     y=y if relu else None)
     close(tag + ".dgamma_acc", dgamma, 2 * before.cpu().double(), torch.float32)
+    # deferred parameter gradients (nst_layernorm_bwd_deferred + nst_ln_finalize_multi): the dx kernels of several
+    # LayerNorms leave their partial sums in the batch's slots, ONE later launch finishes all of them -- bit-identical
+    # to the immediate second stage; d > 512 has no slot and falls back to it
+    batch = K.SplitkBatch(DEV)
+    want_g, want_b = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    kw = dict(y=y) if relu else dict(dres=dres.to(DEV))
+    want_dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, want_g, want_b, **kw)
+    outs = []
+    for k in range(3):
+        g_k, b_k = torch.full((d,), 3.0, device=DEV), torch.full((d,), 3.0, device=DEV)
+        dx_k = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, g_k, b_k, accumulate=(k == 2), batch=batch, **kw)
+        outs.append((dx_k, g_k, b_k))
+    assert batch.ln_n == (3 if d <= 512 else 0)
+    if d <= 512:
+        assert float(outs[0][1][0]) == 3.0, "the deferred stage ran before the flush"
+    batch.flush()
+    assert batch.ln_n == 0
+    for k, (dx_k, g_k, b_k) in enumerate(outs):
+        assert torch.equal(dx_k, want_dx)
+        assert torch.equal(g_k, want_g + 3.0 if k == 2 else want_g), f"{tag}: deferred dgamma {k}"
+        assert torch.equal(b_k, want_b + 3.0 if k == 2 else want_b), f"{tag}: deferred dbeta {k}"
+    if not relu:
+        g_e, b_e = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        dx_e, dz_e = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, g_e, b_e, dres=dres.to(DEV),
+                                     emit_dropout=(0.3, 11, 5), batch=batch)
+        batch.flush()
+        assert torch.equal(dx_e, dx2) and torch.equal(dz_e, dz2) and torch.equal(g_e, dg2) and torch.equal(b_e, db2)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
