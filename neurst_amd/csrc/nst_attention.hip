@@ -209,6 +209,15 @@ __device__ __forceinline__ float key_bias2(const AttnParams& p, int b, int kg) {
   return fmaxf(v, -3.0e38f);
 }
 
+// the same in two halves for software-pipelined loops: the load (raw value, nothing depends on it) a tile ahead, the
+// arithmetic when the value is needed -- a use right behind the load costs a full memory round trip every tile
+__device__ __forceinline__ float key_bias_raw(const AttnParams& p, int b, int kg) {
+  return (p.key_bias && kg < p.Tk) ? p.key_bias[(int64_t)b * p.Tk + kg] : 0.f;
+}
+__device__ __forceinline__ float key_bias_fin(const AttnParams& p, float raw, int kg) {
+  return kg >= p.Tk ? -INFINITY : fmaxf(raw * LOG2E, -3.0e38f);
+}
+
 // write 4 consecutive head dims d..d+3 of one row
 template <typename T, bool VEC>
 __device__ __forceinline__ void store_row4(T* row, int d, int dh, const floatx4_t& v, float mul) {
@@ -276,17 +285,27 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   float kbreg = 0.f;
   tile_load<T, VEC>(kreg, kb, p.ldk, 0, p.Tk, p.dh, tid);
   tile_load<T, VEC>(vreg, vb, p.ldv, 0, p.Tk, p.dh, tid);
-  if (tid < TR) kbreg = key_bias2(p, b, tid);
+  if (tid < TR) kbreg = key_bias_raw(p, b, tid);
+  // dropout-mask words of the previous tile, stored at the top of the next one (behind the barrier, in front of the
+  // prefetch loads: vmcnt retires in order, a store issued after the loads would be waited for with them)
+  int64_t mpend[MI];   // element index into p.mask (an index, not a pointer: a select with nullptr would turn the
+  uint32_t mbits[MI];  // store into a flat_store, which also counts against lgkmcnt)
+  bool mok[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) { mpend[mi] = 0; mbits[mi] = 0; mok[mi] = false; }
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
     tile_store<T>(Ks, kreg, tid);
     tile_store<T>(Vs, vreg, tid);
-    if (tid < TR) kbs[tid] = kbreg;
+    if (tid < TR) kbs[tid] = key_bias_fin(p, kbreg, k0 + tid);
     __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (mok[mi]) p.mask[mpend[mi]] = (uint16_t)mbits[mi];
     if (kt + 1 < nkt) {
       tile_load<T, VEC>(kreg, kb, p.ldk, k0 + TR, p.Tk, p.dh, tid);
       tile_load<T, VEC>(vreg, vb, p.ldv, k0 + TR, p.Tk, p.dh, tid);
-      if (tid < TR) kbreg = key_bias2(p, b, k0 + TR + tid);
+      if (tid < TR) kbreg = key_bias_raw(p, b, k0 + TR + tid);
     }
     floatx4_t kb4[4];
 #pragma unroll
@@ -349,7 +368,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
           bits |= keep ? (1u << e) : 0u;
           s[mi][e >> 2][e & 3] *= keep ? p.drop_inv_keep : 0.f;
         }
-        if (qblk0 < p.Tq) p.mask[((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane] = (uint16_t)bits;
+        mpend[mi] = ((bh * p.nqb + (qblk0 >> 4)) * p.nkt + kt) * 64 + lane;
+        mok[mi] = qblk0 < p.Tq;
+        mbits[mi] = bits;
       }
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -359,6 +380,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
     tmul_acc<T, MI>(o, s, Vs, lane);
     __syncthreads();
   }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    if (mok[mi]) p.mask[mpend[mi]] = (uint16_t)mbits[mi];
 
   T* ob = (T*)p.o + (int64_t)b * p.Tq * p.ldo + h * p.dh;
 #pragma unroll
@@ -487,28 +511,64 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
   const int mlane = g * 4 + 16 * (lc >> 2);
   const int mbit = wave * 4 + (lc & 3);
 
+  // Software pipeline over the query tiles.  vmcnt counts loads and stores in order, so everything this loop waits for
+  // is issued a full tile ahead: Q / dO / lse / delta and the dropout-mask words of tile t+1 at the top of tile t, and the
+  // dS^T stores of tile t at the top of tile t+1 (issued right behind the loads they would otherwise sit in front of: the
+  // next wait then finds stores that have had a whole tile to retire instead of ones issued a moment ago).
   TileRegs<T> qreg, greg;
   float lsreg = 0.f, dlreg = 0.f;
+  uint2 mwn[MI][4];            // mask words of the NEXT tile
+  uint2 dsp[MI][4];            // packed dS^T of the PREVIOUS tile, not yet stored
+  bf16_t* dsrow[MI];
+  bool ds_pending = false;
+  auto mask_load = [&](int q0n) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int kblk0 = k0 + mi * TR + wave * 16;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        mwn[mi][f] = make_uint2(0xffffffffu, 0xffffffffu);
+        if (p.drop_thresh && (q0n >> 4) + f < p.nqb)
+          mwn[mi][f] = *reinterpret_cast<const uint2*>(
+              p.mask + ((bh * p.nqb + ((q0n >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
+      }
+    }
+  };
   auto stat_load = [&](int q) {
     const bool ok = q < p.Tq;
-    lsreg = ok ? p.lse[bh * p.Tq + q] * LOG2E : INFINITY;
+    lsreg = ok ? p.lse[bh * p.Tq + q] : INFINITY;   // raw: the scale by log2(e) waits until the value is needed
     dlreg = ok ? p.delta[bh * p.Tq + q] : 0.f;
   };
   if (qt_first < nqt) {
     tile_load<T, VEC>(qreg, qb, p.ldq, qt_first * TR, p.Tq, p.dh, tid);
     tile_load<T, VEC>(greg, gb, p.ldo, qt_first * TR, p.Tq, p.dh, tid);
     if (tid < TR) stat_load(qt_first * TR + tid);
+    mask_load(qt_first * TR);
   }
   for (int qt = qt_first; qt < nqt; ++qt) {
     const int q0 = qt * TR;
     tile_store<T>(Qs, qreg, tid);
     tile_store<T>(Gs, greg, tid);
-    if (tid < TR) { lss[tid] = lsreg; dls[tid] = dlreg; }
+    if (tid < TR) { lss[tid] = lsreg * LOG2E; dls[tid] = dlreg; }
+    uint2 mwc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) mwc[mi][f] = mwn[mi][f];
     __syncthreads();
+    if constexpr (WDS && sizeof(T) == 2) {
+      if (ds_pending) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) *reinterpret_cast<uint2*>(dsrow[mi] + f * 16) = dsp[mi][f];
+      }
+    }
     if (qt + 1 < nqt) {
       tile_load<T, VEC>(qreg, qb, p.ldq, q0 + TR, p.Tq, p.dh, tid);
       tile_load<T, VEC>(greg, gb, p.ldo, q0 + TR, p.Tq, p.dh, tid);
       if (tid < TR) stat_load(q0 + TR + tid);
+      mask_load(q0 + TR);
     }
     floatx4_t ls4[4], dl4[4];
 #pragma unroll
@@ -541,10 +601,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
       auto elems = [&](auto DIAG, auto DROP) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          uint2 mw = make_uint2(0xffffffffu, 0xffffffffu);
-          if (decltype(DROP)::value && (q0 >> 4) + f < p.nqb)
-            mw = *reinterpret_cast<const uint2*>(
-                p.mask + ((bh * p.nqb + ((q0 >> 4) + f)) * p.nkt + (kblk0 >> 6)) * 64 + mlane);
+          const uint2 mw = mwc[mi][f];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = prob_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
@@ -561,16 +618,24 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(AttnParams p) {
       if constexpr (WDS && sizeof(T) == 2) {
         // dS^T[key][q] for the dQ kernel: this lane's key row, 4 consecutive queries per 16-query block (8-byte stores;
         // the four lane groups of a key cover 32 contiguous bytes).  Rows / columns beyond Tk / Tq hold exact zeros.
-        bf16_t* row = p.dst + ((int64_t)bh * p.tkp + kg) * p.tqp + q0 + g * 4;
+        dsrow[mi] = p.dst + ((int64_t)bh * p.tkp + kg) * p.tqp + q0 + g * 4;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
-          *reinterpret_cast<uint2*>(row + f * 16) =
-              make_uint2(pack_bf16x2(dp[mi][f][0], dp[mi][f][1]), pack_bf16x2(dp[mi][f][2], dp[mi][f][3]));
+          dsp[mi][f] = make_uint2(pack_bf16x2(dp[mi][f][0], dp[mi][f][1]), pack_bf16x2(dp[mi][f][2], dp[mi][f][3]));
+        ds_pending = true;
       }
     }
     tmul_acc<T, MI>(dv, st, Gs, lane);
     tmul_acc<T, MI>(dk, dp, Qs, lane);
     __syncthreads();
+  }
+  if constexpr (WDS && sizeof(T) == 2) {
+    if (ds_pending) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *reinterpret_cast<uint2*>(dsrow[mi] + f * 16) = dsp[mi][f];
+    }
   }
 
   T* dkb = (T*)p.dk + (int64_t)b * p.bsk + h * p.dh;
