@@ -272,7 +272,10 @@ def main():
             # HBM bytes per step of this family from the committed rocprofv3 --pmc passes of the same command
             # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); not re-measured by this run
             try:
-                roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_step"]
+                t = json.load(open(pmc))
+                roofline["traffic"] = t["hbm_bytes_per_launch"]          # per launch, like `achieved`
+                roofline["traffic_per_step"] = t["hbm_bytes_per_step"]
+                roofline["algorithmic_flops_per_launch"] = roofline["algorithmic_flops_per_step"] / roofline["launches_per_step"]
                 roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
             except Exception:
                 pass

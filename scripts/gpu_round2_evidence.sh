@@ -14,6 +14,9 @@ PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUS
   scripts/pmc_kernel.sh gpurun_out/r02_pmc_gemm.json dense_gemm_kernel_v3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --roofline-steps 0 > gpurun_out/r02_pmc_gemm.log 2>&1
 grep -E "dense_gemm|FETCH|WRITE|MFMA" gpurun_out/r02_pmc_gemm.log | head -20
 timeout 300 python scripts/ffn_bench.py --rows 28800,9600 --ablate --out gpurun_out/r02_ffn_bench.json > gpurun_out/r02_ffn_bench.log 2>&1
+timeout 300 python scripts/conv_bench.py --out gpurun_out/r02_conv_bench.json > gpurun_out/r02_conv_bench.log 2>&1
+# graph-mode kernel trace (no host gaps): per-launch timeline of one step
+scripts/gpu_profile2.sh r02final_graph 8 --graph > gpurun_out/r02final_graph_profile.log 2>&1
 timeout 300 python bench.py > gpurun_out/r02_bench_final.json 2> gpurun_out/r02_bench_final.err
 tail -1 gpurun_out/r02_bench_final.json | cut -c1-400
 timeout 300 python bench.py --graph --no-cpu-baseline > gpurun_out/r02_bench_graph.json 2>/dev/null
