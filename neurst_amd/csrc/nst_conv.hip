@@ -1086,6 +1086,28 @@ conv2_wgrad_kernel_v3(GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityR
   gemm_stream_v3<T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>(smem_dyn);
 }
 
+// ... and, the default, on a wide (128 x 256 tile, 8 waves, one workgroup per CU) one-unit-per-workgroup split-K kernel: twice
+// the MFMA work per K step, per DMA round trip and per barrier, and dy is read once per row panel (0.95 against 1.10 ms
+// stand-alone).  The same kernel for the DENSE weight gradients made the step slower (16.4 against 16.3 ms): a 96 KB
+// workgroup cannot share a CU with an 80 KB stream-GEMM workgroup of the dgrad chain, the conv2 weight gradient only
+// ever runs next to the 160 KB dgrad patch kernel.
+template <typename T>
+__global__ void __launch_bounds__(V2W_THREADS)
+conv2_wgrad_wide_kernel(Im2colLoader<T> la, DenseLoader<T> lb, float* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_n,
+                        int ntiles, int kt_per_split, int zx, Epilogue ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  int z, tile;
+  splitk_unit(blockIdx.x, ntiles, zx, z, tile);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
+  const int kt_first = z * kt_per_split;
+  int kt_count = kt_total - kt_first;
+  if (kt_count > kt_per_split) kt_count = kt_per_split;
+  if (kt_count <= 0) return;
+  gemm_block_v2w<T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>(
+      la, lb, C + (int64_t)z * ep.slab_stride, ldc, M, N, tm * BM, tn * 2 * BN, kt_count, ep, smem_dyn, IdentityRowMap(), kt_first, z);
+}
+
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int64_t total4, int split, int accumulate,
                                                                 const float* __restrict__ cs_parts, float* __restrict__ cs_out,
@@ -1671,6 +1693,12 @@ bool conv2_wgrad_v3() {
   return v == 1;
 }
 
+bool conv2_wgrad_wide() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV2_WGRAD_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 bool conv2_wgrad_zxcd() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_GEMM_ZXCD"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1700,15 +1728,18 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   // stream kernel: K slices pinned to XCDs (split = 8 S).  An XCD then owns ntiles * S units for its 64 resident
   // workgroups; take the S (slices of >= 32 K steps, slabs inside the workspace) that wastes the fewest workgroup rounds.
   bool zx = false;
-  if (dma && conv2_wgrad_v3() && conv2_wgrad_zxcd() && ws) {
+  const bool wide = dma && sizeof(T) == 2 && conv2_wgrad_wide() && N % (2 * BN) == 0;
+  const int tiles_nw = wide ? N / (2 * BN) : tiles_n, ntw = wide ? tiles_m * tiles_nw : ntiles;
+  if (dma && (wide || conv2_wgrad_v3()) && conv2_wgrad_zxcd() && ws) {
     int best = 0;
     double best_eff = 0.0;
+    const int slots = wide ? 32 : 64;   // resident workgroups of one XCD
     for (int S = 1; S <= 16; ++S) {
       if (kt_total / (8 * S) < 32 || (int64_t)8 * S * (M + 1) * N * 4 > ws_bytes) break;
       const int kps = (kt_total + 8 * S - 1) / (8 * S);
       if ((kt_total + kps - 1) / kps != 8 * S) continue;  // the slice count has to survive the rounding below
-      const int per_xcd = ntiles * S, rounds = (per_xcd + 63) / 64;
-      const double eff = (double)per_xcd / (64.0 * rounds);
+      const int per_xcd = ntw * S, rounds = (per_xcd + slots - 1) / slots;
+      const double eff = (double)per_xcd / ((double)slots * rounds);
       if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
     }
     if (best) { split = 8 * best; zx = true; }
@@ -1737,7 +1768,14 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
       if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
     }
   }
-  if (slab && dma && conv2_wgrad_v3()) {
+  if (slab && wide) {
+    if constexpr (sizeof(T) == 2) {
+      auto kfn = conv2_wgrad_wide_kernel<T>;
+      conv_allow_big_lds(kfn, V2W_LDS_BYTES);
+      kfn<<<ntw * split, V2W_THREADS, V2W_LDS_BYTES, st>>>(la, lb, out, (int64_t)N, M, N, K, tiles_nw, ntw, kt_per_split, zx ? 1 : 0, ep);
+      if (cs_parts) *db2_done = true;
+    }
+  } else if (slab && dma && conv2_wgrad_v3()) {
     // persistent workgroups, two resident per CU; every workgroup walks the same number of (tile, K slice) units
     GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
     ga.la = la; ga.lb = lb; ga.C = out; ga.ldc = N; ga.M = M; ga.N = N; ga.K = K;

@@ -755,9 +755,12 @@ constexpr int V2W_THREADS = 512;
 constexpr int V2W_STAGE_BYTES = 3 * BM * KBYTES;
 constexpr int V2W_LDS_BYTES = 2 * V2W_STAGE_BYTES;
 
-template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap>
+// kt_first / z: split-K slice (first K step, slab index of the fused column sums).  CS as in gemm_block_v2: the first row
+// of tiles also accumulates ones^T . Bop (the bias gradient of a weight-gradient product).
+template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap, bool CS = false>
 __device__ __forceinline__ void gemm_block_v2w(const ALoader& la, const BLoader& lb, OutT* __restrict__ C, int64_t ldc, int M, int N,
-                                               int m0, int n0, int kt_count, const Epilogue& ep, char* smem, const RowMap rowmap) {
+                                               int m0, int n0, int kt_count, const Epilogue& ep, char* smem, const RowMap rowmap,
+                                               int kt_first = 0, int z = 0) {
   typedef SwzFrag<T, AMODE> RA;
   typedef SwzFrag<T, BMODE> RB;
   constexpr int BK = Tile<T>::BK;
@@ -774,10 +777,16 @@ __device__ __forceinline__ void gemm_block_v2w(const ALoader& la, const BLoader&
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
+  floatx4_t cs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = CS && ep.colsum_dst && m0 == 0 && wm == 0;  // wave-uniform
+  const typename RA::Frag ones = ones_frag<T>();
+
   TileDma<T, AMODE, ALoader> da;
   TileDma<T, BMODE, BLoader> db;
-  if (quad == 0) da.init(la, m0, 0, wq, lane);
-  db.init(lb, n0 + quad * BN, 0, wq, lane);
+  if (quad == 0) da.init(la, m0, kt_first * BK, wq, lane);
+  db.init(lb, n0 + quad * BN, kt_first * BK, wq, lane);
   auto issue = [&](int kt, int stage) {
     const uint32_t sa = smem_addr + stage * V2W_STAGE_BYTES;
     if (quad == 0) {
@@ -814,10 +823,18 @@ __device__ __forceinline__ void gemm_block_v2w(const ALoader& la, const BLoader&
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a0[i], b0[j], acc[i][j]);
+      if (CS && do_cs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b0[j], cs[j]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a1[i], b1[j], acc[i][j]);
+      if (CS && do_cs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b1[j], cs[j]);
+      }
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += KS) {
@@ -831,9 +848,23 @@ __device__ __forceinline__ void gemm_block_v2w(const ALoader& la, const BLoader&
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        if (CS && do_cs) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b[j], cs[j]);
+        }
       }
     }
     stage ^= 1;
+  }
+  if (CS && do_cs && lane < 16) {  // every row of cs holds the column sums; lane = column within the 16-block
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn + j * 16 + lane;
+      if (col < N) {
+        float* dst = ep.colsum_dst + (int64_t)z * ep.colsum_zstride + col;
+        *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
+      }
+    }
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the epilogue reuses the LDS
@@ -849,6 +880,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return start + idx;
 }
 
+
+// (K slice, tile) of workgroup b in a one-unit-per-workgroup split-K launch of ntiles * split workgroups.  zx != 0 (split a
+// multiple of 8): slice z lives on XCD z % 8 -- workgroup ids go round-robin over the XCDs, and all tiles of a slice read
+// the same rows of both operands, so their re-reads then hit one L2.
+__device__ __forceinline__ void splitk_unit(int b, int ntiles, int zx, int& z, int& tile) {
+  if (zx) {
+    const int idx = b >> 3, sl = idx / ntiles;
+    z = (b & 7) + 8 * sl;
+    tile = idx - sl * ntiles;
+  } else {
+    z = b / ntiles;
+    tile = xcd_remap(b - z * ntiles, ntiles);
+  }
+}
 
 // =============================================================================================
 // v3: persistent stream of (output tile, K step) work over the same LDS-DMA stage ring.
