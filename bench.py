@@ -18,7 +18,11 @@ import os
 import sys
 import time
 
-import torch
+# before the HIP runtime initialises: enough hardware queues for compute + weight-gradient + communication + RCCL streams
+# (neurst_amd/__init__.py has the measurement; with the default of 4 two of them share a queue and serialise)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -199,7 +203,8 @@ def main():
     opt.bind(model.store)
     opt.learning_rate = build_lr_schedule({"lr_schedule.class": hp["lr_schedule.class"],
                                            "lr_schedule.params": hp["lr_schedule.params"]})
-    reducer = GradientReducer(model.store)
+    # NST_DIST_FORCE=1 (with one rank): run the exchange path -- buckets, communication stream, RCCL -- on a one-GPU box
+    reducer = GradientReducer(model.store, force=os.environ.get("NST_DIST_FORCE", "0") == "1")
     reducer.broadcast_parameters(0)
     step_fn = TrainStep(model, crit, opt, reducer, use_graph=args.graph)
     ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
@@ -304,13 +309,24 @@ def main():
         "ffn_gemm_mfma_utilisation": ffn_util,
         "host_issue_ms_per_step": t_issued / args.steps * 1e3,   # ~ ms_per_step means the host, not the GPU, paces the step
         "hip_graph": bool(args.graph), "graph_replays": getattr(step_fn, "replays", 0),
-        "rccl_world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
+        "rccl_world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+        "exchange_path_active": bool(reducer.active),
         "reducer_messages_per_step": getattr(reducer, "last_messages", None),
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, T, F, L, V)
-    print(json.dumps(out))
+    try:   # RCCL prints its version banner through C stdio, which a pipe only sees at exit: flush it so the JSON line stays last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

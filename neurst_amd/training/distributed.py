@@ -31,7 +31,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    # NST_DIST_FORCE=1: create the process group even for ONE rank (the collectives are then identities) -- lets a
+    # single-GPU box run the whole exchange path (side stream, fences, RCCL itself), see tests/test_gpu_multi.py
+    force = os.environ.get("NST_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -56,13 +59,16 @@ class GradientReducer(object):
     12-layer encoder becomes a handful of 8-16 MiB collectives that start while the earlier layers still
     back-propagate, instead of one 63 MiB exchange after the whole encoder."""
 
-    def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True, min_bucket_bytes=8 << 20, extra_streams=()):
+    def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True, min_bucket_bytes=8 << 20, extra_streams=(),
+                 force=False):
         self.store, self.group = store, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # exchanges are issued when there is someone to exchange with -- or on request with an initialised one-rank group
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.min_elems = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.on_gpu = store.grad.is_cuda
-        self.overlap = overlap and self.on_gpu and self.world > 1
+        self.overlap = overlap and self.on_gpu and self.active
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
         # streams (besides the current one) whose queued work writes gradients: the exchange waits for them on the
         # COMMUNICATION stream, so the compute streams never stall for a bucket
@@ -111,7 +117,7 @@ class GradientReducer(object):
             self.messages += 1
 
     def _issue(self, start, end):
-        if self.world <= 1 or end <= start:
+        if not self.active or end <= start:
             return
         if self.capture_cut is not None:
             self.capture_cut(start, end)
@@ -176,13 +182,13 @@ class GradientReducer(object):
 
     def broadcast_parameters(self, src=0):
         """BroadcastGlobalVariablesCallback(0) (exps/trainer.py:285)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.store.master, src=src, group=self.group)
             self.store.refresh_shadow()
 
     def broadcast_tensors(self, tensors, src=0):
         """Other replicated state that must start identical on every rank (optimizer moments after a resume)."""
-        if self.world > 1:
+        if self.active:
             for t in tensors:
                 dist.broadcast(t, src=src, group=self.group)
 
@@ -192,7 +198,7 @@ class GradientReducer(object):
         names = sorted(values)
         t = torch.tensor([float(values[n]) for n in names], dtype=torch.float64,
                          device=self.store.grad.device if self.on_gpu else "cpu")
-        if self.world > 1:
+        if self.active:
             if self.on_gpu:
                 t = t.float()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
