@@ -45,6 +45,7 @@ class _StepCapture(object):
         self.segments, self.deferred, self.keep = [], [], []
         self.cur = None
         self._fresh = False      # nothing has been queued since the current segment was opened by a layer boundary
+        self.min_deferred = max(1, int(os.environ.get("NST_GRAPH_MIN_DEFERRED", "6")))
 
     def begin(self):
         self.cur = _Segment()
@@ -80,7 +81,9 @@ class _StepCapture(object):
         self.keep.extend(tensors)      # their memory must not be handed out again inside this capture (the graphs run concurrently)
 
     def layer_boundary(self):
-        if self.deferred:
+        # a cut costs two graph launches (~10-20 us of idle compute stream each); waiting for a few weight-gradient calls
+        # trades that against a later start of the weight-gradient graph (NST_GRAPH_MIN_DEFERRED, measured in DESIGN 5b)
+        if len(self.deferred) >= self.min_deferred:
             self._close()
             self.begin()
             self._fresh = True

@@ -95,7 +95,7 @@ def test_graph_capture_is_cut_where_the_reducer_issues_buckets():
     def factory(log):
         def make(store):
             red = GradientReducer(store, bucket_bytes=1 << 16, min_bucket_bytes=1 << 14)
-            red.world, red.overlap = 2, False
+            red.world, red.active, red.overlap = 2, True, False
             red.issue = lambda s, e: log.append((s, e))
             return red
         return make
