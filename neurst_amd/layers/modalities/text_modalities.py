@@ -67,14 +67,23 @@ class WordEmbeddingSharedWeights(Layer):
             _, x2 = self._stack.pop(idx)
             dl = dy.reshape(-1, V)
             rows = dl.shape[0]
-            K.gemm(dl, x2, V, d, rows, trans_a=True, out=W.grad, accumulate=st.acc_flag(W),
-                   split_k=_wgrad_split(rows, V, d, dl.dtype))
-            if self._bias is not None:
-                K.colsum(dl, self._bias.grad, accumulate=st.acc_flag(self._bias))
+            acc_w = st.acc_flag(W)
+            acc_b = st.acc_flag(self._bias) if self._bias is not None else False
+
+            def table_grads():   # parameter gradients only: off the dgrad chain, on the weight-gradient stream
+                K.gemm(dl, x2, V, d, rows, trans_a=True, out=W.grad, accumulate=acc_w, split_k=_wgrad_split(rows, V, d, dl.dtype))
+                if self._bias is not None:
+                    K.colsum(dl, self._bias.grad, accumulate=acc_b)
+            self.rt.run_wgrad(table_grads, dl, x2)
             return K.gemm(dl, W.compute, rows, d, V).view(*dy.shape[:-1], d)
         idx = max(i for i, s in enumerate(self._stack) if s[0] == "embedding")
         _, ids, scale = self._stack.pop(idx)
-        if not st.acc_flag(W):
-            W.grad.zero_()
-        K.embedding_bwd(dy.contiguous(), ids, W.grad, scale)
+        acc_w = st.acc_flag(W)
+        dyc = dy.contiguous()
+
+        def table_grads():   # same stream as the logits' table gradient above: the two accumulate in program order
+            if not acc_w:
+                W.grad.zero_()
+            K.embedding_bwd(dyc, ids, W.grad, scale)
+        self.rt.run_wgrad(table_grads, dyc, ids)
         return None
