@@ -35,6 +35,7 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
 _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
 _SKIP_WGRAD = os.environ.get("NST_SKIP_WGRAD", "0") == "1"
 _WGRAD_SPLIT8 = os.environ.get("NST_WGRAD_SPLIT8", "1") != "0"
+_WGRAD_UNITS_SMALL = int(os.environ.get("NST_WGRAD_UNITS_SMALL", "128"))   # gradients of fewer than 8 tiles (256 x 256 kernels)
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
@@ -49,6 +50,8 @@ def _wgrad_split(rows, k_in, n_out, dtype, units=None):
     tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
     bk = 64 if dtype == torch.bfloat16 else 32
     kt = (rows + bk - 1) // bk
+    if units is None and tiles < 8:
+        units = _WGRAD_UNITS_SMALL
     split = max(1, min((units or _WGRAD_UNITS) // max(tiles, 1), kt // 8))
     if split >= 8 and tiles >= 8 and _WGRAD_SPLIT8:   # few tiles per slice: little to share, keep the finer split
         # multiples of 8: the stream kernel then pins every K slice to one XCD (its tiles share the slice's rows in that
