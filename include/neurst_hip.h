@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 3
+#define NST_ABI_VERSION 4
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -134,6 +134,16 @@ typedef struct {
    * to 8 such jobs to ONE nst_splitk_reduce_multi launch.  The 92 weight gradients of a step otherwise pay 92 separate
    * reduce launches of 7-20 us each on the weight-gradient stream. */
   struct NstSplitkJob* reduce_job_out;
+  /* Row dots per 64-column head, fused into the epilogue (bf16 output, N % 64 == 0, split_k == 1, 16-byte aligned rows):
+   *   rowdot_dst[(b*rowdot_heads + h)*rowdot_rows + t] = sum_{c < 64} C[b*rowdot_rows + t][h*64 + c] * rowdot_src[same]
+   * with C as stored (rounded to bf16).  The input gradient of the attention output projection (dO = dZ . Wo^T,
+   * multi_head_attention.py:213-215 in reverse) passes the attention output O as rowdot_src and receives
+   * delta = rowsum(dO o O) [B, H, Tq] -- the term the softmax backward subtracts -- without another pass over dO and O;
+   * nst_attention_bwd then takes out == NULL ("delta is already there").  NULL rowdot_dst: off. */
+  const void* rowdot_src;
+  int64_t ldrs;            /* elements */
+  float* rowdot_dst;
+  int rowdot_rows, rowdot_heads;
 } NstGemmDesc;
 
 typedef struct NstSplitkJob {
@@ -196,7 +206,8 @@ int64_t nst_attention_dropout_mask_bytes(const NstAttnDesc* d);
 
 int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
                       void* out, float* lse, void* stream);
-/* dq,dk,dv share the layouts/strides of q,k,v (ldq,ldk,ldv); dout that of out. delta [B,H,Tq] f32 workspace. */
+/* dq,dk,dv share the layouts/strides of q,k,v (ldq,ldk,ldv); dout that of out. delta [B,H,Tq] f32 workspace.
+ * out == NULL: delta already holds rowsum(dout o out) per head (NstGemmDesc.rowdot_dst of the GEMM that produced dout). */
 int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void* k, const void* v, const float* key_bias,
                       const void* out, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                       void* dv, void* stream);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 3
+NST_ABI_VERSION = 4
 
 
 class NstGemmDesc(C.Structure):
@@ -35,6 +35,8 @@ class NstGemmDesc(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("colsum", C.c_void_p), ("colsum_accumulate", C.c_int),
         ("reduce_job_out", C.c_void_p),
+        ("rowdot_src", C.c_void_p), ("ldrs", C.c_int64), ("rowdot_dst", C.c_void_p), ("rowdot_rows", C.c_int),
+        ("rowdot_heads", C.c_int),
     ]
 
 

@@ -948,7 +948,7 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
   memset(&p, 0, sizeof(p));
   int rc = fill_params(d, p);
   if (rc) return rc;
-  NST_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
+  NST_CHECK_ARG(q && k && v && dout && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
   const int esz = nst_dtype_size(d->dtype);
   p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
   p.key_bias = key_bias; p.dq = dq; p.dk = dk; p.dv = dv;
@@ -956,7 +956,7 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
   const bool vec = vec_legal(q, d->ldq, d->dh, esz) && vec_legal(k, d->ldk, d->dh, esz) && vec_legal(v, d->ldv, d->dh, esz) && vo &&
                    vec_legal(dq, d->ldq, d->dh, esz) && vec_legal(dk, d->ldk, d->dh, esz) && vec_legal(dv, d->ldv, d->dh, esz);
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (out) {  // out == NULL: the caller's GEMM already left delta = rowsum(dout o out) there (NstGemmDesc.rowdot_dst)
     const bool fast = vo && d->dh == 64 && (d->H == 1 || d->H == 2 || d->H == 4);
     const int64_t rows = fast ? ((int64_t)d->B * d->Tq * d->H * 16 + 63) / 64 : (int64_t)d->B * d->H * d->Tq;
     const int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);

@@ -276,6 +276,25 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
   ep.colsum_dst = nullptr;
   ep.colsum_zstride = 0;
   ep.colsum_acc = 0;
+  ep.rowdot_src = nullptr;
+  ep.ldrs = 0;
+  ep.rowdot_dst = nullptr;
+  ep.rowdot_T = 1;
+  ep.rowdot_H = 1;
+  if (d->rowdot_dst) {
+    const DenseLoader<bf16_t> ta = make_loader<bf16_t>(A, d->lda, d->trans_a ? MODE_OC : MODE_RC, d->M, d->K);
+    const DenseLoader<bf16_t> tb = make_loader<bf16_t>(B, d->ldb, d->trans_b ? MODE_RC : MODE_OC, d->N, d->K);
+    NST_CHECK_ARG(d->in_dtype == NST_BF16 && d->out_dtype == NST_BF16 && d->split_k <= 1 && ep.vec && use_v2() && use_tr() &&
+                      ta.vec && tb.vec && d->N % 64 == 0 && d->rowdot_src && nst_aligned16(d->rowdot_src) &&
+                      (d->ldrs * 2) % 16 == 0 && d->ldrs >= d->N && d->rowdot_rows > 0 && d->rowdot_heads * 64 == d->N &&
+                      d->M % d->rowdot_rows == 0 && !d->accumulate,
+                  "gemm: rowdot needs the bf16 stream kernel (aligned operands), N = heads * 64, M = batches * rowdot_rows");
+    ep.rowdot_src = d->rowdot_src;
+    ep.ldrs = d->ldrs;
+    ep.rowdot_dst = d->rowdot_dst;
+    ep.rowdot_T = d->rowdot_rows;
+    ep.rowdot_H = d->rowdot_heads;
+  }
   // column sums of the B operand (bias gradient): fused into the MFMA loop when the LDS-DMA kernel runs on
   // OC/OC operands with an f32 output, otherwise a separate nst_colsum pass at the end
   bool cs_fused = false;

@@ -83,6 +83,13 @@ struct Epilogue {
   float* colsum_dst;
   int64_t colsum_zstride;
   int colsum_acc;
+  // row dots per 64-column head (stream kernel, bf16 output only): rowdot_dst[(b*H + h)*T + t] = sum over the head's 64
+  // columns of C[row][.] (as stored, i.e. rounded to bf16) * rowdot_src[row][.], row = b*T + t.  The attention output
+  // projection's input gradient uses it to leave delta = rowsum(dO o O) for the attention backward in the same pass.
+  const void* rowdot_src;
+  int64_t ldrs;
+  float* rowdot_dst;
+  int rowdot_T, rowdot_H;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -996,9 +1003,28 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
     for (int r = 0; r < 16; ++r) v[r] += to_f32<OutT>(tmp[r]);
   }
   if (sizeof(OutT) == 2) {
-    reinterpret_cast<uint4*>(o)[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-    if (nv == NV)
-      reinterpret_cast<uint4*>(o)[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+    const uint4 w0 = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    const uint4 w1 = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+    reinterpret_cast<uint4*>(o)[0] = w0;
+    if (nv == NV) reinterpret_cast<uint4*>(o)[1] = w1;
+    if (ep.rowdot_dst) {  // host guarantees N % 64 == 0: the 4 lanes of a quad hold the 64 columns of one head of this row
+      const bf16_t* sp = reinterpret_cast<const bf16_t*>(ep.rowdot_src) + (int64_t)row * ep.ldrs + n;
+      const uint4 s0 = reinterpret_cast<const uint4*>(sp)[0], s1 = reinterpret_cast<const uint4*>(sp)[1];
+      const uint32_t cw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        dot = fmaf(__uint_as_float(cw[q] << 16), __uint_as_float(sw[q] << 16), dot);
+        dot = fmaf(__uint_as_float(cw[q] & 0xffff0000u), __uint_as_float(sw[q] & 0xffff0000u), dot);
+      }
+      dot = dpp_add(dot, 0);   // + lane ^ 1
+      dot = dpp_add(dot, 1);   // + lane ^ 2: every lane of the quad holds the head's sum
+      if ((n & 63) == 0) {
+        const int b = row / ep.rowdot_T, t = row - b * ep.rowdot_T;
+        ep.rowdot_dst[((int64_t)b * ep.rowdot_H + (n >> 6)) * ep.rowdot_T + t] = dot;
+      }
+    }
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q)

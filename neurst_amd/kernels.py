@@ -5,6 +5,7 @@ passes raw device pointers and the current HIP stream to the library.  All
 inputs must live on a ROCm device; nothing here falls back to torch math.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -224,9 +225,12 @@ def splitk_reduce_multi(jobs, n):
 
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
-         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False, batch=None):
+         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False, batch=None,
+         rowdot=None):
     """C[M,N] = epilogue(alpha * op(A) @ op(B)); A/B are 2-D views with unit inner stride (see neurst_hip.h).
-    colsum_out [N] f32 (+)= column sums of B over the reduction (the bias gradient of a weight-gradient GEMM)."""
+    colsum_out [N] f32 (+)= column sums of B over the reduction (the bias gradient of a weight-gradient GEMM).
+    rowdot=(src [M, N], dst [M/rows, N/64, rows] f32, rows): dst = per-head (64 columns) row sums of C o src, from the same
+    epilogue (bf16 stream kernel only; see rowdot_supported)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     assert A.dtype == B.dtype
     if out is None:
@@ -255,6 +259,11 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     d.emb_scale = emb_scale
     d.accumulate = int(accumulate)
     d.split_k = split_k
+    if rowdot is not None:
+        src, dst, rows = rowdot
+        assert src.stride(-1) == 1 and dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == M * (N // 64)
+        d.rowdot_src, d.ldrs, d.rowdot_dst = src.data_ptr(), src.stride(-2), dst.data_ptr()
+        d.rowdot_rows, d.rowdot_heads = rows, N // 64
     deferred = False
     if split_k > 1:
         need = split_k * (M + 1) * N * 4
@@ -395,11 +404,20 @@ def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, se
     return out, lse, mask
 
 
+def rowdot_supported(x, n):
+    """gemm(rowdot=...) needs the bf16 stream kernel and whole 64-column heads."""
+    return x.is_cuda and x.dtype == torch.bfloat16 and n % 64 == 0 and os.environ.get("NST_GEMM_ROWDOT", "1") != "0"
+
+
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
-                  stream_id=0, drop_mask=None, causal_offset=0):
+                  stream_id=0, drop_mask=None, causal_offset=0, delta=None):
+    """delta [B,H,Tq] f32: rowsum(dout o out) per head if the GEMM that produced dout already computed it (gemm(rowdot=...))."""
     assert dout.is_contiguous() and out.is_contiguous()
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
-    delta = torch.empty_like(lse)
+    have_delta = delta is not None
+    if not have_delta:
+        delta = torch.empty_like(lse)
+    assert delta.dtype == torch.float32 and delta.is_contiguous() and delta.numel() == lse.numel()
     d = _attn_desc(q, k, v, out, H, dh, causal, dropout_p, seed, stream_id, causal_offset)
     if dropout_p > 0:
         assert drop_mask is not None, "attention_bwd: dropout needs the mask written by attention_fwd"
@@ -409,7 +427,7 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, cau
         ds = torch.empty(B * H * ((Tk + 127) // 128 * 128) * ((Tq + 63) // 64 * 64), dtype=torch.bfloat16, device=q.device)
         d.ds_workspace, d.ds_workspace_bytes = ds.data_ptr(), ds.numel() * 2
     ev = PROBE.begin("attention_bwd")
-    check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), _p(out), _p(dout), _p(lse), _p(delta),
+    check(lib.nst_attention_bwd(C.byref(d), _p(q), _p(k), _p(v), _p(key_bias), None if have_delta else _p(out), _p(dout), _p(lse), _p(delta),
                                 _p(dq), _p(dk), _p(dv), _stream()), "attention_bwd")
     PROBE.end(ev, 8.0 * q.shape[0] * H * q.shape[1] * k.shape[1] * dh)
 

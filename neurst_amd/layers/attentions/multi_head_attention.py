@@ -84,6 +84,14 @@ class MultiHeadAttention(Layer):
         cache["kv"][:, t:t + n] = self.kv_transform.forward(memory_chunk).view(B, n, 2 * self.num_units)
         cache["len"] = t + n
 
+    def _output_backward_input(self, dz, ctx2, lse, Tq):
+        """d(context) = dz . Wo^T; with 64-wide heads on the bf16 path the same GEMM epilogue also leaves
+        delta = rowsum(d(context) o context) per head for the attention backward (no separate pass over both tensors)."""
+        if self.dh == 64 and K.rowdot_supported(dz, self.num_units):
+            delta = torch.empty_like(lse)
+            return self.output_transform.backward_input(dz, rowdot=(ctx2, delta, Tq)), delta
+        return self.output_transform.backward_input(dz), None
+
     def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None):
         """Returns d(query) (+ residual, post-norm wrapper); d(memory) is written (or accumulated) into `dmemory`
         [B*Tk, d]."""
@@ -92,13 +100,13 @@ class MultiHeadAttention(Layer):
         d, H, dh = self.num_units, self.num_heads, self.dh
         ctx2 = ctx.view(B * Tq, d)
         self.output_transform.backward_params(ctx2, dz)
-        dctx = self.output_transform.backward_input(dz)
+        dctx, delta = self._output_backward_input(dz, ctx2, lse, Tq)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         q3, kv3, dq3, dkv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d), dq.view(B, Tq, d), dkv.view(B, Tk, 2 * d)
         K.attention_bwd(q3, kv3[..., :d], kv3[..., d:], ctx, dctx.view(B, Tq, d), lse, dq3, dkv3[..., :d],
                         dkv3[..., d:], H, dh, key_bias=bias, causal=lag is not None, causal_offset=lag or 0, dropout_p=p,
-                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask)
+                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask, delta=delta)
         self.q_transform.backward_params(query, dq)
         self.kv_transform.backward_params(memory, dkv)
         if dmemory is not None:
@@ -150,11 +158,11 @@ class MultiHeadSelfAttention(MultiHeadAttention):
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
         self.output_transform.backward_params(ctx.view(B * T, d), dz)
-        dctx = self.output_transform.backward_input(dz)
+        dctx, delta = self._output_backward_input(dz, ctx.view(B * T, d), lse, T)
         dqkv = torch.empty_like(qkv)
         v3, g3 = qkv.view(B, T, 3 * d), dqkv.view(B, T, 3 * d)
         K.attention_bwd(v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], ctx, dctx.view(B, T, d), lse, g3[..., :d],
                         g3[..., d:2 * d], g3[..., 2 * d:], H, dh, key_bias=bias, causal=causal, dropout_p=p,
-                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask)
+                        seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask, delta=delta)
         self.qkv_transform.backward_params(x, dqkv)
         return self.qkv_transform.backward_input(dqkv, **({} if residual is None else {"residual": residual}))

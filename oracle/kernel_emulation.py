@@ -78,7 +78,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
 # ---------------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, relu=False,
          dropout_p=0.0, seed=0, stream_id=0, residual=None, gate_src=None, gate_scale=1.0, posenc=None,
-         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False, batch=None):
+         posenc_period=0, emb_scale=1.0, accumulate=False, split_k=1, colsum_out=None, colsum_accumulate=False, batch=None,
+         rowdot=None):
+    assert rowdot is None, "the emulation tier never asks for the fused row dots (rowdot_supported is False there)"
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype and A.stride(1) == 1 and B.stride(1) == 1
     assert out is None or (out.dim() == 2 and out.stride(1) == 1)
     assert residual is None or residual.stride(1) == 1
@@ -258,8 +260,13 @@ def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, se
     return out.to(q.dtype).contiguous(), lse.float().contiguous(), mask
 
 
+def rowdot_supported(x, n):
+    return False
+
+
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,
-                  stream_id=0, drop_mask=None, causal_offset=0):
+                  stream_id=0, drop_mask=None, causal_offset=0, delta=None):
+    assert delta is None
     assert (dropout_p > 0) == (drop_mask is not None), "attention_bwd: dropout needs the mask written by attention_fwd"
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
     assert dout.is_contiguous() and out.is_contiguous()

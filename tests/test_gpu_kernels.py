@@ -169,6 +169,37 @@ GEMM_SHAPES = [(5, 7, 3), (16, 16, 32), (128, 128, 64), (130, 136, 72), (300, 25
                (64, 520, 40), (1000, 256, 2048)]
 
 
+@pytest.mark.parametrize("B,T,H,Kd", [(3, 75, 4, 256), (2, 225, 4, 256), (5, 16, 2, 64), (1, 130, 8, 512)])
+def test_gemm_rowdot_leaves_the_attention_delta(K, B, T, H, Kd):
+    """NstGemmDesc.rowdot_*: the input gradient of the attention output projection (dO = dZ . Wo^T) also leaves
+    delta[b, h, t] = sum over the head's 64 columns of dO (as stored in bf16) * O -- what attn_delta_*_kernel computes in a
+    separate pass.  nst_attention_bwd with that delta (out == NULL) equals the call that computes it itself."""
+    M, N = B * T, H * 64
+    dz = rnd(M, Kd, dtype=torch.bfloat16, seed=31).to(DEV)
+    w = (rnd(N, Kd, seed=32) / math.sqrt(Kd)).to(torch.bfloat16).to(DEV)       # [in = N, out = Kd] read as the [N, K] operand
+    o = rnd(M, N, dtype=torch.bfloat16, seed=33).to(DEV)
+    assert K.rowdot_supported(dz, N)
+    delta = torch.full((B, H, T), 7.0, device=DEV)
+    do = K.gemm(dz, w, M, N, Kd, trans_b=True, rowdot=(o, delta, T))
+    assert torch.equal(do, K.gemm(dz, w, M, N, Kd, trans_b=True))
+    want = (do.float().view(B, T, H, 64) * o.float().view(B, T, H, 64)).sum(-1).permute(0, 2, 1)
+    assert float((delta - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # the attention backward fed with it
+    q, k, v = (rnd(B, T, N, dtype=torch.bfloat16, seed=40 + i).to(DEV) for i in range(3))
+    ctx, lse, _ = K.attention_fwd(q, k, v, H, 64)
+    outs = []
+    for given in (False, True):
+        dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+        dl = None
+        if given:
+            dl = torch.empty_like(lse)
+            K.gemm(dz, w, M, N, Kd, trans_b=True, rowdot=(ctx.view(M, N), dl, T))
+        K.attention_bwd(q, k, v, ctx, do.view(B, T, N), lse, dq, dk, dv, H, 64, delta=dl)
+        outs.append((dq, dk, dv))
+    for a, b_ in zip(*outs):
+        assert float((a.float() - b_.float()).abs().max()) <= 2e-2 * float(a.float().abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
