@@ -20,7 +20,7 @@ import time
 
 # before the HIP runtime initialises: enough hardware queues for compute + weight-gradient + communication + RCCL streams
 # (neurst_amd/__init__.py has the measurement; with the default of 4 two of them share a queue and serialise)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch  # noqa: E402
 
@@ -163,6 +163,9 @@ def cpu_baseline(args, T, F, L, V, timeout=150):
 
 
 def main():
+    if os.environ.get("NST_BENCH_HANG_DUMP_S"):   # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NST_BENCH_HANG_DUMP_S"]), exit=True)
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args.model, args.cpu_batch, args.frames, 80, max(1, args.frames // 12),
@@ -183,7 +186,7 @@ def main():
     rank, local_rank, world = init_distributed()
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    dev = f"cuda:{local_rank}"
+    dev = f"cuda:{torch.cuda.current_device()}"      # init_distributed pinned it (LOCAL_RANK)
     dtype = "bfloat16" if args.dtype == "bf16" else "float32"
     hp = get_hyper_parameters(args.model)
     if args.dropout is not None:
@@ -204,7 +207,8 @@ def main():
     opt.learning_rate = build_lr_schedule({"lr_schedule.class": hp["lr_schedule.class"],
                                            "lr_schedule.params": hp["lr_schedule.params"]})
     # NST_DIST_FORCE=1 (with one rank): run the exchange path -- buckets, communication stream, RCCL -- on a one-GPU box
-    reducer = GradientReducer(model.store, force=os.environ.get("NST_DIST_FORCE", "0") == "1")
+    reducer = GradientReducer(model.store, force=os.environ.get("NST_DIST_FORCE", "0") == "1",
+                              overlap=os.environ.get("NST_DIST_OVERLAP", "1") != "0")
     reducer.broadcast_parameters(0)
     step_fn = TrainStep(model, crit, opt, reducer, use_graph=args.graph)
     ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
@@ -223,8 +227,12 @@ def main():
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)
 
+    verbose = os.environ.get("NST_BENCH_VERBOSE", "0") == "1"
     for i in range(args.warmup):
         step_fn(batches[i % len(batches)])
+        if verbose:
+            torch.cuda.synchronize()
+            print(f"[bench] rank {rank}: warm-up step {i} done", file=sys.stderr, flush=True)
     barrier()
     t0 = time.perf_counter()
     loss = None
@@ -236,13 +244,17 @@ def main():
     # roofline pass (un-timed, after the measurement): the same steps with HIP events around every launch of the MFMA kernel
     # families, on the stream each launch goes to -- durations are therefore IN-STEP durations (the weight-gradient stream
     # shares the CUs with the dgrad chain), the same thing `rocprofv3 --kernel-trace --stats` of this command reports
+    # EVERY rank runs these steps (they contain the gradient exchange: a rank that skipped them would leave rank 0 alone in
+    # its all-reduce); only rank 0 records events
     probe = {}
-    if rank == 0 and args.roofline_steps > 0:
+    if args.roofline_steps > 0:
         step_fn.use_graph = False          # per-launch events need eager launches (same kernels, same streams)
-        K.PROBE.start(PROBED)
+        if rank == 0:
+            K.PROBE.start(PROBED)
         for i in range(args.roofline_steps):
             step_fn(batches[i % len(batches)])
-        probe = K.PROBE.stop()
+        if rank == 0:
+            probe = K.PROBE.stop()
     barrier()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

@@ -17,6 +17,7 @@ MI355X-first differences:
   * the 1/N of the average is folded into the fused Adam kernel instead of a separate scaling pass.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -30,7 +31,8 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        # (modulo: a control-flow rehearsal of N ranks on a box with fewer GPUs -- NST_DIST_BACKEND=gloo -- shares devices)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     # NST_DIST_FORCE=1: create the process group even for ONE rank (the collectives are then identities) -- lets a
     # single-GPU box run the whole exchange path (side stream, fences, RCCL itself), see tests/test_gpu_multi.py
     force = os.environ.get("NST_DIST_FORCE", "0") == "1"
@@ -38,19 +40,22 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("NST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         # rank 0 alone validates / writes checkpoints while the others wait in the next collective: the default
         # 10-minute watchdog would abort a long beam-search validation (NST_DIST_TIMEOUT_MIN overrides)
         import datetime
         timeout = datetime.timedelta(minutes=float(os.environ.get("NST_DIST_TIMEOUT_MIN", "180")))
         if backend == "nccl":
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     from neurst_amd.utils import compat
     compat.register_distributed_worker_setting(rank, world, "rccl" if world > 1 else None)
     return rank, local_rank, world
+
+
+_DEBUG = os.environ.get("NST_DIST_DEBUG", "0") == "1"   # trace every exchange on stderr
 
 
 class GradientReducer(object):
@@ -115,6 +120,8 @@ class GradientReducer(object):
             h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append(h)
             self.messages += 1
+            if _DEBUG:
+                print(f"[reducer r{dist.get_rank()}] issue #{self.messages} [{s}:{e})", file=sys.stderr, flush=True)
 
     def _issue(self, start, end):
         if not self.active or end <= start:
@@ -174,8 +181,10 @@ class GradientReducer(object):
 
     def wait_issued(self):
         """The current stream waits for every exchange issued so far."""
-        for h in self._pending:
+        for i, h in enumerate(self._pending):
             h.wait()
+            if _DEBUG:
+                print(f"[reducer r{dist.get_rank()}] waited {i + 1}/{len(self._pending)}", file=sys.stderr, flush=True)
         self._pending = []
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
