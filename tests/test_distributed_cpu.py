@@ -114,6 +114,44 @@ def test_single_process_reducer_is_identity():
     assert red.reduce_metrics({"x": 4.0}) == {"x": 4.0}
 
 
+def _forced_worker(port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", NST_DIST_FORCE="1")
+    sys.path.insert(0, ROOT)
+    from neurst_amd.runtime import ParamStore
+    from neurst_amd.training.distributed import GradientReducer, init_distributed
+    assert init_distributed(backend="gloo") == (0, 0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    st = ParamStore()
+    st.add("a/x", (5000,), torch.ones(5000))
+    st.add("b/y", (3000,), torch.ones(3000))
+    st.finalize("cpu", torch.float32)
+    st.grad.fill_(2.0)
+    plain = GradientReducer(st)                               # an initialised one-rank group alone changes nothing
+    forced = GradientReducer(st, bucket_bytes=4096, min_bucket_bytes=1024, force=True)
+    forced.component_ready(["b/"])
+    scale = forced.finish()
+    q.put((plain.active, forced.active, scale, forced.last_messages, float(st.grad.sum()), forced.reduce_metrics({"x": 4.0})))
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_the_exchange_path_as_identities():
+    """NST_DIST_FORCE=1: the process group exists for ONE rank and a reducer built with force=True issues its bucket
+    all-reduces for real (sum over one rank = identity, factor 1/1) -- how a one-GPU box exercises the exchange path
+    (tests/test_gpu_multi.py, bench.py).  Without force the reducer stays inactive even if a group is initialised."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    plain_active, forced_active, scale, messages, gsum, metrics = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert plain_active is False and forced_active is True and scale == 1.0
+    assert messages >= 8 and gsum == 2.0 * 8000 and metrics == {"x": 4.0}      # 32 KB of gradients in <= 4 KB messages
+
+
 def _bcast_worker(rank, world, port, q):
     import os
     import torch

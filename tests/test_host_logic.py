@@ -329,3 +329,24 @@ def test_example_to_input_matches_the_reference_methods():
                 assert np.array_equal(got[k.split(":")[1]].numpy(), z[k]), k
     assert deduce_text_length(torch.from_numpy(z["default_pad_ids"]), 0, compat.PaddingMode.DEFAULT).tolist() == \
         z["default_pad_lengths"].tolist()
+
+
+def test_weight_gradient_split_survives_the_library_rounding_and_pins_to_xcds():
+    """layers/common_layers._wgrad_split: the library re-derives the slice count as ceil(kt / ceil(kt / split)); gradients
+    with >= 8 tiles get a multiple of 8 that survives that rounding (the stream kernel then runs K slice z on XCD z % 8),
+    smaller ones keep a finer split; never more than kt / 8 slices."""
+    import torch
+    from neurst_amd.layers.common_layers import _wgrad_split
+    for rows in (9600, 28800, 115200, 1000):
+        for k_in, n_out in ((256, 256), (256, 768), (256, 2048), (2048, 256), (5120, 256), (256, 8008), (64, 128)):
+            for dtype in (torch.bfloat16, torch.float32):
+                split = _wgrad_split(rows, k_in, n_out, dtype)
+                bk = 64 if dtype == torch.bfloat16 else 32
+                kt = (rows + bk - 1) // bk
+                tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
+                assert 1 <= split <= max(1, kt // 8)
+                if tiles >= 8 and split >= 8:
+                    assert split % 8 == 0 and -(-kt // -(-kt // split)) == split, (rows, k_in, n_out, split)
+    assert _wgrad_split(28800, 256, 2048, torch.bfloat16) == 8          # FFN: 32 tiles x 8 slices = one slice per XCD
+    assert _wgrad_split(28800, 256, 768, torch.bfloat16) == 24
+    assert _wgrad_split(28800, 5120, 256, torch.bfloat16, units=512) == 6
