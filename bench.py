@@ -3,6 +3,7 @@
 (forward + label-smoothed CE + backward + gradient all-reduce + Adam) on synthetic MuST-C-shaped batches.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W      # no launcher environment: starts the N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -59,10 +60,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-stream-priority", type=int, default=int(os.environ.get("NST_MAIN_PRIORITY", "0")),
                     help="-1: run the step on a high-priority HIP stream (the weight-gradient stream keeps the default priority)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from captured HIP graphs (training/train_step.py graph mode) instead of eager launches; "
-                         "on ROCm 7.2 the graph executor overlaps the weight-gradient branch poorly (19.9 vs 17.9 ms/step on one "
-                         "MI355X, profiles/r02_graph_vs_eager.json), so eager is the default")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("NST_TRAIN_GRAPH", "1") != "0",
+                    help="replay the step from captured HIP graphs (training/train_step.py graph mode; the default since round 3: "
+                         "same step time as eager launches, ~1 ms instead of ~12 ms of host time per step)")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="eager launches instead of graph replay")
+    ap.add_argument("--wire", default=os.environ.get("NST_DIST_WIRE", "fp32"), choices=["fp32", "bf16", "fp16"],
+                    help="gradient dtype on the wire (16-bit: the reference's fp16 compression, training_utils.py:381-384)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="extra un-timed steps with per-launch HIP events (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -162,6 +165,26 @@ def cpu_baseline(args, T, F, L, V, timeout=150):
                 "sample": f"timed out after {timeout}s"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher environment: start the N ranks with torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1, a free port) and pass the command line through; rank 0 of the children prints the JSON
+    line on the inherited stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("NST_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} device(s) visible (RCCL needs one GPU per rank; "
+                         "NST_DIST_BACKEND=gloo runs the host-staged control-flow rehearsal on shared devices)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, NST_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     if os.environ.get("NST_BENCH_HANG_DUMP_S"):   # debugging aid: dump every thread's stack and exit if the run takes longer
         import faulthandler
@@ -171,6 +194,8 @@ def main():
         print(json.dumps(cpu_baseline_worker(args.model, args.cpu_batch, args.frames, 80, max(1, args.frames // 12),
                                              args.vocab)))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("NST_BENCH_CHILD") != "1":
+        sys.exit(self_launch(args))
     from neurst_amd import kernels as K
     from neurst_amd.criterions import build_criterion
     from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
@@ -208,7 +233,7 @@ def main():
                                            "lr_schedule.params": hp["lr_schedule.params"]})
     # NST_DIST_FORCE=1 (with one rank): run the exchange path -- buckets, communication stream, RCCL -- on a one-GPU box
     reducer = GradientReducer(model.store, force=os.environ.get("NST_DIST_FORCE", "0") == "1",
-                              overlap=os.environ.get("NST_DIST_OVERLAP", "1") != "0")
+                              overlap=os.environ.get("NST_DIST_OVERLAP", "1") != "0", wire_dtype=args.wire)
     reducer.broadcast_parameters(0)
     step_fn = TrainStep(model, crit, opt, reducer, use_graph=args.graph)
     ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
@@ -271,13 +296,20 @@ def main():
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     families = {}
     for name, rows in probe.items():
-        ms, work = sum(r[0] for r in rows), sum(r[1] for r in rows)
+        ms, work, nbytes = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows)
         families[name] = {"kernel": FAMILY_KERNELS.get(name, name), "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                           "launches_per_step": len(rows) / args.roofline_steps, "ms_per_step": ms / args.roofline_steps,
                           "avg_launch_ms": ms / max(len(rows), 1), "algorithmic_flops_per_step": work / args.roofline_steps,
                           "achieved": (work / (ms * 1e-3) / 1e12) if ms > 0 else None, "traffic": None}
         if families[name]["achieved"] is not None:
             families[name]["frac"] = families[name]["achieved"] / peak
+        if nbytes > 0 and ms > 0:
+            # the same launches against the HBM roof (d_model = 256 puts most of these GEMMs below the machine balance of
+            # 312 FLOP/B): algorithmic operand + output bytes per launch / its duration / 8 TB/s
+            families[name]["algorithmic_bytes_per_step"] = nbytes / args.roofline_steps
+            families[name]["arithmetic_intensity_flop_per_byte"] = work / nbytes
+            families[name]["hbm_bound"] = {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # the roofline object prices the family that takes the most GPU time in the step
     roofline = None
     if families:
@@ -322,6 +354,8 @@ def main():
         "host_issue_ms_per_step": t_issued / args.steps * 1e3,   # ~ ms_per_step means the host, not the GPU, paces the step
         "hip_graph": bool(args.graph), "graph_replays": getattr(step_fn, "replays", 0),
         "rccl_world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+        "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
+        "gradient_wire_dtype": args.wire,
         "exchange_path_active": bool(reducer.active),
         "reducer_messages_per_step": getattr(reducer, "last_messages", None),
     }

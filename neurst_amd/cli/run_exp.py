@@ -52,6 +52,13 @@ def _pre_load_args(args):
     return deep_merge_dict(deep_merge_dict(stored, layered), from_files)
 
 
+def _rank_device(local_rank):
+    """The device init_distributed() pinned for this rank (local_rank modulo the visible devices: a rehearsal of more ranks
+    than GPUs shares devices); CPU hosts keep the literal name so that the error is the usual "no ROCm device"."""
+    import torch
+    return f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else f"cuda:{local_rank}"
+
+
 def run_experiment(args, remaining_argv, device=None):
     """`device` is for the host-logic tests only (they install emulated kernels and pass "cpu"); the product always runs
     on this rank's GPU -- neurst_amd.kernels refuses anything else."""
@@ -59,7 +66,7 @@ def run_experiment(args, remaining_argv, device=None):
     flags_core.verbose_flags(FLAG_LIST, args, remaining_argv)
     task = build_task(args)
     custom_dataset = build_dataset(args)
-    model = task.build_model(args, device=device or f"cuda:{local_rank}", dtype=args["dtype"], seed=args["seed"] + rank)
+    model = task.build_model(args, device=device or _rank_device(local_rank), dtype=args["dtype"], seed=args["seed"] + rank)
     entry = build_exp(args, strategy=args["distribution_strategy"], model=model, task=task,
                       model_dir=args["model_dir"], custom_dataset=custom_dataset)
     if args.get("enable_check_numerics", None):

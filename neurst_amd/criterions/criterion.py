@@ -29,6 +29,12 @@ class Criterion(metaclass=ABCMeta):
     def reduce_sample_metrics(self, eval_res):
         raise NotImplementedError
 
+    def backward(self, loss_scale=1.0, loss_scale_dev=None):
+        """d(reduce_loss * loss_scale * loss_scale_dev)/d(model_out) of the last reduce_loss() call -- the explicit backward
+        the train step drives (no autograd tape).  loss_scale_dev: an extra factor held in a 1-element device tensor (the
+        dynamic loss scale of training/train_step.py); every criterion must accept it."""
+        raise NotImplementedError(f"{type(self).__name__} has no explicit backward")
+
     @abstractmethod
     def as_metric(self):
         raise NotImplementedError

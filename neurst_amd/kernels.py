@@ -68,11 +68,11 @@ class _KernelProbe(object):
         self.names, self.events = ((names,) if isinstance(names, str) else tuple(names)), []
 
     def stop(self):
-        """-> {name: [(milliseconds, work), ...]}"""
+        """-> {name: [(milliseconds, work, bytes), ...]}"""
         torch.cuda.synchronize()
         out = {}
-        for name, a, b, work in self.events:
-            out.setdefault(name, []).append((a.elapsed_time(b), work))
+        for name, a, b, work, nbytes in self.events:
+            out.setdefault(name, []).append((a.elapsed_time(b), work, nbytes))
         self.names, self.events = (), []
         return out
 
@@ -83,11 +83,12 @@ class _KernelProbe(object):
         ev.record(torch.cuda.current_stream())
         return (name, ev)
 
-    def end(self, tok, work=0.0):
+    def end(self, tok, work=0.0, nbytes=0.0):
+        """work: algorithmic FLOP of the launch; nbytes: its algorithmic HBM bytes (operands read once + outputs written once)."""
         if tok is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record(torch.cuda.current_stream())
-            self.events.append((tok[0], tok[1], e2, float(work)))
+            self.events.append((tok[0], tok[1], e2, float(work), float(nbytes)))
 
 
 PROBE = _KernelProbe()
@@ -287,7 +288,11 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
     check(lib.nst_gemm(C.byref(d), _p(A), _p(B), _p(out), _stream()), "gemm")
     if deferred and batch.jobs[batch.n].slabs:     # the library took the deferred path (it may decline: odd shapes)
         batch.n += 1
-    PROBE.end(ev, 2.0 * M * N * K)
+    if ev is not None:
+        esz, osz = A.element_size(), out.element_size()
+        nbytes = (M * K + K * N) * esz + M * N * osz * (2 if accumulate else 1)
+        nbytes += M * N * osz * ((residual is not None) + (gate_src is not None))
+        PROBE.end(ev, 2.0 * M * N * K, nbytes)
     return out
 
 

@@ -168,7 +168,8 @@ class TransformerDecoder(Decoder):
             if layers[i]._with_cross_attention:
                 first = False
             if layer_done is not None:
-                layer_done([layers[i].name + "/"])
+                extra = [self._output_norm_layer.name + "/"] if (i == len(layers) - 1 and self._output_norm_layer is not None) else []
+                layer_done([layers[i].name + "/"] + extra)    # output_ln rides with the top layer (see TransformerEncoder)
         dx = dropped_grad(self.rt, dx, self._p, self._site)
         if dmemory is not None and first:
             dmemory.zero_()

@@ -109,7 +109,10 @@ class TransformerEncoder(Encoder):
         for i in range(len(layers) - 1, -1, -1):
             dx = layers[i].backward(dx, consumer=layers[i - 1].first_backward_site if i > 0 else self)
             if layer_done is not None:
-                layer_done([layers[i].name + "/"])
+                # output_ln is registered right behind the top layer: it travels with that layer's report (alone it would
+                # be a 2 KB all-reduce of its own when the reducer sweeps up what no report covered)
+                extra = [self._output_norm_layer.name + "/"] if (i == len(layers) - 1 and self._output_norm_layer is not None) else []
+                layer_done([layers[i].name + "/"] + extra)
         dx = dropped_grad(self.rt, dx, self._p, self._site)
         return dx.view(B, T, d)
 

@@ -262,7 +262,7 @@ class Runtime(object):
         closed (capture)."""
         self.flush_wgrads()
         if self.capture is not None:
-            self.capture.layer_boundary()
+            self.capture.layer_boundary(report=True)
 
     def sublayer_boundary(self):
         """Capture only: the weight-gradient calls recorded so far may start now (their graph is launched on the

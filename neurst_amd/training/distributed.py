@@ -14,7 +14,16 @@ MI355X-first differences:
     keeps the compute stream busy; the side stream -- not the compute stream -- waits for the weight-gradient stream;
   * slices are cut into <= bucket_bytes pieces (default 32 MiB): on the fully connected 8-GPU xGMI mesh a ring is
     bound by one ~153 GB/s link, so few large messages beat many small ones;
-  * the 1/N of the average is folded into the fused Adam kernel instead of a separate scaling pass.
+  * the 1/N of the average is folded into the fused Adam kernel instead of a separate scaling pass;
+  * optional 16-bit wire (wire_dtype="bf16" / NST_DIST_WIRE=bf16): the reference casts gradients to fp16 on the wire in fp16
+    mode (neurst/training/training_utils.py:381-384, hvd.Compression.fp16); here a slice is cast to bf16 into a staging
+    buffer on the communication stream, all-reduced at half the bytes and added back as fp32.
+
+Rehearsal mode (NOT the product path): NST_DIST_BACKEND=gloo with device tensors runs the same control flow -- hooks,
+bucket order, finish(), 1/N -- on a box with fewer GPUs than ranks; the exchange is then staged through the host
+(synchronise, copy the slice out, CPU all-reduce, copy back), because gloo's own device path takes a fresh pool stream per
+collective and two ranks that share ONE device can close a cross-process wait cycle on its hardware queues (round 2:
+the kept rehearsal logs hang in the third step).
 """
 import os
 import sys
@@ -65,7 +74,7 @@ class GradientReducer(object):
     back-propagate, instead of one 63 MiB exchange after the whole encoder."""
 
     def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True, min_bucket_bytes=8 << 20, extra_streams=(),
-                 force=False):
+                 force=False, wire_dtype=None):
         self.store, self.group = store, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # exchanges are issued when there is someone to exchange with -- or on request with an initialised one-rank group
@@ -73,7 +82,15 @@ class GradientReducer(object):
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.min_elems = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.on_gpu = store.grad.is_cuda
-        self.overlap = overlap and self.on_gpu and self.active
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        # gloo over device tensors = the N-rank rehearsal on fewer GPUs (module docstring): host-staged, synchronous
+        self.host_staged = bool(self.active and self.on_gpu and backend == "gloo")
+        self.overlap = overlap and self.on_gpu and self.active and not self.host_staged
+        wire = wire_dtype if wire_dtype is not None else os.environ.get("NST_DIST_WIRE", "fp32")
+        wire = {"fp32": None, "float32": None, None: None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+                "fp16": torch.float16, "float16": torch.float16}[wire]
+        self.wire_dtype = wire
+        self._wire_buf = None
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
         # streams (besides the current one) whose queued work writes gradients: the exchange waits for them on the
         # COMMUNICATION stream, so the compute streams never stall for a bucket
@@ -117,11 +134,31 @@ class GradientReducer(object):
         g = self.store.grad
         for s in range(start, end, self.bucket_elems):
             e = min(end, s + self.bucket_elems)
-            h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append(h)
             self.messages += 1
             if _DEBUG:
                 print(f"[reducer r{dist.get_rank()}] issue #{self.messages} [{s}:{e})", file=sys.stderr, flush=True)
+            if self.host_staged:            # rehearsal on a shared device: no device-side waits between processes
+                torch.cuda.synchronize(g.device)
+                host = g[s:e].cpu()
+                if self.wire_dtype is not None:
+                    host = host.to(self.wire_dtype).float()      # gloo reduces fp32; the wire rounding is still rehearsed
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                g[s:e].copy_(host)
+                continue
+            if self.wire_dtype is not None:
+                # 16-bit wire: the staging buffer is as long as the gradient buffer, so every in-flight message owns its own
+                # region (no reuse hazard between asynchronous collectives); the add-back is queued on the same stream
+                # behind the collective (Work.wait() orders the current stream after it without blocking the host)
+                if self._wire_buf is None or self._wire_buf.dtype != self.wire_dtype:
+                    self._wire_buf = torch.empty(self.store.total, dtype=self.wire_dtype, device=g.device)
+                w = self._wire_buf[s:e]
+                w.copy_(g[s:e])
+                h = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h.wait()
+                g[s:e].copy_(w)
+                continue
+            h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append(h)
 
     def _issue(self, start, end):
         if not self.active or end <= start:

@@ -17,6 +17,7 @@ exchange still overlaps the rest of the backward pass (no collective is captured
 runs eagerly (allocations, lazy tables), the second captures and replays, later ones only replay.
 """
 import os
+import warnings
 
 import torch
 
@@ -55,7 +56,16 @@ class _StepCapture(object):
     def _close(self):
         """Ends the compute graph of the current segment and captures its weight-gradient graph from the recorded calls."""
         seg = self.cur
-        seg.main.capture_end()
+        # a segment that only carries deferred weight-gradient calls (a join or a bucket cut right behind another cut) has
+        # no compute-stream node: torch warns "The CUDA Graph is empty" -- such a graph is dropped instead of replayed
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            seg.main.capture_end()
+        if any("Graph is empty" in str(w.message) for w in caught):
+            seg.main = None
+        else:
+            for w in caught:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         if self.deferred:
             calls, self.deferred = self.deferred, []
             self.side_stream.wait_stream(self.main_stream)
@@ -80,18 +90,24 @@ class _StepCapture(object):
         self.deferred.append(fn)
         self.keep.extend(tensors)      # their memory must not be handed out again inside this capture (the graphs run concurrently)
 
-    def layer_boundary(self):
+    def layer_boundary(self, report=False):
+        """report=True: the boundary of a gradient REPORT (Runtime.wgrad_boundary: everything that writes the layer's
+        gradients is queued, the reducer's hook fires next).  Only then may the bucket that follows ride on the segment
+        closed here (`_fresh`); a mid-layer boundary (sublayer_boundary) is followed by more compute-stream work of the
+        same layer (LayerNorm backward, bias gradients), so a bucket reported after it must cut the capture again."""
         # a cut costs two graph launches (~10-20 us of idle compute stream each); waiting for a few weight-gradient calls
         # trades that against a later start of the weight-gradient graph (NST_GRAPH_MIN_DEFERRED, measured in DESIGN 5b)
+        self._fresh = False
         if len(self.deferred) >= self.min_deferred:
             self._close()
             self.begin()
-            self._fresh = True
+            self._fresh = bool(report)
 
     def join(self):
         seg = self._close()
         seg.join = True
         self.begin()
+        self._fresh = False
 
     def cut_for_bucket(self, start, stop):
         # the model reports a layer right after its boundary: the bucket then belongs to the segment just closed (every writer
@@ -127,7 +143,13 @@ class TrainStep(object):
         self.loss_scale = None
         if loss_scale:
             if self.clip_value or self.clip_norm:
+                # the clip kernel takes its pre-scale by value; un-scaling by the device-resident loss scale in front of it
+                # is not built (the path computes in bf16, which needs no loss scale) -- refused here, not at the first step
                 raise NotImplementedError("loss scaling together with gradient clipping")
+            import inspect
+            if "loss_scale_dev" not in inspect.signature(criterion.backward).parameters:
+                raise TypeError(f"{type(criterion).__name__}.backward() must accept loss_scale_dev for dynamic loss scaling "
+                                "(see Criterion.backward)")
             cfg = dict(initial_loss_scale=2.0 ** 15, growth_steps=2000, multiplier=2.0)
             if isinstance(loss_scale, dict):
                 cfg.update(loss_scale)
@@ -218,10 +240,12 @@ class TrainStep(object):
         cur = torch.cuda.current_stream(rt.device)
         nb = sum(len(sg.buckets) for sg in cap.segments)
         last = len(cap.segments) - 1
+        msgs0 = red.messages if red is not None else 0
         for i, sg in enumerate(cap.segments):
             if i == last and nb:
                 red.wait_issued()              # every bucket has been exchanged before clip / Adam
-            sg.main.replay()
+            if sg.main is not None:
+                sg.main.replay()
             if sg.wgrad is not None:           # the layer's weight gradients, next to the following layers' backward
                 rt.wgrad_stream.wait_stream(cur)
                 with torch.cuda.stream(rt.wgrad_stream):
@@ -230,8 +254,8 @@ class TrainStep(object):
                 cur.wait_stream(rt.wgrad_stream)
             for bucket in sg.buckets:
                 red.issue(*bucket)
-        if red is not None:
-            red.last_messages = nb
+        if red is not None:     # collectives of THIS replay (a bucket is cut into <= bucket_bytes messages); finish() is not
+            red.last_messages, red.messages = red.messages - msgs0, 0   # called on replays, so the counter is reset here
         self.optimizer.advance()
         rt.advance_step(enqueue=False)   # the increment of the device counter is the graph's last node
         self.replays += 1

@@ -189,3 +189,65 @@ def test_resume_state_is_broadcast_world2_gloo():
         p.join(timeout=60)
     for rank, master, m, v, start in out:
         assert master == [0.0] * 8 and m == [3.0] * 5 and v == [7.0] * 5 and start == 40.0
+
+
+def _wire_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from neurst_amd.models import build_model
+    from neurst_amd.training.distributed import GradientReducer, init_distributed
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    init_distributed(backend="gloo")
+    hp = get_hyper_parameters("speech_transformer_toy")
+    model = build_model(hp, {"audio_feature_dim": 16, "audio_feature_channels": 1},
+                        {"vocab_size": 11, "eos_id": 10, "bos_id": 9, "unk_id": 8}, device="cpu", dtype="float32", init_seed=1)
+    st = model.store
+    g = torch.Generator().manual_seed(5 + rank)
+    mine = torch.randn(st.total, generator=g)
+    others = [torch.randn(st.total, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+    # (a) 16-bit wire: every rank's slice is rounded to bf16, summed in bf16 by the collective, widened again
+    red = GradientReducer(st, bucket_bytes=4096, wire_dtype="bf16")
+    st.grad.copy_(mine)
+    issued = []
+    orig = red._allreduce_slice
+    red._allreduce_slice = lambda s, e: (issued.append((s, e)), orig(s, e))[1]
+    # the model's own report order (EncoderDecoderModel.backward): the top layer carries output_ln
+    for i in (1, 0):
+        red.component_ready([f"TransformerDecoder/layer_{i}/"] + (["TransformerDecoder/output_ln/"] if i == 1 else []))
+    red.component_ready(["TransformerDecoder/"])
+    red.component_ready(["target_symbol_modality/"])
+    for i in (1, 0):
+        red.component_ready([f"TransformerEncoder/layer_{i}/"] + (["TransformerEncoder/output_ln/"] if i == 1 else []))
+    red.component_ready(["TransformerEncoder/"])
+    scale = red.finish()
+    acc = others[0].to(torch.bfloat16)
+    for o in others[1:]:
+        acc = acc + o.to(torch.bfloat16)          # bf16 + bf16 -> bf16, like the collective's reduction
+    ok_wire = torch.equal(st.grad, acc.float())
+    exact = sum(others)
+    rel = float((st.grad - exact).norm() / exact.norm())
+    # (b) no slice of a few hundred elements travels alone: output_ln was part of its top layer's report
+    ln = [red.range_of([f"{s}/output_ln/"]) for s in ("TransformerDecoder", "TransformerEncoder")]
+    alone = [r for r in issued if r in ln]
+    q.put((rank, ok_wire, rel, scale, alone, len(issued)))
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_and_no_standalone_output_ln_message_world2_gloo():
+    """16-bit gradient wire (the reference's fp16 compression, neurst/training/training_utils.py:381-384) and the report
+    layout that keeps the 2 KB output_ln slices inside their top layer's message."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_wire, rel, scale, alone, n in res:
+        assert ok_wire, "the 16-bit wire must carry bf16-rounded slices and widen the bf16 sum"
+        assert rel < 1e-2 and scale == 0.5
+        assert alone == [] and n >= 4

@@ -162,7 +162,10 @@ def test_post_norm_and_untied_softmax_host_schedule(cpu_kernels, variant):
         from neurst_amd.training.distributed import GradientReducer
         comp = ["TransformerDecoder/", "softmax_linear/"]
         n_dec = len(model._decoder._stacking_layers)    # per-layer reports first (last layer first), then the component
-        assert fired[:n_dec] == [[f"TransformerDecoder/layer_{i}/"] for i in range(n_dec - 1, -1, -1)] and fired[n_dec] == comp
+        # (the top layer's report carries output_ln, which is registered right behind it)
+        want = [[f"TransformerDecoder/layer_{i}/"] + (["TransformerDecoder/output_ln/"] if i == n_dec - 1 and model._decoder._output_norm_layer is not None else [])
+                for i in range(n_dec - 1, -1, -1)]
+        assert fired[:n_dec] == want and fired[n_dec] == comp
         s, e = GradientReducer(model.store).range_of(comp)
         inside = [p for p in model.store.params.values() if s <= p.offset < e]
         assert all(p.name.startswith(("TransformerDecoder/", "softmax_linear/")) for p in inside)
