@@ -99,6 +99,46 @@ def test_ffn_backward(M, F, with_residual):
     assert rel(dh, dh_g.float().cpu()) <= 1e-2
 
 
+def test_ffn_pair_at_the_benchmark_shape():
+    """The shape and the kernel variants bench.py times: 28 800 rows x 2048 hidden units, 128-row workgroups on full tiles
+    (ffn_pair_kernel<fwd, 4, dropout on both sites, full> and <bwd, 4, full>).  Forward without dropout and the backward
+    against float64; with dropout the masks must equal the stream-GEMM path's masks for the same (seed, site) -- that path
+    is pinned on the Philox restatement at the smaller sizes above -- and the values its outputs."""
+    from neurst_amd import kernels as K
+    M, F = 28800, 2048
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=99)
+    xd, rd = x.to(DEV), res.to(DEV)
+    w1d, w2d, b1d, b2d = w1.to(DEV), w2.to(DEV), b1.to(DEV), b2.to(DEV)
+    w1t, w2t = w1.t().contiguous().to(DEV), w2.t().contiguous().to(DEV)
+    y, h = K.ffn_fwd(xd, w1t, b1d, w2t, b2d, residual=rd)
+    h_ref = (x.double() @ w1.double() + b1.double()).clamp_min(0)
+    assert rel(h, h_ref) <= 1e-2
+    y_ref = h.float().cpu().double() @ w2.double() + b2.double() + res.double()
+    assert rel(y, y_ref) <= 1e-2
+    del h_ref, y_ref
+    p1, p2, seed, s1, s2 = 0.1, 0.1, 24681357, 21, 22
+    yd, hd = K.ffn_fwd(xd, w1t, b1d, w2t, b2d, residual=rd, hidden_p=p1, hidden_seed=seed, hidden_site=s1, out_p=p2,
+                       out_seed=seed, out_site=s2)
+    h_g = K.gemm(xd, w1d, M, F, 256, bias=b1d, relu=True, dropout_p=p1, seed=seed, stream_id=s1)
+    # a unit is zero where it was dropped or where its pre-activation is negative -- on both paths alike, up to the sign of
+    # pre-activations within bf16 rounding of zero
+    differ = int(((h_g != 0) != (hd != 0)).sum())
+    assert differ <= 1e-5 * M * F, f"{differ} hidden units differ in their zero pattern"
+    assert rel(hd, h_g.float().cpu()) <= 1e-2
+    y_g = K.gemm(hd, w2d, M, 256, F, bias=b2d, dropout_p=p2, seed=seed, stream_id=s2, residual=rd)
+    assert rel(yd, y_g.float().cpu()) <= 1e-2
+    keep = abs(float((hd != 0).float().mean()) / max(float((h != 0).float().mean()), 1e-9) - (1.0 - p1))
+    assert keep < 5e-3, "hidden keep rate"
+    # backward on the saved (dropped) hidden tile
+    dy = rnd(M, 256, seed=5).to(DEV)
+    dx, dh = K.ffn_bwd(dy, hd, w2d, w1d, hidden_p=p1, residual=rd)
+    gate = torch.where(hd.cpu() > 0, K.dropout_inv_keep(p1), 0.0).double()
+    dh_ref = (dy.cpu().double() @ w2.double().t()) * gate
+    assert rel(dh, dh_ref) <= 1e-2
+    dx_ref = dh.float().cpu().double() @ w1.double().t() + res.double()
+    assert rel(dx, dx_ref) <= 1e-2
+
+
 def test_transposed_weight_copies_follow_the_optimizer():
     """The forward reads transposed bf16 copies of the two FFN kernels: they must equal the bf16 shadow transposed after
     construction, after a state-dict load and after every optimizer step."""

@@ -123,3 +123,60 @@ def test_graph_capture_is_cut_where_the_reducer_issues_buckets():
     assert sum(1 for sg in cap.segments if sg.wgrad is not None) >= 4             # weight gradients in graphs of their own
     assert max(abs(a - b) for a, b in zip(out[False][0], out[True][0])) < 1e-5
     assert float(((out[False][1] - out[True][1]).abs() * _solid(out[False][3])).max()) < 2e-5
+
+
+def test_graph_replay_at_the_benchmark_configuration():
+    """bench.py replays the step from HIP graphs by default: speech_transformer_s itself (12 + 6 layers, d = 256, V = 8008,
+    dropout 0.1, bf16) at 80 x 900 frames -- 18 000 encoder rows, i.e. the one-launch feed-forward pair, the conv2 patch
+    kernels, batched split-K second stages -- through a reducer that behaves like world_size 2.  Graph replay must follow the
+    eager run (same masks: the step counter is a device scalar), cut the capture at the same buckets, and no captured
+    segment may be an empty graph."""
+    import warnings
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
+    from neurst_amd.optimizers import build_lr_schedule, build_optimizer
+    from neurst_amd.tasks import build_task
+    from neurst_amd.training.distributed import GradientReducer
+    from neurst_amd.training.train_step import TrainStep
+    from neurst_amd.utils import compat
+    from neurst_amd.utils.hparams_sets import get_hyper_parameters
+    B, T, F, V = 80, 900, 80, 8008
+    L = T // 12
+    hp = get_hyper_parameters("speech_transformer_s")
+    task = build_task({"task.class": "speech2text", "task.params": {"audio_feature_dim": F, "vocab_size": V}})
+    ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,
+                                 "ragged": True, "seed": 4321})
+    it = ds.build_iterator(map_func=lambda b: task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=0, total_shards=1,
+                           device=DEV)
+    batches = [next(it) for _ in range(2)]
+    out, logs = {}, {}
+    for use_graph in (False, True):
+        log = logs[use_graph] = []
+        model = task.build_model(hp, device=DEV, dtype="bfloat16", seed=99, init_seed=42)
+        crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+        opt = build_optimizer({"optimizer.class": hp["optimizer.class"], "optimizer.params": hp["optimizer.params"]})
+        opt.bind(model.store)
+        opt.learning_rate = build_lr_schedule({"lr_schedule.class": hp["lr_schedule.class"],
+                                               "lr_schedule.params": hp["lr_schedule.params"]})
+        red = GradientReducer(model.store)
+        red.world, red.active, red.overlap = 2, True, False
+        red.issue = lambda s, e, log=log: log.append((s, e))
+        step = TrainStep(model, crit, opt, red, use_graph=use_graph)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            losses = [float(step(batches[i % 2])) for i in range(5)]
+            torch.cuda.synchronize()
+        assert not [w for w in caught if "Graph is empty" in str(w.message)], "an empty graph segment was captured"
+        out[use_graph] = (losses, model.store.master.clone(), opt.v.clone(), step)
+        del model, opt, step
+    (le, we, ve, _), (lg, wg, _, gstep) = out[False], out[True]
+    assert gstep.replays == 4 and len(gstep._captured) == 1
+    per_step = len(logs[False]) // 5
+    assert per_step >= 8 and logs[True] == logs[False]                      # the same >= 8 MiB buckets, in the same order
+    assert all((e - s) * 4 >= (1 << 20) for s, e in logs[False]), "a bucket of less than 1 MiB travels alone"
+    cap = next(iter(gstep._captured.values()))
+    assert all(sg.main is not None or sg.wgrad is not None for sg in cap.segments)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
+    d = (we - wg).abs() * _solid(ve, 1e-4)
+    assert float((d > 1e-3).float().mean()) < 1e-3, float(d.max())

@@ -628,6 +628,35 @@ def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
         close(f"conv2_patch[B{B}T{T1}F{F1}].db2", db2, dy.double().sum((0, 1, 2)), torch.float32)
 
 
+def test_conv2_kernels_at_the_benchmark_grid(K):
+    """The conv2 kernels at the grid bench.py times (B = 128, T1 = 450, F1 = 40, C = 256: 576 000 output pixels, 4 500 patch
+    workgroups, the 56-slice XCD-pinned wide weight gradient).  A float64 convolution of this size takes minutes on the
+    host, so the reference here is the library's own exact-fp32 path (implicit GEMM on v_mfma_f32_16x16x4_f32), which the
+    cases above pin on float64 autograd at every smaller grid; bf16 tolerance 1e-2 relative to the tensor's magnitude."""
+    B, T1, F1, C = 128, 450, 40, 256
+    bf = torch.bfloat16
+    x = rnd(B, T1, F1, C, dtype=bf, seed=21).to(DEV)
+    w2 = (rnd(3, 3, C, C, seed=22) * (1.0 / math.sqrt(9 * C))).to(bf).to(DEV)
+    b2 = (rnd(C, seed=23) * 0.1).to(DEV)
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    dy = rnd(B, T2, F2, C, dtype=bf, seed=24).to(DEV)
+    y = K.conv2_fwd(x, w2, b2)
+    y32 = K.conv2_fwd(x.float(), w2.float(), b2)
+    close("conv2_bench_grid.y", y, y32.cpu(), bf)
+    del y, y32
+    dx = K.conv2_dgrad(dy, w2, T1, F1)
+    dx32 = K.conv2_dgrad(dy.float(), w2.float(), T1, F1)
+    close("conv2_bench_grid.dx", dx, dx32.cpu(), bf, scale=2.0)
+    del dx, dx32
+    dw, db = torch.zeros(3, 3, C, C, device=DEV), torch.zeros(C, device=DEV)
+    dw32, db32 = torch.zeros(3, 3, C, C, device=DEV), torch.zeros(C, device=DEV)
+    K.conv2_wgrad(x, dy, dw, db2=db)
+    K.conv2_wgrad(x.float(), dy.float(), dw32, db2=db32)
+    close("conv2_bench_grid.dw2", dw, dw32.cpu(), bf, scale=2.0)
+    close("conv2_bench_grid.db2", db, db32.cpu(), torch.float32)
+    close("conv2_bench_grid.db2_vs_sum", db, dy.float().sum((0, 1, 2)).cpu(), torch.float32)
+
+
 # ------------------------------------------------------------------------------------------------ embedding / elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_embedding(K, dtype):

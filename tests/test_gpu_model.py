@@ -156,7 +156,7 @@ def test_frontend_matches_reference_neurst_pt_hip(tag):
 
 
 # ------------------------------------------------------------------------------------------------ model fwd/bwd vs oracle
-def _speech_case(name, dtype, **extra):
+def _speech_case(name, dtype, device=None, batch=None, **extra):
     cases = {
         # d, H, enc, dec, ffn, C, B, T, F, L, V, ragged
         "toy": (8, 2, 2, 2, 10, 5, 2, 11, 80, 3, 5, False),
@@ -167,6 +167,8 @@ def _speech_case(name, dtype, **extra):
         "s_real": (256, 4, 12, 6, 2048, 256, 3, 900, 80, 75, 8008, True),
     }
     d, H, ne, nd, ffn, C, B, T, F, L, V, ragged = cases[name]
+    if batch is not None:
+        B, ragged = batch, False
     from neurst_amd.models import build_model
     from neurst_amd.utils.hparams_sets import get_hyper_parameters
     hp = get_hyper_parameters("speech_transformer_toy")
@@ -180,7 +182,7 @@ def _speech_case(name, dtype, **extra):
     p.update(extra)
     model = build_model({"model.class": "SpeechTransformer", "model.params": p},
                         {"audio_feature_dim": F, "audio_feature_channels": 1},
-                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=DEV, dtype=dtype,
+                        {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device=device or DEV, dtype=dtype,
                         init_seed=3)
     g = torch.Generator().manual_seed(11)
     # non-trivial biases / LN affine so every gradient path is exercised
@@ -243,7 +245,9 @@ def test_speech_transformer_forward_backward(case, dtype):
         REPORT[f"{tag}.grad.{n}"] = e_max if dtype == "float32" else e_l2
         e = e_max if dtype == "float32" else e_l2
         worst = max(worst, e)
-        if not (e <= (2e-3 if dtype == "float32" else 0.25)):
+        # bf16: 1.5 x the worst per-tensor error measured on these small cases (8.3e-2, profiles/r01_model_parity_report.json;
+        # few rows, so single ReLU-gate flips weigh most here)
+        if not (e <= (2e-3 if dtype == "float32" else 0.125)):
             bad.append((n, e))
     glob = math.sqrt(num / max(den, 1e-30))
     REPORT[tag + ".grad_worst"] = worst
@@ -322,6 +326,167 @@ def test_speech_transformer_s_real_configuration_parity(dtype):
     assert own[2] <= 3e-2, f"global gradient rel-L2 vs the oracle {own[2]:.3e}"
     # with the discrete gate flips taken out, the bf16 path meets the north-star tolerance on the whole gradient
     assert gated[2] <= 1e-2 and gated[0] <= 1e-2, (gated, own)
+
+
+def _grad_errors(grads, grads_ref):
+    """-> ({name: rel-L2 error}, global rel-L2 error) of a dict of gradients against a reference dict."""
+    per, num, den = {}, 0.0, 0.0
+    for n, g in grads.items():
+        g, r = g.detach().float().cpu().double(), grads_ref[n].detach().double().cpu()
+        per[n] = float((g - r).norm() / max(float(r.norm()), 1e-12))
+        num += float(((g - r) ** 2).sum())
+        den += float((r ** 2).sum())
+    return per, math.sqrt(num / max(den, 1e-30))
+
+
+def s_real_bf16_noise_report(tag):
+    """Runs the real speech_transformer_s configuration in bf16 through the HIP path, the float64 oracle, and the float64
+    EMULATION of every C-ABI contract (oracle/kernel_emulation.py: the same layer classes, the same bf16 rounding points
+    between kernels, exact arithmetic inside them), all on the same weights and batch.  The emulation's distance from the
+    oracle is what rounding activations to bf16 at those points costs with perfect kernels -- any quantised path decorrelates
+    from the exact one to that level within a few stages (two emulations that differ only in fp32 vs fp64 accumulation end
+    2.2e-2 apart on the gradients) -- so the assertable statement about the KERNELS is that the HIP path is no farther from
+    the oracle than the emulation is, tensor by tensor.  Returns the report dict (also merged into REPORT)."""
+    import pytest as _pytest
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    from oracle import kernel_emulation as E
+    model, inputs, cfg = _speech_case("s_real", "bfloat16")
+    W = {n: p.data.detach().cpu().clone() for n, p in model.store.params.items()}
+    for n, p in model.store.params.items():
+        if n.endswith("/kernel") and "conv1" not in n or n.endswith("shared/weights"):
+            W[n] = p.compute.detach().float().cpu()
+    state = {n: p.data.detach().cpu().clone() for n, p in model.store.params.items()}
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    loss = float(crit.reduce_loss(dinp, logits))
+    import neurst_amd.layers.common_layers as CL
+    ffn0 = model._encoder._stacking_layers[0]._ffn_layer.layer
+    rows0 = ffn0._saved[1].shape[0]
+    fused = {"rows": rows0, "one_launch_pair": bool(ffn0.fused and rows0 >= CL._FFN_FUSED_MIN_ROWS and CL._FFN_FUSED_BWD),
+             "NST_FFN_NW": os.environ.get("NST_FFN_NW", "")}
+    model.backward(crit.backward())
+    torch.cuda.synchronize()
+    logits_hip = logits.float().cpu()
+    grads_hip = {n: p.grad.detach().float().cpu().clone() for n, p in model.store.params.items()}
+    del model, logits
+    loss_ref, logits_ref, grads_ref = O.train_step_reference({k: v.double() for k, v in W.items()},
+                                                             {k: (v.double() if v.is_floating_point() else v)
+                                                              for k, v in inputs.items()}, cfg, 0.1)
+    # the emulation: same classes on CPU tensors with the kernels module swapped (restored below)
+    mp = _pytest.MonkeyPatch()
+    try:
+        E.install(mp)
+        emu, _, _ = _speech_case("s_real", "bfloat16", device="cpu")
+        emu.store.load_state_dict(state)
+        crit2 = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+        lg = emu(inputs, is_training=True)
+        loss_emu = float(crit2.reduce_loss(inputs, lg))
+        emu.backward(crit2.backward())
+        logits_emu = lg.float()
+        grads_emu = {n: p.grad.detach().float().clone() for n, p in emu.store.params.items()}
+    finally:
+        mp.undo()
+    e_hip, g_hip = _grad_errors(grads_hip, grads_ref)
+    e_emu, g_emu = _grad_errors(grads_emu, grads_ref)
+    ratio = {n: e_hip[n] / max(e_emu[n], 1e-12) for n in e_hip}
+    worst_n = max(ratio, key=ratio.get)
+    rep = {"logits_hip": rel_err(logits_hip, logits_ref), "logits_emulation": rel_err(logits_emu, logits_ref),
+           "loss_hip_abs_err": abs(loss - float(loss_ref)), "loss_emulation_abs_err": abs(loss_emu - float(loss_ref)),
+           "grad_global_hip": g_hip, "grad_global_emulation": g_emu,
+           "grad_worst_hip": max(e_hip.values()), "grad_worst_emulation": max(e_emu.values()),
+           "ratio_median": float(np.median(list(ratio.values()))), "ratio_max": ratio[worst_n], "ratio_max_tensor": worst_n,
+           "tensors": len(ratio), "tensors_above_1e-2_hip": sum(v > 1e-2 for v in e_hip.values()),
+           "tensors_above_1e-2_emulation": sum(v > 1e-2 for v in e_emu.values()), "first_encoder_ffn": fused}
+    for k, v in rep.items():
+        REPORT[f"{tag}.{k}"] = v
+    return rep, e_hip, e_emu
+
+
+def _assert_bf16_noise_level(rep, e_hip, e_emu):
+    # loss / logits: the north-star bf16 bar
+    assert rep["logits_hip"] <= 1e-2 and rep["loss_hip_abs_err"] <= 1e-2, rep
+    # gradients: tensor by tensor no farther from the oracle than exact kernels with the same rounding points (measured in
+    # round 2 on this case: ratio 0.74 .. 1.65, median 0.93); the small absolute term covers tensors whose emulation error
+    # happens to be tiny
+    bad = {n: (e_hip[n], e_emu[n]) for n in e_hip if e_hip[n] > 2.0 * e_emu[n] + 2e-3}
+    assert not bad, f"{len(bad)} gradient tensors farther from the oracle than bf16 rounding explains: {list(bad.items())[:6]}"
+    assert 0.6 <= rep["ratio_median"] <= 1.3, rep
+    assert rep["grad_global_hip"] <= 1.3 * rep["grad_global_emulation"] + 1e-3, rep
+    # 1.5 x the worst per-tensor error measured on this case (6.5e-2, profiles/r02_model_parity_report.json)
+    assert rep["grad_worst_hip"] <= 0.1, rep
+
+
+def test_speech_transformer_s_bf16_gradient_error_is_rounding_noise():
+    """bf16 gradients of the real configuration: per tensor within 2x of the float64 emulation's distance from the oracle."""
+    rep, e_hip, e_emu = s_real_bf16_noise_report("st[s_real,bfloat16].noise")
+    assert rep["first_encoder_ffn"]["one_launch_pair"] is False      # 675 rows: the two-GEMM feed-forward
+    _assert_bf16_noise_level(rep, e_hip, e_emu)
+
+
+def test_speech_transformer_s_parity_with_the_benchmark_kernel_selection():
+    """The same comparison with the kernel selection bench.py runs with forced at the small batch: the one-launch feed-forward
+    pair (engaged from 16 384 rows on, i.e. never at B = 3) with 128-row workgroups, in forward and backward.  The switches are
+    read once per process, so the case runs in a child interpreter."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NST_FFN_MIN_ROWS="1", NST_FFN_NW="4", NST_FFN_FUSED="1", NST_FFN_FUSED_BWD="1")
+    code = ("import json, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_model as T\n"
+            "rep, e_hip, e_emu = T.s_real_bf16_noise_report('child')\n"
+            "print('REPORT ' + json.dumps({'rep': rep, 'e_hip': e_hip, 'e_emu': e_emu}))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("REPORT ")][-1]
+    got = json.loads(line[len("REPORT "):])
+    rep, e_hip, e_emu = got["rep"], got["e_hip"], got["e_emu"]
+    for k, v in rep.items():
+        REPORT[f"st[s_real,bfloat16].bench_selection.{k}"] = v
+    assert rep["first_encoder_ffn"] == {"rows": 675, "one_launch_pair": True, "NST_FFN_NW": "4"}, rep["first_encoder_ffn"]
+    _assert_bf16_noise_level(rep, e_hip, e_emu)
+
+
+def test_benchmark_shape_bf16_step_against_the_fp32_hip_path():
+    """B = 128 x 900 frames, the batch bench.py times -- fused feed-forward on full 128-row tiles, 4 500-workgroup conv2 patch
+    grids, 256-unit XCD-pinned split-K weight gradients -- in bf16 against the exact-fp32 HIP path on the same batch and the
+    same (bf16-rounded) weights.  The fp32 path is pinned on the float64 oracle at 8e-6 (real configuration, B = 3); a float64
+    oracle run of this batch would take the better part of an hour on the host.  Bounds: the bf16 rounding-noise level measured
+    against the oracle at B = 3 (loss / logits: north-star 1e-2)."""
+    from neurst_amd.criterions import build_criterion
+    res = {}
+    state = None
+    for dtype in ("bfloat16", "float32"):
+        model, inputs, cfg = _speech_case("s_real", dtype, batch=128)
+        if dtype == "bfloat16":
+            state = {n: p.data.detach().cpu().clone() for n, p in model.store.params.items()}
+            for n, p in model.store.params.items():   # the fp32 path multiplies the same rounded weights
+                if n.endswith("/kernel") and "conv1" not in n or n.endswith("shared/weights"):
+                    state[n] = p.compute.detach().float().cpu()
+        else:
+            model.store.load_state_dict(state)
+        dinp = {k: v.to(DEV) for k, v in inputs.items()}
+        crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+        logits = model(dinp, is_training=True)
+        loss = float(crit.reduce_loss(dinp, logits))
+        rows = model._encoder._stacking_layers[0]._ffn_layer.layer._saved[1].shape[0]
+        model.backward(crit.backward())
+        torch.cuda.synchronize()
+        res[dtype] = (logits.float().cpu(), loss, {n: p.grad.detach().float().cpu().clone() for n, p in model.store.params.items()}, rows)
+        del model, logits, dinp
+        torch.cuda.empty_cache()
+    (lg16, loss16, g16, rows16), (lg32, loss32, g32, _) = res["bfloat16"], res["float32"]
+    assert rows16 == 128 * 225
+    per, glob = _grad_errors(g16, g32)
+    tag = "st[s_real,B128].bf16_vs_fp32_hip"
+    REPORT[tag + ".logits"], REPORT[tag + ".loss_abs_err"] = rel_err(lg16, lg32), abs(loss16 - loss32)
+    REPORT[tag + ".grad_global_rel_l2"], REPORT[tag + ".grad_worst_rel_l2"] = glob, max(per.values())
+    REPORT[tag + ".grad_worst_tensor"] = max(per, key=per.get)
+    assert math.isfinite(loss16) and abs(loss16 - loss32) <= 1e-2 * max(1.0, abs(loss32)), (loss16, loss32)
+    assert REPORT[tag + ".logits"] <= 3e-2, REPORT[tag + ".logits"]
+    assert glob <= 3e-2, f"global gradient rel-L2 between the bf16 and the fp32 HIP step: {glob:.3e}"
+    assert max(per.values()) <= 0.1, (REPORT[tag + ".grad_worst_tensor"], max(per.values()))
 
 
 # ------------------------------------------------------------------------------------------------ text Transformer (§8(f) rank 1)
@@ -405,7 +570,9 @@ def test_text_transformer_forward_backward(case, dtype):
         REPORT[f"{tag}.grad.{n}"] = e
         num += float(((gg - r) ** 2).sum())
         den += float((r ** 2).sum())
-        if not (e <= (2e-3 if dtype == "float32" else 0.25)):
+        # bf16: 1.5 x the worst per-tensor error measured on these small cases (8.3e-2, profiles/r01_model_parity_report.json;
+        # few rows, so single ReLU-gate flips weigh most here)
+        if not (e <= (2e-3 if dtype == "float32" else 0.125)):
             bad.append((n, e))
     glob = math.sqrt(num / max(den, 1e-30))
     REPORT[tag + ".grad_global_rel_l2"] = glob
