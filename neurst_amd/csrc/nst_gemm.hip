@@ -24,12 +24,34 @@ __global__ void __launch_bounds__(THREADS) dense_gemm_kernel(DenseLoader<T> la, 
                                             kt_first, kt_count, ep, smem);
 }
 
-template <typename T, typename OutT, int AMODE, int BMODE, bool CS>
+// EF: compile-time epilogue stages (nst_gemm_core.h: EF_*), EF_GENERIC = every stage a runtime branch
+template <typename T, typename OutT, int AMODE, int BMODE, bool CS, int EF = EF_GENERIC>
 __global__ void __launch_bounds__(THREADS, 2)
 dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> args) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   (void)args;  // read through the kernarg segment, see gemm_stream_v3
-  gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS>(smem_dyn);
+  gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS, EF>(smem_dyn);
+}
+
+bool specialised_epilogues() {   // NST_GEMM_GENERIC_EPI=1: the runtime-flag kernels only (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_GENERIC_EPI"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+// the stages an Epilogue asks for, as an EF_* mask; -1 when a stage has no compile-time form (alpha, atomics, scalar stores)
+int epilogue_mask(const Epilogue& ep) {
+  if (!ep.vec || ep.alpha != 1.0f || ep.atomic) return -1;
+  int m = 0;
+  if (ep.bias) m |= EF_BIAS;
+  if (ep.relu) m |= EF_RELU;
+  if (ep.drop_thresh) m |= EF_DROP;
+  if (ep.residual) m |= EF_RESID;
+  if (ep.gate_src) m |= EF_GATE;
+  if (ep.posenc) m |= EF_POSENC;
+  if (ep.accumulate) m |= EF_ACCUM;
+  if (ep.rowdot_dst) m |= EF_ROWDOT;
+  return m;
 }
 
 // workgroups of the persistent kernels: two per CU are resident (64 KB of LDS each); every workgroup gets the same
@@ -183,12 +205,54 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
     ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
     ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0 && g3.x % 8 == 0) ? 1 : 0;
-#define NST_GEMM_LAUNCH3(AM, BMO, CS_)                                                                                \
+#define NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_)                                                                          \
   do {                                                                                                               \
-    auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_>;                                                           \
+    auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_, EF_>;                                                      \
     allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
     kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
   } while (0)
+#define NST_GEMM_LAUNCH3(AM, BMO, CS_) NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_GENERIC)
+    // Specialised instantiations: the epilogue configurations a training step of the Transformer models actually issues
+    // (enumerated by tracing a step; everything else takes the generic kernel below).
+    const int em = (sizeof(T) == 2 && specialised_epilogues()) ? epilogue_mask(ep) : -1;
+    if (em >= 0) {
+      if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+        if (amode == MODE_RC && bmode == MODE_OC && !ep.colsum_dst) {   // forward projections: x [M,K] . W [K,N]
+          switch (em) {
+            case 0: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, 0); return 0;
+            case EF_BIAS: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS); return 0;
+            case EF_BIAS | EF_DROP | EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_DROP | EF_RESID); return 0;
+            case EF_BIAS | EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_RESID); return 0;
+            case EF_BIAS | EF_RELU | EF_DROP: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_RELU | EF_DROP); return 0;
+            case EF_BIAS | EF_RELU: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_RELU); return 0;
+            case EF_BIAS | EF_POSENC: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_POSENC); return 0;
+            default: break;
+          }
+        }
+        if (amode == MODE_RC && bmode == MODE_RC && !ep.colsum_dst) {   // input gradients / tied logits: dz [M,K] . W^T
+          switch (em) {
+            case 0: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, 0); return 0;
+            case EF_BIAS: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_BIAS); return 0;
+            case EF_GATE: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_GATE); return 0;
+            case EF_ROWDOT: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_ROWDOT); return 0;
+            case EF_ACCUM: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_ACCUM); return 0;
+            case EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_RESID); return 0;
+            default: break;
+          }
+        }
+      }
+      if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
+        if (amode == MODE_OC && bmode == MODE_OC) {                     // weight gradients: x^T . dz, slabs or in place
+          if (ep.colsum_dst) {
+            if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, EF_ACCUM); return 0; }
+          } else {
+            if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, false, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, false, EF_ACCUM); return 0; }
+          }
+        }
+      }
+    }
     if (ep.colsum_dst) {  // host guarantees: OC/OC operands, f32 output
       if constexpr (sizeof(OutT) == 4) { NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, true); return 0; }
     }
@@ -197,6 +261,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH3(MODE_OC, MODE_RC, false);
     else NST_GEMM_LAUNCH3(MODE_OC, MODE_OC, false);
 #undef NST_GEMM_LAUNCH3
+#undef NST_GEMM_LAUNCH3E
     return 0;
   }
 #define NST_GEMM_LAUNCH(AM, BMO, TR)                                                                                   \

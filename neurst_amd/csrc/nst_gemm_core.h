@@ -473,10 +473,10 @@ struct SwzFrag<bf16_t, MODE_OC> {
     typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
     short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + r0 * RB + (off ^ s0)));
     short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + r1 * RB + (off ^ s1)));
-    union { short s[8]; Frag f; } u;
-    u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
-    u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
-    return u.f;
+    // register-pair concatenation: element-wise copies through a union became v_bfi_b32 merges behind a full
+    // s_waitcnt lgkmcnt(0) -- every fragment read of the K step had to land before the first MFMA
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    return __builtin_bit_cast(Frag, (short8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   }
 };
 template <>
@@ -937,18 +937,31 @@ __device__ __forceinline__ float acc_pick(const floatx4_t (&acc)[4][4], int q) {
 // owns the 16 consecutive columns (l&3)*16.. of row l>>2, i.e. 4 adjacent lanes cover one 128-byte (bf16) row segment
 // and the stores coalesce.  The buffer lives behind the DMA stages (it is never a DMA target), so the prefetch of
 // the next unit keeps running underneath.  16-byte chunk index ^= row & 3 keeps the b128 reads conflict free.
+// Compile-time epilogue configuration of the v3 stream kernels.  EF < 0 (EF_GENERIC): every stage is a runtime branch on the
+// Epilogue fields -- one kernel serves every call, but it keeps ~100 scalars of the argument block alive around its
+// epilogue (205-224 SGPR spills in round 2) and pays a branch per stage per 16 outputs.  EF >= 0: a bit mask of the stages
+// that EXIST in the instantiation; the dispatcher (nst_gemm.hip) picks it when the call's stages equal the mask exactly, the
+// vector epilogue is legal and alpha == 1.  Unused fields of the argument block are then never loaded.
+enum : int { EF_BIAS = 1, EF_RELU = 2, EF_DROP = 4, EF_RESID = 8, EF_GATE = 16, EF_POSENC = 32, EF_ACCUM = 64, EF_ROWDOT = 128,
+             EF_GENERIC = -1 };
+template <int EF, int F>
+__device__ __forceinline__ bool ef_on(bool runtime) {
+  if constexpr (EF < 0) return runtime;
+  else return (EF & F) != 0;
+}
+
 constexpr int V3_EPI_BYTES_PER_WAVE = 16 * 64 * 4;
 constexpr int V3_LDS_BYTES = 2 * V2_STAGE_BYTES + 4 * V3_EPI_BYTES_PER_WAVE;  // 80 KB: two workgroups fill the 160 KB of a CU
 
-template <typename OutT>
+template <typename OutT, int EF = EF_GENERIC>
 __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict__ C, int64_t ldc, int row, int64_t out_row, int n, int N,
                                                const Epilogue& ep) {
   // v: outputs (row, n .. n+15) with alpha and bias already applied
-  if (ep.relu) {
+  if (ef_on<EF, EF_RELU>(ep.relu)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
   }
-  if (ep.drop_thresh) {
+  if (ef_on<EF, EF_DROP>(ep.drop_thresh != 0)) {
     float m0[8], m1[8];
     const uint64_t idx = (uint64_t)row * (uint64_t)N + (uint64_t)n;  // multiple of 8 (N % 8 == 0, n % 16 == 0)
     dropout_keep8(ep.seed, ep.stream_id, idx, ep.drop_thresh, ep.drop_inv_keep, m0);
@@ -961,7 +974,7 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
   OutT tmp[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) tmp[r] = (OutT)0;
-  if (ep.residual) {
+  if (ef_on<EF, EF_RESID>(ep.residual != nullptr)) {
     const OutT* p = reinterpret_cast<const OutT*>(ep.residual) + (int64_t)row * ep.ldr + n;
 #pragma unroll
     for (int q = 0; q < NV; ++q)
@@ -969,7 +982,7 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] += to_f32<OutT>(tmp[r]);
   }
-  if (ep.gate_src) {
+  if (ef_on<EF, EF_GATE>(ep.gate_src != nullptr)) {
     const OutT* p = reinterpret_cast<const OutT*>(ep.gate_src) + (int64_t)row * ep.ldg + n;
 #pragma unroll
     for (int q = 0; q < NV; ++q)
@@ -977,7 +990,7 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] *= to_f32<OutT>(tmp[r]) > 0.f ? ep.gate_scale : 0.f;
   }
-  if (ep.posenc) {
+  if (ef_on<EF, EF_POSENC>(ep.posenc != nullptr)) {
     const float* p = ep.posenc + (int64_t)(row % ep.posenc_period) * N + n;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -989,13 +1002,15 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
     }
   }
   OutT* o = C + out_row * ldc + n;
-  if (ep.atomic) {
+  if constexpr (EF < 0) {   // atomic split-K exists in the generic kernel only
+    if (ep.atomic) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (n + r < N) atomicAdd(reinterpret_cast<float*>(o) + r, v[r]);
-    return;
+      for (int r = 0; r < 16; ++r)
+        if (n + r < N) atomicAdd(reinterpret_cast<float*>(o) + r, v[r]);
+      return;
+    }
   }
-  if (ep.accumulate) {
+  if (ef_on<EF, EF_ACCUM>(ep.accumulate != 0)) {
 #pragma unroll
     for (int q = 0; q < NV; ++q)
       if (q < nv) reinterpret_cast<uint4*>(tmp)[q] = reinterpret_cast<const uint4*>(o)[q];
@@ -1007,7 +1022,7 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
     const uint4 w1 = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
     reinterpret_cast<uint4*>(o)[0] = w0;
     if (nv == NV) reinterpret_cast<uint4*>(o)[1] = w1;
-    if (ep.rowdot_dst) {  // host guarantees N % 64 == 0: the 4 lanes of a quad hold the 64 columns of one head of this row
+    if (ef_on<EF, EF_ROWDOT>(ep.rowdot_dst != nullptr)) {  // host guarantees N % 64 == 0: the 4 lanes of a quad hold the 64 columns of one head of this row
       const bf16_t* sp = reinterpret_cast<const bf16_t*>(ep.rowdot_src) + (int64_t)row * ep.ldrs + n;
       const uint4 s0 = reinterpret_cast<const uint4*>(sp)[0], s1 = reinterpret_cast<const uint4*>(sp)[1];
       const uint32_t cw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -1033,7 +1048,7 @@ __device__ __forceinline__ void epi_piece16_v3(float (&v)[16], OutT* __restrict_
 }
 
 // one 16-row block i of the wave tile: acc_i[j][r] = output (row g*4 + r, column j*16 + lc) of the block
-template <typename OutT, typename RowMap>
+template <typename OutT, typename RowMap, int EF = EF_GENERIC>
 __device__ __forceinline__ void epi_block_v3(const floatx4_t (&a)[4], float* __restrict__ epi, OutT* __restrict__ C, int64_t ldc, int M,
                                              int N, int row0, int nw, const float (&bias16)[16], const Epilogue& ep,
                                              const RowMap& rowmap, int lane) {
@@ -1052,38 +1067,51 @@ __device__ __forceinline__ void epi_block_v3(const floatx4_t (&a)[4], float* __r
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 x = *reinterpret_cast<const float4*>(epi + rr * 64 + (((c16 * 4 + q) ^ (rr & 3)) << 2));
-    v[q * 4 + 0] = x.x * ep.alpha + bias16[q * 4 + 0]; v[q * 4 + 1] = x.y * ep.alpha + bias16[q * 4 + 1];
-    v[q * 4 + 2] = x.z * ep.alpha + bias16[q * 4 + 2]; v[q * 4 + 3] = x.w * ep.alpha + bias16[q * 4 + 3];
+    if constexpr (EF >= 0) {   // alpha == 1 (dispatcher); without a bias stage the sums go through untouched
+      if constexpr ((EF & EF_BIAS) != 0) {
+        v[q * 4 + 0] = x.x + bias16[q * 4 + 0]; v[q * 4 + 1] = x.y + bias16[q * 4 + 1];
+        v[q * 4 + 2] = x.z + bias16[q * 4 + 2]; v[q * 4 + 3] = x.w + bias16[q * 4 + 3];
+      } else {
+        v[q * 4 + 0] = x.x; v[q * 4 + 1] = x.y; v[q * 4 + 2] = x.z; v[q * 4 + 3] = x.w;
+      }
+    } else {
+      v[q * 4 + 0] = x.x * ep.alpha + bias16[q * 4 + 0]; v[q * 4 + 1] = x.y * ep.alpha + bias16[q * 4 + 1];
+      v[q * 4 + 2] = x.z * ep.alpha + bias16[q * 4 + 2]; v[q * 4 + 3] = x.w * ep.alpha + bias16[q * 4 + 3];
+    }
   }
   __builtin_amdgcn_wave_barrier();  // every lane has read before the next block overwrites the buffer
   const int row = row0 + rr, n = nw + c16 * 16;
-  if (row < M && n < N) epi_piece16_v3<OutT>(v, C, ldc, row, rowmap(row), n, N, ep);
+  if (row < M && n < N) epi_piece16_v3<OutT, EF>(v, C, ldc, row, rowmap(row), n, N, ep);
 }
 
-template <typename OutT, typename RowMap>
+template <typename OutT, typename RowMap, int EF = EF_GENERIC>
 __device__ __forceinline__ void epilogue_v3(floatx4_t (&acc)[4][4], float* __restrict__ epi, OutT* __restrict__ C, int64_t ldc, int M,
                                             int N, int mw, int nw, const Epilogue& ep, const RowMap& rowmap, int lane) {
-  if (ep.vec) {  // N % 8 == 0, 16-byte aligned rows; a 16-column piece may be cut to 8 at the right edge
+  if (EF >= 0 || ep.vec) {  // N % 8 == 0, 16-byte aligned rows; a 16-column piece may be cut to 8 at the right edge
     const int c16 = lane & 3;
     float bias16[16];
-    {
+    if constexpr (EF >= 0 && (EF & EF_BIAS) == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bias16[q] = 0.f;
+    } else {
       const int n = nw + c16 * 16;
       // unconditional loads (zero block without a bias) consumed unconditionally: a load left pending on some path
       // makes the compiler drain vmcnt(0) -- and with it the LDS-DMA prefetch -- inside the K loop
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float* bp = (ep.bias && n + q * 4 < N) ? ep.bias + n + q * 4 : reinterpret_cast<const float*>(g_nst_zero16);
+        const float* bp = (ef_on<EF, EF_BIAS>(ep.bias != nullptr) && n + q * 4 < N) ? ep.bias + n + q * 4
+                                                                                    : reinterpret_cast<const float*>(g_nst_zero16);
         const float4 x = *reinterpret_cast<const float4*>(bp);
         bias16[q * 4] = x.x; bias16[q * 4 + 1] = x.y; bias16[q * 4 + 2] = x.z; bias16[q * 4 + 3] = x.w;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(bias16[q]));
     }
-    epi_block_v3<OutT, RowMap>(acc[0], epi, C, ldc, M, N, mw, nw, bias16, ep, rowmap, lane);
-    epi_block_v3<OutT, RowMap>(acc[1], epi, C, ldc, M, N, mw + 16, nw, bias16, ep, rowmap, lane);
-    epi_block_v3<OutT, RowMap>(acc[2], epi, C, ldc, M, N, mw + 32, nw, bias16, ep, rowmap, lane);
-    epi_block_v3<OutT, RowMap>(acc[3], epi, C, ldc, M, N, mw + 48, nw, bias16, ep, rowmap, lane);
-  } else {  // unaligned / odd-N outputs: one element at a time in a rolled loop
+    epi_block_v3<OutT, RowMap, EF>(acc[0], epi, C, ldc, M, N, mw, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap, EF>(acc[1], epi, C, ldc, M, N, mw + 16, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap, EF>(acc[2], epi, C, ldc, M, N, mw + 32, nw, bias16, ep, rowmap, lane);
+    epi_block_v3<OutT, RowMap, EF>(acc[3], epi, C, ldc, M, N, mw + 48, nw, bias16, ep, rowmap, lane);
+  } else if constexpr (EF < 0) {  // unaligned / odd-N outputs: one element at a time in a rolled loop
     const int g = lane >> 4, lc = lane & 15;
 #pragma unroll 1
     for (int q = 0; q < 64; ++q) {
@@ -1127,7 +1155,8 @@ __device__ __forceinline__ const NST_AS4 A* launder(const NST_AS4 A* p) {
   return p;
 }
 
-template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap, bool CS>
+template <typename T, typename OutT, int AMODE, int BMODE, typename ALoader, typename BLoader, typename RowMap, bool CS,
+          int EF = EF_GENERIC>
 __device__ __forceinline__ void gemm_stream_v3(char* smem) {
   typedef GemmArgs<OutT, ALoader, BLoader, RowMap> Args;
   const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1276,7 +1305,7 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
     if (++ckt == cq.kt_count) {
       const NST_AS4 Args* k2 = launder(ka);
       Epilogue ep = kload(&k2->ep);
-      if (ep.drop_thresh) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
+      if (ef_on<EF, EF_DROP>(ep.drop_thresh != 0)) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
       const RowMap rowmap = kload(&k2->rowmap);
       const int M = k2->M, N = k2->N;
       if (CS && do_cs && lane < 16) {  // every row of cs holds the column sums; lane = column within the 16-block
@@ -1289,7 +1318,7 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
           }
         }
       }
-      epilogue_v3<OutT, RowMap>(acc, reinterpret_cast<float*>(smem + 2 * V2_STAGE_BYTES + wave * V3_EPI_BYTES_PER_WAVE),
+      epilogue_v3<OutT, RowMap, EF>(acc, reinterpret_cast<float*>(smem + 2 * V2_STAGE_BYTES + wave * V3_EPI_BYTES_PER_WAVE),
                                 k2->C + (int64_t)cq.z * ep.slab_stride, k2->ldc, M, N, cq.m0 + wm, cq.n0 + wn, ep, rowmap, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
