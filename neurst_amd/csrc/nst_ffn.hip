@@ -68,6 +68,7 @@ struct FfnArgs {
   float drop1_inv_keep, drop2_inv_keep;
   float gate_scale;
   uint64_t seed1, stream1, seed2, stream2;
+  int rot_mode;   // v2: 0 = chunk order rotated per workgroup, 1 = per XCD (workgroup id & 7), 2 = none
 };
 
 __device__ __forceinline__ int pi32(int r) { return (((r >> 2) & 1) << 4) + ((r >> 3) << 2) + (r & 3); }
@@ -155,6 +156,20 @@ __device__ __forceinline__ void glds_piece(const void* sbase, const uint32_t (&v
           "s"(sbase), "s"(lds_addr_uniform)
         : "memory", "scc");
   }
+}
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) -> LDS [lds_addr_uniform + lane * 16]
+__device__ __forceinline__ void glds_one(const void* sbase, uint32_t voff, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 4\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr_uniform)
+      : "memory");
 }
 
 template <int MODE, int NW>
@@ -517,6 +532,421 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   }
 }
 
+// =====================================================================================================================
+// v2 (round 3): the same two-GEMM chain on EIGHT waves per workgroup -- two per SIMD -- so that one wave's MFMAs run under
+// its partner's epilogue VALU work, fragment reads and waits (the one-wave-per-SIMD kernel above serialises them:
+// MFMA 29 us + fragment reads / epilogue 28 us + DMA / stores 26 us of an 87 us launch, profiles/r02_ffn_bench_ablation.json).
+//
+//   workgroup = 128 rows = 4 row groups of 32 rows; wave w: row group rg = w & 3, half hh = w >> 2 (waves w and w + 4 share
+//   a SIMD and a row group).  The hidden dimension is walked in chunks of 64 units:
+//     first product  (A phase): wave (rg, hh) computes hidden units 32 hh .. 32 hh + 31 of the chunk for its 32 rows
+//                               (16 MFMAs 32x32x16 over K = 256, X fragments resident in 64 registers);
+//     mid epilogue            : bias + ReLU + dropout, packed to bf16 -> the P tile [128 rows][64 units] in LDS: the two
+//                               halves of a row group exchange their hidden halves through it, and the saved activation is
+//                               stored to HBM FROM it in whole 128-byte row segments;
+//     second product (B phase): wave (rg, hh) computes output columns 128 hh .. 128 hh + 127 over all 64 units of the chunk
+//                               (4 blocks x 4 k-steps = 16 MFMAs; B operand = P fragments, A operand = W2 fragments).
+//   256 accumulator/operand registers per wave: X 64 + output 64 + hidden 16 + packed tile 8 + fragments.
+//   Software pipeline: iteration c runs  A(c+1) | barrier Y | B(c) interleaved with the mid epilogue of c+1 | barrier X |
+//   P(c+1) write + DMA issue -- so the epilogue VALU sits between the second product's MFMAs, and every barrier has a phase of
+//   matrix work on either side.
+//   LDS (152 KB): W1 chunks double buffered 2 x 32 KB [64 units][256 k] (slot ^= row & 15 within the low 16 slots),
+//   W2 chunks 2 x 32 KB [256 out][64 units] and P 16 KB [128 rows][64 units] (128-byte rows, slot ^= (row >> 1) & 7),
+//   first-layer bias (pre-scaled) <= 8 KB.  Weights arrive by LDS-DMA a full iteration ahead (issued behind barrier X of
+//   iteration c for iterations c+2 / c+3, waited for -- counted, behind the two hidden-tile stores -- before barrier X of
+//   iteration c+1).  The hidden-unit permutation pi of the kernel above gives every lane 16 consecutive units / columns.
+// =====================================================================================================================
+constexpr int CH2 = 64;
+constexpr int V2_W1 = 0, V2_W2 = 2 * 32768, V2_P = 4 * 32768, V2_BIAS = V2_P + 16384;
+constexpr int V2_ROWS = 128;
+
+template <int MODE, int DROP, bool FULL, int DBG = 0>
+__global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
+  static_assert(MODE == MODE_FWD || DROP == 0, "the backward has no dropout of its own (the gate carries the forward's mask)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 3, hh = wave >> 2;
+  const int i_l = lane & 31, h = lane >> 5;
+  const int F = a.F, M = a.M;
+  const int nch = F / CH2;
+  const int m0 = blockIdx.x * V2_ROWS;
+  // rotated chunk order: the chip writes all columns of the hidden tensor at once (mode 0: per workgroup; mode 1: per XCD --
+  // the 28 workgroups of an XCD then stream the SAME weight chunk through their shared L2 at about the same time)
+  const int rot = a.rot_mode == 0 ? (int)(blockIdx.x % nch) : (a.rot_mode == 1 ? (int)(blockIdx.x & 7) * (nch >> 3) % nch : 0);
+  auto phys = [&](int c) { const int q = c + rot; return q >= nch ? q - nch : q; };
+  const int row = m0 + rg * 32 + i_l;   // this lane's row of Xin / outputs
+  const bool row_ok = FULL || row < M;
+  const int row_c = row_ok ? row : M - 1;
+
+  uint64_t seed_off = 0;
+  if (MODE == MODE_FWD && DROP != 0) seed_off = seed_with_offset(0, a.seed_dev);
+
+  // ---------------------------------------------------------------- DMA source offsets (per lane, constant)
+  uint32_t voff1[4], voff2[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int t = wave * 4 + s;
+    {
+      const int r = 2 * t + (lane >> 5), sl = lane & 31;                       // W1 chunk: 512-byte rows, 32 slots
+      voff1[s] = (uint32_t)(r * (D * 2) + ((sl ^ (r & 15)) << 4));
+    }
+    {
+      const int r = 8 * t + (lane >> 3), sl = lane & 7;                        // W2 chunk: 128-byte pieces of 2F-byte rows
+      voff2[s] = (uint32_t)r * (uint32_t)(F * 2) + (uint32_t)((sl ^ ((r >> 1) & 7)) << 4);
+    }
+  }
+  auto issue_w1 = [&](int c_logical) {
+    const int c = phys(c_logical);
+    glds_piece<4>(reinterpret_cast<const char*>(a.wa) + (int64_t)c * CH2 * D * 2, voff1,
+                  smem_addr + V2_W1 + (uint32_t)(c_logical & 1) * 32768u + (uint32_t)wave * 4096u);
+  };
+  auto issue_w2 = [&](int c_logical) {
+    const int c = phys(c_logical);
+    glds_piece<4>(reinterpret_cast<const char*>(a.wb) + (int64_t)c * CH2 * 2, voff2,
+                  smem_addr + V2_W2 + (uint32_t)(c_logical & 1) * 32768u + (uint32_t)wave * 4096u);
+  };
+  issue_w1(0);
+  issue_w2(0);
+  if (nch > 1) issue_w1(1);
+
+  // ---------------------------------------------------------------- Xin fragments (B operand of the first product)
+  bf16x8_t xf[16];
+  {
+    const bf16_t* xr = a.xin + (int64_t)row_c * D + h * 8;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) xf[kb] = *reinterpret_cast<const bf16x8_t*>(xr + kb * 16);
+  }
+  float* bias_lds = reinterpret_cast<float*>(smem + V2_BIAS);
+  if constexpr (MODE == MODE_FWD) {
+    const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;   // relu(z) * inv_keep == relu(z * inv_keep)
+    for (int i = tid; i < F; i += 512) bias_lds[i] = a.bias_a ? a.bias_a[i] * sc : 0.f;
+  }
+  // backward: the gate (the saved activation of this wave's 32 rows x 32 units of a chunk, 2 KB) arrives by LDS-DMA in a
+  // region PRIVATE to the wave (the 16 KB the forward's bias occupies): issued by the wave right after its epilogue has read
+  // the previous chunk's gate, waited for (counted) by the wave before the next epilogue -- no barrier involved
+  const uint32_t g_lds = smem_addr + V2_BIAS + (uint32_t)wave * 2048u;
+  uint32_t voffg[2] = {0u, 0u};
+  if constexpr (MODE == MODE_BWD) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int rgate = m0 + 32 * rg + 16 * q + (lane >> 2);
+      rgate = rgate < M ? rgate : M - 1;
+      voffg[q] = (uint32_t)rgate * (uint32_t)(F * 2) + (uint32_t)((lane & 3) << 4);
+    }
+  }
+  auto issue_g = [&](int c_logical) {   // chunk index clamped: a copy past the end lands in the region nobody reads again
+    const int c = phys(c_logical < nch ? c_logical : nch - 1);
+    const char* src = reinterpret_cast<const char*>(a.gate) + ((int64_t)c * CH2 + 32 * hh) * 2;
+    glds_one(src, voffg[0], g_lds);
+    glds_one(src, voffg[1], g_lds + 1024u);
+  };
+  if constexpr (MODE == MODE_BWD) issue_g(0);
+
+  // ---------------------------------------------------------------- LDS read offsets (per lane, constant)
+  const int pr = pi32(i_l);
+  // W1 fragment (k-block kb): row R = 32 hh + pr, slot (2 kb + h) ^ (R & 15) on the low 4 slot bits:
+  //   byte = R * 512 + (kb >> 3) * 256 + ((((2 kb) & 15) | h) ^ (pr & 15)) * 16  =  offA ^ (((2 kb) & 15) << 4)  + (kb >> 3) * 256
+  const uint32_t offA = (uint32_t)((32 * hh + pr) * 512 + ((h ^ (pr & 15)) << 4));
+  // W2 fragment (output block ob, k-step ks): row 128 hh + 32 ob + pr, slot (2 ks + h) ^ ((pr >> 1) & 7)
+  uint32_t offB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) offB[ks] = (uint32_t)((128 * hh + pr) * 128 + (((2 * ks + h) ^ ((pr >> 1) & 7)) << 4));
+  // P tile: row 32 rg + i_l, slot ^ ((i_l >> 1) & 7)
+  const uint32_t pz = (uint32_t)((i_l >> 1) & 7);
+  const uint32_t offP = (uint32_t)((32 * rg + i_l) * 128);
+  // hidden-tile store: this wave writes rows 32 rg + 16 hh + 8 q + (lane >> 3), q = 0, 1; 8 lanes = one 128-byte row piece
+  const int st_r0 = 32 * rg + 16 * hh + (lane >> 3), st_slot = lane & 7;
+  const bool st_ok0 = FULL || (m0 + st_r0) < M, st_ok1 = FULL || (m0 + st_r0 + 8) < M;
+
+  floatx16_t accH, accY[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accY[i][v] = 0.f;
+  uint32_t packed[8];
+
+  // ---- first product of chunk c (logical): 16 dependent MFMAs (same accumulator: the matrix core forwards it)
+  auto a_phase = [&](int c_logical) {
+    const char* w1 = smem + V2_W1 + (c_logical & 1) * 32768;
+    if constexpr ((DBG & 64) != 0) {   // variant: two accumulators (even / odd k-blocks), summed at the end
+      floatx16_t acc1;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const uint32_t o = (offA ^ (uint32_t)(((2 * kb) & 15) << 4)) + (uint32_t)((kb >> 3) * 256);
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(w1 + o);
+        const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kb == 0) accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[0], zero, 0, 0, 0);
+        else if (kb == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[1], zero, 0, 0, 0);
+        else if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[kb], acc1, 0, 0, 0);
+        else accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[kb], accH, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accH[e] += acc1[e];
+      return;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      const uint32_t o = (offA ^ (uint32_t)(((2 * kb) & 15) << 4)) + (uint32_t)((kb >> 3) * 256);
+      bf16x8_t wf;
+      if constexpr ((DBG & 8) != 0) wf = xf[(kb + 1) & 15];   // ablation: no fragment reads
+      else wf = *reinterpret_cast<const bf16x8_t*>(w1 + o);
+      if constexpr ((DBG & 4) != 0) {                          // ablation: no MFMAs (the reads stay alive)
+        asm volatile("" ::"v"(wf));
+        if (kb == 0) { for (int e = 0; e < 16; ++e) accH[e] = 1.0f; }
+      } else if (kb == 0) {
+        const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[0], zero, 0, 0, 0);
+      } else {
+        accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[kb], accH, 0, 0, 0);
+      }
+    }
+  };
+  // ---- mid epilogue of chunk c: accH -> packed (bias, ReLU, dropout, bf16)
+  auto mid_epilogue = [&](int c_logical, auto first_tag) {   // first_tag: the prologue's call (everything has been drained)
+    const int c = phys(c_logical);
+    const int col0 = c * CH2 + 32 * hh + 16 * h;   // this lane's 16 consecutive hidden units
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = accH[e];
+    if constexpr ((DBG & 16) != 0) {   // ablation: no bias / ReLU / dropout work
+#pragma unroll
+      for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      return;
+    }
+    if constexpr (MODE == MODE_BWD) {
+      // this lane's 16 gate values: row i_l of the wave's region (64-byte rows), bytes [32 h, +32)
+      if constexpr (decltype(first_tag)::value || !FULL) wait_vm<0>(); else wait_vm<10>();   // (2 stores + 8 weight DMAs are younger than the gate copy)
+      const uint4* gp = reinterpret_cast<const uint4*>(smem + V2_BIAS + wave * 2048 + i_l * 64 + h * 32);
+      union { uint4 u[2]; short s[16]; } g;
+      g.u[0] = gp[0];
+      g.u[1] = gp[1];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = g.s[e] > 0 ? v[e] * a.gate_scale : 0.f;   // bf16 > 0 <=> its bits as int16 > 0
+#pragma unroll
+      for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the gate reads have returned: the region may be overwritten
+      issue_g(c_logical + 1);
+      return;
+    }
+    const float4* bp = reinterpret_cast<const float4*>(bias_lds + col0);
+    const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = bp[q];
+      v[4 * q + 0] = fmaxf(fmaf(v[4 * q + 0], sc, b.x), 0.f);
+      v[4 * q + 1] = fmaxf(fmaf(v[4 * q + 1], sc, b.y), 0.f);
+      v[4 * q + 2] = fmaxf(fmaf(v[4 * q + 2], sc, b.z), 0.f);
+      v[4 * q + 3] = fmaxf(fmaf(v[4 * q + 3], sc, b.w), 0.f);
+    }
+    if constexpr ((DROP & 1) != 0) {
+      const uint64_t idx = (uint64_t)row * (uint64_t)F + (uint64_t)col0;   // multiple of 8
+      const Philox4 r0 = philox4x32_10(a.seed1 + seed_off, a.stream1, idx >> 3);
+      const Philox4 r1 = philox4x32_10(a.seed1 + seed_off, a.stream1, (idx >> 3) + 1);
+      const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t f = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+        v[e] = f >= a.drop1_thresh ? v[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+  };
+  auto write_p = [&]() {   // this lane's 16 units = slots 4 hh + 2 h, + 1 of its row
+    char* prow = smem + V2_P + offP;
+    *reinterpret_cast<uint4*>(prow + ((((uint32_t)(4 * hh + 2 * h)) ^ pz) << 4)) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    *reinterpret_cast<uint4*>(prow + ((((uint32_t)(4 * hh + 2 * h + 1)) ^ pz) << 4)) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+  };
+  // ---- the saved activation of chunk c, stored from the P tile in whole row pieces
+  auto store_hidden = [&](int c_logical) {
+    if constexpr ((DBG & 1) == 0) {
+      const int c = phys(c_logical);
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = st_r0 + 8 * q;
+        const uint4 d = *reinterpret_cast<const uint4*>(smem + V2_P + r * 128 + ((st_slot ^ ((r >> 1) & 7)) << 4));
+        bf16_t* o = a.mid_out + (int64_t)(m0 + r) * F + (c * CH2 + st_slot * 8);
+        if (q == 0 ? st_ok0 : st_ok1) __builtin_nontemporal_store(u32x4_t{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4_t*>(o));
+      }
+    }
+  };
+  auto barrier = [&]() {
+    if constexpr ((DBG & 32) == 0) __builtin_amdgcn_s_barrier();   // (ablation 32: no workgroup barriers -- timing only)
+    asm volatile("" ::: "memory");
+  };
+
+  // ---------------------------------------------------------------- fragment stream of one span
+  // A span (between two barrier pairs) multiplies the NEXT chunk's first product (stream positions 0..15 = k-block) and the
+  // CURRENT chunk's second product (positions 16..31 = (k-step, output block)).  Weight fragments travel through a ring of PD
+  // register quads read LOOK positions ahead of the MFMA that consumes them -- with one read in flight per wave the LDS
+  // latency (not its bandwidth) paced the MFMAs: "no fragment reads" took 16 of 85 us (gpurun_out/r03_ffn_v2_ablation.log).
+  constexpr int PD = 8, LOOK = 6;
+  bf16x8_t wq[PD], pf[4];
+  auto read_frag = [&](auto stag, const char* w1, const char* w2) {
+    constexpr int S = decltype(stag)::value;
+    if constexpr ((DBG & 8) != 0) {
+      wq[S % PD] = xf[S & 15];
+    } else if constexpr (S < 16) {
+      const uint32_t o = (offA ^ (uint32_t)(((2 * S) & 15) << 4)) + (uint32_t)((S >> 3) * 256);
+      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(w1 + o);
+    } else {
+      constexpr int ks = (S - 16) >> 2, ob = (S - 16) & 3;
+      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(w2 + offB[ks] + ob * 4096);
+    }
+  };
+  auto mfma_at = [&](auto stag) {
+    constexpr int S = decltype(stag)::value;
+    if constexpr ((DBG & 4) != 0) {
+      const bf16x8_t keep_alive = wq[S % PD];
+      asm volatile("" ::"v"(keep_alive));
+      if constexpr (S == 0) { for (int e = 0; e < 16; ++e) accH[e] = 1.0f; }
+    } else if constexpr (S == 0) {
+      const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xf[0], zero, 0, 0, 0);
+    } else if constexpr (S < 16) {
+      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], xf[S], accH, 0, 0, 0);
+    } else {
+      constexpr int ks = (S - 16) >> 2, ob = (S - 16) & 3;
+      accY[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], pf[ks], accY[ob], 0, 0, 0);
+    }
+  };
+  auto read_p_frags = [&]() {
+    const char* prow = smem + V2_P + offP;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr ((DBG & 8) != 0) pf[ks] = xf[ks];
+      else pf[ks] = *reinterpret_cast<const bf16x8_t*>(prow + ((((uint32_t)(2 * ks + h)) ^ pz) << 4));
+    }
+  };
+  // the first LOOK fragments of a span, issued right behind barrier X (the P write, barrier Y and the DMA issue cover their latency)
+  auto burst = [&](auto s0tag, const char* w1, const char* w2) {
+    constexpr int S0 = decltype(s0tag)::value;
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      (read_frag(std::integral_constant<int, S0 + I>(), w1, w2), ...);
+    }(std::make_integer_sequence<int, LOOK>());
+  };
+  // one span: HAS_A = it contains the first product of chunk c_next (all spans but the last)
+  auto span = [&](auto has_a_tag, int c_cur, const char* w1, const char* w2) {
+    constexpr bool HAS_A = decltype(has_a_tag)::value;
+    constexpr int S0 = HAS_A ? 0 : 16;
+    // the weights of the spans after the next: W1 chunk c_cur + 3 -> the buffer the PREVIOUS span's first product read,
+    // W2 chunk c_cur + 2 -> the buffer its second product read (both free since barrier X).  One DMA instruction rides behind
+    // each of the first eight MFMAs (issuing the eight back to back costs the wave 500-800 cycles with the matrix core idle).
+    // Chunks past the end are clamped to the last one: the copy lands in a buffer nobody reads again, and the span stays
+    // one basic block.
+    const int cw1 = phys(c_cur + 2 < nch ? c_cur + 2 : nch - 1), cw2 = phys(c_cur + 1 < nch ? c_cur + 1 : nch - 1);
+    const char* src1 = reinterpret_cast<const char*>(a.wa) + (int64_t)cw1 * CH2 * D * 2;
+    const char* src2 = reinterpret_cast<const char*>(a.wb) + (int64_t)cw2 * CH2 * 2;
+    const uint32_t dst1 = smem_addr + V2_W1 + (uint32_t)(c_cur & 1) * 32768u + (uint32_t)wave * 4096u;
+    const uint32_t dst2 = smem_addr + V2_W2 + (uint32_t)((c_cur + 1) & 1) * 32768u + (uint32_t)wave * 4096u;
+    read_p_frags();
+    store_hidden(c_cur);
+    [&]<int... SS>(std::integer_sequence<int, SS...>) {
+      ([&] {
+        constexpr int S = S0 + SS;
+        mfma_at(std::integral_constant<int, S>());
+        if constexpr (HAS_A && (DBG & 2) == 0 && S >= 1 && S <= 8) {
+          if constexpr (S <= 4) glds_one(src1, voff1[S - 1], dst1 + (uint32_t)(S - 1) * 1024u);
+          else glds_one(src2, voff2[S - 5], dst2 + (uint32_t)(S - 5) * 1024u);
+        }
+        if constexpr (S + LOOK < 32) read_frag(std::integral_constant<int, S + LOOK>(), w1, w2);
+        if constexpr (HAS_A && S == 15) mid_epilogue(c_cur + 1, std::false_type());   // program order: behind the first product; scheduled into the slots below
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (HAS_A && S >= 16) __builtin_amdgcn_sched_group_barrier(0x002, (DROP & 1) ? 11 : 4, 0);
+      }(), ...);
+    }(std::make_integer_sequence<int, 32 - S0>());
+  };
+
+  // ---------------------------------------------------------------- prologue: chunk 0's first product and epilogue
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the bias writes
+  barrier();
+  a_phase(0);
+  mid_epilogue(0, std::true_type());
+  barrier();                            // X of "span -1": every wave is done with W1 buffer 0
+  if (nch > 1) burst(std::integral_constant<int, 0>(), smem + V2_W1 + 32768, smem + V2_W2);
+  else burst(std::integral_constant<int, 16>(), smem + V2_W1, smem + V2_W2);
+  write_p();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the P writes have landed before the barrier publishes them
+  barrier();                            // Y (span 0 issues the DMAs of W1 chunk 2 and W2 chunk 1 itself)
+
+#pragma unroll 1
+  for (int c = 0; c < nch - 1; ++c) {
+    const char* w1 = smem + V2_W1 + ((c + 1) & 1) * 32768;
+    const char* w2 = smem + V2_W2 + (c & 1) * 32768;
+    span(std::true_type(), c, w1, w2);
+    // the packed tile is complete HERE (otherwise the compiler sinks the epilogue behind the barrier, next to its only use)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(packed[e]));
+    // the weight DMAs issued early in this span have landed (the two hidden-tile stores are older still); the backward's two
+    // gate DMAs of the next chunk are the youngest and stay in flight
+    if (MODE == MODE_BWD && FULL) wait_vm<2>(); else wait_vm<0>();
+    barrier();                          // X: P(c), W2 buffer c & 1 and W1 buffer (c+1) & 1 are free; the next span's weights are visible
+    if (c + 2 < nch) burst(std::integral_constant<int, 0>(), smem + V2_W1 + (c & 1) * 32768, smem + V2_W2 + ((c + 1) & 1) * 32768);
+    else burst(std::integral_constant<int, 16>(), smem + V2_W1, smem + V2_W2 + ((c + 1) & 1) * 32768);
+    write_p();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();                          // Y: P(c+1) visible
+  }
+  // the residual rows of the final epilogue: requested HERE, so that their HBM latency runs under the last span (no LDS-DMA is
+  // outstanding any more; in the loop an ordinary load would make the compiler's vmcnt wait drain the weight prefetch)
+  uint4 rres[4][2];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) rres[ob][0] = rres[ob][1] = make_uint4(0u, 0u, 0u, 0u);
+  if (a.residual) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const uint4* rp = reinterpret_cast<const uint4*>(a.residual + (int64_t)row_c * D + 128 * hh + 32 * ob + 16 * h);
+      rres[ob][0] = rp[0];
+      rres[ob][1] = rp[1];
+    }
+  }
+  span(std::false_type(), nch - 1, smem + V2_W1, smem + V2_W2 + ((nch - 1) & 1) * 32768);
+
+  if constexpr (MODE == MODE_BWD) wait_vm<0>();   // (the clamped gate copy of "chunk nch")
+  // ---------------------------------------------------------------- final epilogue: 16 consecutive output columns per lane and block
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) {
+    const int col0 = 128 * hh + 32 * ob + 16 * h;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = accY[ob][e];
+    if (MODE == MODE_FWD && a.bias_b) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias_b + col0 + 4 * q);
+        v[4 * q + 0] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
+      }
+    }
+    if constexpr ((DROP & 2) != 0) {
+      const uint64_t idx = (uint64_t)row * (uint64_t)D + (uint64_t)col0;
+      float k0[8], k1[8];
+      dropout_keep8(a.seed2 + seed_off, a.stream2, idx, a.drop2_thresh, a.drop2_inv_keep, k0);
+      dropout_keep8(a.seed2 + seed_off, a.stream2, idx + 8, a.drop2_thresh, a.drop2_inv_keep, k1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] *= k0[e]; v[8 + e] *= k1[e]; }
+    }
+    {
+      union { uint4 u[2]; bf16_t s[16]; } r;   // zeros without a residual
+      r.u[0] = rres[ob][0];
+      r.u[1] = rres[ob][1];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bf16_to_f32(r.s[e]);
+    }
+    if (row_ok) {
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+      u32x4_t* o = reinterpret_cast<u32x4_t*>(a.out + (int64_t)row * D + col0);
+      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, o);
+      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])}, o + 1);
+    }
+  }
+}
+
 template <typename KernelT>
 void allow_lds(KernelT kernel, int bytes) {
   static thread_local const void* done[16];
@@ -572,6 +1002,71 @@ int launch_pair(const FfnArgs& a, hipStream_t st) {
     if (full && drop == 0) return launch_one<MODE, NW, 0, true>(a, st);
     return launch_one<MODE, NW, 3, false>(a, st);
   }
+}
+
+// v2 (eight waves, two per SIMD): forward, full chip (>= 160 workgroups of 128 rows), F a multiple of 64 whose bias fits the
+// 16 KB behind the P tile.  NST_FFN_V2=0 keeps the one-wave-per-SIMD kernel (A/B switch).
+bool use_v2_fwd(const FfnArgs& a) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_FFN_V2"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1 && a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
+}
+
+template <int DROP, bool FULL, int DBG = 0>
+int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
+  const int lds = V2_BIAS + a.F * 4;
+  auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, DBG>;
+  allow_lds(k, lds);
+  k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+  return NST_OK;
+}
+
+bool use_v2_bwd(const FfnArgs& a) {   // NST_FFN_V2_BWD=0: the one-wave-per-SIMD backward
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_FFN_V2_BWD"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1 && a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
+}
+
+int launch_pair_v2_bwd(const FfnArgs& a_in, hipStream_t st) {
+  FfnArgs a = a_in;
+  a.rot_mode = 0;
+  const int lds = V2_BIAS + 16384;   // the eight 2 KB gate regions
+  if (a.M % V2_ROWS == 0) {
+    auto k = ffn_pair8_kernel<MODE_BWD, 0, true, 0>;
+    allow_lds(k, lds);
+    k<<<a.M / V2_ROWS, 512, lds, st>>>(a);
+  } else {
+    auto k = ffn_pair8_kernel<MODE_BWD, 0, false, 0>;
+    allow_lds(k, lds);
+    k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+  }
+  return NST_OK;
+}
+
+int launch_pair_v2_fwd(const FfnArgs& a_in, hipStream_t st) {
+  FfnArgs a = a_in;
+  { static int m = -1; if (m < 0) { const char* e = getenv("NST_FFN_ROT"); m = e ? atoi(e) : 0; } a.rot_mode = m; }
+  const bool full = a.M % V2_ROWS == 0;
+  const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
+  const char* e = getenv("NST_FFN_DBG");
+  if (e && full && drop == 0) {   // ablation builds (benchmark shape, no dropout): see the DBG bits of ffn_pair8_kernel
+    switch (atoi(e)) {
+      case 1: return launch_v2_fwd<0, true, 1>(a, st);
+      case 2: return launch_v2_fwd<0, true, 2>(a, st);
+      case 4: return launch_v2_fwd<0, true, 4>(a, st);
+      case 8: return launch_v2_fwd<0, true, 8>(a, st);
+      case 16: return launch_v2_fwd<0, true, 16>(a, st);
+      case 32: return launch_v2_fwd<0, true, 32>(a, st);
+      case 12: return launch_v2_fwd<0, true, 12>(a, st);
+      case 31: return launch_v2_fwd<0, true, 31>(a, st);
+      case 64: return launch_v2_fwd<0, true, 64>(a, st);
+      default: break;
+    }
+  }
+  if (e && full && drop == 3 && atoi(e) == 116) return launch_v2_fwd<3, true, 16>(a, st);
+  if (full && drop == 3) return launch_v2_fwd<3, true>(a, st);
+  if (full && drop == 0) return launch_v2_fwd<0, true>(a, st);
+  return launch_v2_fwd<3, false>(a, st);
 }
 
 // rows per workgroup: 128 when that still gives every CU a workgroup, else 64 (NST_FFN_NW overrides: 4 | 2)
@@ -632,7 +1127,8 @@ extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, 
   nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
   nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);
   a.seed1 = d->hidden_seed; a.stream1 = d->hidden_stream_id; a.seed2 = d->output_seed; a.stream2 = d->output_stream_id;
-  const int rc = pick_nw(a.M) == 4 ? launch_pair<MODE_FWD, 4>(a, (hipStream_t)stream) : launch_pair<MODE_FWD, 2>(a, (hipStream_t)stream);
+  const int rc = use_v2_fwd(a) ? launch_pair_v2_fwd(a, (hipStream_t)stream)
+                 : pick_nw(a.M) == 4 ? launch_pair<MODE_FWD, 4>(a, (hipStream_t)stream) : launch_pair<MODE_FWD, 2>(a, (hipStream_t)stream);
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_fwd");
   return NST_OK;
@@ -658,8 +1154,9 @@ extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidd
   nst_dropout_params16(d->hidden_dropout_p, &th, &inv);
   a.gate_scale = th ? inv : 1.0f;
   // the gate pieces are 64 rows: a workgroup of 128 rows needs M >= 64 (row clamp), 64-row workgroups one piece
-  const int rc = (pick_nw(a.M) == 4 && a.M >= 64) ? launch_pair<MODE_BWD, 4>(a, (hipStream_t)stream)
-                                                  : launch_pair<MODE_BWD, 2>(a, (hipStream_t)stream);
+  const int rc = use_v2_bwd(a) ? launch_pair_v2_bwd(a, (hipStream_t)stream)
+                 : (pick_nw(a.M) == 4 && a.M >= 64) ? launch_pair<MODE_BWD, 4>(a, (hipStream_t)stream)
+                                                    : launch_pair<MODE_BWD, 2>(a, (hipStream_t)stream);
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_bwd");
   return NST_OK;
