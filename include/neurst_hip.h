@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 4
+#define NST_ABI_VERSION 5
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -425,6 +425,21 @@ typedef struct {
   int rows, cols, tiles_c, tile0;
 } NstTransposeJob;
 int nst_transpose_bf16(const NstTransposeJob* jobs_dev, int njobs, int total_tiles, void* stream);
+
+/* Batched strided block copies, one launch for a table of jobs (device memory): rows x row_bytes from src (pitch src_pitch
+ * bytes) to dst (pitch dst_pitch).  Used for PACKED copies of weights that several layers apply to the same input: the six
+ * cross-attention kv_transform kernels [d, 2d] of the decoder layers (neurst/layers/transformer_layers.py:213-234,
+ * multi_head_attention.py:166-223) side by side as one [d, 6*2d] operand, so the projection of the encoder output is ONE GEMM
+ * (and its input gradient one GEMM with K = 6*2d); refreshed once per optimizer step like the transposed copies.
+ * block0 = number of 256-thread blocks of all earlier jobs, nblocks = blocks of this job; total_blocks = their sum. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int rows, row_bytes;
+  int64_t src_pitch, dst_pitch;
+  int block0, nblocks;
+} NstPack2dJob;
+int nst_pack2d(const NstPack2dJob* jobs_dev, int njobs, int total_blocks, void* stream);
 
 #ifdef __cplusplus
 }

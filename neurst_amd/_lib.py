@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 4
+NST_ABI_VERSION = 5
 
 
 class NstGemmDesc(C.Structure):
@@ -130,6 +130,7 @@ SIGNATURES = {
     "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
+    "nst_pack2d": [_P, _I, _I, _P],
 }
 
 

@@ -1098,7 +1098,42 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const TransposeJob*
   }
 }
 
+// strided block copies for packed weight copies: job j copies rows x row_bytes from src (pitch src_pitch) to dst (pitch dst_pitch),
+// 16 bytes per thread when everything is 16-byte aligned, byte-wise otherwise; block0 = number of 256-thread blocks of earlier jobs
+struct Pack2dJob { const char* src; char* dst; int rows, row_bytes; int64_t src_pitch, dst_pitch; int block0, nblocks; };
+
+__global__ void __launch_bounds__(256) pack2d_kernel(const Pack2dJob* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+  const Pack2dJob q = jobs[j];
+  const int b = blockIdx.x - q.block0;
+  const bool vec = (((uintptr_t)q.src | (uintptr_t)q.dst | (uintptr_t)q.src_pitch | (uintptr_t)q.dst_pitch | (uintptr_t)q.row_bytes) & 15) == 0;
+  if (vec) {
+    const int cpr = q.row_bytes >> 4;
+    const int64_t total = (int64_t)q.rows * cpr;
+    for (int64_t e = (int64_t)b * 256 + threadIdx.x; e < total; e += (int64_t)q.nblocks * 256) {
+      const int r = (int)(e / cpr), c = (int)(e - (int64_t)r * cpr);
+      *reinterpret_cast<uint4*>(q.dst + r * q.dst_pitch + c * 16) = *reinterpret_cast<const uint4*>(q.src + r * q.src_pitch + c * 16);
+    }
+  } else {
+    const int64_t total = (int64_t)q.rows * q.row_bytes;
+    for (int64_t e = (int64_t)b * 256 + threadIdx.x; e < total; e += (int64_t)q.nblocks * 256) {
+      const int r = (int)(e / q.row_bytes), c = (int)(e - (int64_t)r * q.row_bytes);
+      q.dst[r * q.dst_pitch + c] = q.src[r * q.src_pitch + c];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int nst_pack2d(const NstPack2dJob* jobs_dev, int njobs, int total_blocks, void* stream) {
+  NST_CHECK_ARG(njobs >= 0 && total_blocks >= 0 && (njobs == 0 || jobs_dev), "pack2d: bad arguments");
+  if (njobs == 0 || total_blocks == 0) return NST_OK;
+  static_assert(sizeof(Pack2dJob) == sizeof(NstPack2dJob), "job table layout");
+  pack2d_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const Pack2dJob*)jobs_dev, njobs);
+  NST_CHECK_LAUNCH("pack2d");
+  return NST_OK;
+}
 
 extern "C" int nst_ffn_supported(int d_model, int filter_size, int dtype) {
   return dtype == NST_BF16 && d_model == D && filter_size >= CH && filter_size % CH == 0 && filter_size <= 8192 ? 1 : 0;

@@ -205,6 +205,9 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
     ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
     ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0 && g3.x % 8 == 0) ? 1 : 0;
+    // NST_GEMM_SPLIT_ISSUE=1: next step's DMA in two halves between the MFMA groups.  Measured WORSE here (two workgroups per
+    // CU already cover each other's issue time): ffn2 forward 37.2 -> 40.3 us, step +0.15 ms (r03_ab_split_issue.log); off.
+    { static int si = -1; if (si < 0) { const char* e = getenv("NST_GEMM_SPLIT_ISSUE"); si = (e && e[0] == '1') ? 1 : 0; } ga.split_issue = si; }
 #define NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_)                                                                          \
   do {                                                                                                               \
     auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_, EF_>;                                                      \

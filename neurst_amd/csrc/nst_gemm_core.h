@@ -1137,6 +1137,7 @@ struct GemmArgs {
   int64_t ldc;
   int M, N, K, tiles_n, ntiles, split, kt_per_split;
   int z_per_xcd;   // != 0 (needs split % 8 == 0, grid % 8 == 0): K slice z lives on XCD z % 8, see unit_of
+  int split_issue; // != 0: the next step's DMA is issued in two halves between the MFMA groups (0: in front of the step; A/B switch)
   Epilogue ep;
   RowMap rowmap;
 };
@@ -1232,15 +1233,25 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
   Unit cq = unit_of(cu);
   int ckt = 0;
 
-  auto issue_next = [&](int stage) {
+  // the DMA of one K step in two halves (A tile, then B tile + the unit bookkeeping): the main loop puts the halves BEHIND the
+  // fragment reads and between its two groups of 16 MFMAs -- issuing the eight DMA instructions back to back in front of the
+  // step cost the wave 500-800 cycles with the matrix core idle (measured on the feed-forward kernel, r03_ffn_v2_ablation.log)
+  auto issue_a = [&](int stage) {
     const uint32_t sa = smem_addr + stage * V2_STAGE_BYTES;
     da.next(sa + wave * 1024, sa, wave);
+  };
+  auto issue_b = [&](int stage) {
+    const uint32_t sa = smem_addr + stage * V2_STAGE_BYTES;
     db.next(sa + BM * KBYTES + wave * 1024, sa + BM * KBYTES, wave);
     if (++ikt == ikt_count) {
       iu += gridDim.x;
       ikt = 0;
       if (iu < units) cursor_init(iu);
     }
+  };
+  auto issue_next = [&](int stage) {
+    issue_a(stage);
+    issue_b(stage);
   };
 
   issue_next(0);
@@ -1249,7 +1260,10 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
     wait_vmcnt<0>();                 // the K step about to be multiplied has landed (and older stores have retired)
     __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is also done reading the other stage
     asm volatile("" ::: "memory");
-    if (iu < units) issue_next(stage ^ 1);
+    const bool split_issue = (BK / KS == 2) && ka->split_issue != 0;
+    const bool more_now = iu < units;
+    if (!split_issue && more_now) issue_next(stage ^ 1);
+    const bool more = split_issue && more_now;
     const char* As = smem + stage * V2_STAGE_BYTES;
     const char* Bs = As + BM * KBYTES;
     const bool do_cs = has_cs && cq.m0 == 0 && wm == 0;  // wave-uniform
@@ -1266,6 +1280,8 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1[i] = RA::read(As, wm + i * 16, KS, lane);
       __builtin_amdgcn_sched_barrier(0);
+      if (more) issue_a(stage ^ 1);     // the next step's A tile: its issue runs under the fragment reads' latency
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1274,6 +1290,9 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b0[j], cs[j]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) issue_b(stage ^ 1);     // ... and its B tile behind the first 16 MFMAs (they run while the wave issues the DMA)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -352,6 +352,11 @@ def transpose_bf16(table, njobs, total_tiles):
     check(lib.nst_transpose_bf16(_p(table), njobs, total_tiles, _stream()), "transpose_bf16")
 
 
+def pack2d(table, njobs, total_blocks):
+    """Runs a device-resident table of NstPack2dJob (see ParamStore._build_packed): strided block copies, one launch."""
+    check(lib.nst_pack2d(_p(table), njobs, total_blocks, _stream()), "pack2d")
+
+
 def grad_clip(grad, table, nentries, seg_first, nseg, pre_scale=1.0, clip_value=None, clip_norm=None):
     """In place on the flat gradient buffer: g *= pre_scale, then clamp to +-clip_value or scale every tensor to an L2 norm
     of at most clip_norm (neurst_hip.h nst_grad_clip; gradaccum_keras_model.py:228-233)."""

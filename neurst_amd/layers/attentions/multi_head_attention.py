@@ -62,6 +62,10 @@ class MultiHeadAttention(Layer):
                 if "kv" not in cache:
                     cache["kv"] = self.kv_transform.forward(memory)
                 kv = cache["kv"]
+            elif getattr(self, "_kv_pre", None) is not None:
+                # the decoder projected the memory for ALL its layers in one GEMM over the packed kv_transform kernels
+                # (TransformerDecoder._project_memory): this layer's k|v are a column block of that output (row stride = all blocks)
+                kv, self._kv_pre = self._kv_pre, None
             else:
                 kv = self.kv_transform.forward(memory)
             kv3 = kv.view(B, Tk, 2 * d)
@@ -102,14 +106,16 @@ class MultiHeadAttention(Layer):
         self.output_transform.backward_params(ctx2, dz)
         dctx, delta = self._output_backward_input(dz, ctx2, lse, Tq)
         dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        grouped = getattr(self, "_dkv_out", None) is not None    # d(k|v) goes into the decoder's packed buffer; the decoder
+        dkv = self._dkv_out if grouped else torch.empty_like(kv)  # turns all layers' blocks into d(memory) with ONE GEMM
+        self._dkv_out = None
         q3, kv3, dq3, dkv3 = q.view(B, Tq, d), kv.view(B, Tk, 2 * d), dq.view(B, Tq, d), dkv.view(B, Tk, 2 * d)
         K.attention_bwd(q3, kv3[..., :d], kv3[..., d:], ctx, dctx.view(B, Tq, d), lse, dq3, dkv3[..., :d],
                         dkv3[..., d:], H, dh, key_bias=bias, causal=lag is not None, causal_offset=lag or 0, dropout_p=p,
                         seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask, delta=delta)
         self.q_transform.backward_params(query, dq)
         self.kv_transform.backward_params(memory, dkv)
-        if dmemory is not None:
+        if dmemory is not None and not grouped:
             self.kv_transform.backward_input(dkv, out=dmemory, accumulate=dmemory_accumulate)
         return self.q_transform.backward_input(dq, **({} if residual is None else {"residual": residual}))
 

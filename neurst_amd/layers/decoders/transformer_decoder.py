@@ -1,5 +1,7 @@
 """TransformerDecoder (neurst/layers/decoders/transformer_decoder.py:23-228): the training branch
 (cache["decoding_states"] is None) and incremental decoding with per-layer caches (wait-k lagging is not built)."""
+import os
+
 import torch
 
 from neurst_amd import kernels as K
@@ -38,7 +40,27 @@ class TransformerDecoder(Decoder):
         self._output_norm_layer = None if p["post_normalize"] else LayerNorm(
             rt, f"{self.name}/output_ln", p["hidden_size"], p["layer_postprocess_epsilon"])
         self._site = rt.new_dropout_site()
+        # Training: every layer's cross attention projects the SAME encoder output with its own kv_transform
+        # (transformer_layers.py:213-234, multi_head_attention.py:166-223).  The kernels are kept side by side in a packed
+        # copy [d, n * 2d] (refreshed once per optimizer step), so the projection is ONE GEMM whose output the layers read as
+        # column blocks, and d(memory) = [d(k|v) of all layers] . packed^T is ONE GEMM with K = n * 2d instead of n
+        # accumulating ones.  The weight gradients stay per layer (the data-parallel reducer ships a layer's gradients as soon
+        # as that layer's backward is queued).  NST_DEC_KV_GROUP=0: per-layer projections.
+        self._kv_group, self._kv_atts = None, []
+        atts = [l._cross.att for l in self._stacking_layers if l._with_cross_attention]
+        if os.environ.get("NST_DEC_KV_GROUP", "1") != "0" and len(atts) >= 2 \
+                and len({tuple(a.kv_transform.kernel.shape) for a in atts}) == 1:
+            self._kv_group = rt.store.add_packed([a.kv_transform.kernel for a in atts], [a.kv_transform.bias for a in atts])
+            self._kv_atts = atts
         return self
+
+    def _project_memory(self, mem2):
+        """One GEMM for the k|v of every layer; hands each layer its column block."""
+        g = self._kv_group
+        kv_all = K.gemm(mem2, g.w, mem2.shape[0], g.w.shape[1], g.w.shape[0], bias=g.b)
+        for a, c0 in zip(self._kv_atts, g.col0):
+            a._kv_pre = kv_all[:, c0:c0 + a.kv_transform.out_dim]
+        return kv_all
 
     def create_decoding_internal_cache(self, encoder_outputs, encoder_inputs_padding, is_inference=False,
                                        decode_padded_length=None):
@@ -143,6 +165,9 @@ class TransformerDecoder(Decoder):
         self._p = p
         if p > 0:
             x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
+        self._grouped = self._kv_group is not None and mem2 is not None and is_training
+        if self._grouped:
+            self._project_memory(mem2)
         for layer in self._stacking_layers:
             x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
         out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
@@ -162,6 +187,12 @@ class TransformerDecoder(Decoder):
         elif not dx.is_contiguous():
             dx = dx.contiguous()
         first = True
+        dkv_all = None
+        if getattr(self, "_grouped", False) and Tm:
+            g = self._kv_group
+            dkv_all = torch.empty(B * Tm, g.w.shape[1], dtype=dout.dtype, device=dout.device)
+            for a, c0 in zip(self._kv_atts, g.col0):
+                a._dkv_out = dkv_all[:, c0:c0 + a.kv_transform.out_dim]
         for i in range(len(layers) - 1, -1, -1):
             dx = layers[i].backward(dx, dmemory, dmemory_accumulate=not first,
                                     consumer=layers[i - 1].first_backward_site if i > 0 else self)
@@ -171,6 +202,10 @@ class TransformerDecoder(Decoder):
                 extra = [self._output_norm_layer.name + "/"] if (i == len(layers) - 1 and self._output_norm_layer is not None) else []
                 layer_done([layers[i].name + "/"] + extra)    # output_ln rides with the top layer (see TransformerEncoder)
         dx = dropped_grad(self.rt, dx, self._p, self._site)
+        if dkv_all is not None:     # d(memory) of all layers at once: [B*Tm, n*2d] . packed^T (K = n * 2d)
+            g = self._kv_group
+            K.gemm(dkv_all, g.w, B * Tm, d, g.w.shape[1], trans_b=True, out=dmemory)
+            first = False
         if dmemory is not None and first:
             dmemory.zero_()
         return dx.view(B, L, d), (dmemory.view(B, Tm, d) if dmemory is not None else None)

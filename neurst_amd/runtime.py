@@ -38,6 +38,15 @@ class TransposedCopy(object):
         self.param, self.offset, self.t = param, -1, None
 
 
+class PackedCopy(object):
+    """Handle of a packed copy of several [rows, cols_i] kernels side by side (ParamStore.add_packed): `w` [rows, sum cols_i] in
+    the compute dtype, `b` [sum cols_i] fp32 (the biases)."""
+    __slots__ = ("kernels", "biases", "w", "b", "col0")
+
+    def __init__(self, kernels, biases):
+        self.kernels, self.biases, self.w, self.b, self.col0 = list(kernels), list(biases), None, None, []
+
+
 class ParamStore(object):
     def __init__(self):
         self.params = collections.OrderedDict()
@@ -45,6 +54,7 @@ class ParamStore(object):
         self._touched = set()
         self.accumulate_all = False
         self._transposed = []     # (param, handle): bf16 copies stored transposed (the fused feed-forward's forward operands)
+        self._packed = []         # PackedCopy handles: kernels of several layers side by side as one GEMM operand
 
     def add(self, name, shape, init):
         """init: CPU float tensor of `shape` (the reference's initializer already applied)."""
@@ -65,6 +75,16 @@ class ParamStore(object):
         assert len(param.shape) == 2
         handle = TransposedCopy(param)
         self._transposed.append(handle)
+        return handle
+
+    def add_packed(self, kernels, biases):
+        """Registers a packed copy of 2-D kernels with equal row counts (and their biases); after finalize() `handle.w` /
+        `handle.b` hold them side by side, kept in step with the weights wherever the bf16 shadow is refreshed."""
+        if self.finalized:
+            raise RuntimeError("ParamStore already finalized")
+        assert len({k.shape[0] for k in kernels}) == 1 and len(kernels) == len(biases)
+        handle = PackedCopy(kernels, biases)
+        self._packed.append(handle)
         return handle
 
     def finalize(self, device, compute_dtype):
@@ -89,6 +109,7 @@ class ParamStore(object):
             p.grad = self.grad[sl].view(p.shape)
             p.compute = (self.shadow if self.shadow is not None else self.master)[sl].view(p.shape)
         self._build_transposed()
+        self._build_packed()
         self.finalized = True
         self.refresh_shadow()
         return self
@@ -117,8 +138,54 @@ class ParamStore(object):
         if self.device.type == "cuda":
             self._tr_table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
 
+    def _build_packed(self):
+        self._pk_table, self._pk_jobs, self._pk_blocks = None, 0, 0
+        if not self._packed:
+            return
+        import numpy as np
+        rows_tab = []
+        for hnd in self._packed:
+            rows = hnd.kernels[0].shape[0]
+            cols = [k.shape[1] for k in hnd.kernels]
+            wdt = self.compute_dtype
+            hnd.w = torch.zeros(rows, sum(cols), dtype=wdt, device=self.device)
+            hnd.b = torch.zeros(sum(cols), dtype=torch.float32, device=self.device)
+            hnd.col0, c0 = [], 0
+            esz = hnd.w.element_size()
+            for k, b in zip(hnd.kernels, hnd.biases):
+                hnd.col0.append(c0)
+                nb = max(1, min(64, (rows * k.shape[1] * esz // 16 + 255) // 256))
+                rows_tab.append((k.compute.data_ptr(), hnd.w.data_ptr() + c0 * esz, rows, k.shape[1] * esz, k.shape[1] * esz,
+                                 sum(cols) * esz, self._pk_blocks, nb))
+                self._pk_blocks += nb
+                if b is not None:
+                    rows_tab.append((b.data.data_ptr(), hnd.b.data_ptr() + c0 * 4, 1, k.shape[1] * 4, k.shape[1] * 4, sum(cols) * 4,
+                                     self._pk_blocks, 1))
+                    self._pk_blocks += 1
+                c0 += k.shape[1]
+        self._pk_jobs = len(rows_tab)
+        arr = np.array(rows_tab, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("row_bytes", "<i4"),
+                                                 ("src_pitch", "<i8"), ("dst_pitch", "<i8"), ("block0", "<i4"), ("nblocks", "<i4")]))
+        if self.device.type == "cuda":
+            self._pk_table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+
+    def refresh_packed(self):
+        """Re-derives the packed copies from the compute weights / fp32 biases: one launch for all of them."""
+        if not self._packed:
+            return
+        if self.master.is_cuda:
+            from neurst_amd import kernels
+            kernels.pack2d(self._pk_table, self._pk_jobs, self._pk_blocks)
+        else:   # host-side tests of the layer scheduling
+            for hnd in self._packed:
+                for k, b, c0 in zip(hnd.kernels, hnd.biases, hnd.col0):
+                    hnd.w[:, c0:c0 + k.shape[1]].copy_(k.compute)
+                    if b is not None:
+                        hnd.b[c0:c0 + k.shape[1]].copy_(b.data)
+
     def refresh_transposed(self):
-        """Re-derives the transposed bf16 copies from the bf16 shadow: one launch for all of them."""
+        """Re-derives the transposed bf16 copies from the bf16 shadow: one launch for all of them (and the packed copies)."""
+        self.refresh_packed()
         if getattr(self, "shadow_t", None) is None:
             return
         if self.master.is_cuda:
@@ -135,7 +202,7 @@ class ParamStore(object):
                 kernels.cast_f32_to_bf16(self.master, self.shadow)
             else:  # host-side unit tests of the store itself
                 self.shadow.copy_(self.master.to(torch.bfloat16))
-            self.refresh_transposed()
+        self.refresh_transposed()     # (fp32 too: the packed copies follow the master weights)
 
     # --- gradient bookkeeping: the first kernel that writes a parameter's gradient in a backward pass
     # overwrites, later writers (tied embedding, gradient accumulation micro-steps) accumulate.

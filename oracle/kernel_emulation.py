@@ -194,6 +194,13 @@ def transpose_bf16(table, njobs, total_tiles):
         dst.copy_(src.t())
 
 
+def pack2d(table, njobs, total_blocks):
+    """`table` on the CPU tier is a Python list of (src, dst) tensor pairs (dst a strided block of the packed buffer);
+    ParamStore itself refreshes its packed copies without this entry point on CPU tensors."""
+    for src, dst in table:
+        dst.copy_(src)
+
+
 def colsum(x, out, accumulate=False):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
     s = x.to(F64).sum(0).float()
@@ -489,7 +496,7 @@ def cast_f32_to_bf16(src, dst):
 _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "attention_fwd", "attention_bwd",
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
-          "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16",
+          "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
           "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi"]
 
 
