@@ -1217,12 +1217,22 @@ Epilogue plain_epilogue() {
 // (1070 us), a double-buffered 32-channel patch (1086 us), even/odd row regions reloaded under the multiply steps
 // (1008 us) -- the K loop, not the patch reload, is the limit: ~2100 cycles per K step for 1024 MFMA cycles per SIMD.
 // =============================================================================================
+// NST_CONV_ISSUE_LATE=1: the next weight tile's DMA behind this step's fragment reads instead of in front of them.  Measured
+// SLOWER in the step (15.12 -> 15.31 ms, gpurun_out/r03_conv_issue_late.log: the tile then has less than a step to land); off.
+static int conv_issue_late() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV_ISSUE_LATE"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v;
+}
+
 struct PatchArgs {
   const bf16_t* x;
   const bf16_t* w2;
   bf16_t* y;
   int T2, F1, F2, C, M, PW, in_rows, ntiles;
   FastDiv dF2, dT2, dPW;
+  int issue_late;   // != 0: the next weight tile's DMA is issued BEHIND this step's fragment reads (its issue time then covers
+                    // their LDS latency; with one workgroup per CU both waves of a SIMD otherwise sit in the issue together)
   Epilogue ep;
 };
 constexpr int CP_THREADS = 512;
@@ -1323,8 +1333,11 @@ __global__ void __launch_bounds__(CP_THREADS) conv2_fwd_patch_kernel(PatchArgs a
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (tap < 8) issue_b((tap + 1) * a.C + cc * 64, buf ^ 1);
-      else if (cc + 1 < ncc) issue_b((cc + 1) * 64, buf ^ 1);
+      auto issue_next_b = [&]() {
+        if (tap < 8) issue_b((tap + 1) * a.C + cc * 64, buf ^ 1);
+        else if (cc + 1 < ncc) issue_b((cc + 1) * 64, buf ^ 1);
+      };
+      if (!a.issue_late) issue_next_b();
       const char* Bs = smem + CP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
       const int wnl = wn & 127;
       const int toff = kh * a.PW + kw;
@@ -1342,6 +1355,8 @@ __global__ void __launch_bounds__(CP_THREADS) conv2_fwd_patch_kernel(PatchArgs a
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (a.issue_late) issue_next_b();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1386,6 +1401,7 @@ bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, in
   a.T2 = T2; a.F1 = F1; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.in_rows = B * T1;
   a.ntiles = (int)((M + BM - 1) / BM);
   a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
+  a.issue_late = conv_issue_late();
   a.ep = plain_epilogue();
   a.ep.bias = b2; a.ep.relu = relu; a.ep.vec = 1;
   conv_allow_big_lds(conv2_fwd_patch_kernel, CP_LDS_BYTES);
@@ -1454,6 +1470,7 @@ struct DgradPatchArgs {
   bf16_t* dx;
   int T1, F1, T2, F2, C, M, PW, dy_rows, ntiles;
   FastDiv dF2, dT2, dPW;
+  int issue_late;   // see PatchArgs
 };
 constexpr int DP_ZERO_OFF = CP_LDS_BYTES - 2 * CP_BBUF - 1024;   // patch bytes available: 97280 = 190 positions
 constexpr int DP_B_OFF = DP_ZERO_OFF + 1024;
@@ -1548,8 +1565,11 @@ __global__ void __launch_bounds__(CP_THREADS) conv2_dgrad_patch_kernel(DgradPatc
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (cc < 3) issue_b(DP_TAP[e], cc + 1, buf ^ 1);
-      else if (!last) issue_b(DP_TAP[e + 1], 0, buf ^ 1);
+      auto issue_next_b = [&]() {
+        if (cc < 3) issue_b(DP_TAP[e], cc + 1, buf ^ 1);
+        else if (!last) issue_b(DP_TAP[e + 1], 0, buf ^ 1);
+      };
+      if (!a.issue_late) issue_next_b();
       const char* Bs = smem + DP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
       const int wnl = wn & 127;
       bf16x8_t a0[4], a1[4];
@@ -1566,6 +1586,8 @@ __global__ void __launch_bounds__(CP_THREADS) conv2_dgrad_patch_kernel(DgradPatc
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (a.issue_late) issue_next_b();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1641,6 +1663,7 @@ bool conv2_dgrad_patch(const void* dy, const void* w2, void* dx, int B, int T1, 
   a.T1 = T1; a.F1 = F1; a.T2 = T2; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.dy_rows = B * T2;
   a.ntiles = (int)((M + BM - 1) / BM);
   a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
+  a.issue_late = conv_issue_late();
   conv_allow_big_lds(conv2_dgrad_patch_kernel, CP_LDS_BYTES);
   conv2_dgrad_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
   return true;
