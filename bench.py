@@ -91,6 +91,14 @@ def algorithmic_flops(model_args, B, T, F, L, V):
             "forward": conv1 + conv2 + dense + enc + dec + logits}
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round that has one (the PMC summaries are captured by separate rocprofv3 --pmc passes
+    of this command and committed; this run does not re-measure them)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return hits[-1] if hits else None
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     host's cores inside a container, and oversubscribing torch's thread pool slows the oracle by orders of magnitude)."""
@@ -316,8 +324,8 @@ def main():
         top = max(families, key=lambda n: families[n]["ms_per_step"])
         roofline = dict(families[top])
         roofline["selected_as"] = "largest share of in-step GPU time among the MFMA kernel families (see roofline_families)"
-        pmc = os.path.join(ROOT, "profiles", f"r02_pmc_{top}.json")
-        if args.dtype == "bf16" and B == 128 and T == 900 and os.path.exists(pmc):
+        pmc = latest_profile(f"pmc_{top}.json")
+        if args.dtype == "bf16" and B == 128 and T == 900 and pmc:
             # HBM bytes per step of this family from the committed rocprofv3 --pmc passes of the same command
             # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); not re-measured by this run
             try:
@@ -326,13 +334,15 @@ def main():
                 roofline["traffic_per_step"] = t["hbm_bytes_per_step"]
                 roofline["algorithmic_flops_per_launch"] = roofline["algorithmic_flops_per_step"] / roofline["launches_per_step"]
                 roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
+                roofline["traffic_captured_at_commit"] = t.get("captured_at_commit")   # stale once the GEMM kernels change
             except Exception:
                 pass
     ffn_util = None
-    pmc_ffn = os.path.join(ROOT, "profiles", "r02_pmc_ffn_gemm.json")
-    if os.path.exists(pmc_ffn):
+    pmc_ffn = latest_profile("pmc_ffn_gemm.json")
+    if pmc_ffn:
         try:
-            ffn_util = {"source": "profiles/r02_pmc_ffn_gemm.json", **json.load(open(pmc_ffn))["summary"]}
+            t = json.load(open(pmc_ffn))
+            ffn_util = {"source": os.path.relpath(pmc_ffn, ROOT), "captured_at_commit": t.get("captured_at_commit"), **t["summary"]}
         except Exception:
             pass
     out = {

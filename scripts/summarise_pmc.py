@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Turn the raw per-kernel PMC tables of scripts/pmc_kernel.sh into the two small files bench.py reads:
 
-  profiles/r02_pmc_ffn_gemm.json  {"summary": {...}}            MFMA utilisation of the FFN GEMM kernels
-  profiles/r02_pmc_gemm.json      {"hbm_bytes_per_step": ...}   HBM bytes of the dense GEMM family in one train step
+  profiles/<tag>_pmc_ffn_gemm.json  {"summary": {...}}            MFMA utilisation of the FFN GEMM kernels
+  profiles/<tag>_pmc_gemm.json      {"hbm_bytes_per_step": ...}   HBM bytes of the dense GEMM family in one train step
+(both stamped with the git commit the counters were captured at: bench.py copies that stamp into its JSON line)
 
 Counter arithmetic (MI355X_MICROARCH.md, rocprofv3 section):
   * SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over all SIMDs (32 per v_mfma_f32_32x32x16_bf16);
@@ -63,19 +64,33 @@ def gemm_traffic(path, steps):
             "per_kernel": per_kernel}
 
 
+def head_commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        return None
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ffn", default=os.path.join(ROOT, "gpurun_out", "r02_pmc_ffn_fused.json"))
-    ap.add_argument("--gemm", default=os.path.join(ROOT, "gpurun_out", "r02_pmc_gemm.json"))
+    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--ffn", default=None)
+    ap.add_argument("--gemm", default=None)
     ap.add_argument("--gemm-steps", type=int, default=6, help="train steps inside the profiled bench command (steps + warmup)")
+    ap.add_argument("--commit", default=None, help="commit the counters were captured at (default: HEAD)")
     a = ap.parse_args()
-    ffn = {"command": "scripts/pmc_kernel.sh ... ffn_pair_kernel scripts/ffn_bench.py --rows 28800 --iters 5 (stand-alone launches, M=28800 d=256 ffn=2048)",
-           "formula": "mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8)",
+    a.ffn = a.ffn or os.path.join(ROOT, "gpurun_out", f"{a.tag}_pmc_ffn_fused.json")
+    a.gemm = a.gemm or os.path.join(ROOT, "gpurun_out", f"{a.tag}_pmc_gemm.json")
+    commit = a.commit or head_commit()
+    ffn = {"command": "scripts/pmc_kernel.sh ... ffn_pair scripts/ffn_bench.py --rows 28800 --iters 5 (stand-alone launches, M=28800 d=256 ffn=2048)",
+           "formula": "mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8)", "captured_at_commit": commit,
            "summary": ffn_summary(a.ffn)}
-    json.dump(ffn, open(os.path.join(ROOT, "profiles", "r02_pmc_ffn_gemm.json"), "w"), indent=1)
+    json.dump(ffn, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc_ffn_gemm.json"), "w"), indent=1)
     g = gemm_traffic(a.gemm, a.gemm_steps)
-    g["command"] = "scripts/pmc_kernel.sh ... dense_gemm_kernel_v3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --roofline-steps 0"
-    json.dump(g, open(os.path.join(ROOT, "profiles", "r02_pmc_gemm.json"), "w"), indent=1)
+    g["command"] = "scripts/pmc_kernel.sh ... dense_gemm_kernel_v3 bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --roofline-steps 0"
+    g["captured_at_commit"] = commit
+    json.dump(g, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc_gemm.json"), "w"), indent=1)
     print(json.dumps(ffn["summary"], indent=1))
     print(json.dumps({k: v for k, v in g.items() if k != "per_kernel"}, indent=1))
     for k, v in g["per_kernel"].items():
