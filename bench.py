@@ -60,9 +60,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-stream-priority", type=int, default=int(os.environ.get("NST_MAIN_PRIORITY", "0")),
                     help="-1: run the step on a high-priority HIP stream (the weight-gradient stream keeps the default priority)")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("NST_TRAIN_GRAPH", "1") != "0",
-                    help="replay the step from captured HIP graphs (training/train_step.py graph mode; the default since round 3: "
-                         "same step time as eager launches, ~1 ms instead of ~12 ms of host time per step)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step from captured HIP graphs (training/train_step.py graph mode): the default on one rank "
+                         "since round 3 (same step time as eager launches, ~1 ms instead of ~12 ms of host time per step).  With "
+                         "more than one rank the default stays eager -- the step is GPU-bound either way and the capture next to "
+                         "RCCL's watchdog thread has only been exercised with one forced rank; NST_TRAIN_GRAPH=0|1 or the flags decide")
     ap.add_argument("--eager", dest="graph", action="store_false", help="eager launches instead of graph replay")
     ap.add_argument("--wire", default=os.environ.get("NST_DIST_WIRE", "fp32"), choices=["fp32", "bf16", "fp16"],
                     help="gradient dtype on the wire (16-bit: the reference's fp16 compression, training_utils.py:381-384)")
@@ -217,6 +219,9 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = init_distributed()
+    if args.graph is None:
+        env = os.environ.get("NST_TRAIN_GRAPH")
+        args.graph = (env != "0") if env is not None else (world == 1)
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dev = f"cuda:{torch.cuda.current_device()}"      # init_distributed pinned it (LOCAL_RANK)

@@ -51,7 +51,10 @@ class _StepCapture(object):
     def begin(self):
         self.cur = _Segment()
         self.cur.main = torch.cuda.CUDAGraph()
-        self.cur.main.capture_begin(pool=self.pool)
+        # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events while this thread
+        # captures -- in the default (global) mode such a call from ANOTHER thread invalidates the capture and aborts the
+        # process (seen once in five forced-exchange runs of bench.py, round 3)
+        self.cur.main.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def _close(self):
         """Ends the compute graph of the current segment and captures its weight-gradient graph from the recorded calls."""
@@ -73,7 +76,7 @@ class _StepCapture(object):
                 cap, self.rt.capture = self.rt.capture, None      # the calls run for real inside this capture
                 try:
                     seg.wgrad = torch.cuda.CUDAGraph()
-                    seg.wgrad.capture_begin(pool=self.pool)
+                    seg.wgrad.capture_begin(pool=self.pool, capture_error_mode="thread_local")
                     for fn in calls:
                         fn()
                     seg.wgrad.capture_end()
