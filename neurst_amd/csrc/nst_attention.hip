@@ -725,6 +725,215 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_from_ds_kernel(AttnParams p) 
 }
 
 // =============================================================================================
+// backward, fused (bf16, Tq <= 256 and Tk <= 256, round 3): ONE workgroup per (batch, head) computes dK, dV AND dQ.
+//
+// The two-kernel path above moves dS^T through HBM (B*H*Tk'*Tq' bf16 written by the dK/dV kernel, read by the dQ kernel: 134 MB
+// of the ~240 MB an encoder layer's attention backward touches at the benchmark shape) and re-reads Q / dO once per 64-key
+// workgroup.  At these sequence lengths a whole head fits in LDS:
+//   * Q, dO and K of the (batch, head) are staged ONCE (<= 4 tiles of 64 rows each, 108 KB), next to lse / delta / key bias of
+//     its <= 256 positions and the head's dropout keep bits (<= 8 KB);
+//   * the workgroup walks the key blocks of 64 (wave w: keys 16 w .. 16 w + 15, K / V fragments in registers -- V straight
+//     from HBM in fragment layout, prefetched one block ahead) and, inside, the query tiles: S and dP, the element-wise part
+//     and the dV / dK products exactly as in attn_bwd_dkdv_kernel;
+//   * dS^T of a step (64 keys x 64 queries) goes into a double-buffered LDS tile instead of the workspace; behind ONE barrier
+//     per step wave w adds K^T . dS^T for queries 16 w .. 16 w + 15 of the tile to its dQ accumulators, which stay in
+//     registers for all four query tiles until the end (64 registers).
+// 140 KB of LDS: one workgroup (4 waves) per CU; B*H workgroups.
+// =============================================================================================
+constexpr int FB_MAXT = 256, FB_NT = FB_MAXT / TR;
+constexpr int FB_TB = AT<bf16_t>::TILE_BYTES;
+constexpr int FB_Q = 0, FB_G = FB_NT * FB_TB, FB_K = 2 * FB_NT * FB_TB, FB_D = 3 * FB_NT * FB_TB, FB_STAT = FB_D + 2 * FB_TB;
+constexpr int FB_MASK = FB_STAT + 3 * FB_MAXT * 4;
+constexpr int FB_LDS_BYTES = FB_MASK + (FB_MAXT / 16) * FB_NT * 64 * 2;
+
+__global__ void __launch_bounds__(256, 1) attn_bwd_fused_kernel(AttnParams p) {
+  typedef bf16_t T;
+  typedef FragT<T>::type Frag;
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  float* lss = reinterpret_cast<float*>(fsm + FB_STAT);   // lse * log2(e) of the queries (inf beyond Tq)
+  float* dls = lss + FB_MAXT;                             // delta
+  float* kbs = dls + FB_MAXT;                             // key term of the logits, log2 domain (-inf beyond Tk)
+  const uint16_t* mks = reinterpret_cast<const uint16_t*>(fsm + FB_MASK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lc = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const T* qb = (const T*)p.q + (int64_t)b * p.Tq * p.ldq + h * p.dh;
+  const T* kb = (const T*)p.k + (int64_t)b * p.bsk + h * p.dh;
+  const T* vb = (const T*)p.v + (int64_t)b * p.bsv + h * p.dh;
+  const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
+  const int64_t bh = (int64_t)b * p.H + h;
+  const int nqt = (p.Tq + TR - 1) / TR, nkt = (p.Tk + TR - 1) / TR;
+
+  // ---------------------------------------------------------------- prologue: the whole head into LDS
+  {
+    TileRegs<T> r0, r1;
+    for (int t = 0; t < nqt; ++t) {
+      tile_load<T, true>(r0, qb, p.ldq, t * TR, p.Tq, p.dh, tid);
+      tile_load<T, true>(r1, gb, p.ldo, t * TR, p.Tq, p.dh, tid);
+      tile_store<T>(fsm + FB_Q + t * FB_TB, r0, tid);
+      tile_store<T>(fsm + FB_G + t * FB_TB, r1, tid);
+    }
+    for (int t = 0; t < nkt; ++t) {
+      tile_load<T, true>(r0, kb, p.ldk, t * TR, p.Tk, p.dh, tid);
+      tile_store<T>(fsm + FB_K + t * FB_TB, r0, tid);
+    }
+    {
+      const int i = tid;   // 256 threads = FB_MAXT positions
+      const bool okq = i < p.Tq;
+      lss[i] = okq ? p.lse[bh * p.Tq + i] * LOG2E : INFINITY;
+      dls[i] = okq ? p.delta[bh * p.Tq + i] : 0.f;
+      kbs[i] = key_bias2(p, b, i);
+    }
+    if (p.drop_thresh) {
+      const int nwords = p.nqb * p.nkt * 32;   // u32 words of the head's keep bits
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(p.mask + bh * p.nqb * (int64_t)p.nkt * 64);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(fsm + FB_MASK);
+      for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
+    }
+  }
+  // V fragments (B operand: column = key 16 w + lc, head dims s * 32 + g * 8 ..) straight from HBM, one key block ahead
+  auto load_vf = [&](int kbi, Frag (&dst)[2]) {
+    const int row = kbi * TR + wave * 16 + lc;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int col = s2 * 32 + g * 8;
+      const bool ok = row < p.Tk && col < p.dh;
+      const uint4 v = *reinterpret_cast<const uint4*>(ok ? vb + (int64_t)row * p.ldv + col : vb);
+      dst[s2] = __builtin_bit_cast(Frag, ok ? v : make_uint4(0u, 0u, 0u, 0u));
+    }
+  };
+  Frag vfn[2];
+  load_vf(0, vfn);
+  __syncthreads();
+
+  floatx4_t dq[FB_NT][4];
+#pragma unroll
+  for (int t = 0; t < FB_NT; ++t)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dq[t][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+  const int mlane = g * 4 + 16 * (lc >> 2);
+  const int mbit = wave * 4 + (lc & 3);
+  const int roff = (g * 4 + (lc >> 2)) * AT<T>::RS + (lc & 3) * 8;   // transpose-read row / chunk of this lane
+  T* dkb = (T*)p.dk + (int64_t)b * p.bsk + h * p.dh;
+  T* dvb = (T*)p.dv + (int64_t)b * p.bsv + h * p.dh;
+  int buf = 0;
+
+  for (int kbi = 0; kbi < nkt; ++kbi) {
+    const int k0 = kbi * TR;
+    const char* Kt = fsm + FB_K + kbi * FB_TB;
+    Frag kf[1][2], vf[1][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      kf[0][s2] = rc_frag<T>(Kt, wave * 16, s2 * AT<T>::KS, lane);
+      vf[0][s2] = vfn[s2];
+    }
+    if (kbi + 1 < nkt) load_vf(kbi + 1, vfn);
+    const int kblk0 = k0 + wave * 16, kg = kblk0 + lc;
+    const float kb2 = kbs[kg];
+    floatx4_t dk[1][4], dv[1][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { dk[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int qt_first = (p.causal && k0 > p.coff) ? (k0 - p.coff) / TR : 0;   // queries before the block's first key never see it
+
+#pragma unroll
+    for (int qt = 0; qt < FB_NT; ++qt) {
+      if (qt < nqt && qt >= qt_first) {   // workgroup-uniform
+        const int q0 = qt * TR;
+        const char* Qt = fsm + FB_Q + qt * FB_TB;
+        const char* Gt = fsm + FB_G + qt * FB_TB;
+        uint2 mwc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          mwc[f] = make_uint2(0xffffffffu, 0xffffffffu);
+          if (p.drop_thresh && (q0 >> 4) + f < p.nqb)
+            mwc[f] = *reinterpret_cast<const uint2*>(mks + (((q0 >> 4) + f) * p.nkt + kbi) * 64 + mlane);
+        }
+        floatx4_t ls4[4], dl4[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          ls4[f] = *reinterpret_cast<const floatx4_t*>(lss + q0 + f * 16 + g * 4);
+          dl4[f] = *reinterpret_cast<const floatx4_t*>(dls + q0 + f * 16 + g * 4);
+        }
+        floatx4_t st[1][4], dp[1][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { st[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const Frag aq = rc_frag<T>(Qt, f * 16, s2 * AT<T>::KS, lane);
+            const Frag ag = rc_frag<T>(Gt, f * 16, s2 * AT<T>::KS, lane);
+            st[0][f] = Mma<T>::run(aq, kf[0][s2], st[0][f]);
+            dp[0][f] = Mma<T>::run(ag, vf[0][s2], dp[0][f]);
+          }
+        const bool diag = p.causal && (kblk0 + 15 > q0 + p.coff);
+        auto elems = [&](auto DIAG, auto DROP) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const uint2 mw = mwc[f];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = prob_exp2(fmaf(st[0][f][r], p.scale2, kb2 - ls4[f][r]));
+              if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r + p.coff)) pv = 0.f;
+              float keep = 1.f;
+              if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
+              st[0][f][r] = pv * keep;                                          // dropped P, feeds dV
+              dp[0][f][r] = pv * (keep * dp[0][f][r] - dl4[f][r]) * p.scale;      // dS (scaled), feeds dK and dQ
+            }
+          }
+        };
+        if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
+        else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
+        // dS^T[key][q] of this step: the lane's key row, 4 consecutive queries per 16-query block
+        char* Dt = fsm + FB_D + buf * FB_TB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          *reinterpret_cast<uint2*>(Dt + (wave * 16 + lc) * AT<T>::RS + (f * 16 + g * 4) * 2) =
+              make_uint2(pack_bf16x2(dp[0][f][0], dp[0][f][1]), pack_bf16x2(dp[0][f][2], dp[0][f][3]));
+        tmul_acc<T, 1>(dv, st, Gt, lane);
+        tmul_acc<T, 1>(dk, dp, Qt, lane);
+        __syncthreads();   // every wave's key rows of dS^T are in the tile (the other buffer is free again two steps on)
+        {
+          typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            union { short4_t hh[2]; bf16x8_t f; } bfr;
+            const char* pb = Dt + roff + s2 * 32 * AT<T>::RS + wave * 32;
+            bfr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb));
+            bfr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb + 16 * AT<T>::RS));
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+              union { short4_t hh[2]; bf16x8_t f; } afr;
+              const char* pa = Kt + roff + s2 * 32 * AT<T>::RS + fd * 32;
+              afr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa));
+              afr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa + 16 * AT<T>::RS));
+              dq[qt][fd] = Mma<T>::run(afr.f, bfr.f, dq[qt][fd]);
+            }
+          }
+        }
+        buf ^= 1;
+      }
+    }
+    if (kg < p.Tk) {
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        store_row4<T, true>(dkb + (int64_t)kg * p.ldk, fd * 16 + g * 4, p.dh, dk[0][fd], 1.f);
+        store_row4<T, true>(dvb + (int64_t)kg * p.ldv, fd * 16 + g * 4, p.dh, dv[0][fd], 1.f);
+      }
+    }
+  }
+  T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
+#pragma unroll
+  for (int qt = 0; qt < FB_NT; ++qt) {
+    const int qg = qt * TR + wave * 16 + lc;
+    if (qg < p.Tq) {
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) store_row4<T, true>(dqb + (int64_t)qg * p.ldq, fd * 16 + g * 4, p.dh, dq[qt][fd], 1.f);
+    }
+  }
+}
+
+// =============================================================================================
 // backward, step 2: dQ.  Same blocking as the forward kernel.
 //   S^T = K.Q^T ; P^T = exp(S^T*scale + bias - lse[q]) ; dP^T = V.dO^T ; dS^T = P^T o (keep*dP^T - delta[q])
 //   dQ^T += scale * K^T.dS^T
@@ -970,6 +1179,21 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
       else attn_delta_kernel<bf16_t><<<blocks, 256, 0, st>>>(p);
     }
     NST_CHECK_LAUNCH("attention_bwd(delta)");
+  }
+  // short sequences in bf16: the whole head in LDS, dK / dV / dQ from one kernel, no dS^T round trip through HBM.
+  // NST_ATTN_FUSED_BWD=1 selects it; OFF by default: stand-alone it is 4 % faster than the two kernels (encoder shape 82.6 vs
+  // 86.1 us, scripts/attn_bench.py), but its 140 KB of LDS keep the weight-gradient stream's workgroups off its CUs and the
+  // step gets SLOWER (15.15 -> 15.30 ms, gpurun_out/r03_ab_attn_fused_bwd.log).  One wave per SIMD walking 16 dependent
+  // steps is latency-bound; the next thing to try is two wave groups per workgroup on alternate query tiles.
+  if (d->dtype == NST_BF16 && vec && d->Tq <= FB_MAXT && d->Tk <= FB_MAXT && env_int("NST_ATTN_FUSED_BWD", 0) != 0) {
+    static bool lds_ok = false;
+    if (!lds_ok) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+      lds_ok = true;
+    }
+    attn_bwd_fused_kernel<<<dim3(d->H, d->B), 256, FB_LDS_BYTES, st>>>(p);
+    NST_CHECK_LAUNCH("attention_bwd(fused)");
+    return NST_OK;
   }
   const int mik = pick_mi("NST_ATTN_MI_DKDV", d->Tk, (int64_t)d->B * d->H, false);
   const int miq = pick_mi("NST_ATTN_MI_DQ", d->Tq, (int64_t)d->B * d->H, false);

@@ -332,12 +332,15 @@ ATTN_CASES = [  # B, H, Tq, Tk, dh, causal, key-padding
     (1, 3, 130, 70, 24, False, True), (1, 2, 64, 64, 64, True, False)]
 
 
-@pytest.fixture(params=[1, 2])
+@pytest.fixture(params=[1, 2, "fused_bwd"])
 def attn_mi(request, monkeypatch):
-    """Force the number of 16-row blocks per wave (64*MI rows per workgroup) in all three attention kernels."""
+    """Force the number of 16-row blocks per wave (64*MI rows per workgroup) in all three attention kernels; "fused_bwd": the
+    one-workgroup-per-head backward (attn_bwd_fused_kernel: bf16, sequences <= 256; other cases fall back by themselves)."""
+    mi = 1 if request.param == "fused_bwd" else request.param
     for k in ("NST_ATTN_MI_FWD", "NST_ATTN_MI_DKDV", "NST_ATTN_MI_DQ"):
-        monkeypatch.setenv(k, str(request.param))
-    return request.param
+        monkeypatch.setenv(k, str(mi))
+    monkeypatch.setenv("NST_ATTN_FUSED_BWD", "1" if request.param == "fused_bwd" else "0")
+    return mi
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
