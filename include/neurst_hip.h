@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 5
+#define NST_ABI_VERSION 6
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -406,9 +406,18 @@ typedef struct {
   float output_dropout_p;          /* layer_postprocess_dropout_rate (forward only) */
   uint64_t output_seed, output_stream_id;
   const uint64_t* seed_offset;     /* device scalar or NULL */
+  /* Optional gate bits (ABI 6).  The backward needs of `hidden` only the test hidden > 0; when nst_ffn_gate_bits_bytes(desc)
+   * is > 0 the caller may hand nst_ffn_fwd a buffer of that many bytes (4-byte aligned, device memory): the forward fills it
+   * with one bit per hidden element (layout private to the library), and nst_ffn_bwd given the SAME buffer reads it instead
+   * of the [rows, filter_size] activation (1/16 of the traffic; `hidden` must still be passed and is what every other
+   * path uses).  NULL: the activation is the gate.  0 from the query: this shape runs a kernel that has no bit path --
+   * passing a buffer to nst_ffn_fwd is then an argument error. */
+  void* gate_bits;
+  int64_t gate_bits_bytes;
 } NstFfnDesc;
 
 int nst_ffn_supported(int d_model, int filter_size, int dtype);
+int64_t nst_ffn_gate_bits_bytes(const NstFfnDesc* desc);   /* rows, d_model, filter_size, dtype are read */
 /* b1 [filter_size] f32 (nullable = 0), b2 [256] f32 (nullable), residual [rows,256] (nullable); hidden [rows, filter_size]
  * and y [rows,256] are written. */
 int nst_ffn_fwd(const NstFfnDesc* desc, const void* x, const void* w1t, const float* b1, const void* w2t, const float* b2,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 5
+NST_ABI_VERSION = 6
 
 
 class NstGemmDesc(C.Structure):
@@ -77,6 +77,7 @@ class NstFfnDesc(C.Structure):
         ("output_dropout_p", C.c_float),
         ("output_seed", C.c_uint64), ("output_stream_id", C.c_uint64),
         ("seed_offset", C.c_void_p),
+        ("gate_bits", C.c_void_p), ("gate_bits_bytes", C.c_int64),
     ]
 
 
@@ -127,6 +128,7 @@ SIGNATURES = {
     "nst_dropout_seed_offset_set": [_U64, _P],
     "nst_dropout_seed_offset_add": [_U64, _P],
     "nst_ffn_supported": [_I, _I, _I],
+    "nst_ffn_gate_bits_bytes": [C.POINTER(NstFfnDesc)],
     "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
@@ -144,7 +146,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "nst_last_error_string"
-                      else C.c_int64 if name == "nst_attention_dropout_mask_bytes"
+                      else C.c_int64 if name in ("nst_attention_dropout_mask_bytes", "nst_ffn_gate_bits_bytes")
                       else C.c_uint32 if name == "nst_crc32c" else C.c_int)
     ver = lib.nst_abi_version()
     if ver != NST_ABI_VERSION:

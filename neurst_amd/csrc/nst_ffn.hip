@@ -69,6 +69,9 @@ struct FfnArgs {
   float gate_scale;
   uint64_t seed1, stream1, seed2, stream2;
   int rot_mode;   // v2: 0 = chunk order rotated per workgroup, 1 = per XCD (workgroup id & 7), 2 = none
+  // v2: the gate of the backward as one bit per hidden element (opaque layout, see ffn_pair8_kernel): written by the forward
+  // when non-null, read by the backward INSTEAD of the saved activation when non-null
+  uint16_t* gate_bits;
 };
 
 __device__ __forceinline__ int pi32(int r) { return (((r >> 2) & 1) << 4) + ((r >> 3) << 2) + (r & 3); }
@@ -166,6 +169,19 @@ __device__ __forceinline__ void glds_one(const void* sbase, uint32_t voff, uint3
       "s_mov_b32 m0, %3\n\t"
       "s_nop 4\n\t"
       "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr_uniform)
+      : "memory");
+}
+// the 4-byte form: 64 lanes x 4 bytes -> LDS [lds_addr_uniform + lane * 4]
+__device__ __forceinline__ void glds_one_dword(const void* sbase, uint32_t voff, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 4\n\t"
+      "global_load_lds_dword %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_addr_uniform)
@@ -560,7 +576,12 @@ constexpr int CH2 = 64;
 constexpr int V2_W1 = 0, V2_W2 = 2 * 32768, V2_P = 4 * 32768, V2_BIAS = V2_P + 16384;
 constexpr int V2_ROWS = 128;
 
-template <int MODE, int DROP, bool FULL, int DBG = 0>
+// Gate bits (BITS): the backward needs of the saved activation only its sign test (hidden > 0).  The forward packs that test
+// for each lane's 16 hidden units of a chunk into 16 bits (unit 2k -> bit 7-k, unit 2k+1 -> bit 15-k, taken from the SAME bf16
+// values it stores) and writes them as gate_bits[(2 chunk + hh) * M + row][h] (uint16): one 128-byte store per wave and chunk.
+// The backward then fetches 4 bytes per row and half chunk (one LDS-DMA instruction per wave and chunk) instead of 64:
+// 7.4 MB instead of 118 MB at the benchmark shape, and the weight-gradient stream running beside it keeps that bandwidth.
+template <int MODE, int DROP, bool FULL, int DBG = 0, bool BITS = false>
 __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   static_assert(MODE == MODE_FWD || DROP == 0, "the backward has no dropout of its own (the gate carries the forward's mask)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -636,9 +657,14 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
       rgate = rgate < M ? rgate : M - 1;
       voffg[q] = (uint32_t)rgate * (uint32_t)(F * 2) + (uint32_t)((lane & 3) << 4);
     }
+    if constexpr (BITS) voffg[0] = (uint32_t)row_c * 4u;   // the row's 32 gate bits of a half chunk
   }
   auto issue_g = [&](int c_logical) {   // chunk index clamped: a copy past the end lands in the region nobody reads again
     const int c = phys(c_logical < nch ? c_logical : nch - 1);
+    if constexpr (BITS) {
+      glds_one_dword(reinterpret_cast<const char*>(a.gate_bits) + (int64_t)(2 * c + hh) * M * 4, voffg[0], g_lds);
+      return;
+    }
     const char* src = reinterpret_cast<const char*>(a.gate) + ((int64_t)c * CH2 + 32 * hh) * 2;
     glds_one(src, voffg[0], g_lds);
     glds_one(src, voffg[1], g_lds + 1024u);
@@ -719,6 +745,21 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     if constexpr (MODE == MODE_BWD) {
       // this lane's 16 gate values: row i_l of the wave's region (64-byte rows), bytes [32 h, +32)
       if constexpr (decltype(first_tag)::value || !FULL) wait_vm<0>(); else wait_vm<10>();   // (2 stores + 8 weight DMAs are younger than the gate copy)
+      if constexpr (BITS) {
+        // bit -> all-ones / all-zeros word (v_bfe_i32) ANDed onto the scaled value: two VALU operations per element, no VCC
+        const int m = (int)(*reinterpret_cast<const uint32_t*>(smem + V2_BIAS + wave * 2048 + lane * 4) >> (16 * h));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          uint32_t keep;   // (asm: the compiler rewrites a plain sign-extended bit into and / compare / select, five operations per pair)
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"((7 - (e >> 1)) + 8 * (e & 1)));
+          v[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v[e] * a.gate_scale) & keep);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_g(c_logical + 1);
+        return;
+      }
       const uint4* gp = reinterpret_cast<const uint4*>(smem + V2_BIAS + wave * 2048 + i_l * 64 + h * 32);
       union { uint4 u[2]; short s[16]; } g;
       g.u[0] = gp[0];
@@ -754,6 +795,18 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    if constexpr (BITS) {   // the values are +x, +0 or -0: "bf16 > 0" <=> the low 15 bits are not all zero
+      uint32_t acc = 0;
+      const uint32_t ones = 0x00010001u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t nz;   // min(half, 1) per 16-bit half: 0 / 1 (asm: the generic vector min is legalised into compares and selects)
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(packed[k] & 0x7fff7fffu), "s"(ones));
+        acc = (acc << 1) | nz;
+      }
+      const uint32_t m16 = (acc & 0xffu) | ((acc >> 8) & 0xff00u);
+      if (row_ok) a.gate_bits[((int64_t)(2 * c + hh) * M + row) * 2 + h] = (uint16_t)m16;
+    }
   };
   auto write_p = [&]() {   // this lane's 16 units = slots 4 hh + 2 h, + 1 of its row
     char* prow = smem + V2_P + offP;
@@ -857,7 +910,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
         if constexpr (HAS_A && S == 15) mid_epilogue(c_cur + 1, std::false_type());   // program order: behind the first product; scheduled into the slots below
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if constexpr (HAS_A && S >= 16) __builtin_amdgcn_sched_group_barrier(0x002, (DROP & 1) ? 11 : 4, 0);
+        if constexpr (HAS_A && S >= 16) __builtin_amdgcn_sched_group_barrier(0x002, ((DROP & 1) ? 11 : 4) + (MODE == MODE_FWD && BITS ? 2 : 0), 0);
       }(), ...);
     }(std::make_integer_sequence<int, 32 - S0>());
   };
@@ -885,7 +938,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(packed[e]));
     // the weight DMAs issued early in this span have landed (the two hidden-tile stores are older still); the backward's two
     // gate DMAs of the next chunk are the youngest and stay in flight
-    if (MODE == MODE_BWD && FULL) wait_vm<2>(); else wait_vm<0>();
+    if (MODE == MODE_BWD && FULL) { if constexpr (BITS) wait_vm<1>(); else wait_vm<2>(); } else wait_vm<0>();
     barrier();                          // X: P(c), W2 buffer c & 1 and W1 buffer (c+1) & 1 are free; the next span's weights are visible
     if (c + 2 < nch) burst(std::integral_constant<int, 0>(), smem + V2_W1 + (c & 1) * 32768, smem + V2_W2 + ((c + 1) & 1) * 32768);
     else burst(std::integral_constant<int, 16>(), smem + V2_W1, smem + V2_W2 + ((c + 1) & 1) * 32768);
@@ -1015,6 +1068,12 @@ bool use_v2_fwd(const FfnArgs& a) {
 template <int DROP, bool FULL, int DBG = 0>
 int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
   const int lds = V2_BIAS + a.F * 4;
+  if (DBG == 0 && a.gate_bits) {
+    auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true>;
+    allow_lds(k, lds);
+    k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+    return NST_OK;
+  }
   auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, DBG>;
   allow_lds(k, lds);
   k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
@@ -1031,6 +1090,18 @@ int launch_pair_v2_bwd(const FfnArgs& a_in, hipStream_t st) {
   FfnArgs a = a_in;
   a.rot_mode = 0;
   const int lds = V2_BIAS + 16384;   // the eight 2 KB gate regions
+  if (a.gate_bits) {
+    if (a.M % V2_ROWS == 0) {
+      auto k = ffn_pair8_kernel<MODE_BWD, 0, true, 0, true>;
+      allow_lds(k, lds);
+      k<<<a.M / V2_ROWS, 512, lds, st>>>(a);
+    } else {
+      auto k = ffn_pair8_kernel<MODE_BWD, 0, false, 0, true>;
+      allow_lds(k, lds);
+      k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+    }
+    return NST_OK;
+  }
   if (a.M % V2_ROWS == 0) {
     auto k = ffn_pair8_kernel<MODE_BWD, 0, true, 0>;
     allow_lds(k, lds);
@@ -1162,11 +1233,28 @@ extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, 
   nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
   nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);
   a.seed1 = d->hidden_seed; a.stream1 = d->hidden_stream_id; a.seed2 = d->output_seed; a.stream2 = d->output_stream_id;
+  if (d->gate_bits) {
+    const int64_t need = nst_ffn_gate_bits_bytes(d);
+    NST_CHECK_ARG(need > 0 && d->gate_bits_bytes >= need && ((uintptr_t)d->gate_bits & 3) == 0,
+                  "ffn_fwd: gate_bits given (%lld bytes) where nst_ffn_gate_bits_bytes says %lld", (long long)d->gate_bits_bytes,
+                  (long long)need);
+    a.gate_bits = (uint16_t*)d->gate_bits;
+  }
   const int rc = use_v2_fwd(a) ? launch_pair_v2_fwd(a, (hipStream_t)stream)
                  : pick_nw(a.M) == 4 ? launch_pair<MODE_FWD, 4>(a, (hipStream_t)stream) : launch_pair<MODE_FWD, 2>(a, (hipStream_t)stream);
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_fwd");
   return NST_OK;
+}
+
+extern "C" int64_t nst_ffn_gate_bits_bytes(const NstFfnDesc* d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("NST_FFN_GATE_BITS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || !d || !nst_ffn_supported(d->d_model, d->filter_size, d->dtype) || d->rows <= 0 || d->rows >= (1 << 30)) return 0;
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = (int)d->rows; a.F = d->filter_size;
+  return (use_v2_fwd(a) && use_v2_bwd(a)) ? (int64_t)a.M * (a.F / 32) * 4 : 0;
 }
 
 extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidden, const void* w2, const void* w1,
@@ -1188,6 +1276,11 @@ extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidd
   uint32_t th; float inv;
   nst_dropout_params16(d->hidden_dropout_p, &th, &inv);
   a.gate_scale = th ? inv : 1.0f;
+  if (d->gate_bits && use_v2_bwd(a)) {   // (otherwise the saved activation is the gate)
+    NST_CHECK_ARG(d->gate_bits_bytes >= (int64_t)a.M * (a.F / 32) * 4 && ((uintptr_t)d->gate_bits & 3) == 0,
+                  "ffn_bwd: gate_bits holds %lld bytes", (long long)d->gate_bits_bytes);
+    a.gate_bits = (uint16_t*)d->gate_bits;
+  }
   // the gate pieces are 64 rows: a workgroup of 128 rows needs M >= 64 (row clamp), 64-row workgroups one piece
   const int rc = use_v2_bwd(a) ? launch_pair_v2_bwd(a, (hipStream_t)stream)
                  : (pick_nw(a.M) == 4 && a.M >= 64) ? launch_pair<MODE_BWD, 4>(a, (hipStream_t)stream)

@@ -311,9 +311,11 @@ def _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p=0.0, out_see
 
 
 def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0, out_seed=0,
-            out_site=0):
+            out_site=0, save_gate_bits=False):
     """y = residual + dropout_out(dropout_hidden(relu(x @ w1 + b1)) @ w2 + b2) in one launch; w1t [F, d] / w2t [d, F] are the
-    TRANSPOSED bf16 copies of dense1/kernel [d, F] / dense2/kernel [F, d].  Returns (y, hidden); hidden is the saved activation."""
+    TRANSPOSED bf16 copies of dense1/kernel [d, F] / dense2/kernel [F, d].  Returns (y, hidden); hidden is the saved activation.
+    save_gate_bits: returns (y, hidden, gate_bits) -- gate_bits is an opaque uint8 tensor holding `hidden > 0` as one bit per
+    element for ffn_bwd (None where the library has no bit path for the shape)."""
     rows, d = x.shape
     f = w1t.shape[0]
     assert x.is_contiguous() and w1t.is_contiguous() and w2t.is_contiguous() and w1t.shape == (f, d) and w2t.shape == (d, f)
@@ -322,16 +324,22 @@ def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hid
     hidden = torch.empty(rows, f, dtype=x.dtype, device=x.device)
     y = torch.empty_like(x)
     desc = _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p, out_seed, out_site)
+    bits = None
+    if save_gate_bits:
+        nbytes = int(lib.nst_ffn_gate_bits_bytes(C.byref(desc)))
+        if nbytes > 0:
+            bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            desc.gate_bits, desc.gate_bits_bytes = bits.data_ptr(), nbytes
     ev = PROBE.begin("ffn_fwd")
     check(lib.nst_ffn_fwd(C.byref(desc), _p(x), _p(w1t), _p(b1), _p(w2t), _p(b2), _p(residual), _p(hidden), _p(y), _stream()),
           "ffn_fwd")
     PROBE.end(ev, 4.0 * rows * d * f)
-    return y, hidden
+    return (y, hidden, bits) if save_gate_bits else (y, hidden)
 
 
-def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None):
+def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None, gate_bits=None):
     """dhidden = (dy @ w2^T) * gate(hidden); dx = dhidden @ w1^T (+ residual) in one launch; w2 [F, d], w1 [d, F] as stored.
-    Returns (dx, dhidden)."""
+    gate_bits: what ffn_fwd(save_gate_bits=True) returned for this `hidden` (read instead of it).  Returns (dx, dhidden)."""
     rows, d = dy.shape
     f = w2.shape[0]
     assert dy.is_contiguous() and hidden.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
@@ -340,6 +348,9 @@ def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None):
     dhidden = torch.empty_like(hidden)
     dx = torch.empty_like(dy)
     desc = _ffn_desc(rows, d, f, hidden_p, 0, 0)
+    if gate_bits is not None:
+        assert gate_bits.dtype == torch.uint8 and gate_bits.is_contiguous() and gate_bits.device == dy.device
+        desc.gate_bits, desc.gate_bits_bytes = gate_bits.data_ptr(), gate_bits.numel()
     ev = PROBE.begin("ffn_bwd")
     check(lib.nst_ffn_bwd(C.byref(desc), _p(dy), _p(hidden), _p(w2), _p(w1), _p(residual), _p(dhidden), _p(dx), _stream()),
           "ffn_bwd")

@@ -193,23 +193,26 @@ class TransformerFFN(Layer):
         use_fused = self.fused and x.shape[0] >= _FFN_FUSED_MIN_ROWS and x.is_contiguous() \
             and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"})
         if use_fused:
-            y, h = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
-                             residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed, hidden_site=self.site,
-                             out_p=epi.get("dropout_p", 0.0), out_seed=epi.get("seed", 0), out_site=epi.get("stream_id", 0))
+            y, h, bits = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
+                                   residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed,
+                                   hidden_site=self.site, out_p=epi.get("dropout_p", 0.0), out_seed=epi.get("seed", 0),
+                                   out_site=epi.get("stream_id", 0), save_gate_bits=bool(is_training))
         else:
+            bits = None
             h = self.dense1.forward(x, relu=True, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
             y = self.dense2.forward(h, **epi)
         if is_training:
-            self._saved = (x, h, p)
+            self._saved = (x, h, p, bits)
         return y
 
     def backward(self, dz, residual=None):
         """residual (post-norm wrapper): added to the returned input gradient in the last GEMM's epilogue."""
-        x, h, p = self._saved
+        x, h, p, bits = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
         if self.fused and _FFN_FUSED_BWD and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
-            dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual)
+            dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual,
+                               gate_bits=bits)
             self.dense1.backward_params(x, dh)
             return dx
         dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=K.dropout_inv_keep(p))

@@ -156,7 +156,7 @@ def ffn_supported(d_model, filter_size, dtype):
 
 
 def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0, out_seed=0,
-            out_site=0):
+            out_site=0, save_gate_bits=False):
     rows, d = x.shape
     f = w1t.shape[0]
     assert x.is_contiguous() and w1t.is_contiguous() and w2t.is_contiguous() and w1t.shape == (f, d) and w2t.shape == (d, f)
@@ -171,10 +171,10 @@ def ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=0.0, hidden_seed=0, hid
         y = y * _keep(out_p, out_seed, out_site, (rows, d))
     if residual is not None:
         y = y + residual.to(F64)
-    return y.to(x.dtype), h
+    return (y.to(x.dtype), h, None) if save_gate_bits else (y.to(x.dtype), h)   # (no bit path: the activation is the gate)
 
 
-def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None):
+def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None, gate_bits=None):
     rows, d = dy.shape
     f = w2.shape[0]
     assert dy.is_contiguous() and hidden.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()

@@ -53,10 +53,16 @@ def main():
             def fused_fwd():
                 return K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r, hidden_p=p, hidden_seed=1, hidden_site=1, out_p=p, out_seed=1, out_site=2)
 
+            def fused_fwd_bits():
+                return K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r, hidden_p=p, hidden_seed=1, hidden_site=1, out_p=p, out_seed=1,
+                                 out_site=2, save_gate_bits=True)
+
             def two_fwd():
                 h = K.gemm(x, w1, M, F, d, bias=b1, relu=True, dropout_p=p, seed=1, stream_id=1)
                 return K.gemm(h, w2, M, d, F, bias=b2, dropout_p=p, seed=1, stream_id=2, residual=r), h
             t_f, t_2 = timeit(fused_fwd, args.iters), timeit(two_fwd, args.iters)
+            t_fb = timeit(fused_fwd_bits, args.iters)
+            row[f"fwd_p{p}_gate_bits"] = {"fused_us": t_fb}
             row[f"fwd_p{p}"] = {"fused_us": t_f, "two_gemm_us": t_2, "fused_tflops": flop / t_f / 1e6, "fused_mfma_frac": flop / t_f / 1e6 / 2500.0}
         if args.ablate and M % 128 == 0 and M >= 20480:   # ablation builds of the forward (NST_FFN_DBG is read per call)
             # interleaved rounds, median per variant: single runs move by +-10 % with the clock state of the chip
@@ -74,7 +80,7 @@ def main():
             for dbg, what in variants:
                 v = sorted(samples[dbg])
                 row[f"fwd_p0_dbg{dbg}_{what}"] = {"median_us": v[len(v) // 2], "min_us": v[0], "max_us": v[-1]}
-        _, h = K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r, hidden_p=0.1, hidden_seed=1, hidden_site=1)
+        _, h, bits = K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r, hidden_p=0.1, hidden_seed=1, hidden_site=1, save_gate_bits=True)
 
         def fused_bwd():
             return K.ffn_bwd(dy, h, w2, w1, hidden_p=0.1)
@@ -83,6 +89,8 @@ def main():
             dh = K.gemm(dy, w2, M, F, d, trans_b=True, gate_src=h, gate_scale=K.dropout_inv_keep(0.1))
             return K.gemm(dh, w1, M, d, F, trans_b=True), dh
         t_f, t_2 = timeit(fused_bwd, args.iters), timeit(two_bwd, args.iters)
+        if bits is not None:
+            row["bwd_gate_bits"] = {"fused_us": timeit(lambda: K.ffn_bwd(dy, h, w2, w1, hidden_p=0.1, gate_bits=bits), args.iters)}
         row["bwd"] = {"fused_us": t_f, "two_gemm_us": t_2, "fused_tflops": flop / t_f / 1e6, "fused_mfma_frac": flop / t_f / 1e6 / 2500.0}
         res[f"M{M}_F{F}"] = row
         print(M, json.dumps(row))

@@ -139,6 +139,50 @@ def test_ffn_pair_at_the_benchmark_shape():
     assert rel(dx, dx_ref) <= 1e-2
 
 
+@pytest.mark.parametrize("M,F,p1", [(28800, 2048, 0.1), (28800, 2048, 0.0), (20480 + 40, 256, 0.25), (25600, 128, 0.1)])
+def test_ffn_gate_bits_give_the_backward_of_the_saved_activation(M, F, p1):
+    """The eight-wave forward can hand the backward `hidden > 0` as one bit per element (NstFfnDesc.gate_bits) instead of
+    the [rows, F] activation.  Both gates are the same predicate on the same bf16 values, so the two backwards must agree
+    BIT FOR BIT (full and ragged workgroups, with and without hidden dropout), and the forward's outputs do not change."""
+    from neurst_amd import kernels as K
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=M + 3 * F)
+    xd, rd = x.to(DEV), res.to(DEV)
+    w1d, w2d, b1d, b2d = w1.to(DEV), w2.to(DEV), b1.to(DEV), b2.to(DEV)
+    w1t, w2t = w1.t().contiguous().to(DEV), w2.t().contiguous().to(DEV)
+    kw = dict(residual=rd, hidden_p=p1, hidden_seed=1234, hidden_site=5, out_p=0.1, out_seed=1234, out_site=6)
+    y0, h0 = K.ffn_fwd(xd, w1t, b1d, w2t, b2d, **kw)
+    y1, h1, bits = K.ffn_fwd(xd, w1t, b1d, w2t, b2d, save_gate_bits=True, **kw)
+    assert bits is not None and bits.numel() == M * (F // 32) * 4, "this shape runs the eight-wave kernels"
+    assert torch.equal(y0, y1) and torch.equal(h0, h1)
+    zero_frac = float((h1 == 0).float().mean())
+    assert 0.3 < zero_frac < 0.8                      # the gate is neither all ones nor all zeros
+    dy = rnd(M, 256, seed=5).to(DEV)
+    dx_h, dh_h = K.ffn_bwd(dy, h1, w2d, w1d, hidden_p=p1, residual=rd)
+    dx_b, dh_b = K.ffn_bwd(dy, h1, w2d, w1d, hidden_p=p1, residual=rd, gate_bits=bits)
+    assert torch.equal(dh_h, dh_b), "gate bits and the saved activation gate differently"
+    assert torch.equal(dx_h, dx_b)
+    assert torch.equal(dh_b != 0, (h1 > 0) & (dh_b != 0)) and int((dh_b != 0).sum()) > 0.9 * int((h1 > 0).sum())
+
+
+def test_ffn_gate_bits_are_refused_where_no_kernel_writes_them():
+    import ctypes as C
+    from neurst_amd import kernels as K
+    from neurst_amd._lib import lib
+    M, F = 512, 256
+    x, res, w1, w2, b1, b2 = _operands(M, F, seed=1)
+    y, h, bits = K.ffn_fwd(x.to(DEV), w1.t().contiguous().to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV),
+                           save_gate_bits=True)
+    assert bits is None
+    desc = K._ffn_desc(M, 256, F, 0.0, 0, 0)
+    assert lib.nst_ffn_gate_bits_bytes(C.byref(desc)) == 0
+    buf = torch.zeros(M * F // 8, dtype=torch.uint8, device=DEV)
+    desc.gate_bits, desc.gate_bits_bytes = buf.data_ptr(), buf.numel()
+    yy, hh = torch.empty_like(y), torch.empty_like(h)
+    rc = lib.nst_ffn_fwd(C.byref(desc), x.to(DEV).data_ptr(), w1.t().contiguous().to(DEV).data_ptr(), None,
+                         w2.t().contiguous().to(DEV).data_ptr(), None, None, hh.data_ptr(), yy.data_ptr(), None)
+    assert rc != 0 and b"gate_bits" in lib.nst_last_error_string()
+
+
 def test_transposed_weight_copies_follow_the_optimizer():
     """The forward reads transposed bf16 copies of the two FFN kernels: they must equal the bf16 shadow transposed after
     construction, after a state-dict load and after every optimizer step."""

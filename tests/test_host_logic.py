@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, s), f"{s} declared in include/neurst_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 5
+    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 6
     out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (nst_[a-z0-9_]+)", out))
     assert exported == set(syms)
@@ -38,7 +38,7 @@ def test_struct_layouts_match_header_sizes():
     # field order/types mirror the header; sizes guard against silent drift (x86-64 SysV layout)
     assert ctypes.sizeof(_lib.NstGemmDesc) == 232
     assert ctypes.sizeof(_lib.NstAttnDesc) == 152
-    assert ctypes.sizeof(_lib.NstFfnDesc) == 72 and ctypes.sizeof(_lib.NstTransposeJob) == 32 and ctypes.sizeof(_lib.NstSplitkJob) == 64
+    assert ctypes.sizeof(_lib.NstFfnDesc) == 88 and ctypes.sizeof(_lib.NstTransposeJob) == 32 and ctypes.sizeof(_lib.NstSplitkJob) == 64
 
 
 def test_kernels_refuse_cpu_tensors():
