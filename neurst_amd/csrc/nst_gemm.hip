@@ -33,6 +33,21 @@ dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowM
   gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS, EF>(smem_dyn);
 }
 
+// the weight-gradient form (reduction-major bf16 operands, f32 output): five half-step slots in the same 80 KB
+template <bool CS, int EF, int SLOTS = 5, int DBG = 0>
+__global__ void __launch_bounds__(THREADS, 2)
+dense_wgrad_ring_kernel(GemmArgs<float, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;
+  gemm_stream_v3_ring<float, IdentityRowMap, CS, EF, SLOTS, DBG>(smem_dyn);
+}
+
+int wgrad_ring() {   // NST_GEMM_RING=0: the two-stage stream kernel for the weight gradients too (A/B switch); 3 / 4: shallower rings
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_RING"); v = e ? atoi(e) : 5; }
+  return v;
+}
+
 bool specialised_epilogues() {   // NST_GEMM_GENERIC_EPI=1: the runtime-flag kernels only (A/B switch)
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_GEMM_GENERIC_EPI"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -245,6 +260,27 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
         }
       }
       if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
+#define NST_GEMM_LAUNCH_RING(CS_, EF_)                                                                                 \
+  do {                                                                                                               \
+    auto kfn = dense_wgrad_ring_kernel<CS_, EF_>;                                                                     \
+    allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
+    kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
+  } while (0)
+        if (amode == MODE_OC && bmode == MODE_OC && wgrad_ring() && kt_per_split >= 4) {
+          if (ep.colsum_dst) {
+#define NST_RING_DBG(V, D) if (em == 0 && wgrad_ring() == V) { auto kfn = dense_wgrad_ring_kernel<true, 0, 5, D>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
+            NST_RING_DBG(51, 1) NST_RING_DBG(52, 2) NST_RING_DBG(54, 4) NST_RING_DBG(58, 8) NST_RING_DBG(53, 3) NST_RING_DBG(55, 5) NST_RING_DBG(57, 7) NST_RING_DBG(515, 15)
+#undef NST_RING_DBG
+            if (em == 0 && wgrad_ring() == 3) { auto kfn = dense_wgrad_ring_kernel<true, 0, 3>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
+            if (em == 0 && wgrad_ring() == 4) { auto kfn = dense_wgrad_ring_kernel<true, 0, 4>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
+            if (em == 0) { NST_GEMM_LAUNCH_RING(true, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_RING(true, EF_ACCUM); return 0; }
+          } else {
+            if (em == 0) { NST_GEMM_LAUNCH_RING(false, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_RING(false, EF_ACCUM); return 0; }
+          }
+        }
+#undef NST_GEMM_LAUNCH_RING
         if (amode == MODE_OC && bmode == MODE_OC) {                     // weight gradients: x^T . dz, slabs or in place
           if (ep.colsum_dst) {
             if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, 0); return 0; }

@@ -87,11 +87,14 @@ class AudioConv2dSubsamplingLayer(Layer):
         acc2 = st.acc_flag(self.w2)
         assert st.acc_flag(self.b2) == acc2
         import os
-        if os.environ.get("NST_SKIP_WGRAD", "0") != "1":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
+        where = os.environ.get("NST_CONV2_WGRAD_AT", "side")   # side | after_dgrad | last  (main stream for the latter two)
+        if os.environ.get("NST_SKIP_WGRAD", "0") != "1" and where == "side":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
             # overlaps the dgrad below and the conv1 backward
             self.rt.run_wgrad(lambda: K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2), a1, dy2)
             self.rt.sublayer_boundary()
         da1 = K.conv2_dgrad(dy2, self.w2.compute, a1.shape[1], a1.shape[2])
+        if where == "after_dgrad":
+            K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
         acc = st.acc_flag(self.w1)
         st.acc_flag(self.b1)
         if ln:
@@ -100,4 +103,6 @@ class AudioConv2dSubsamplingLayer(Layer):
         K.conv1_ln_relu_bwd(src, self.w1.data, self.b1.data, self.g1.data if ln else None,
                             self.be1.data if ln else None, mean1, rstd1, da1, self.w1.grad, self.b1.grad,
                             self.g1.grad if ln else None, self.be1.grad if ln else None, ln, 1e-6, accumulate=acc)
+        if where == "last":
+            K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
         return None  # the audio features are data, not a differentiable input

@@ -104,6 +104,16 @@ def main():
     cases[f"qkv.wgrad [256,768,M] split {sk}"] = (
         lambda: K.gemm(x, dz, d, 3 * d, M, trans_a=True, out=dw, accumulate=True, split_k=sk, colsum_out=db, colsum_accumulate=True),
         2.0 * M * d * 3 * d)
+    for tag, kin, nout in (("out", d, d), ("ffn1", d, F), ("ffn2", F, d)):
+        xx = torch.randn(M, kin, device=dev).bfloat16()
+        dd = torch.randn(M, nout, device=dev).bfloat16()
+        ww = torch.zeros(kin, nout, device=dev)
+        bb = torch.zeros(nout, device=dev)
+        s2 = _wgrad_split(M, kin, nout, torch.bfloat16)
+        cases[f"{tag}.wgrad [{kin},{nout},M] split {s2}"] = (
+            lambda xx=xx, dd=dd, ww=ww, bb=bb, kin=kin, nout=nout, s2=s2: K.gemm(
+                xx, dd, kin, nout, M, trans_a=True, out=ww, accumulate=True, split_k=s2, colsum_out=bb, colsum_accumulate=True),
+            2.0 * M * kin * nout)
     us = timed_rounds({n: f for n, (f, _) in cases.items()})
     out["us"] = us
     out["tflops"] = {n: cases[n][1] / us[n] / 1e6 for n in us}

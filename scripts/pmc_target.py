@@ -27,6 +27,15 @@ elif which == "conv1_bwd":
     dout = (torch.randn_like(a1.float()) * 0.1).to(dt)
     dw1, db1, dg1, dbe1 = torch.zeros_like(w1), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     fn = lambda: K.conv1_ln_relu_bwd(src, w1, b1, g1, be1, mean1, rstd1, dout, dw1, db1, dg1, dbe1, True, 1e-6, accumulate=True)  # noqa: E731
+elif which.endswith("_wgrad"):   # ffn1_wgrad / ffn2_wgrad / qkv_wgrad: dW = x^T . dz over 28 800 rows, split-K slabs
+    from neurst_amd.layers.common_layers import _wgrad_split
+    M = 28800
+    kin, nout = {"ffn1_wgrad": (256, 2048), "ffn2_wgrad": (2048, 256), "qkv_wgrad": (256, 768)}[which]
+    x, dz = torch.randn(M, kin, device=DEV).to(dt), torch.randn(M, nout, device=DEV).to(dt)
+    dw, db = torch.zeros(kin, nout, device=DEV), torch.zeros(nout, device=DEV)
+    sk = _wgrad_split(M, kin, nout, dt)
+    fn = lambda: K.gemm(x, dz, kin, nout, M, trans_a=True, out=dw, accumulate=True, split_k=sk, colsum_out=db,  # noqa: E731
+                        colsum_accumulate=True)
 else:
     M, d, ffn = 28800, 256, 2048
     if which == "ffn2_fwd":
