@@ -375,6 +375,16 @@ uint32_t nst_crc32c(const void* data, int64_t n, uint32_t crc);
  * nst_probe_mfma: writes the raw lane->value maps of the MFMA / LDS-transpose-read instructions the
  * kernels rely on, so the layout assumptions are verified on real hardware. */
 int nst_probe_mfma(float* out_c16, float* out_c16_f32, uint16_t* out_tr, void* stream);
+/* nst_probe_fetch (measurement only): `workgroups` workgroups of 4 waves each stream steps x 32 KB from
+ * src + (workgroup % group_mod) * wg_stride (cyclically over `span` bytes, a multiple of 32 KB) into a ring of `ring` (2..4) LDS
+ * slots with the LDS-DMA pattern of the stream kernels (mode 0) or with plain 16-byte register loads (mode 1) and do nothing
+ * else: the time of the launch gives the fetch rate a kernel of that tile shape cannot exceed.  group_mod = workgroups: private
+ * regions; 8: the workgroups of an XCD (ids go round-robin over the 8 XCDs) share a region, as the tiles of a split-K slice
+ * do; wg_stride = 0: one region for all.  pattern (mode 0): how the 64 lanes of a 1 KB piece address it -- 0 contiguous, 1 / 2 the
+ * swizzled reduction-major / row-major tile images of the stream GEMM, 3 / 4 the same with rows 4 KB apart.  sink: one float,
+ * never written. */
+int nst_probe_fetch(const void* src, int64_t wg_stride, int64_t span, int steps, int ring, int mode, int workgroups, int group_mod,
+                    int pattern, float* sink, void* stream);
 
 /* ------------------------------------------------------------------ fused position-wise feed-forward (d_model = 256, bf16)
  * TransformerFFN.call inside PrePostProcessingWrapper.call (pre-norm), neurst/layers/common_layers.py:145-160, 73-85:

@@ -124,6 +124,7 @@ SIGNATURES = {
     "nst_cast_f32_to_bf16": [_P, _P, _L, _P],
     "nst_cast_bf16_to_f32": [_P, _P, _L, _P],
     "nst_probe_mfma": [_P, _P, _P, _P],
+    "nst_probe_fetch": [_P, C.c_int64, C.c_int64, _I, _I, _I, _I, _I, _I, _P, _P],
     "nst_dropout_seed_offset_bind": [_P],
     "nst_dropout_seed_offset_set": [_U64, _P],
     "nst_dropout_seed_offset_add": [_U64, _P],

@@ -62,7 +62,108 @@ __global__ void probe_kernel(float* out_c16, float* out_c16_f32, uint16_t* out_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fetch probe: what a CU can pull through its vector-memory path when it does NOTHING else.  Every workgroup (4 waves)
+// streams `steps` pieces of 32 KB into a ring of LDS slots exactly like the stream GEMM does (8 LDS-DMA instructions of 1 KB
+// per wave and step, counted vmcnt waits, one barrier per step) -- or with plain 16-byte loads into registers (MODE 1) --
+// and multiplies nothing.  wg_stride = 0: all workgroups read the same `span` bytes (the weight stream of the feed-forward
+// pair / conv2 kernels: L2 hits after the first pass); wg_stride = span: private regions (operands streamed from HBM once).
+// The rate this reaches is the ceiling of every kernel whose tile re-fetches its operands per workgroup
+// (profiles/r03_fetch_ceiling.json).
+template <int MODE, int pat>
+__global__ void __launch_bounds__(256) fetch_probe_kernel(const char* __restrict__ src, int64_t wg_stride, int64_t span, int steps,
+                                                          int ring, int group_mod, float* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem_dyn);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* base = src + (int64_t)(blockIdx.x % group_mod) * wg_stride;
+  // piece i of a step: bytes [i KB, i KB + 1 KB) of the 32 KB; wave w issues pieces w, w + 4, ...
+  int64_t off = 0;
+  float acc = 0.f;
+  if constexpr (MODE == 1) {   // plain loads, one step (8 x 16 bytes per lane) in flight behind the one being consumed
+    float4 cur[8], nxt[8];
+    auto load = [&](float4 (&v)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(base + off + (int64_t)((i * 4 + wave) * 1024 + lane * 16));
+      off += 32768;
+      if (off >= span) off -= span;
+    };
+    load(cur);
+    for (int s = 0; s < steps; ++s) {
+      if (s + 1 < steps) load(nxt);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += cur[i].x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+    return;
+  }
+  // lane -> byte of the 1 KB piece.  pat 0: lane * 16 (contiguous).  pat 1: the reduction-major tile of the stream GEMM -- 4 rows
+  // of 256 B, the 16-byte chunks of a row XOR-ed by the row's swizzle (even masks: 32-byte pairs stay together).  pat 2: the
+  // row-major tile -- 8 rows of 128 B, chunks XOR-ed by (row >> 1) & 7 (any mask).  pat 3 / 4: as 1 / 2 with rows 4 KB apart
+  // (a piece then touches 4 / 8 separate segments, as a tile of a wide matrix does).
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = i * 4 + wave;
+      int64_t byte;
+      if (pat == 0) {
+        byte = q * 1024 + lane * 16;
+      } else if (pat == 1 || pat == 3) {
+        const int r = q * 4 + (lane >> 4), c16 = lane & 15;
+        const int g = (r & 3) | (((r >> 3) & 1) << 2);
+        byte = (pat == 1 ? (int64_t)r * 256 : (int64_t)(r & 7) * 4096 + (r >> 3) * 256) + ((c16 ^ (g << 1)) << 4);
+      } else {
+        const int r = q * 8 + (lane >> 3), c8 = lane & 7;
+        byte = (pat == 2 ? (int64_t)r * 128 : (int64_t)(r & 7) * 4096 + (r >> 3) * 128) + ((c8 ^ ((r >> 1) & 7)) << 4);
+      }
+      nstgemm::glds16(base + off + byte, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)slot * 32768u + (uint32_t)(q * 1024)));
+    }
+    off += 32768;
+    if (off >= span) off -= span;
+  };
+  int issued = 0, slot = 0;
+  for (; issued < ring - 1 && issued < steps; ++issued) { issue(slot); slot = slot + 1 == ring ? 0 : slot + 1; }
+  for (int s = 0; s < steps; ++s) {
+    const int younger = issued - s - 1;   // steps in flight behind the one waited for (8 instructions each)
+    if (younger >= 3) nstgemm::wait_vmcnt<24>();
+    else if (younger == 2) nstgemm::wait_vmcnt<16>();
+    else if (younger == 1) nstgemm::wait_vmcnt<8>();
+    else nstgemm::wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < steps) { issue(slot); slot = slot + 1 == ring ? 0 : slot + 1; ++issued; }
+    acc += *reinterpret_cast<const volatile float*>(smem_dyn + ((s % ring) * 32768) + tid * 4);
+  }
+  if (acc == 12345.678f) sink[0] = acc;   // (keeps the LDS reads alive)
+}
+
 }  // namespace
+
+extern "C" int nst_probe_fetch(const void* src, int64_t wg_stride, int64_t span, int steps, int ring, int mode, int workgroups,
+                               int group_mod, int pattern, float* sink, void* stream) {
+  NST_CHECK_ARG(src && sink && steps > 0 && ring >= 2 && ring <= 4 && span >= 32768 && span % 32768 == 0 && workgroups > 0 &&
+                    (mode == 0 || mode == 1) && nst_aligned16(src) && group_mod > 0 && pattern >= 0 && pattern <= 4,
+                "probe_fetch: bad arguments");
+  const int lds = ring * 32768;
+#define NST_PROBE_LAUNCH(M_, P_)                                                                                             \
+  do {                                                                                                                     \
+    NST_CHECK_HIP(hipFuncSetAttribute((const void*)fetch_probe_kernel<M_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    fetch_probe_kernel<M_, P_><<<workgroups, 256, lds, (hipStream_t)stream>>>((const char*)src, wg_stride, span, steps, ring,   \
+                                                                             group_mod, sink);                             \
+  } while (0)
+  if (mode == 1) NST_PROBE_LAUNCH(1, 0);
+  else if (pattern == 0) NST_PROBE_LAUNCH(0, 0);
+  else if (pattern == 1) NST_PROBE_LAUNCH(0, 1);
+  else if (pattern == 2) NST_PROBE_LAUNCH(0, 2);
+  else if (pattern == 3) NST_PROBE_LAUNCH(0, 3);
+  else NST_PROBE_LAUNCH(0, 4);
+#undef NST_PROBE_LAUNCH
+  NST_CHECK_LAUNCH("probe_fetch");
+  return NST_OK;
+}
 
 extern "C" int nst_probe_mfma(float* out_c16, float* out_c16_f32, uint16_t* out_tr, void* stream) {
   NST_CHECK_ARG(out_c16 && out_c16_f32 && out_tr, "probe_mfma: null pointer");

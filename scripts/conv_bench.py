@@ -50,6 +50,21 @@ def main():
         us = timed(fn, a.iters)
         res[name] = {"us": us, "tflops": flops / us / 1e6, "mfma_frac": flops / us / 1e6 / 2500.0}
         print(name, res[name])
+    # layer 1 (C_in = 1): forward conv + LayerNorm + ReLU and its backward (HBM / VALU kernels: bytes per second)
+    T, F = 2 * T1, 2 * F1
+    src = torch.randn(B, T, F, generator=g).to(dev)
+    w1 = (torch.randn(3, 3, 1, C, generator=g) * 0.3).to(dev)
+    b1, g1, be1 = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    a1, mean1, rstd1 = K.conv1_ln_relu_fwd(src, w1, b1, g1, be1, True, 1e-6, torch.bfloat16)
+    dout = (torch.randn(B, T1, F1, C, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    dw1, db1, dg1, dbe1 = torch.zeros_like(w1), torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    nbytes = B * T1 * F1 * C * 2
+    for name, fn in (("conv1_fwd", lambda: K.conv1_ln_relu_fwd(src, w1, b1, g1, be1, True, 1e-6, torch.bfloat16)),
+                     ("conv1_bwd", lambda: K.conv1_ln_relu_bwd(src, w1, b1, g1, be1, mean1, rstd1, dout, dw1, db1, dg1, dbe1, True,
+                                                               1e-6, accumulate=True))):
+        us = timed(fn, a.iters)
+        res[name] = {"us": us, "activation_tb_per_s": nbytes / us / 1e6}
+        print(name, res[name])
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 
