@@ -42,9 +42,12 @@ dense_wgrad_ring_kernel(GemmArgs<float, DenseLoader<bf16_t>, DenseLoader<bf16_t>
   gemm_stream_v3_ring<float, IdentityRowMap, CS, EF, SLOTS, DBG>(smem_dyn);
 }
 
-int wgrad_ring() {   // NST_GEMM_RING=0: the two-stage stream kernel for the weight gradients too (A/B switch); 3 / 4: shallower rings
+// NST_GEMM_RING=5 (3, 4): the weight gradients on the ring of five (three, four) half-step slots; 5x: its timing ablations.
+// Default 0 = the two-stage stream kernel: the ring measured SLOWER (ffn1 weight gradient 59.5 -> 81 us, step +0.2 ms,
+// profiles/r03_history/r03_wgrad_ring_ablation.log) -- a deeper ring does not buy what the issue of the loads costs.
+int wgrad_ring() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_RING"); v = e ? atoi(e) : 5; }
+  if (v < 0) { const char* e = getenv("NST_GEMM_RING"); v = e ? atoi(e) : 0; }
   return v;
 }
 
@@ -266,7 +269,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
     kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
   } while (0)
-        if (amode == MODE_OC && bmode == MODE_OC && wgrad_ring() && kt_per_split >= 4) {
+        if (amode == MODE_OC && bmode == MODE_OC && wgrad_ring() != 0 && kt_per_split >= 4) {
           if (ep.colsum_dst) {
 #define NST_RING_DBG(V, D) if (em == 0 && wgrad_ring() == V) { auto kfn = dense_wgrad_ring_kernel<true, 0, 5, D>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
             NST_RING_DBG(51, 1) NST_RING_DBG(52, 2) NST_RING_DBG(54, 4) NST_RING_DBG(58, 8) NST_RING_DBG(53, 3) NST_RING_DBG(55, 5) NST_RING_DBG(57, 7) NST_RING_DBG(515, 15)
