@@ -281,6 +281,21 @@ def test_gemm_wgrad_fused_colsum(K, dtype, rows, Kin, N):
         close(tag + ".db_acc", db, 2 * ref_b, torch.float32)
 
 
+def test_gemm_wgrad_on_the_half_step_ring_kernel():
+    """NST_GEMM_RING=5 routes the bf16 weight gradients (slabs, fused column sums, accumulate) to gemm_stream_v3_ring (five
+    half-step slots; opt-in, slower than the default: DESIGN.md 5d).  The switch is read once per process: the weight-gradient
+    cases above run again in a child interpreter, where a wrong half-step order or slot would show as a wrong dW."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, NST_GEMM_RING="5")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"), "-q", "-x", "-k",
+                          "test_gemm_wgrad_fused_colsum or test_gemm_splitk_wgrad", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dropout_epilogue(K, dtype):
     M, N, K_ = 256, 256, 64
