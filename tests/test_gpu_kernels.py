@@ -709,7 +709,7 @@ def test_scale_posenc_dropout(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,V,ls", [(6, 5, 0.1), (64, 8008, 0.1), (10, 1000, 0.0), (33, 300, 0.3)])
+@pytest.mark.parametrize("rows,V,ls", [(6, 5, 0.1), (64, 8008, 0.1), (10, 1000, 0.0), (33, 300, 0.3), (4, 16384, 0.1), (3, 40000, 0.1)])
 def test_ls_xent(K, dtype, rows, V, ls):
     logits = (rnd(rows, V, seed=1) * 2.0).to(dtype)
     labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
