@@ -373,16 +373,24 @@ __device__ __forceinline__ void c1_split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 constexpr int C1M_PT = 12;  // floats per pixel in the wave's patch table: 9 taps, -mean*rstd, rstd, pixel mask
 constexpr int C1M_WAVES = 4;  // one wave per SIMD: the kernel needs ~300 registers (64 MFMA accumulators + per-pixel state)
 
-template <int NCB>
+// WV waves per workgroup, NB dout-tile buffers per wave.  (4, 2): one wave per SIMD, the next group's tile lands under the
+// current group's work.  (8, 1) -- the V2 form below, C = 256: two waves per SIMD in the same 160 KB; a wave's next tile is
+// requested when it has finished reading the current one and the SIMD's other wave computes while it lands.
+template <int NCB, int WV = C1M_WAVES, int NB = 2>
 struct C1mLds {
   uint4 w[NCB][64];                    // B operand of product (1) per channel block
   float2 gb[NCB * 16];                 // (gamma, beta)
-  float pt[C1M_WAVES][32][C1M_PT];     // per-wave patch table
-  char dst[C1M_WAVES][2][32 * NCB * 32];  // per-wave dout tiles (double buffered): 32 pixels x C bf16, 32-byte units XOR-swizzled by (pix>>2)&3
+  float pt[WV][32][C1M_PT];            // per-wave patch table
+  char dst[WV][NB][32 * NCB * 32];     // per-wave dout tiles: 32 pixels x C bf16, 32-byte units XOR-swizzled by (pix>>2)&3
 };
 
-template <int NCB, bool LN>
-__global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
+// V2 (round 3): the element-wise loops in packed-f32 form on transposed LDS reads.  The first form needs 497 registers (the
+// compiler parks 241 of them in the accumulation file: 887 v_accvgpr moves, one wave per SIMD) and ~3800 instructions per
+// 32-pixel group, 320 of them 2-byte LDS reads; it is bound by instruction issue (a software pipeline over its channel blocks
+// changed nothing).  V2 reads the 4 pixels x 1 channel a lane needs with ONE ds_read_b64_tr_b16, does the arithmetic on float2
+// pairs (v_pk_fma_f32 ...), is written branch-free, and is compiled for 256 registers so that eight waves fit a CU.
+template <int NCB, bool LN, int WV = C1M_WAVES, int NB = 2, bool V2 = false>
+__global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) conv1_bwd_mfma_kernel(
     const float* __restrict__ src, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const bf16_t* __restrict__ dout, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dgamma,
@@ -390,14 +398,15 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
   constexpr int C = NCB * 16;
   constexpr int ROWB = C * 2;  // bytes per pixel row of dout
   extern __shared__ __attribute__((aligned(16))) char c1m_smem[];
-  C1mLds<NCB>& L = *reinterpret_cast<C1mLds<NCB>*>(c1m_smem);
+  typedef C1mLds<NCB, WV, NB> Lds;
+  Lds& L = *reinterpret_cast<Lds*>(c1m_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, lc = lane & 15;
 
   // ---- weights -> MFMA B fragments (once per workgroup).  K slot (g, j) carries, for channel c:
   //   g=0: w_hi[tap j]   g=1: w_lo[tap j]   g=2: w_hi[tap j]   (taps 0..7; the A side holds x_hi, x_hi, x_lo)
   //   g=3: j=0 w_hi[8], j=1 w_lo[8], j=2 w_hi[8], j=3 b_hi, j=4 b_lo, j=5..7 zero
-  for (int i = tid; i < NCB * 64; i += C1M_WAVES * 64) {
+  for (int i = tid; i < NCB * 64; i += WV * 64) {
     const int cb = i >> 6, l = i & 63, gg = l >> 4, c = cb * 16 + (l & 15);
     bf16_t v[8];
 #pragma unroll
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
     pk.z = v[4] | ((uint32_t)v[5] << 16); pk.w = v[6] | ((uint32_t)v[7] << 16);
     L.w[cb][l] = pk;
   }
-  for (int c = tid; c < C; c += C1M_WAVES * 64) L.gb[c] = LN ? make_float2(gamma[c], beta[c]) : make_float2(1.f, 0.f);
+  for (int c = tid; c < C; c += WV * 64) L.gb[c] = LN ? make_float2(gamma[c], beta[c]) : make_float2(1.f, 0.f);
   __syncthreads();
 
   floatx4_t accw[NCB];
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
   const uint32_t dst_addr0 = (uint32_t)(uintptr_t)((lds_char_ptr)L.dst[wave][0]);
   const int64_t ngroups = (npix + 31) / 32;
-  const int64_t gstride = (int64_t)gridDim.x * C1M_WAVES;
+  const int64_t gstride = (int64_t)gridDim.x * WV;
 
   // dout tile of a group -> LDS by LDS-DMA (1 KB = 2 pixel rows per instruction); pixels past the end stage zeros
   auto stage_tile = [&](int64_t p0, int buf) {
@@ -483,7 +492,7 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
     }
   };
 
-  int64_t grp = (int64_t)blockIdx.x * C1M_WAVES + wave;
+  int64_t grp = (int64_t)blockIdx.x * WV + wave;
   int buf = 0;
   if (grp < ngroups) {
     stage_tile(grp * 32, 0);
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
     const int64_t nxt = grp + gstride;
     PixRow nrow;
     if (nxt < ngroups) {
-      stage_tile(nxt * 32, buf ^ 1);
+      if (NB == 2) stage_tile(nxt * 32, buf ^ 1);   // (one buffer: requested below, behind this group's last read of the tile)
       nrow = gather_row(nxt * 32);
     }
     // dout of channel block cb for the lane's 8 pixels from the staged tile: row (u*16+g*4+r)*ROWB, 32-byte unit cb ^ g
@@ -568,6 +577,108 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
         }
     };
 
+    if constexpr (V2) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      typedef short4_t __attribute__((address_space(3))) * lds_tr_ptr_t;
+      // dout of channel block cb for pixels u*16 + g*4 + 0..3 at channel cb*16 + lc: ONE transposed read per u.  The 16 lanes of a
+      // group address the 4 x 16 block (row u*16 + g*4 + (lc >> 2), 8 bytes at channel (lc & 3) * 4 of the 32-byte unit cb ^ g)
+      // and receive it transposed.
+      const int trofs = (g * 4 + (lc >> 2)) * ROWB + ((lc & 3) << 3);
+      int trl = trofs;
+      asm volatile("" : "+v"(trl));
+      auto load_go2 = [&](int cb, short4_t (&raw)[2]) {
+        const int unit = ((cb & ~3) << 5) + (((cb & 3) ^ g) << 5);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          raw[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(dst + trl + u * 16 * ROWB + unit));
+      };
+      auto unpack = [&](const short4_t& r, int pr) {   // pixels 2 pr, 2 pr + 1 of the lane's four
+        const uint32_t w = pr == 0 ? __builtin_bit_cast(uint2, r).x : __builtin_bit_cast(uint2, r).y;
+        return f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+      };
+      f2 rs2[2][2], nm2[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          rs2[u][pr] = f2{rs[u][2 * pr], rs[u][2 * pr + 1]};
+          nm2[u][pr] = f2{nmr[u][2 * pr], nmr[u][2 * pr + 1]};
+        }
+      f2 c1v[2][2], c2v[2][2];
+      if (LN) {
+        f2 s1[2][2], s2[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) { s1[u][pr] = f2{0.f, 0.f}; s2[u][pr] = f2{0.f, 0.f}; }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          short4_t raw[2];
+          load_go2(cb, raw);
+          const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, L.w[cb][wofs]);
+          const float2 gbv = L.gb[cb * 16 + gofs];
+          const f2 gx = f2{gbv.x, gbv.x}, gy = f2{gbv.y, gbv.y};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const floatx4_t z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf, floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const f2 xhat = __builtin_elementwise_fma(f2{z[2 * pr], z[2 * pr + 1]}, rs2[u][pr], nm2[u][pr]);
+              const f2 y = __builtin_elementwise_fma(xhat, gx, gy);
+              const f2 go = unpack(raw[u], pr);
+              const f2 d = f2{y.x > 0.f ? go.x : 0.f, y.y > 0.f ? go.y : 0.f} * gx;
+              s1[u][pr] += d;
+              s2[u][pr] = __builtin_elementwise_fma(d, xhat, s2[u][pr]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // bounds how far LDS reads are hoisted (register pressure)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            c1v[u][pr] = f2{c1_row16_sum(s1[u][pr].x), c1_row16_sum(s1[u][pr].y)} * inv_c;
+            c2v[u][pr] = f2{c1_row16_sum(s2[u][pr].x), c1_row16_sum(s2[u][pr].y)} * inv_c;
+          }
+        asm volatile("" : "+v"(wofs), "+v"(gofs), "+v"(trl));   // the second pass re-reads the tables (see the first form)
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        short4_t raw[2];
+        load_go2(cb, raw);
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, L.w[cb][wofs]);
+        const float2 gbv = L.gb[cb * 16 + gofs];
+        const f2 gx = f2{gbv.x, gbv.x}, gy = f2{gbv.y, gbv.y};
+        f2 la = f2{0.f, 0.f}, lb = f2{0.f, 0.f};
+        uint32_t packed[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const floatx4_t z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf, floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const f2 go = unpack(raw[u], pr);
+            f2 dz;
+            if (LN) {
+              const f2 xhat = __builtin_elementwise_fma(f2{z[2 * pr], z[2 * pr + 1]}, rs2[u][pr], nm2[u][pr]);
+              const f2 y = __builtin_elementwise_fma(xhat, gx, gy);
+              const f2 gv = f2{y.x > 0.f ? go.x : 0.f, y.y > 0.f ? go.y : 0.f};
+              la = __builtin_elementwise_fma(gv, xhat, la);
+              lb += gv;
+              // rs * (gv * gamma - c1 - xhat * c2)
+              dz = rs2[u][pr] * (__builtin_elementwise_fma(gv, gx, -c1v[u][pr]) - xhat * c2v[u][pr]);
+            } else {
+              dz = f2{z[2 * pr] > 0.f ? go.x : 0.f, z[2 * pr + 1] > 0.f ? go.y : 0.f};
+            }
+            packed[u][pr] = pack_bf16x2(dz.x, dz.y);
+          }
+        }
+        if (LN) { ag[cb] += la.x + la.y; abe[cb] += lb.x + lb.y; }
+        union { uint32_t w[4]; bf16x8_t f; } b2;
+        b2.w[0] = packed[0][0]; b2.w[1] = packed[0][1]; b2.w[2] = packed[1][0]; b2.w[3] = packed[1][1];
+        accw[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2.f, accw[cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     float c1[2][4], c2[2][4];
     if (LN) {
       float s1[2][4], s2[2][4];
@@ -636,8 +747,14 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
       accw[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2.f, accw[cb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
+    if (NB == 1 && nxt < ngroups) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile's last reads have returned
+      __builtin_amdgcn_wave_barrier();
+      stage_tile(nxt * 32, 0);
+    }
     if (nxt < ngroups) write_row(nrow);
-    buf ^= 1;
+    if (NB == 2) buf ^= 1;
   }
 
   // ---- reductions: accw[cb][r] = gradient of (tap g*4+r | db1 at 9, channel cb*16+lc); ag/abe per (cb, lc) summed over g.
@@ -662,10 +779,10 @@ __global__ void __launch_bounds__(C1M_WAVES * 64) conv1_bwd_mfma_kernel(
     }
     __syncthreads();
     if (q < 10 || LN) {
-      for (int c = tid; c < C; c += C1M_WAVES * 64) {
+      for (int c = tid; c < C; c += WV * 64) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < C1M_WAVES; ++w) t += red[w * C + c];
+        for (int w = 0; w < WV; ++w) t += red[w * C + c];
         if (q < 9) atomicAdd(dw1 + q * C + c, t);
         else if (q == 9) atomicAdd(db1 + c, t);
         else atomicAdd((q == 10 ? dgamma : dbeta) + c, t);
@@ -1911,6 +2028,25 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
     kfn<<<mb, C1M_WAVES * 64, sizeof(C1mLds<NCB>), st>>>(src, w1, b1, gamma, beta, mean, rstd, (const bf16_t*)dout, dw1, \
                                                         db1, dgamma, dbeta, T, F, T1, F1, npix, dF1, dT1);             \
   } while (0)
+    static int v2 = -1;   // NST_CONV1_BWD_V2=0: the first form (one wave per SIMD) for C = 256 too
+    if (v2 < 0) { const char* e = getenv("NST_CONV1_BWD_V2"); v2 = (e && e[0] == '0') ? 0 : 1; }
+    if (v2 && C == 256) {
+      typedef C1mLds<16, 8, 1> Lds2;
+      const int mb2 = (int)((ngroups + 7) / 8 > cus ? cus : (ngroups + 7) / 8);
+      if (layer_norm) {
+        auto kfn = conv1_bwd_mfma_kernel<16, true, 8, 1, true>;
+        conv_allow_big_lds(kfn, (int)sizeof(Lds2));
+        kfn<<<mb2, 512, sizeof(Lds2), st>>>(src, w1, b1, gamma, beta, mean, rstd, (const bf16_t*)dout, dw1, db1, dgamma, dbeta, T, F,
+                                            T1, F1, npix, dF1, dT1);
+      } else {
+        auto kfn = conv1_bwd_mfma_kernel<16, false, 8, 1, true>;
+        conv_allow_big_lds(kfn, (int)sizeof(Lds2));
+        kfn<<<mb2, 512, sizeof(Lds2), st>>>(src, w1, b1, gamma, beta, mean, rstd, (const bf16_t*)dout, dw1, db1, dgamma, dbeta, T, F,
+                                            T1, F1, npix, dF1, dT1);
+      }
+      NST_CHECK_LAUNCH("conv1_bwd(mfma, v2)");
+      return NST_OK;
+    }
     if (layer_norm) { if (C == 256) NST_C1M(16, true); else if (C == 128) NST_C1M(8, true); else NST_C1M(4, true); }
     else { if (C == 256) NST_C1M(16, false); else if (C == 128) NST_C1M(8, false); else NST_C1M(4, false); }
 #undef NST_C1M
