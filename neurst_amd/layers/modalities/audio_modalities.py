@@ -76,6 +76,7 @@ class AudioConv2dSubsamplingLayer(Layer):
             dz = K.scale_dropout_bwd(dz.contiguous(), float(d) ** 0.5, 0.0)
         a2_2d = a2.view(B * T2, F2 * C)
         self._dense_layer.backward_params(a2_2d, dz)
+        self.rt.sublayer_boundary(force=True)   # (K = 5120 weight gradient next to the dgrad and the LayerNorm backward below)
         if ln:
             da2 = self._dense_layer.backward_input(dz)
             acc = st.acc_flag(self.g2)
@@ -91,7 +92,7 @@ class AudioConv2dSubsamplingLayer(Layer):
         if os.environ.get("NST_SKIP_WGRAD", "0") != "1" and where == "side":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
             # overlaps the dgrad below and the conv1 backward
             self.rt.run_wgrad(lambda: K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2), a1, dy2)
-            self.rt.sublayer_boundary()
+            self.rt.sublayer_boundary(force=True)
         da1 = K.conv2_dgrad(dy2, self.w2.compute, a1.shape[1], a1.shape[2])
         if where == "after_dgrad":
             K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)

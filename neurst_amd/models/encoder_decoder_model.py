@@ -232,6 +232,7 @@ class EncoderDecoderModel(BaseModel):
             # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
             shared = self._src_modality is self._trg_modality
             ddec = self._output_logits_backward(dlogits)
+            self.rt.sublayer_boundary(force=True)   # the logits weight gradient (vocabulary x d) starts with the decoder's backward
             ddec_in, dmemory = self._decoder.backward(ddec, layer_done=hook)
             # softmax_linear (untied logits) is registered right after the decoder: one contiguous slice with it
             hook([self._decoder.name + "/"] + (["softmax_linear/"] if self._output_linear_layer is not None else []))

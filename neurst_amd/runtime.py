@@ -331,11 +331,14 @@ class Runtime(object):
         if self.capture is not None:
             self.capture.layer_boundary(report=True)
 
-    def sublayer_boundary(self):
+    def sublayer_boundary(self, force=False):
         """Capture only: the weight-gradient calls recorded so far may start now (their graph is launched on the
-        weight-gradient stream next to what follows).  Eager launches start on their own."""
+        weight-gradient stream next to what follows).  Eager launches start on their own.  force: cut even when only a
+        few calls are pending (a LONG weight gradient in front of long compute-stream kernels: without the cut it
+        starts when the whole segment has been replayed -- the conv2 weight gradient then ran alone at the end of every
+        step, 1.1 ms behind the last compute-stream kernel)."""
         if self.capture is not None:
-            self.capture.layer_boundary()
+            self.capture.layer_boundary(force=force)
 
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""

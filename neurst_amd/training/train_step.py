@@ -47,6 +47,7 @@ class _StepCapture(object):
         self.cur = None
         self._fresh = False      # nothing has been queued since the current segment was opened by a layer boundary
         self.min_deferred = max(1, int(os.environ.get("NST_GRAPH_MIN_DEFERRED", "6")))
+        self.force_cuts = os.environ.get("NST_GRAPH_FORCE_CUTS", "1") != "0"   # A/B switch of Runtime.sublayer_boundary(force=True)
 
     def begin(self):
         self.cur = _Segment()
@@ -93,7 +94,7 @@ class _StepCapture(object):
         self.deferred.append(fn)
         self.keep.extend(tensors)      # their memory must not be handed out again inside this capture (the graphs run concurrently)
 
-    def layer_boundary(self, report=False):
+    def layer_boundary(self, report=False, force=False):
         """report=True: the boundary of a gradient REPORT (Runtime.wgrad_boundary: everything that writes the layer's
         gradients is queued, the reducer's hook fires next).  Only then may the bucket that follows ride on the segment
         closed here (`_fresh`); a mid-layer boundary (sublayer_boundary) is followed by more compute-stream work of the
@@ -101,7 +102,7 @@ class _StepCapture(object):
         # a cut costs two graph launches (~10-20 us of idle compute stream each); waiting for a few weight-gradient calls
         # trades that against a later start of the weight-gradient graph (NST_GRAPH_MIN_DEFERRED, measured in DESIGN 5b)
         self._fresh = False
-        if len(self.deferred) >= self.min_deferred:
+        if len(self.deferred) >= self.min_deferred or (force and self.deferred and self.force_cuts):
             self._close()
             self.begin()
             self._fresh = bool(report)
