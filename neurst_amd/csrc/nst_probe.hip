@@ -1,4 +1,4 @@
-// Hardware probes for the lane maps the MFMA kernels assume (tests/test_gpu_probe.py checks them against numpy):
+// Hardware probes for the lane maps the MFMA kernels assume (tests/test_gpu_kernels.py checks them against numpy):
 //   out_c16     [16x16] f32 : D = A.B computed with ONE v_mfma_f32_16x16x32_bf16, fragments loaded and the result
 //                             scattered with exactly the index formulas of nst_gemm_core.h
 //   out_c16_f32 [16x16] f32 : same for v_mfma_f32_16x16x4_f32
