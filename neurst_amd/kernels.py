@@ -28,7 +28,7 @@ def _workspace(nbytes, device):
     """Persistent scratch for two-stage reductions (split-K slabs, LayerNorm / bias-gradient partial sums); grown
     on demand.  One buffer per (device, stream): launches on one stream are ordered, so consecutive users never
     overlap, and concurrent streams never share a buffer."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _stream())   # (callers run on `device`: the runtime pins one device per process)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
@@ -52,7 +52,15 @@ def _p(t):
     return t.data_ptr()
 
 
+# raw handle of the current stream of the current device: two C calls instead of torch.cuda.current_stream()'s Python objects
+# (an eager step issues ~500 launches; the Stream object cost ~5 us of host time each)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
