@@ -557,8 +557,14 @@ def _conv1_ref(src, w1, b1, gamma, beta, ln):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T,F,C,ln", [(1, 11, 80, 5, True), (2, 33, 16, 8, True), (2, 14, 12, 6, False),
-                                        (2, 50, 80, 256, True), (1, 9, 20, 512, True), (3, 23, 16, 64, False)])
+                                        (2, 50, 80, 256, True), (1, 9, 20, 512, True), (3, 23, 16, 64, False),
+                                        # C = 256 takes the second (eight-wave, packed-f32) backward: without LayerNorm, and
+                                        # with more 32-pixel groups (2500) than waves (2048: a wave re-stages its one tile buffer)
+                                        (2, 37, 24, 256, False), (20, 200, 80, 256, True)])
 def test_conv1(K, dtype, B, T, F, C, ln):
+    if B == 20 and dtype == torch.float32:
+        pytest.skip("the 80 000-pixel case exists for the bf16 kernel's tile re-staging; in fp32 the sums of 80 000 random-sign "
+                    "terms cancel to ~1e-4 relative whatever the kernel does")
     src = rnd(B, T, F, seed=1)
     w1 = rnd(3, 3, 1, C, seed=2) * 0.4
     b1 = rnd(C, seed=3) * 0.1
