@@ -2,7 +2,7 @@
 # Round 3, first GPU call:  gpurun --timeout 1500 -- 'bash scripts/r03_call1.sh'
 #  1. the whole -m gpu tier (incl. the round-3 parity cases on the timed path), 2. smoke, 3. the bench line (graph replay,
 #  the default) and the eager one, 4. the two-rank rehearsal started by bench.py itself (host-staged gloo, shared device).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q --tb=short -x --durations=15 > $O/r03_gpu_tests_call1.log 2>&1

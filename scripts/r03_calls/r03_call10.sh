@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, call 10: whole GPU tier with the eight-wave feed-forward kernels and the LayerNorm finalize, then the step A/B.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q --tb=short > $O/r03_gpu_tests_call10.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "gemm" > $O/r03_gemm_tests_call11.log 2>&1

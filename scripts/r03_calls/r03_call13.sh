@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_zz_gpu_widening.py tests/test_gpu_graph.py tests/test_gpu_multi.py -m gpu -q --tb=short -x > $O/r03_tests_call13.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 timeout 900 python -m pytest tests/test_gpu_ffn.py -x -q 2>&1 | tail -5
 for r in 1 2; do timeout 300 python scripts/ffn_bench.py --rows 28800 --iters 30 2>/dev/null | python -c "
 import sys,json

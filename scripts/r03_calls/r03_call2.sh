@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, second GPU call: specialised GEMM epilogues -- parity (whole tier), stand-alone timings and the K sweep with and
 # without them, and the interleaved A/B on the benchmark step.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q --tb=short --durations=10 > $O/r03_gpu_tests_call2.log 2>&1

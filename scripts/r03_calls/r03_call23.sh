@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 export NST_GEMM_RING=0
 for u in 256 512 1024; do NST_WGRAD_UNITS=$u timeout 300 python scripts/gemm_iso.py 2>/dev/null | python -c "
 import sys,json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, call 3: the eight-wave feed-forward forward kernel -- parity, then timing against the one-wave-per-SIMD kernel.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 900 python -m pytest tests/test_gpu_ffn.py -m gpu -q --tb=short -x > $O/r03_ffn_tests_call3.log 2>&1

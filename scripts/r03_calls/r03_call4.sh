@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, call 4: ablations of the eight-wave feed-forward forward kernel (no dropout, M = 28800), interleaved rounds.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 for r in 1 2; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, call 6: LN finalize rewrite (parity), FFN v2 forward with the residual prefetch (parity + time), PMC of the v2 kernel.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 O=gpurun_out
 timeout 900 python -m pytest tests/test_gpu_ffn.py tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "ffn or layernorm or ln" > $O/r03_tests_call6.log 2>&1

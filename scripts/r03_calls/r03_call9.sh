@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_ffn.py -m gpu -q --tb=short -x > gpurun_out/r03_ffn_tests_call9.log 2>&1
 echo "ffn tests rc=$? $(tail -n 1 gpurun_out/r03_ffn_tests_call9.log)"; grep -E "^FAILED|^ERROR|^E  " gpurun_out/r03_ffn_tests_call9.log | head

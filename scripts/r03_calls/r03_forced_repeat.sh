@@ -1,6 +1,6 @@
 #!/bin/bash
 # the forced one-rank exchange path (graph replay, RCCL) several times in a row: every run must print its JSON line
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out
 for i in 1 2 3 4 5 6 7 8; do
   NST_DIST_FORCE=1 timeout 200 python bench.py --no-cpu-baseline --roofline-steps 0 --steps 5 --warmup 3 > gpurun_out/forced_$i.log 2>&1
