@@ -1497,6 +1497,176 @@ __global__ void __launch_bounds__(CP_THREADS) conv2_fwd_patch_kernel(PatchArgs a
   gemm_epilogue<bf16_t, IdentityRowMap, 4>(acc, a.y, (int64_t)a.C, a.M, a.C, m0, 0, a.ep, smem, IdentityRowMap());
 }
 
+// =============================================================================================
+// conv2 forward, 256 output pixels per workgroup (round 3).
+//
+// The kernel above is bound by what its waves have to ISSUE per MFMA: every K step a wave issues 4 weight-tile
+// DMA instructions (and 1.3 of the patch) next to 32 MFMAs.  Here a workgroup owns 256 consecutive output pixels: the patch is
+// staged per 32-channel slice (64-byte positions: 29 band rows x 42 columns = 76 KB) so that it still fits, a wave owns
+// 128 pixels x 64 channels (128 accumulators), and the weight tile of a (tap, slice) step is 32 rows x 256 channels = 16 KB:
+// 2 DMA instructions per wave and step for the same 32 MFMAs, and half as many workgroups re-fetch the weights.
+//   * patch layout: position pos lives in 64-byte slot pos ^ ((pos >> 2) & 1), its four 16-byte chunks XOR-ed by (pos >> 3) & 3
+//     (the 16 lanes of a fragment read walk positions two apart); the DMA applies the same involutions on the source side;
+//   * pixels of a wave: quad q = wave >> 2 takes rows [64 q, 64 q + 64) of BOTH 128-pixel halves of the tile, so that the two
+//     halves of its accumulators are two ordinary 128 x 256 epilogues (gemm_epilogue with four waves side by side);
+//   * four weight tiles in LDS (three steps ahead, counted vmcnt): with one tile ahead the kernel took 1025 us.
+// Measured (B = 128): 914 us stand-alone -- the SAME as the 128-pixel kernel, i.e. the step time (~3450 cycles at the nominal
+// clock, 30 % MFMA) is set by neither the DMA count nor the DMA latency but by the barrier-synchronised sequence
+// "issue, read 12 fragments, 32 MFMAs shared with the SIMD's other wave"; in the training step it is worth 0.07 ms (half as
+// many workgroups pull the weights while the other stream runs).  NST_CONV2_PATCH256=0 selects the 128-pixel kernel.
+// =============================================================================================
+constexpr int CQ_PX = 256;
+constexpr int CQ_WBUF = 2 * 32 * 256;                             // one (tap, 32-channel slice) weight tile: two 128-column images of 8 KB
+constexpr int CQ_NBUF = 4;                                          // weight tiles in LDS: three steps ahead of the one being multiplied
+constexpr int CQ_B_OFF = CP_LDS_BYTES - CQ_NBUF * CQ_WBUF;
+constexpr int CQ_ZERO_OFF = CQ_B_OFF - 1024;                       // 64-byte zero block (1 KB slot) behind the patch
+constexpr int CQ_PATCH_MAX = CQ_ZERO_OFF;                          // 97280 B = 1520 positions
+constexpr int CQ_MAXPOS = 1408;                                    // positions staged at most (88 pieces of 16 = 11 per wave)
+constexpr int CQ_NIT = CQ_MAXPOS / 16 / 8;
+
+__global__ void __launch_bounds__(CP_THREADS, 2) conv2_fwd_patch256_kernel(PatchArgs a) {
+  typedef SwzFrag<bf16_t, MODE_OC> RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave >> 2, wq = wave & 3;
+  const int wn = wq * 64;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int m0 = tile * CQ_PX;
+  const int last_p = (m0 + CQ_PX - 1 < a.M) ? m0 + CQ_PX - 1 : a.M - 1;
+  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
+  const int band_row0 = 2 * orow_first - 1;
+  const int npos = (2 * (orow_last - orow_first) + 3) * a.PW;
+  const int npieces = (npos + 15) >> 4;
+  if (tid < 16) reinterpret_cast<uint32_t*>(smem + CQ_ZERO_OFF)[tid] = 0u;
+
+  // a patch piece = 16 positions x 64 bytes; the source address of a lane is re-derived at every staging (eight per workgroup:
+  // the 11 offsets would cost registers the 128 accumulators need)
+  auto stage_patch = [&](int cc) {
+#pragma unroll 1
+    for (int it = 0; it < CQ_NIT; ++it) {
+      const int piece = it * 8 + wave;
+      if (piece < npieces) {
+        const int S = piece * 16 + (lane >> 2);                  // LDS slot this lane fills
+        const int pos = S ^ ((S >> 2) & 1);                      // the position that lives there
+        const int prow = (int)a.dPW.div((uint32_t)pos), pc = pos - prow * a.PW;
+        const int grow = band_row0 + prow;
+        const bool ok = pos < npos && pc >= 1 && pc <= a.F1 && grow >= 0 && grow < a.in_rows;
+        const uint32_t chunk = (uint32_t)((lane & 3) ^ ((pos >> 3) & 3));
+        const char* src = ok ? reinterpret_cast<const char*>(a.x) + ((uint32_t)(grow * a.F1 + pc - 1) * (uint32_t)(a.C * 2) + chunk * 16u) +
+                                   cc * 64
+                             : reinterpret_cast<const char*>(g_nst_zero16);
+        glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
+      }
+    }
+  };
+  // weight tile (rows k0 .. k0 + 31 of w2 viewed as [9C, C]; this wave's quarter of image `quad`)
+  uint32_t boff[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int c = (s2 * 4 + wq) * 64 + lane;
+    const int r = c >> 4, c16 = c & 15;
+    const int g = (r & 3) | (((r >> 3) & 1) << 2);
+    boff[s2] = (uint32_t)((r * a.C + quad * BM + (c16 ^ (g << 1)) * 8) * 2);
+  }
+  auto issue_b = [&](int k0, int buf) {
+    const char* wb = reinterpret_cast<const char*>(a.w2) + (int64_t)k0 * a.C * 2;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      glds16(wb + boff[s2], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(CQ_B_OFF + buf * CQ_WBUF + quad * 8192 +
+                                                                                (s2 * 4 + wq) * 1024)));
+  };
+
+  // this lane's eight A rows: patch position of tap (0, 0) and the top-padding flag
+  int pb[8];
+  uint32_t topmask = 0;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = m0 + (i >> 2) * 128 + quad * 64 + (i & 3) * 16 + (lane & 15);
+    const bool ok = p < a.M;
+    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
+    const int fo = (ok ? p : m0) - orow * a.F2;
+    const int to = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
+    pb[i] = ok ? 2 * (orow - orow_first) * a.PW + 2 * fo : 0;
+    topmask |= (ok && to == 0) ? (1u << i) : 0u;
+  }
+
+  floatx4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  // Step t = 9 cc + tap multiplies weight tile t out of ring slot t % 4; the tiles of steps t + 1 .. t + 3 are in flight (two
+  // DMA instructions per wave each).  With ONE tile ahead a step took as long as a tile needs to land (~3500 cycles whatever
+  // the step holds: the first build of this kernel was slower than the 128-pixel one for that reason).
+  const int ncc = a.C / 32;
+  const int nsteps = ncc * 9;
+  stage_patch(0);
+  issue_b(0, 0);
+  issue_b(a.C, 1);
+  issue_b(2 * a.C, 2);
+  int buf = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    // the 72 fragment addresses (8 pixels x 9 taps) do not depend on the slice: laundering the positions once per slice keeps the
+    // compiler from holding all of them in registers next to the 128 accumulators (it spilled 62 of them)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pb[i]));
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+      const int t = cc * 9 + tap;
+      // tile t has landed; behind it only tiles t + 1, t + 2 (4 instructions) may be pending -- except at the first tap of a
+      // slice, where the patch pieces issued at the end of the previous slice are younger than those and must have landed too
+      if (tap == 0 || t + 2 >= nsteps) wait_vmcnt<0>(); else wait_vmcnt<4>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {
+        const int tap3 = (tap + 3) % 9, dcc = (tap + 3) / 9;   // (constants once the tap loop is unrolled)
+        if (t + 3 < nsteps) issue_b(tap3 * a.C + (cc + dcc) * 32, (buf + 3) & 3);
+      }
+      const char* Bs = smem + CQ_B_OFF + buf * CQ_WBUF + (wn >> 7) * 8192;
+      const int wnl = wn & 127;
+      const int toff = kh * a.PW + kw;
+      bf16x8_t af[8];
+      typename RB::Frag bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = RB::read(Bs, wnl + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pos = pb[i] + toff;
+        int ad = ((pos ^ ((pos >> 2) & 1)) << 6) + ((g ^ ((pos >> 3) & 3)) << 4);
+        if (kh == 0) ad = ((topmask >> i) & 1u) ? CQ_ZERO_OFF + (g << 4) : ad;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i][j] = Mma<bf16_t>::run(af[i], bfr[j], acc[i][j]);
+      buf = (buf + 1) & 3;
+    }
+    if (cc + 1 < ncc) {
+      __builtin_amdgcn_s_barrier();  // every wave has read its last fragment of this slice's patch
+      asm volatile("" ::: "memory");
+      stage_patch(cc + 1);
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // two 128 x 256 epilogues: accumulators 0..3 are rows [64 quad, +64) of the first 128 pixels, 4..7 of the second
+  gemm_epilogue<bf16_t, IdentityRowMap, 4>(reinterpret_cast<floatx4_t(&)[4][4]>(acc[0]), a.y, (int64_t)a.C, a.M, a.C, m0, 0, a.ep, smem,
+                                           IdentityRowMap());
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (m0 + 128 < a.M)
+    gemm_epilogue<bf16_t, IdentityRowMap, 4>(reinterpret_cast<floatx4_t(&)[4][4]>(acc[4]), a.y, (int64_t)a.C, a.M, a.C, m0 + 128, 0, a.ep,
+                                             smem, IdentityRowMap());
+}
+
 bool conv2_use_patch() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_CONV2_PATCH"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1521,6 +1691,18 @@ bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, in
   a.issue_late = conv_issue_late();
   a.ep = plain_epilogue();
   a.ep.bias = b2; a.ep.relu = relu; a.ep.vec = 1;
+  static int p256 = -1;   // NST_CONV2_PATCH256=0: the 128-pixel tile (A/B switch)
+  if (p256 < 0) { const char* e = getenv("NST_CONV2_PATCH256"); p256 = (e && e[0] == '0') ? 0 : 1; }
+  {
+    const int rows_out2 = (F2 - 1 + CQ_PX - 1) / F2 + 1;          // output rows a 256-pixel run can touch
+    const int npos_max2 = (2 * (rows_out2 - 1) + 3) * PW;
+    if (p256 && npos_max2 <= CQ_MAXPOS && M >= 4 * CQ_PX) {
+      a.ntiles = (int)((M + CQ_PX - 1) / CQ_PX);
+      conv_allow_big_lds(conv2_fwd_patch256_kernel, CP_LDS_BYTES);
+      conv2_fwd_patch256_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
+      return true;
+    }
+  }
   conv_allow_big_lds(conv2_fwd_patch_kernel, CP_LDS_BYTES);
   conv2_fwd_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
   return true;
