@@ -33,6 +33,35 @@ dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowM
   gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS, EF>(smem_dyn);
 }
 
+// eight-wave form of the stream kernel (two wave groups split every K step; nst_gemm_core.h: gemm_stream_v3_ks)
+template <typename OutT, int AMODE, int BMODE, bool CS, int EF>
+__global__ void __launch_bounds__(512, 2)
+dense_gemm_kernel_v3ks(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;
+  gemm_stream_v3_ks<OutT, AMODE, BMODE, IdentityRowMap, CS, EF>(smem_dyn);
+}
+
+// NST_GEMM_KS=1 (opt-in): the weight gradients of at most one workgroup per CU (units <= CUs, >= 4 K steps per unit) on the
+// eight-wave form.  Measured: ffn weight gradients 59.2 -> 55.5 us stand-alone, the step 14.90 -> 15.00 ms (worse): all eight
+// waves still issue their loads FIRST and multiply AFTER every barrier, so the two phases do not overlap any better than with
+// four waves (the decoder's 150-unit GEMMs and the logits' input gradient did not move at all when this form was tried on
+// them: 27.0 / 100.2 us either way) -- profiles/r03_history/r03_small_experiments.log.
+bool ks_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM_KS"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+
 // the weight-gradient form (reduction-major bf16 operands, f32 output): five half-step slots in the same 80 KB
 template <bool CS, int EF, int SLOTS = 5, int DBG = 0>
 __global__ void __launch_bounds__(THREADS, 2)
@@ -226,6 +255,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     // NST_GEMM_SPLIT_ISSUE=1: next step's DMA in two halves between the MFMA groups.  Measured WORSE here (two workgroups per
     // CU already cover each other's issue time): ffn2 forward 37.2 -> 40.3 us, step +0.15 ms (r03_ab_split_issue.log); off.
     { static int si = -1; if (si < 0) { const char* e = getenv("NST_GEMM_SPLIT_ISSUE"); si = (e && e[0] == '1') ? 1 : 0; } ga.split_issue = si; }
+    const bool use_ks = sizeof(T) == 2 && ks_enabled() && units <= device_cus() && kt_per_split >= 4;
 #define NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_)                                                                          \
   do {                                                                                                               \
     auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_, EF_>;                                                      \
@@ -284,6 +314,22 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
           }
         }
 #undef NST_GEMM_LAUNCH_RING
+#define NST_GEMM_LAUNCH_KS(AM, BMO, CS_, EF_)                                                                          \
+  do {                                                                                                               \
+    auto kfn8 = dense_gemm_kernel_v3ks<OutT, AM, BMO, CS_, EF_>;                                                       \
+    allow_big_lds(kfn8, V3_LDS_BYTES);                                                                                 \
+    kfn8<<<g3, 512, V3_LDS_BYTES, st>>>(ga);                                                                           \
+  } while (0)
+        if (amode == MODE_OC && bmode == MODE_OC && use_ks) {           // (opt-in) eight-wave form of the weight gradients
+          if (ep.colsum_dst) {
+            if (em == 0) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, true, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, true, EF_ACCUM); return 0; }
+          } else {
+            if (em == 0) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, false, 0); return 0; }
+            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, false, EF_ACCUM); return 0; }
+          }
+        }
+#undef NST_GEMM_LAUNCH_KS
         if (amode == MODE_OC && bmode == MODE_OC) {                     // weight gradients: x^T . dz, slabs or in place
           if (ep.colsum_dst) {
             if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, 0); return 0; }

@@ -287,14 +287,18 @@ def test_gemm_wgrad_fused_colsum(K, dtype, rows, Kin, N):
         close(tag + ".db_acc", db, 2 * ref_b, torch.float32)
 
 
-def test_gemm_wgrad_on_the_half_step_ring_kernel():
+@pytest.mark.parametrize("switch", ["NST_GEMM_RING=5", "NST_GEMM_KS=1"])
+def test_gemm_wgrad_on_the_opt_in_kernels(switch):
     """NST_GEMM_RING=5 routes the bf16 weight gradients (slabs, fused column sums, accumulate) to gemm_stream_v3_ring (five
-    half-step slots; opt-in, slower than the default: DESIGN.md 5d).  The switch is read once per process: the weight-gradient
-    cases above run again in a child interpreter, where a wrong half-step order or slot would show as a wrong dW."""
+    half-step slots), NST_GEMM_KS=1 to gemm_stream_v3_ks (eight waves, the two wave groups split every K step and exchange their
+    partial sums through LDS) -- both opt-in, neither faster in the step.  The switches are read once per
+    process: the weight-gradient cases above run again in a child interpreter, where a wrong slot order or a wrong exchange would
+    show as a wrong dW / db."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, NST_GEMM_RING="5")
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"), "-q", "-x", "-k",
                           "test_gemm_wgrad_fused_colsum or test_gemm_splitk_wgrad", "-p", "no:cacheprovider"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
