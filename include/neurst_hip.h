@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 6
+#define NST_ABI_VERSION 7
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -157,6 +157,11 @@ typedef struct NstSplitkJob {
 } NstSplitkJob;
 
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
+/* Edge of the output tile nst_gemm will cut desc's product into: 256 for the bf16 weight gradients (trans_a, f32 output, M and
+ * N >= 256, plain epilogue) that run on the phase-staggered 256 x 256 kernel, 128 otherwise.  Only M, N, the dtypes, the
+ * transposes and the epilogue fields are read.  The host sizes split_k with it (tiles * split_k workgroups; a multiple of 8
+ * keeps every K slice on one XCD).  ABI 7. */
+int nst_gemm_tile(const NstGemmDesc* desc);
 /* C (+)= sum of the slabs (and the column sums) of up to 8 deferred split-K products, one launch. */
 int nst_splitk_reduce_multi(const NstSplitkJob* jobs_host, int njobs, void* stream);
 

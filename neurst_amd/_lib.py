@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 6
+NST_ABI_VERSION = 7
 
 
 class NstGemmDesc(C.Structure):
@@ -102,6 +102,7 @@ SIGNATURES = {
     "nst_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_ln_finalize_multi": [_P, _I, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
+    "nst_gemm_tile": [C.POINTER(NstGemmDesc)],
     "nst_splitk_reduce_multi": [_P, _I, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],
     "nst_attention_dropout_mask_bytes": [C.POINTER(NstAttnDesc)],

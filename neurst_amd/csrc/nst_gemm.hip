@@ -1,5 +1,6 @@
 // Dense GEMM entry point (projections, FFN, front-end dense, tied logits and all their gradients).
 #include "nst_gemm_core.h"
+#include "nst_gemm256.h"
 
 #include <stdlib.h>
 
@@ -40,6 +41,30 @@ dense_gemm_kernel_v3ks(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, 
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   (void)args;
   gemm_stream_v3_ks<OutT, AMODE, BMODE, IdentityRowMap, CS, EF>(smem_dyn);
+}
+
+
+// 256 x 256 tile, eight waves in two phase-staggered groups (nst_gemm256.h)
+template <typename OutT, int AMODE, int BMODE, bool CS, int EF, int DBG = 0>
+__global__ void __launch_bounds__(G256_THREADS, 2)
+dense_gemm256_kernel(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;
+  gemm256_block<OutT, AMODE, BMODE, IdentityRowMap, CS, EF, DBG>(smem_dyn);
+}
+
+// NST_GEMM256: 1 (default) = weight gradients whose output holds at least one 256 x 256 tile run on the staggered kernel;
+// 0 = the 128 x 128 stream kernel everywhere (A/B switch of round 4); 11 / 12 / 14 = timing ablations (results wrong)
+int g256_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_GEMM256"); v = e ? atoi(e) : 1; }
+  return v;
+}
+// the shapes nst_gemm sends to the 256 x 256 kernel (operand alignment is checked again at launch)
+bool g256_shape(const NstGemmDesc* d) {
+  return g256_mode() != 0 && d->in_dtype == NST_BF16 && d->out_dtype == NST_F32 && d->trans_a && !d->trans_b && d->M >= 256 &&
+         d->N >= 256 && d->alpha == 1.0f && !d->bias && !d->relu && d->dropout_p == 0.f && !d->residual && !d->gate_src &&
+         !d->posenc && !d->rowdot_dst;
 }
 
 // NST_GEMM_KS=1 (opt-in): the weight gradients of at most one workgroup per CU (units <= CUs, >= 4 K steps per unit) on the
@@ -229,6 +254,12 @@ bool use_tr() {
   return v == 1;
 }
 
+// g256_shape + what the LDS-DMA loaders need of the operands (16-byte aligned rows, 8-element granular extents)
+bool g256_launchable(const NstGemmDesc* d, const void* A, const void* B) {
+  return g256_shape(d) && use_v2() && use_tr() && nst_aligned16(A) && nst_aligned16(B) && (d->lda * 2) % 16 == 0 &&
+         (d->ldb * 2) % 16 == 0 && d->M % 8 == 0 && d->N % 8 == 0;
+}
+
 template <typename T, typename OutT>
 int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Epilogue& ep, int split, hipStream_t st) {
   // Aop[i][r]: trans_a==0 -> A[i*lda + r] (RC);  trans_a==1 -> A[r*lda + i] (OC)
@@ -241,10 +272,41 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   const int kt_total = (d->K + Tile<T>::BK - 1) / Tile<T>::BK;
   if (split > kt_total) split = kt_total;
   if (split < 1) split = 1;
+  const bool tr = use_tr();
+  if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
+    // weight gradients (both operands reduction-major, f32 slabs or in place) on 256 x 256 tiles
+    const int em256 = epilogue_mask(ep);
+    if (g256_launchable(d, A, B) && (em256 == 0 || em256 == EF_ACCUM)) {
+      const int t_m = (d->M + 255) / 256, t_n = (d->N + 255) / 256, nt = t_m * t_n;
+      const int kt_per_split = (kt_total + split - 1) / split;   // (unused by the kernel: it cuts kt_total into `split` even slices)
+      GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
+      ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
+      ga.tiles_n = t_n; ga.ntiles = nt; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
+      ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0) ? 1 : 0;
+      ga.split_issue = 0;
+      dim3 g(nt * split, 1, 1);
+#define NST_G256(CS_, EF_, DBG_)                                                                                       \
+  do {                                                                                                               \
+    auto kfn = dense_gemm256_kernel<OutT, MODE_OC, MODE_OC, CS_, EF_, DBG_>;                                          \
+    allow_big_lds(kfn, G256_LDS_BYTES);                                                                              \
+    kfn<<<g, G256_THREADS, G256_LDS_BYTES, st>>>(ga);                                                                \
+  } while (0)
+      const int mode = g256_mode();
+      if (mode == 11 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 1); return 0; }
+      if (mode == 12 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 2); return 0; }
+      if (mode == 14 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 4); return 0; }
+      if (ep.colsum_dst) {
+        if (em256 == 0) NST_G256(true, 0, 0); else NST_G256(true, EF_ACCUM, 0);
+      } else {
+        if (em256 == 0) NST_G256(false, 0, 0); else NST_G256(false, EF_ACCUM, 0);
+      }
+#undef NST_G256
+      return 0;
+    }
+  }
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
-  const bool tr = use_tr();
   if (use_v2() && tr && la.vec && lb.vec) {  // LDS-DMA stream kernel: needs 16-byte aligned, 8-element granular operands
     const int units = ntiles * split;
     dim3 g3(v3_grid(units), 1, 1);
@@ -383,6 +445,10 @@ extern "C" int nst_splitk_reduce_multi(const NstSplitkJob* jobs, int njobs, void
   return NST_OK;
 }
 
+extern "C" int nst_gemm_tile(const NstGemmDesc* d) {
+  return (d && g256_shape(d) && use_v2() && use_tr()) ? G256_TILE : BM;
+}
+
 extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void* C, void* stream) {
   NST_CHECK_ARG(d && A && B && C, "gemm: null pointer");
   NST_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "gemm: negative dims");
@@ -465,8 +531,10 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
                   "gemm: split_k supports only the plain alpha*A*B (+accumulate) epilogue");
     const int kt_total = (d->K + (d->in_dtype == NST_BF16 ? 64 : 32) - 1) / (d->in_dtype == NST_BF16 ? 64 : 32);
     if (split > kt_total) split = kt_total;
-    const int kps = (kt_total + split - 1) / split;
-    split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
+    if (!g256_launchable(d, A, B)) {   // (the 256 x 256 kernel cuts the K steps into exactly `split` even slices)
+      const int kps = (kt_total + split - 1) / split;
+      split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
+    }
     const int64_t need = (int64_t)split * d->M * d->N * 4 + (cs_fused ? (int64_t)split * d->N * 4 : 0);
     const bool slab = split > 1 && d->workspace && d->workspace_bytes >= need && nst_aligned16(d->workspace) &&
                       (d->N % 4 == 0) && ((d->ldc * 4) % 16 == 0) && nst_aligned16(C);

@@ -228,6 +228,18 @@ class SplitkBatch(object):
         self.ln_n = 0
 
 
+def wgrad_tile(k_in, n_out, dtype):
+    """Edge of the output tile nst_gemm cuts the weight gradient dW[k_in, n_out] = X^T dY into (nst_gemm_tile): 256 on the
+    phase-staggered bf16 kernel, 128 otherwise.  A host-side query (no device work)."""
+    d = NstGemmDesc()
+    d.M, d.N, d.K = k_in, n_out, 64
+    d.trans_a, d.trans_b = 1, 0
+    d.in_dtype = NST_BF16 if dtype == torch.bfloat16 else NST_F32
+    d.out_dtype = NST_F32
+    d.alpha = 1.0
+    return int(lib.nst_gemm_tile(C.byref(d)))
+
+
 def splitk_reduce_multi(jobs, n):
     check(lib.nst_splitk_reduce_multi(C.addressof(jobs), n, _stream()), "splitk_reduce_multi")
 

@@ -268,10 +268,15 @@ def test_gemm_splitk_wgrad(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,Kin,N", [(3000, 136, 264), (28800 // 8, 256, 768), (517, 2048, 256), (300, 130, 132)])
+@pytest.mark.parametrize("rows,Kin,N", [(3000, 136, 264), (28800 // 8, 256, 768), (517, 2048, 256), (300, 130, 132),
+                                        (1000, 520, 264), (2500, 1000, 520), (130, 256, 256), (64, 512, 256)])
 def test_gemm_wgrad_fused_colsum(K, dtype, rows, Kin, N):
     """dW = X^T.dZ with db = colsum(dZ) produced by the same kernel (MFMA ones-row), all split factors, accumulate;
-    the last shape is not 8-element granular and takes the separate column-sum pass behind the same interface."""
+    the fourth shape is not 8-element granular and takes the separate column-sum pass behind the same interface.  bf16 outputs
+    of at least 256 x 256 run on the phase-staggered 256 x 256 kernel (nst_gemm256.h): the shapes from (28800 // 8, 256, 768)
+    on cover whole tiles, ragged edge tiles in both output dimensions (520 = 2 tiles + 8, 264 = 1 tile + 8), reduction
+    lengths that are not a multiple of the K step (517, 1000, 130) and a single K step (64); split 5 / 32 exercise its even
+    K slicing (32 slices of 2500 rows: one or two K steps each)."""
     X, dZ = rnd(rows, Kin, dtype=dtype, seed=1), rnd(rows, N, dtype=dtype, seed=2)
     ref_w, ref_b = X.double().t() @ dZ.double(), dZ.double().sum(0)
     for split in (1, 5, 32):
