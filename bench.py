@@ -28,10 +28,12 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROBED = ("gemm", "ffn_fwd", "ffn_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "attention_fwd", "attention_bwd")
+PROBED = ("gemm", "gemm_wgrad_group", "ffn_fwd", "ffn_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "attention_fwd", "attention_bwd")
 FAMILY_KERNELS = {
     "gemm": "dense_gemm_kernel_v3 family (every nst_gemm launch of a step: projections, logits, front dense, their input "
             "and weight gradients incl. split-K reduce; work = sum 2MNK)",
+    "gemm_wgrad_group": "gemm256_group_kernel (nst_gemm_wgrad_group: the weight gradients of a layer stack as ONE launch of "
+                        "256 x 256 phase-staggered tiles, no split-K; work = sum 2MNK)",
     "ffn_fwd": "ffn_fwd_fused_kernel (dense1 + ReLU + dropout + dense2 in one launch; work = 4*M*d*ffn)",
     "ffn_bwd": "ffn_bwd_fused_kernel (d hidden + gate + d input in one launch; work = 4*M*d*ffn)",
     "conv2_fwd": "conv2_fwd_patch_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C; LDS-resident input patch)",

@@ -162,6 +162,17 @@ int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, voi
  * transposes and the epilogue fields are read.  The host sizes split_k with it (tiles * split_k workgroups; a multiple of 8
  * keeps every K slice on one XCD).  ABI 7. */
 int nst_gemm_tile(const NstGemmDesc* desc);
+/* n weight gradients dW_i[M_i, N_i] (+)= X_i^T . dZ_i in ONE launch (ABI 7): descs[i] describes product i exactly as for
+ * nst_gemm (trans_a = 1, trans_b = 0, bf16 in, f32 out, plain epilogue; accumulate, colsum / colsum_accumulate honoured;
+ * split_k must be <= 1), A[i] / B[i] / C[i] are its operands.  Every 256 x 256 output tile of every product is one workgroup of
+ * the same grid, so a whole layer stack's gradients fill the chip without split-K slabs (the reference leaves these products
+ * to TF's gradient tape: tf.GradientTape.gradient in neurst/training/gradaccum_keras_model.py:162-197).  Operands must be
+ * 16-byte aligned with 8-element granular extents; returns NST_ERR_UNSUPPORTED (nothing launched) when a product does not
+ * qualify -- the caller then issues nst_gemm per product.  Up to 56 products travel in the kernel arguments; more (n <= 1024)
+ * need `workspace` (device memory, 16-byte aligned, >= 72 * n bytes, untouched until the launch has run): the product table is
+ * written there by tiny kernels on the same stream, so the call stays capturable into a HIP graph. */
+int nst_gemm_wgrad_group(const NstGemmDesc* descs, const void* const* A, const void* const* B, void* const* C, int n,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 /* C (+)= sum of the slabs (and the column sums) of up to 8 deferred split-K products, one launch. */
 int nst_splitk_reduce_multi(const NstSplitkJob* jobs_host, int njobs, void* stream);
 

@@ -53,11 +53,28 @@ dense_gemm256_kernel(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, Id
   gemm256_block<OutT, AMODE, BMODE, IdentityRowMap, CS, EF, DBG>(smem_dyn);
 }
 
-// NST_GEMM256: 1 (default) = weight gradients whose output holds at least one 256 x 256 tile run on the staggered kernel;
-// 0 = the 128 x 128 stream kernel everywhere (A/B switch of round 4); 11 / 12 / 14 = timing ablations (results wrong)
+template <int DBG>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_group_kernel(G256GroupArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  (void)args;
+  gemm256_group_block<DBG>(smem_dyn);
+}
+
+// copies a by-value chunk of the product table into device memory (tables of more than G256_MAX_PROBLEMS products)
+__global__ void __launch_bounds__(256) g256_table_write_kernel(G256GroupArgs chunk, G256Problem* dst) {
+  const int nw = chunk.nprob * (int)(sizeof(G256Problem) / 4);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&chunk.p[0]);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) d[i] = src[i];
+}
+
+// NST_GEMM256: 0 (default) = a single nst_gemm weight gradient stays on the 128 x 128 stream kernel -- stand-alone it needs
+// 32 K slices to fill the chip with 256 x 256 tiles and the slabs cost more than the tile saves (profiles/r04_g256_*.json);
+// the 256 x 256 kernel is reached through nst_gemm_wgrad_group (many products, no split).  1 = also single weight gradients of
+// at least 256 x 256 outputs (the measurement above); 11 / 12 / 14 = timing ablations of the kernel (results wrong)
 int g256_mode() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM256"); v = e ? atoi(e) : 1; }
+  if (v < 0) { const char* e = getenv("NST_GEMM256"); v = e ? atoi(e) : 0; }
   return v;
 }
 // the shapes nst_gemm sends to the 256 x 256 kernel (operand alignment is checked again at launch)
@@ -442,6 +459,80 @@ extern "C" int nst_splitk_reduce_multi(const NstSplitkJob* jobs, int njobs, void
   int blocks = (int)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
   splitk_reduce_multi_kernel<<<dim3(blocks, njobs), 256, 0, (hipStream_t)stream>>>(packed);
   NST_CHECK_LAUNCH("splitk_reduce_multi");
+  return NST_OK;
+}
+
+extern "C" int nst_gemm_wgrad_group(const NstGemmDesc* descs, const void* const* A, const void* const* B, void* const* C, int n,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  constexpr int MAXN = 1024;
+  NST_CHECK_ARG(n >= 0 && n <= MAXN && (n == 0 || (descs && A && B && C)), "gemm_wgrad_group: 0..%d products", MAXN);
+  if (n == 0) return NST_OK;
+  for (int i = 0; i < n; ++i) {
+    const NstGemmDesc* d = &descs[i];
+    NST_CHECK_ARG(A[i] && B[i] && C[i] && d->M > 0 && d->N > 0 && d->K > 0, "gemm_wgrad_group: bad product %d", i);
+    const bool ok = d->in_dtype == NST_BF16 && d->out_dtype == NST_F32 && d->trans_a && !d->trans_b && d->alpha == 1.0f &&
+                    !d->bias && !d->relu && d->dropout_p == 0.f && !d->residual && !d->gate_src && !d->posenc &&
+                    !d->rowdot_dst && d->split_k <= 1 && nst_aligned16(A[i]) && nst_aligned16(B[i]) && nst_aligned16(C[i]) &&
+                    (d->lda * 2) % 16 == 0 && (d->ldb * 2) % 16 == 0 && (d->ldc * 4) % 16 == 0 && d->M % 8 == 0 &&
+                    d->N % 8 == 0 && d->lda >= d->M && d->ldb >= d->N && d->ldc >= d->N && d->lda < (1ll << 31) &&
+                    d->ldb < (1ll << 31) && d->ldc < (1ll << 31) && (!d->colsum || ((uintptr_t)d->colsum & 3) == 0);
+    if (!ok) {
+      nst_set_error("gemm_wgrad_group: product %d is not a plain aligned bf16 weight gradient (trans_a, f32 output)", i);
+      return NST_ERR_UNSUPPORTED;
+    }
+  }
+  const bool ext = n > G256_MAX_PROBLEMS;
+  NST_CHECK_ARG(!ext || (workspace && nst_aligned16(workspace) && workspace_bytes >= (int64_t)n * (int64_t)sizeof(G256Problem)),
+                "gemm_wgrad_group: %d products need a table workspace of %lld bytes", n, (long long)n * (long long)sizeof(G256Problem));
+  // longest reductions first (the hardware hands out workgroups in index order), then the products with most tiles
+  static thread_local int order[MAXN];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  auto tiles_of = [&](int i) { return ((descs[i].M + 255) / 256) * ((descs[i].N + 255) / 256); };
+  for (int i = 1; i < n; ++i) {   // insertion sort (stable; the host usually hands the products over nearly sorted)
+    const int v = order[i];
+    int j = i - 1;
+    while (j >= 0 && (descs[order[j]].K < descs[v].K || (descs[order[j]].K == descs[v].K && tiles_of(order[j]) < tiles_of(v)))) {
+      order[j + 1] = order[j];
+      --j;
+    }
+    order[j + 1] = v;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  G256GroupArgs ga;
+  int units = 0;
+  for (int base = 0; base < n; base += G256_MAX_PROBLEMS) {
+    const int m = n - base < G256_MAX_PROBLEMS ? n - base : G256_MAX_PROBLEMS;
+    for (int i = 0; i < m; ++i) {
+      const int q = order[base + i];
+      const NstGemmDesc* d = &descs[q];
+      G256Problem& p = ga.p[i];
+      p.A = (const bf16_t*)A[q]; p.B = (const bf16_t*)B[q]; p.C = (float*)C[q]; p.colsum = d->colsum;
+      p.lda = (int)d->lda; p.ldb = (int)d->ldb; p.ldc = (int)d->ldc;
+      p.M = d->M; p.N = d->N; p.K = d->K;
+      p.tiles_n = (d->N + 255) / 256;
+      units += tiles_of(q);
+      p.unit_end = units;
+      p.flags = (d->accumulate ? 1 : 0) | (d->colsum_accumulate ? 2 : 0);
+      p.reserved = 0;
+    }
+    if (ext) {
+      ga.nprob = m; ga.nunits = 0; ga.ext = nullptr;
+      g256_table_write_kernel<<<1, 256, 0, st>>>(ga, (G256Problem*)workspace + base);
+      NST_CHECK_LAUNCH("gemm_wgrad_group(table)");
+    }
+  }
+  ga.nprob = n;
+  ga.nunits = units;
+  ga.ext = ext ? (const G256Problem*)workspace : nullptr;
+  const int grid = (units + 63) / 64 * 64;
+  const int mode = g256_mode();
+#define NST_G256G(DBG_) do { auto kfn = gemm256_group_kernel<DBG_>; allow_big_lds(kfn, G256_LDS_BYTES); kfn<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(ga); } while (0)
+  if (mode == 11) NST_G256G(1);
+  else if (mode == 12) NST_G256G(2);
+  else if (mode == 14) NST_G256G(4);
+  else NST_G256G(0);
+#undef NST_G256G
+  NST_CHECK_LAUNCH("gemm_wgrad_group");
   return NST_OK;
 }
 

@@ -148,43 +148,26 @@ struct Frag256<MODE_OC> {   // [64 k][128 cols] image, 32-byte pair ^= (r & 3) |
 
 __device__ __forceinline__ void g256_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
 
+// Main loop of one unit: acc (+)= A[m0.., k-range] . B[n0.., k-range]; cs = column sums of the B operand (do_cs, wave-uniform).
 // DBG (timing ablations, results wrong): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads
-template <typename OutT, int AMODE, int BMODE, typename RowMap, bool CS, int EF, int DBG = 0>
-__device__ __forceinline__ void gemm256_block(char* smem) {
+template <int AMODE, int BMODE, bool CS, int DBG = 0>
+__device__ __forceinline__ void gemm256_mainloop(char* smem, const DenseLoader<bf16_t>& la, const DenseLoader<bf16_t>& lb, int m0, int n0,
+                                                 int kt_first, int nk, bool do_cs, floatx4_t (&acc)[2][4][4], floatx4_t (&cs)[4]) {
   typedef bf16_t T;
-  typedef DenseLoader<T> Loader;
-  typedef GemmArgs<OutT, Loader, Loader, RowMap> Args;
-  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
 
-  // ---- unit -> tile origin and K range
-  int z, tile;
-  splitk_unit(blockIdx.x, ka->ntiles, ka->z_per_xcd, z, tile);
-  const int tiles_n = ka->tiles_n;
-  const int tm = tile / tiles_n;
-  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
-  // K slice z of `split`: steps [kt_total * z / split, kt_total * (z + 1) / split) -- every slice holds floor or ceil of the
-  // mean, so ANY split <= kt_total yields exactly `split` non-empty slices (the 128 x 128 kernels round the count instead)
-  const int kt_total = (ka->K + 63) >> 6, split = ka->split;
-  const int kt_first = (int)(((int64_t)kt_total * z) / split);
-  const int nk = (int)(((int64_t)kt_total * (z + 1)) / split) - kt_first;
-
   Dma256<AMODE> da;
   Dma256<BMODE> db;
-  {
-    const Loader la = kload(&ka->la), lb = kload(&ka->lb);
-    da.init(la, m0, kt_first * 64, wave, lane);
-    db.init(lb, n0, kt_first * 64, wave, lane);
-  }
+  da.init(la, m0, kt_first * 64, wave, lane);
+  db.init(lb, n0, kt_first * 64, wave, lane);
   Frag256<AMODE> fa;
   Frag256<BMODE> fb;
   fa.init(lane);
   fb.init(lane);
 
-  floatx4_t acc[2][4][4], cs[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -193,7 +176,6 @@ __device__ __forceinline__ void gemm256_block(char* smem) {
       for (int j = 0; j < 4; ++j) acc[h][i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = CS && ka->ep.colsum_dst != nullptr && m0 == 0 && wr == 0;   // wave-uniform
   const bf16x8_t ones = ones_frag<T>();
 
   // ---- prologue: K step 0 entirely, B of K step 1
@@ -364,6 +346,34 @@ __device__ __forceinline__ void gemm256_block(char* smem) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last barrier: nobody reads the stage buffers any more
   asm volatile("" ::: "memory");
 
+}
+
+// One product per launch (nst_gemm): unit = (K slice z, tile) of GemmArgs.
+template <typename OutT, int AMODE, int BMODE, typename RowMap, bool CS, int EF, int DBG = 0>
+__device__ __forceinline__ void gemm256_block(char* smem) {
+  typedef bf16_t T;
+  typedef DenseLoader<T> Loader;
+  typedef GemmArgs<OutT, Loader, Loader, RowMap> Args;
+  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int z, tile;
+  splitk_unit(blockIdx.x, ka->ntiles, ka->z_per_xcd, z, tile);
+  const int tiles_n = ka->tiles_n;
+  const int tm = tile / tiles_n;
+  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
+  // K slice z of `split`: steps [kt_total * z / split, kt_total * (z + 1) / split) -- every slice holds floor or ceil of the
+  // mean, so ANY split <= kt_total yields exactly `split` non-empty slices (the 128 x 128 kernels round the count instead)
+  const int kt_total = (ka->K + 63) >> 6, split = ka->split;
+  const int kt_first = (int)(((int64_t)kt_total * z) / split);
+  const int nk = (int)(((int64_t)kt_total * (z + 1)) / split) - kt_first;
+  const bool do_cs = CS && ka->ep.colsum_dst != nullptr && m0 == 0 && wr == 0;   // wave-uniform
+  floatx4_t acc[2][4][4], cs[4];
+  {
+    const Loader la = kload(&ka->la), lb = kload(&ka->lb);
+    gemm256_mainloop<AMODE, BMODE, CS, DBG>(smem, la, lb, m0, n0, kt_first, nk, do_cs, acc, cs);
+  }
+
   // ---- epilogue: each 64 x 64 quarter through the v3 epilogue (4 KB wave-private staging in the dead stage buffers)
   const NST_AS4 Args* k2 = launder(ka);
   Epilogue ep = kload(&k2->ep);
@@ -384,6 +394,99 @@ __device__ __forceinline__ void gemm256_block(char* smem) {
   OutT* Cz = k2->C + (int64_t)z * ep.slab_stride;
   epilogue_v3<OutT, RowMap, EF>(acc[0], epi, Cz, k2->ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
   epilogue_v3<OutT, RowMap, EF>(acc[1], epi, Cz, k2->ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
+}
+
+// -----------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: MANY products dW_p[M_p, N_p] (+)= X_p^T . dZ_p (both operands reduction-major bf16, f32 output)
+// in ONE launch.  The weight gradients of a layer stack do not feed the backward chain, so they can all wait until the stack
+// is done; with every 256 x 256 output tile of every product as a unit of the same grid the chip fills WITHOUT split-K: no
+// partial-sum slabs, no second stage, and a unit runs the whole reduction (hundreds of K steps) behind one prologue.
+// (Stand-alone, one 256 x 2048 gradient over 28 800 rows needs 32 K slices to fill 256 CUs: 67 MB of slabs written and read
+// next to 133 MB of operands, which is why the 256 x 256 kernel LOSES to the 128 x 128 one there -- profiles/r04.)
+//
+// Unit order: the host sorts the products by reduction length (longest first) and the kernel deals "bundles" of 8 consecutive
+// logical units round-robin to the 8 XCDs (workgroup b runs on XCD b % 8): the column tiles of one product share its X rows,
+// sit in one bundle, start together on one XCD and hit its L2; every XCD gets the same mix of long and short units.
+// -----------------------------------------------------------------------------------------------------------------------
+constexpr int G256_MAX_PROBLEMS = 56;
+struct G256Problem {       // 72 bytes
+  const bf16_t* A;         // X  [K rows][lda], output rows M = its columns
+  const bf16_t* B;         // dZ [K rows][ldb], output columns N = its columns
+  float* C;                // dW [M][ldc]
+  float* colsum;           // db [N] or NULL
+  int lda, ldb, ldc;
+  int M, N, K;
+  int tiles_n;
+  int unit_end;            // logical units [unit_end of the previous problem, unit_end) belong to this one
+  int flags;               // 1: C += , 2: colsum +=
+  int reserved;
+};
+struct G256GroupArgs {
+  int nprob, nunits;
+  const G256Problem* ext;   // != NULL: the table lives in device memory (more than G256_MAX_PROBLEMS products), p[] is unused
+  G256Problem p[G256_MAX_PROBLEMS];
+};
+
+template <int DBG = 0>
+__device__ __forceinline__ void gemm256_group_block(char* smem) {
+  typedef bf16_t T;
+  typedef DenseLoader<T> Loader;
+  const NST_AS4 G256GroupArgs* ka = (const NST_AS4 G256GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // workgroup -> logical unit: bundle ((k / 8) * 8 + xcd), member k % 8, with xcd = b % 8 and k = b / 8
+  const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+  const int unit = (((k >> 3) << 3) + xcd) * 8 + (k & 7);
+  if (unit >= ka->nunits) return;   // (the grid is padded to whole rounds of 8 bundles; uniform for the workgroup)
+  // the table is read with scalar loads either way (it does not change while the kernel runs)
+  const NST_AS4 G256Problem* tab = ka->ext ? (const NST_AS4 G256Problem*)(uintptr_t)ka->ext : &ka->p[0];
+  int pi = 0, ubase = 0;
+  {
+    const int np = ka->nprob;
+#pragma unroll 1
+    for (; pi < np - 1; ++pi) {
+      const int ue = tab[pi].unit_end;
+      if (unit < ue) break;
+      ubase = ue;
+    }
+  }
+  const NST_AS4 G256Problem* pp = &tab[pi];
+  const int tile = unit - ubase, tiles_n = pp->tiles_n;
+  const int tm = tile / tiles_n;
+  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
+  const int M = pp->M, N = pp->N, Kd = pp->K;
+  const bool do_cs = pp->colsum != nullptr && m0 == 0 && wr == 0;   // wave-uniform
+  floatx4_t acc[2][4][4], cs[4];
+  {
+    Loader la, lb;   // reduction-major operands: element (r, i) at base[r * ld + i]
+    la.base = pp->A; la.ld = pp->lda; la.outer_limit = Kd; la.contig_limit = M; la.vec = 1;
+    lb.base = pp->B; lb.ld = pp->ldb; lb.outer_limit = Kd; lb.contig_limit = N; lb.vec = 1;
+    gemm256_mainloop<MODE_OC, MODE_OC, true, DBG>(smem, la, lb, m0, n0, 0, (Kd + 63) >> 6, do_cs, acc, cs);
+  }
+  asm volatile("" ::: "memory");
+  const NST_AS4 G256Problem* p2 = launder(pp);
+  const int flags = p2->flags;
+  if (do_cs && lane < 16) {
+    float* csd = p2->colsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + lane;
+      if (col < N) csd[col] = (flags & 2) ? csd[col] + cs[j][0] : cs[j][0];
+    }
+  }
+  Epilogue ep{};   // only .vec is read by the compile-time epilogues used here
+  ep.vec = 1;
+  float* epi = reinterpret_cast<float*>(smem + wave * V3_EPI_BYTES_PER_WAVE);
+  float* C = p2->C;
+  const int64_t ldc = p2->ldc;
+  const IdentityRowMap rowmap;
+  if (flags & 1) {
+    epilogue_v3<float, IdentityRowMap, EF_ACCUM>(acc[0], epi, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
+    epilogue_v3<float, IdentityRowMap, EF_ACCUM>(acc[1], epi, C, ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
+  } else {
+    epilogue_v3<float, IdentityRowMap, 0>(acc[0], epi, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
+    epilogue_v3<float, IdentityRowMap, 0>(acc[1], epi, C, ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
+  }
 }
 
 }  // namespace nstgemm

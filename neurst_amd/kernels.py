@@ -240,6 +240,70 @@ def wgrad_tile(k_in, n_out, dtype):
     return int(lib.nst_gemm_tile(C.byref(d)))
 
 
+class WgradGroup(object):
+    """Weight-gradient products dW (+)= X^T dZ waiting for ONE nst_gemm_wgrad_group launch: every 256 x 256 output tile of every
+    product becomes a workgroup of the same grid, so the gradients of a whole layer stack fill the chip without split-K slabs.
+    The group keeps its operands alive until launch()."""
+
+    MIN_OUTPUTS = 128 * 128    # smaller gradients waste most of a 256 x 256 tile: they keep the per-product path
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []
+        self.table = None       # device copy of the product table for launches of more than 56 products
+
+    @staticmethod
+    def _al(t, esz):
+        return t.data_ptr() % 16 == 0 and (t.stride(0) * esz) % 16 == 0 and t.stride(1) == 1
+
+    def accepts(self, x, dz, out, colsum_out=None):
+        """x [rows, M], dz [rows, N] bf16 views, out [M, N] f32 view: what the grouped kernel can take."""
+        M, N = x.shape[1], dz.shape[1]
+        return (x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and out.dtype == torch.float32
+                and x.device.type == torch.device(self.device).type and M % 8 == 0 and N % 8 == 0 and M * N >= self.MIN_OUTPUTS and x.shape[0] == dz.shape[0] and x.shape[0] > 0
+                and self._al(x, 2) and self._al(dz, 2) and self._al(out, 4)
+                and (colsum_out is None or (colsum_out.dtype == torch.float32 and colsum_out.is_contiguous())))
+
+    def add(self, x, dz, out, accumulate=False, colsum_out=None, colsum_accumulate=False):
+        self.items.append((x, dz, out, bool(accumulate), colsum_out, bool(colsum_accumulate)))
+
+    def __len__(self):
+        return len(self.items)
+
+    def launch(self):
+        items, self.items = self.items, []
+        if items:
+            if len(items) > 56 and self.table is None:
+                self.table = torch.empty(1024 * 72, dtype=torch.uint8, device=self.device)
+            gemm_wgrad_group(items, self.table)
+
+
+def gemm_wgrad_group(items, table=None):
+    """items: [(x [rows, M], dz [rows, N], out [M, N] f32, accumulate, colsum_out [N] | None, colsum_accumulate)] -> one launch."""
+    n = len(items)
+    descs = (NstGemmDesc * n)()
+    Ap, Bp, Cp = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    flops = 0.0
+    for i, (x, dz, out, acc, cs, cs_acc) in enumerate(items):
+        d = descs[i]
+        d.M, d.N, d.K = x.shape[1], dz.shape[1], x.shape[0]
+        d.trans_a, d.trans_b = 1, 0
+        d.lda, d.ldb, d.ldc = x.stride(0), dz.stride(0), out.stride(0)
+        d.in_dtype, d.out_dtype = NST_BF16, NST_F32
+        d.alpha = 1.0
+        d.accumulate = int(acc)
+        d.split_k = 1
+        if cs is not None:
+            d.colsum, d.colsum_accumulate = cs.data_ptr(), int(cs_acc)
+        Ap[i], Bp[i], Cp[i] = x.data_ptr(), dz.data_ptr(), out.data_ptr()
+        flops += 2.0 * d.M * d.N * d.K
+    ev = PROBE.begin("gemm_wgrad_group")
+    check(lib.nst_gemm_wgrad_group(descs, Ap, Bp, Cp, n, _p(table), table.numel() if table is not None else 0, _stream()),
+          "gemm_wgrad_group")
+    if ev is not None:
+        PROBE.end(ev, flops, sum(x.numel() * 2 + dz.numel() * 2 + 2 * out.numel() * 4 for x, dz, out, *_ in items))
+
+
 def splitk_reduce_multi(jobs, n):
     check(lib.nst_splitk_reduce_multi(C.addressof(jobs), n, _stream()), "splitk_reduce_multi")
 

@@ -160,6 +160,12 @@ class Dense(Layer):
         if _SKIP_WGRAD:      # timing experiment only (NST_SKIP_WGRAD=1): the dgrad chain without the weight-gradient stream
             return
         acc_k = st.acc_flag(self.kernel)
+        grp = self.rt.wgrad_group()
+        if grp is not None and grp.accepts(x, dz, self.kernel.grad, None if self.bias is None else self.bias.grad):
+            # waits for the stack's grouped launch (Runtime.launch_wgrad_group): no split-K, no slabs
+            grp.add(x, dz, self.kernel.grad, acc_k, None if self.bias is None else self.bias.grad,
+                    False if self.bias is None else st.acc_flag(self.bias))
+            return
         bias_kw = {}
         if self.bias is not None:  # dbias rides on the same pass over dz (ones^T.dz inside the MFMA loop)
             bias_kw = dict(colsum_out=self.bias.grad, colsum_accumulate=st.acc_flag(self.bias))

@@ -1,5 +1,7 @@
 """EncoderDecoderModel (neurst/models/encoder_decoder_model.py:27-279): modalities -> encoder -> decoder ->
 tied logits, training path, with an explicit backward pass."""
+import os
+
 import torch
 
 from neurst_amd.layers.common_layers import Dense, PositionEmbeddingWrapper
@@ -64,6 +66,11 @@ class _DecodeSession(object):
         graph.replay()
         self._set_len(time + 1)
         return static_logits
+
+
+# where the grouped weight-gradient launches go: "end" = one launch behind the whole backward, "stack" = one behind each
+# layer stack, "decoder" = the decoder's behind the decoder, everything else at the end
+_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "end")
 
 
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
@@ -225,8 +232,10 @@ class EncoderDecoderModel(BaseModel):
             user_hook = self.grad_ready_hook or (lambda prefixes: None)
 
             def hook(prefixes):   # a report promises that everything writing these gradients is QUEUED: incl. deferred reduces
-                self.rt.wgrad_boundary()
-                user_hook(prefixes)
+                def report():
+                    self.rt.wgrad_boundary()
+                    user_hook(prefixes)
+                self.rt.report_or_defer(report)   # (weight gradients waiting in the group: the report follows their launch)
             # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
             # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
             # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
@@ -239,10 +248,15 @@ class EncoderDecoderModel(BaseModel):
             self._trg_modality.backward(ddec_in, mode="embedding")
             if not shared:
                 hook([self._modality_scope(self._trg_modality) + "/"])
+            if _WGRAD_GROUP_AT in ("stack", "decoder"):
+                self.rt.launch_wgrad_group()   # the decoder's weight gradients: one launch
             denc_in = self._encoder.backward(dmemory, layer_done=hook)
             hook([self._encoder.name + "/"])
+            if _WGRAD_GROUP_AT == "stack":
+                self.rt.launch_wgrad_group()   # the encoder's
             self._src_modality.backward(denc_in, mode="embedding")
             hook([self._modality_scope(self._src_modality) + "/"])
+            self.rt.launch_wgrad_group()       # whatever is still waiting (with "end": everything, in one launch)
             self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here

@@ -318,6 +318,39 @@ class Runtime(object):
             self._wgrad_batch = kernels.SplitkBatch(self.device)
         return self._wgrad_batch
 
+    def wgrad_group(self):
+        """The pending weight-gradient group (kernels.WgradGroup) or None: NST_WGRAD_GROUP=0, or a runtime without a device."""
+        if self.device.type != "cuda" and not getattr(self, "_wgrad_group_on_cpu", False):
+            return None
+        if os.environ.get("NST_WGRAD_GROUP", "1") == "0":
+            return None
+        if getattr(self, "_wgrad_group", None) is None:
+            from neurst_amd import kernels
+            self._wgrad_group = kernels.WgradGroup(self.device)
+            self._deferred_reports = []
+        return self._wgrad_group
+
+    def report_or_defer(self, report):
+        """`report()` tells the data-parallel reducer that everything writing some gradients has been queued.  While weight
+        gradients wait in the group that is not true yet: the report then runs right behind the group's launch."""
+        g = getattr(self, "_wgrad_group", None)
+        if g is not None and len(g):
+            self._deferred_reports.append(report)
+        else:
+            report()
+
+    def launch_wgrad_group(self):
+        """One launch for every weight gradient queued since the last call (on the current stream), then the reports that
+        waited for it."""
+        g = getattr(self, "_wgrad_group", None)
+        if g is None:
+            return
+        if len(g):
+            g.launch()
+        reports, self._deferred_reports = self._deferred_reports, []
+        for r in reports:
+            r()
+
     def flush_wgrads(self):
         """Launches the pending (deferred) second stages of the weight gradients queued so far, on their stream."""
         b = getattr(self, "_wgrad_batch", None)
@@ -342,6 +375,7 @@ class Runtime(object):
 
     def join_wgrad_stream(self):
         """The current stream waits for every weight gradient queued so far."""
+        self.launch_wgrad_group()
         self.flush_wgrads()
         b = getattr(self, "_wgrad_batch", None)
         if b is not None:

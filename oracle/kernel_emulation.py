@@ -497,7 +497,20 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
-          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi"]
+          "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi",
+          "gemm_wgrad_group", "wgrad_tile"]
+
+
+def wgrad_tile(k_in, n_out, dtype):
+    """nst_gemm_tile: the emulated gemm has no tiles; 128 keeps the host on the split rules of the 128 x 128 kernel."""
+    return 128
+
+
+def gemm_wgrad_group(items, table=None):
+    """nst_gemm_wgrad_group: every product exactly as the plain weight-gradient gemm (no split)."""
+    for x, dz, out, acc, cs, cs_acc in items:
+        gemm(x, dz, x.shape[1], dz.shape[1], x.shape[0], trans_a=True, out=out, accumulate=acc, colsum_out=cs,
+             colsum_accumulate=cs_acc)
 
 
 def install(monkeypatch):

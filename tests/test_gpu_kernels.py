@@ -292,6 +292,45 @@ def test_gemm_wgrad_fused_colsum(K, dtype, rows, Kin, N):
         close(tag + ".db_acc", db, 2 * ref_b, torch.float32)
 
 
+@pytest.mark.parametrize("nprob", [1, 7, 60])
+def test_gemm_wgrad_group(K, nprob):
+    """nst_gemm_wgrad_group: n weight gradients dW_i (+)= X_i^T dZ_i with db_i (+)= colsum(dZ_i) from ONE launch of the
+    phase-staggered 256 x 256 kernel, every output tile of every product a workgroup (no split-K).  Products of different
+    shapes and reduction lengths (one K step ... dozens, lengths that are not a multiple of 64), ragged edge tiles, column-block
+    views of wider buffers (the packed q|k|v / k|v gradients), with and without the column sums, overwrite and accumulate;
+    60 products take the device-side product table (more than the 56 that travel as kernel arguments).  Against fp64 on the
+    same bf16 inputs: the kernel accumulates in fp32 over the whole reduction."""
+    shapes = [(1800, 256, 2048), (1800, 2048, 256), (900, 256, 768), (1000, 520, 264), (130, 256, 256), (64, 512, 256),
+              (2500, 1000, 520), (300, 128, 128), (77 * 8, 136, 264), (4096, 256, 512)]
+    items, refs = [], []
+    for i in range(nprob):
+        rows, kin, n = shapes[i % len(shapes)]
+        wide_x = rnd(rows, kin + 16, dtype=torch.bfloat16, seed=100 + i).to(DEV)
+        wide_z = rnd(rows, n + 24, dtype=torch.bfloat16, seed=200 + i).to(DEV)
+        x, dz = wide_x[:, 8:8 + kin], wide_z[:, 16:16 + n]           # strided views, 16-byte aligned starts
+        acc = bool(i % 2)
+        dw = torch.full((kin, n + 8), 3.0, device=DEV)[:, :n]        # ldc > N
+        has_b = i % 3 != 2
+        db = torch.full((n,), 5.0, device=DEV) if has_b else None
+        items.append((x, dz, dw, acc, db, acc))
+        ref_w = x.cpu().double().t() @ dz.cpu().double() + (3.0 if acc else 0.0)
+        ref_b = dz.cpu().double().sum(0) + (5.0 if acc else 0.0) if has_b else None
+        refs.append((ref_w, ref_b))
+    g = K.WgradGroup(torch.device(DEV))
+    for it in items:
+        assert g.accepts(it[0], it[1], it[2], it[4])
+        g.add(*it)
+    g.launch()
+    assert len(g) == 0
+    for i, ((x, dz, dw, acc, db, _), (ref_w, ref_b)) in enumerate(zip(items, refs)):
+        tag = f"gemm_wgrad_group[{nprob}].{i}[{x.shape[0]}x{x.shape[1]}x{dz.shape[1]}]"
+        close(tag + ".dw", dw, ref_w, torch.float32)     # fp32 accumulation of exact bf16 products: the fp32 bounds apply
+        if db is not None:
+            close(tag + ".db", db, ref_b, torch.float32)
+    # neighbours of the ldc > N views stay untouched
+    assert float(items[0][2]._base[:, -8:].min()) == 3.0 and float(items[0][2]._base[:, -8:].max()) == 3.0
+
+
 @pytest.mark.parametrize("switch", ["NST_GEMM_RING=5", "NST_GEMM_KS=1"])
 def test_gemm_wgrad_on_the_opt_in_kernels(switch):
     """NST_GEMM_RING=5 routes the bf16 weight gradients (slabs, fused column sums, accumulate) to gemm_stream_v3_ring (five

@@ -65,11 +65,12 @@ def _speech_model(case, dropout=0.0, **extra):
     for k in list(p):
         if k.endswith("dropout_rate"):
             p[k] = dropout
+    dtype = extra.pop("dtype", "float32")
     p.update(extra)
     model = build_model({"model.class": "SpeechTransformer", "model.params": p},
                         {"audio_feature_dim": F, "audio_feature_channels": 1},
                         {"vocab_size": V, "eos_id": V - 1, "bos_id": V - 2, "unk_id": V - 3}, device="cpu",
-                        dtype="float32", init_seed=3)
+                        dtype=dtype, init_seed=3)
     g = torch.Generator().manual_seed(11)
     sd = {}
     for n, prm in model.store.params.items():
@@ -122,6 +123,41 @@ def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
     for p in model.store.params.values():
         used[p.offset:p.offset + p.numel] = True
     assert float(model.store.grad[~used].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("at", ["end", "stack", "decoder"])
+def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_follow_the_launch(cpu_kernels, monkeypatch, at):
+    """Runtime.wgrad_group / launch_wgrad_group: with the group on, Dense.backward_params only queues its product; the model
+    launches the queue once per stack (or once at the end).  Same gradients as the per-product schedule (bit-identical over
+    the emulated kernels), nothing left queued after backward(), and a data-parallel report for a layer is delivered only
+    AFTER the launch that writes that layer's weight gradients -- in the original order, each exactly once."""
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    monkeypatch.setattr(K.WgradGroup, "MIN_OUTPUTS", 1)
+    monkeypatch.setattr("neurst_amd.models.encoder_decoder_model._WGRAD_GROUP_AT", at)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    grads, reports = [], []
+    for grouped in (False, True):
+        model, cfg, shape = _speech_model("small", dtype="bfloat16")
+        model.rt._wgrad_group_on_cpu = grouped
+        inputs = _speech_inputs(shape)
+        seen = []
+        launches = []
+        if grouped:
+            real = K.gemm_wgrad_group
+            monkeypatch.setattr(K, "gemm_wgrad_group", lambda items, table=None: (launches.append(len(items)), real(items, table))[1])
+        model.grad_ready_hook = lambda prefixes: seen.append((tuple(prefixes), len(model.rt.wgrad_group() or ())))
+        logits = model(inputs, is_training=True)
+        crit.reduce_loss(inputs, logits)
+        model.backward(crit.backward())
+        grads.append(model.store.grad.clone())
+        reports.append([p for p, _ in seen])
+        if grouped:
+            assert len(model.rt.wgrad_group()) == 0
+            assert all(pending == 0 for _, pending in seen), "a report ran while its weight gradients were still queued"
+            assert len(launches) == {"end": 1, "stack": 3, "decoder": 2}[at] and sum(launches) >= 2 * (4 + 6) + 1, launches
+    assert torch.equal(grads[0], grads[1])
+    assert reports[0] == reports[1]
 
 
 @pytest.mark.parametrize("variant", ["post_norm", "post_norm_encoder_only", "untied_softmax", "post_norm_untied"])
