@@ -270,12 +270,22 @@ class WgradGroup(object):
     def __len__(self):
         return len(self.items)
 
-    def launch(self):
+    def take(self):
+        """-> (launch, tensors): the queued products leave the group; launch() issues them on the stream current THEN
+        (Runtime.run_wgrad defers it while a step is captured), tensors are the operands it reads."""
         items, self.items = self.items, []
-        if items:
-            if len(items) > 56 and self.table is None:
-                self.table = torch.empty(1024 * 72, dtype=torch.uint8, device=self.device)
-            gemm_wgrad_group(items, self.table)
+        table = None
+        if len(items) > 56:      # the product table travels through device memory: one buffer per launch in flight
+            if self.table is None:
+                self.table = [torch.empty(1024 * 72, dtype=torch.uint8, device=self.device) for _ in range(4)]
+                self._table_next = 0
+            table = self.table[self._table_next]
+            self._table_next = (self._table_next + 1) % len(self.table)
+        return (lambda: gemm_wgrad_group(items, table)), [t for it in items for t in it[:2]]
+
+    def launch(self):
+        if self.items:
+            self.take()[0]()
 
 
 def gemm_wgrad_group(items, table=None):

@@ -11,6 +11,8 @@ forward : packed projection GEMM (bias fused) -> fused flash attention kernel re
 backward: hand scheduled; dq|dk|dv are written by the attention backward kernels directly into one packed
           buffer that feeds the projection wgrad / dgrad GEMMs.
 """
+import os
+
 import torch
 
 from neurst_amd import kernels as K
@@ -43,6 +45,9 @@ class MultiHeadAttention(Layer):
                                                     is_output_transform=True)
         self.q_transform = MultiHeadDenseLayer(self.rt, self.name + "/q_transform", self.input_depth, d, H, gen)
         self.kv_transform = MultiHeadDenseLayer(self.rt, self.name + "/kv_transform", self.memory_depth, [d, d], H, gen)
+        # reduces over the ENCODER's rows (3 x the decoder's): long tiles that do not fit next to the encoder stack's 240 in one
+        # round of the grouped launch -- split-K path on the weight-gradient stream, like the front dense layer
+        self.kv_transform.wgrad_grouped = False
 
     def forward(self, query, memory, B, Tq, Tk, memory_bias=None, is_training=True, epilogue=None, cache=None, lagging=None):
         """query [B*Tq, d], memory [B*Tk, d]; memory_bias [B,Tk] f32 (padding*FLOAT_MIN) or None.

@@ -148,6 +148,7 @@ class Dense(Layer):
         self.kernel = rt.store.add(name + "/kernel", (in_dim, out_dim), glorot_uniform((in_dim, out_dim), gen))
         self.bias = rt.store.add(name + "/bias", (out_dim,), torch.zeros(out_dim)) if use_bias else None
         self.wgrad_units = None   # workgroups the weight gradient is cut into (None: NST_WGRAD_UNITS)
+        self.wgrad_grouped = True  # the weight gradient may wait for the stack's grouped launch (Runtime.wgrad_group)
 
     def forward(self, x, **epi):
         return K.gemm(x, self.kernel.compute, x.shape[0], self.out_dim, self.in_dim,
@@ -161,7 +162,7 @@ class Dense(Layer):
             return
         acc_k = st.acc_flag(self.kernel)
         grp = self.rt.wgrad_group()
-        if grp is not None and grp.accepts(x, dz, self.kernel.grad, None if self.bias is None else self.bias.grad):
+        if grp is not None and self.wgrad_grouped and grp.accepts(x, dz, self.kernel.grad, None if self.bias is None else self.bias.grad):
             # waits for the stack's grouped launch (Runtime.launch_wgrad_group): no split-K, no slabs
             grp.add(x, dz, self.kernel.grad, acc_k, None if self.bias is None else self.bias.grad,
                     False if self.bias is None else st.acc_flag(self.bias))

@@ -68,8 +68,9 @@ class _DecodeSession(object):
         return static_logits
 
 
-# where the grouped weight-gradient launches go: "end" = one launch behind the whole backward, "stack" = one behind each
-# layer stack, "decoder" = the decoder's behind the decoder, everything else at the end
+# where the grouped weight-gradient launches go: "end" = one launch behind the whole backward; "stack" = one behind each
+# layer stack on the compute stream; "side" = like "stack", but the groups that cannot fill the chip (decoder, front dense
+# layer) go to the weight-gradient stream and only the encoder's 240 tiles run as a full-chip launch on the compute stream
 _WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "end")
 
 
@@ -248,15 +249,17 @@ class EncoderDecoderModel(BaseModel):
             self._trg_modality.backward(ddec_in, mode="embedding")
             if not shared:
                 hook([self._modality_scope(self._trg_modality) + "/"])
-            if _WGRAD_GROUP_AT in ("stack", "decoder"):
-                self.rt.launch_wgrad_group()   # the decoder's weight gradients: one launch
+            if _WGRAD_GROUP_AT in ("stack", "side"):
+                # the decoder's weight gradients (+ the cross-attention k|v projections over the encoder output): one launch
+                self.rt.launch_wgrad_group(side=_WGRAD_GROUP_AT == "side")
             denc_in = self._encoder.backward(dmemory, layer_done=hook)
             hook([self._encoder.name + "/"])
-            if _WGRAD_GROUP_AT == "stack":
-                self.rt.launch_wgrad_group()   # the encoder's
+            if _WGRAD_GROUP_AT in ("stack", "side"):
+                self.rt.launch_wgrad_group()   # the encoder's: a full-chip launch on the compute stream
             self._src_modality.backward(denc_in, mode="embedding")
             hook([self._modality_scope(self._src_modality) + "/"])
-            self.rt.launch_wgrad_group()       # whatever is still waiting (with "end": everything, in one launch)
+            # whatever is still waiting ("end": everything in one launch; "side": the front dense layer's 20 tiles)
+            self.rt.launch_wgrad_group(side=_WGRAD_GROUP_AT == "side")
             self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here

@@ -125,7 +125,7 @@ def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
     assert float(model.store.grad[~used].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("at", ["end", "stack", "decoder"])
+@pytest.mark.parametrize("at", ["end", "stack", "side"])
 def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_follow_the_launch(cpu_kernels, monkeypatch, at):
     """Runtime.wgrad_group / launch_wgrad_group: with the group on, Dense.backward_params only queues its product; the model
     launches the queue once per stack (or once at the end).  Same gradients as the per-product schedule (bit-identical over
@@ -155,7 +155,7 @@ def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_fol
         if grouped:
             assert len(model.rt.wgrad_group()) == 0
             assert all(pending == 0 for _, pending in seen), "a report ran while its weight gradients were still queued"
-            assert len(launches) == {"end": 1, "stack": 3, "decoder": 2}[at] and sum(launches) >= 2 * (4 + 6) + 1, launches
+            assert len(launches) == {"end": 1, "stack": 3, "side": 3}[at] and sum(launches) >= 2 * (4 + 6) + 1, launches
     assert torch.equal(grads[0], grads[1])
     assert reports[0] == reports[1]
 
