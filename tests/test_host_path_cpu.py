@@ -155,7 +155,9 @@ def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_fol
         if grouped:
             assert len(model.rt.wgrad_group()) == 0
             assert all(pending == 0 for _, pending in seen), "a report ran while its weight gradients were still queued"
-            assert len(launches) == {"end": 1, "stack": 3, "side": 3}[at] and sum(launches) >= 2 * (4 + 6) + 1, launches
+            # 2 encoder layers x (qkv, out, ffn1, ffn2) + 2 decoder layers x (qkv, out, q, out, ffn1, ffn2); the cross-attention
+            # k|v projections and the front dense layer (long, few tiles) stay on the per-product path
+            assert len(launches) == {"end": 1, "stack": 2, "side": 2}[at] and sum(launches) == 2 * 4 + 2 * 6, launches
     assert torch.equal(grads[0], grads[1])
     assert reports[0] == reports[1]
 
