@@ -9,6 +9,7 @@
 //   dgrad splits the input pixels into the 4 stride-2 parity classes so every K step is a real tap
 //   (no multiply-by-zero work), wgrad reduces over the pixels with split-K.
 #include "nst_gemm_core.h"
+#include "nst_gemm256.h"
 
 #include <stdlib.h>
 
@@ -1708,12 +1709,147 @@ bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, in
   return true;
 }
 
+
+// =============================================================================================
+// conv2 on the phase-staggered 256 x 256 tile kernel (nst_gemm256.h), bf16, C == 256 (round 4).
+//
+// forward: y[pixel, co] = sum over (tap, ci) im2col[pixel, (tap, ci)] . w2[(tap, ci), co] + b2: a workgroup owns 256
+// consecutive output pixels x all 256 output channels; a K step is one 64-channel slice of one tap (36 steps).  The A
+// half-tile images (128 pixels x 64 channels, 128-byte rows) are gathered by LDS-DMA straight from the NHWC input: per
+// (half, piece) a lane keeps the address of its pixel's tap (0, 0) and a 9-bit mask of the taps that fall inside the image;
+// a K step adds a wave-uniform (tap, slice) offset, padding taps read the zero block.  Every input element crosses the L2
+// interface 2.25 times this way (the patch kernels above fetch it once) -- but the loop runs at ~60 % of the MFMA peak
+// instead of ~30 %, and the re-reads hit the L2: neighbouring taps of neighbouring pixels a few K steps apart.
+// =============================================================================================
+struct Im2colDma256 {
+  const char* base[2][2];   // [half][piece]: &x[b][2*to - 1][2*fo - 1][kchunk * 8] of the chunk's pixel (never dereferenced at a padding tap)
+  uint32_t mask[2];         // [piece]: bits 0..8 = valid taps of half 0's pixel, bits 16..24 of half 1's
+  int F1, C;
+  int tap[2], c0[2];        // per half (wave-uniform): the (tap, first channel) of the K step issued next
+  __device__ __forceinline__ void init(const Im2colLoader<bf16_t>& l, int m0, int wave, int lane) {
+    F1 = l.F1; C = l.C;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = (s * 8 + wave) * 64 + lane;
+      const int row = c >> 3, slot = c & 7;
+      const int kchunk = slot ^ ((row >> 1) & 7);
+      uint32_t m = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pixel = m0 + h * 128 + row;
+        uint32_t q, fo, b, to;
+        l.dF2.divmod((uint32_t)pixel, q, fo);
+        l.dT2.divmod(q, b, to);
+        uint32_t mm = 0;
+        if (pixel < l.outer_limit) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int ti = 2 * (int)to + kh - 1, fi = 2 * (int)fo + kw - 1;
+              if (ti >= 0 && ti < l.T1 && fi >= 0 && fi < l.F1) mm |= 1u << (kh * 3 + kw);
+            }
+        }
+        m |= mm << (16 * h);
+        base[h][s] = reinterpret_cast<const char*>(l.x + (((int64_t)b * l.T1 + (2 * (int)to - 1)) * l.F1 + (2 * (int)fo - 1)) * l.C +
+                                                   kchunk * 8);
+      }
+      mask[s] = m;
+    }
+    tap[0] = tap[1] = 0;
+    c0[0] = c0[1] = 0;
+  }
+  template <int H>
+  __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
+    const uint32_t dst = img + (uint32_t)wave * 1024u;
+    const int tp = tap[H], kh = (tp * 11) >> 5, kw = tp - kh * 3;
+    const int64_t off = (((int64_t)kh * F1 + kw) * C + c0[H]) * 2;   // wave-uniform
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bool ok = (mask[s] >> (16 * H + tp)) & 1u;
+      const void* src = ok ? (const void*)(base[H][s] + off) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)s * 8192u));
+    }
+    c0[H] += 64;
+    if (c0[H] == C) { c0[H] = 0; ++tap[H]; }
+  }
+};
+
+struct Conv2Fwd256Args {
+  Im2colLoader<bf16_t> la;
+  const bf16_t* w2;
+  bf16_t* y;
+  const float* bias;
+  int M;
+};
+
+template <int EF>
+__global__ void __launch_bounds__(G256_THREADS, 2) conv2_fwd256_kernel(Conv2Fwd256Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = blockIdx.x * G256_TILE;
+  const int C = a.la.C;
+  floatx4_t acc[2][4][4], cs[4];
+  {
+    Im2colDma256 da;
+    da.init(a.la, m0, wave, lane);
+    DenseLoader<bf16_t> lb;   // Bop[j = co][r] = w2[r * C + co]  (reduction-major: outer = r, contig = co)
+    lb.base = a.w2; lb.ld = C; lb.outer_limit = 9 * C; lb.contig_limit = C; lb.vec = 1;
+    Dma256<MODE_OC> db;
+    db.init(lb, 0, 0, wave, lane);
+    gemm256_mainloop<MODE_RC, MODE_OC, false, 0>(smem_dyn, da, db, (9 * C) >> 6, false, acc, cs);
+  }
+  asm volatile("" ::: "memory");
+  Epilogue ep{};
+  ep.vec = 1;
+  ep.bias = a.bias;
+  float* epi = reinterpret_cast<float*>(smem_dyn + wave * V3_EPI_BYTES_PER_WAVE);
+  const IdentityRowMap rowmap;
+  epilogue_v3<bf16_t, IdentityRowMap, EF>(acc[0], epi, a.y, (int64_t)C, a.M, C, m0 + wr * 128, wc * 64, ep, rowmap, lane);
+  epilogue_v3<bf16_t, IdentityRowMap, EF>(acc[1], epi, a.y, (int64_t)C, a.M, C, m0 + wr * 128 + 64, wc * 64, ep, rowmap, lane);
+}
+
+// NST_CONV2_G256=0: the patch kernels (A/B switch of round 4)
+bool conv2_use_g256() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NST_CONV2_G256"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+// returns true when the 256 x 256 kernel handled the call
+bool conv2_fwd_g256(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  const int64_t M = (int64_t)B * T2 * F2;
+  if (!conv2_use_g256() || C != 256 || !b2 || !nst_aligned16(x) || !nst_aligned16(w2) || !nst_aligned16(y) ||
+      (((uintptr_t)b2) & 15) != 0 || M >= (1ll << 30) || M < 256)
+    return false;
+  Conv2Fwd256Args a;
+  a.la.x = (const bf16_t*)x; a.la.B = B; a.la.T1 = T1; a.la.F1 = F1; a.la.C = C; a.la.T2 = T2; a.la.F2 = F2;
+  a.la.outer_limit = (int)M; a.la.contig_limit = 9 * C; a.la.vec = 1;
+  a.la.init_divs();
+  a.w2 = (const bf16_t*)w2; a.y = (bf16_t*)y; a.bias = b2; a.M = (int)M;
+  const int grid = (int)((M + G256_TILE - 1) / G256_TILE);
+  if (relu) {
+    auto kfn = conv2_fwd256_kernel<EF_BIAS | EF_RELU>;
+    conv_allow_big_lds(kfn, G256_LDS_BYTES);
+    kfn<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(a);
+  } else {
+    auto kfn = conv2_fwd256_kernel<EF_BIAS>;
+    conv_allow_big_lds(kfn, G256_LDS_BYTES);
+    kfn<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(a);
+  }
+  return true;
+}
+
 template <typename T>
 int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int M = B * T2 * F2, N = C, K = 9 * C;
-  if constexpr (sizeof(T) == 2)
+  if constexpr (sizeof(T) == 2) {
+    if (conv2_fwd_g256(x, w2, b2, y, B, T1, F1, C, relu, st)) return 0;
     if (conv2_fwd_patch(x, w2, b2, y, B, T1, F1, C, relu, st)) return 0;
+  }
   Im2colLoader<T> la;
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
   la.outer_limit = M; la.contig_limit = K;

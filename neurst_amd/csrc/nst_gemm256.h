@@ -150,19 +150,17 @@ __device__ __forceinline__ void g256_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0
 
 // Main loop of one unit: acc (+)= A[m0.., k-range] . B[n0.., k-range]; cs = column sums of the B operand (do_cs, wave-uniform).
 // DBG (timing ablations, results wrong): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads
-template <int AMODE, int BMODE, bool CS, int DBG = 0>
-__device__ __forceinline__ void gemm256_mainloop(char* smem, const DenseLoader<bf16_t>& la, const DenseLoader<bf16_t>& lb, int m0, int n0,
-                                                 int kt_first, int nk, bool do_cs, floatx4_t (&acc)[2][4][4], floatx4_t (&cs)[4]) {
+// da / db: DMA cursors of the two operands, positioned on the unit's first K step; cursor.issue<H>(t, image, wave) stages
+// half-tile H of the unit's K step t (called with t = 0, 1, 2, ... in order for either half).  AMODE / BMODE: layout of their
+// half-tile images (fragment readers).
+template <int AMODE, int BMODE, bool CS, int DBG = 0, typename DA, typename DB>
+__device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int nk, bool do_cs, floatx4_t (&acc)[2][4][4],
+                                                 floatx4_t (&cs)[4]) {
   typedef bf16_t T;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-
-  Dma256<AMODE> da;
-  Dma256<BMODE> db;
-  da.init(la, m0, kt_first * 64, wave, lane);
-  db.init(lb, n0, kt_first * 64, wave, lane);
   Frag256<AMODE> fa;
   Frag256<BMODE> fb;
   fa.init(lane);
@@ -371,7 +369,11 @@ __device__ __forceinline__ void gemm256_block(char* smem) {
   floatx4_t acc[2][4][4], cs[4];
   {
     const Loader la = kload(&ka->la), lb = kload(&ka->lb);
-    gemm256_mainloop<AMODE, BMODE, CS, DBG>(smem, la, lb, m0, n0, kt_first, nk, do_cs, acc, cs);
+    Dma256<AMODE> da;
+    Dma256<BMODE> db;
+    da.init(la, m0, kt_first * 64, wave, lane);
+    db.init(lb, n0, kt_first * 64, wave, lane);
+    gemm256_mainloop<AMODE, BMODE, CS, DBG>(smem, da, db, nk, do_cs, acc, cs);
   }
 
   // ---- epilogue: each 64 x 64 quarter through the v3 epilogue (4 KB wave-private staging in the dead stage buffers)
@@ -461,7 +463,10 @@ __device__ __forceinline__ void gemm256_group_block(char* smem) {
     Loader la, lb;   // reduction-major operands: element (r, i) at base[r * ld + i]
     la.base = pp->A; la.ld = pp->lda; la.outer_limit = Kd; la.contig_limit = M; la.vec = 1;
     lb.base = pp->B; lb.ld = pp->ldb; lb.outer_limit = Kd; lb.contig_limit = N; lb.vec = 1;
-    gemm256_mainloop<MODE_OC, MODE_OC, true, DBG>(smem, la, lb, m0, n0, 0, (Kd + 63) >> 6, do_cs, acc, cs);
+    Dma256<MODE_OC> da, db;
+    da.init(la, m0, 0, wave, lane);
+    db.init(lb, n0, 0, wave, lane);
+    gemm256_mainloop<MODE_OC, MODE_OC, true, DBG>(smem, da, db, (Kd + 63) >> 6, do_cs, acc, cs);
   }
   asm volatile("" ::: "memory");
   const NST_AS4 G256Problem* p2 = launder(pp);
