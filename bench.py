@@ -63,10 +63,9 @@ def parse():
     ap.add_argument("--main-stream-priority", type=int, default=int(os.environ.get("NST_MAIN_PRIORITY", "0")),
                     help="-1: run the step on a high-priority HIP stream (the weight-gradient stream keeps the default priority)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
-                    help="replay the step from captured HIP graphs (training/train_step.py graph mode): the default on one rank "
-                         "since round 3 (same step time as eager launches, ~1 ms instead of ~12 ms of host time per step).  With "
-                         "more than one rank the default stays eager -- the step is GPU-bound either way and the capture next to "
-                         "RCCL's watchdog thread has only been exercised with one forced rank; NST_TRAIN_GRAPH=0|1 or the flags decide")
+                    help="replay the step from captured HIP graphs (training/train_step.py graph mode): the default -- on one rank "
+                         "since round 3 (~1 ms instead of ~12 ms of host time per step), for any number of ranks since round 4 "
+                         "(the exchange is replayed eagerly between the captured segments); NST_TRAIN_GRAPH=0|1 or the flags decide")
     ap.add_argument("--eager", dest="graph", action="store_false", help="eager launches instead of graph replay")
     ap.add_argument("--wire", default=os.environ.get("NST_DIST_WIRE", "fp32"), choices=["fp32", "bf16", "fp16"],
                     help="gradient dtype on the wire (16-bit: the reference's fp16 compression, training_utils.py:381-384)")
@@ -220,10 +219,19 @@ def main():
     from neurst_amd.utils.hparams_sets import get_hyper_parameters
     import torch.distributed as dist
 
+    # RCCL's footprint next to the step's kernels: a channel is one 256-thread workgroup on a CU of its own for the
+    # duration of a collective.  A step exchanges 117 MB of fp32 gradients in >= 8 MiB messages that are issued while the
+    # front end's backward (~2.5 ms) still runs; 16 channels move that several times over (>= 100 GB/s over the 7 xGMI links)
+    # and leave 240 of the 256 CUs to the compute stream, whose kernels are sized for whole-chip rounds (one 8-wave workgroup
+    # per CU).  RCCL's default for large messages takes several times as many.  Override with NCCL_MAX_NCHANNELS.
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
     rank, local_rank, world = init_distributed()
     if args.graph is None:
+        # graph replay is the default for ANY number of ranks since round 4: host issue time is ~1 ms instead of ~11 ms per
+        # step, and the exchange is replayed eagerly between the captured segments (TrainStep); soak log of the forced
+        # exchange path over RCCL in graph mode: profiles/r04_graph_rccl_soak.log.  NST_TRAIN_GRAPH=0 / --eager: eager launches
         env = os.environ.get("NST_TRAIN_GRAPH")
-        args.graph = (env != "0") if env is not None else (world == 1)
+        args.graph = (env != "0") if env is not None else True
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dev = f"cuda:{torch.cuda.current_device()}"      # init_distributed pinned it (LOCAL_RANK)

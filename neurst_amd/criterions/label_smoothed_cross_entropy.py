@@ -73,7 +73,9 @@ class LabelSmoothedCrossEntropy(Criterion):
         if loss_scale_dev is not None:
             inv = inv * loss_scale_dev.reshape(1)
         inv = inv.contiguous()
-        return K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), gscale_dev=inv).view(B, L, V)
+        # the gradient keeps the logits' row stride (rows padded to whole 128-byte lines, text_modalities.py)
+        out = torch.empty_strided(l2.shape, l2.stride(), dtype=l2.dtype, device=l2.device)
+        return K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), out=out, gscale_dev=inv).view(B, L, V)
 
     def reduce_metrics(self, eval_res_list):
         nll_sum = nll_samples = nll_tokens = 0.

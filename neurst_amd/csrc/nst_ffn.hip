@@ -1000,13 +1000,16 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   }
 }
 
+// Raises the kernel's dynamic-LDS limit to the whole 160 KB of a CU, once per kernel and thread: the launches of one
+// instantiation ask for different sizes (the forward's depends on the filter size), so remembering only "already set" would
+// leave a later, larger request above the limit of an earlier, smaller one.
 template <typename KernelT>
-void allow_lds(KernelT kernel, int bytes) {
+void allow_lds(KernelT kernel, int /*bytes*/) {
   static thread_local const void* done[16];
   static thread_local int ndone = 0;
   for (int i = 0; i < ndone; ++i)
     if (done[i] == (const void*)kernel) return;
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (ndone < 16) done[ndone++] = (const void*)kernel;
 }
 
@@ -1263,6 +1266,9 @@ extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidd
   NST_CHECK_ARG(nst_ffn_supported(d->d_model, d->filter_size, d->dtype), "ffn_bwd: unsupported shape d=%d ffn=%d dtype=%d",
                 d->d_model, d->filter_size, d->dtype);
   NST_CHECK_ARG(d->rows >= 0 && d->rows < (1 << 30), "ffn_bwd: rows=%lld", (long long)d->rows);
+  // the eight-wave backward addresses its gate (rows x filter x 2 bytes) with 32-bit offsets
+  NST_CHECK_ARG((int64_t)d->rows * d->filter_size * 2 < (1ll << 32), "ffn_bwd: rows * filter_size = %lld x %d exceeds the 4 GiB the "
+                "gate offsets cover", (long long)d->rows, d->filter_size);
   NST_CHECK_ARG(nst_aligned16(dy) && nst_aligned16(hidden) && nst_aligned16(w1) && nst_aligned16(w2) && nst_aligned16(dhidden) &&
                     nst_aligned16(dx) && (!residual || nst_aligned16(residual)),
                 "ffn_bwd: operands must be 16-byte aligned");

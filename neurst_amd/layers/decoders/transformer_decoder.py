@@ -166,18 +166,39 @@ class TransformerDecoder(Decoder):
         if p > 0:
             x = K.scale_posenc_dropout_fwd(x, None, 1, 1.0, p, self.rt.step_seed, self._site)
         self._grouped = self._kv_group is not None and mem2 is not None and is_training
+        self._clear_kv_handoff()      # a forward / backward that aborted half way must not leave another batch's k|v behind
         if self._grouped:
             self._project_memory(mem2)
-        for layer in self._stacking_layers:
-            x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
+        try:
+            for layer in self._stacking_layers:
+                x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
+        finally:
+            for a in getattr(self, "_kv_atts", ()):
+                a._kv_pre = None
         out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
         self._shapes = (B, L, d, Tm)
         return out.view(B, L, d)
 
     __call__ = forward
 
+    def _clear_kv_handoff(self):
+        """The grouped cross-attention k|v projection reaches the layers through per-layer attributes (_kv_pre: this batch's
+        k|v block, _dkv_out: where its gradient goes); each is consumed by its layer.  Cleared here at the start of every
+        forward and backward and again behind them, so an exception between hand-over and use cannot leak them into the next
+        call (which would attend over another batch's keys, or write d(k|v) into a dead buffer)."""
+        for a in getattr(self, "_kv_atts", ()):
+            a._kv_pre = None
+            a._dkv_out = None
+
     def backward(self, dout, layer_done=None):
         """Returns (d decoder_inputs [B,L,d], d memory [B,Tm,d]).  layer_done: see TransformerEncoder.backward."""
+        try:
+            return self._backward(dout, layer_done)
+        finally:
+            for a in getattr(self, "_kv_atts", ()):
+                a._dkv_out = None
+
+    def _backward(self, dout, layer_done=None):
         B, L, d, Tm = self._shapes
         dmemory = torch.empty(B * Tm, d, dtype=dout.dtype, device=dout.device) if Tm else None
         layers = self._stacking_layers
@@ -188,6 +209,8 @@ class TransformerDecoder(Decoder):
             dx = dx.contiguous()
         first = True
         dkv_all = None
+        for a in getattr(self, "_kv_atts", ()):
+            a._dkv_out = None
         if getattr(self, "_grouped", False) and Tm:
             g = self._kv_group
             dkv_all = torch.empty(B * Tm, g.w.shape[1], dtype=dout.dtype, device=dout.device)

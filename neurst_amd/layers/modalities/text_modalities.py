@@ -51,8 +51,17 @@ class WordEmbeddingSharedWeights(Layer):
             return out
         if mode == "linear":
             x2 = inputs.reshape(-1, d)
+            out = None
+            esz = x2.element_size()
+            if is_training and (V * esz) % 128 != 0:
+                # training: the logits are the largest activation of the decoder (9600 x 8008 at the benchmark shape) and are
+                # written once and read twice (criterion forward / backward).  A row of V = 8008 bf16 values is 16 016 bytes:
+                # rows start 16 bytes further into their 128-byte line each time, every store and load straddles lines.  Rows
+                # padded to whole lines (the tensor handed out is the [rows, V] view of the [rows, Vp] buffer)
+                vp = ((V * esz + 127) // 128) * (128 // esz)
+                out = torch.empty(x2.shape[0], vp, dtype=x2.dtype, device=x2.device)[:, :V]
             logits = K.gemm(x2, self._shared_weights.compute, x2.shape[0], V, d, trans_b=True,
-                            bias=None if self._bias is None else self._bias.data)
+                            bias=None if self._bias is None else self._bias.data, out=out)
             if is_training:
                 self._stack.append(("linear", x2))
             return logits.view(*inputs.shape[:-1], V)

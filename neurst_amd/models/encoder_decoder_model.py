@@ -70,8 +70,11 @@ class _DecodeSession(object):
 
 # where the grouped weight-gradient launches go: "end" = one launch behind the whole backward; "stack" = one behind each
 # layer stack on the compute stream; "side" = like "stack", but the groups that cannot fill the chip (decoder, front dense
-# layer) go to the weight-gradient stream and only the encoder's 240 tiles run as a full-chip launch on the compute stream
-_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "end")
+# layer) go to the weight-gradient stream and only the encoder's 240 tiles run as a full-chip launch on the compute stream;
+# "encoder" = one launch behind the encoder stack (decoder + encoder products), the rest at the end.
+# Measured (profiles/r04_history/c3..c5_ab_step.log): end 14.46, stack 15.18, side 14.75 ms per step with every product in the
+# group -- a group that cannot fill the chip, or fills it 1.06 times, wastes more than the launch saves
+_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "encoder")
 
 
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
@@ -236,7 +239,11 @@ class EncoderDecoderModel(BaseModel):
                 def report():
                     self.rt.wgrad_boundary()
                     user_hook(prefixes)
-                self.rt.report_or_defer(report)   # (weight gradients waiting in the group: the report follows their launch)
+                # the layer's deferred second stages (LayerNorm parameter gradients, split-K reduces) start now either way ...
+                self.rt.flush_wgrads()
+                self.rt.sublayer_boundary()
+                # ... the REPORT waits while weight gradients of the layer sit in the group: it follows their launch
+                self.rt.report_or_defer(report)
             # A report means "everything that writes these gradients has been QUEUED" (on the current stream or on the
             # weight-gradient stream); the reducer orders its side stream behind both.  The compute stream itself only
             # joins the weight-gradient stream once, at the end -- a join per component would stall the dgrad chain.
@@ -254,8 +261,10 @@ class EncoderDecoderModel(BaseModel):
                 self.rt.launch_wgrad_group(side=_WGRAD_GROUP_AT == "side")
             denc_in = self._encoder.backward(dmemory, layer_done=hook)
             hook([self._encoder.name + "/"])
-            if _WGRAD_GROUP_AT in ("stack", "side"):
-                self.rt.launch_wgrad_group()   # the encoder's: a full-chip launch on the compute stream
+            if _WGRAD_GROUP_AT in ("stack", "side", "encoder"):
+                # "encoder": decoder + encoder stacks in ONE full-chip launch here, in front of the front end's backward -- their
+                # gradients (94 % of the parameters) are then reported to the data-parallel reducer ~2.5 ms before the step ends
+                self.rt.launch_wgrad_group()
             self._src_modality.backward(denc_in, mode="embedding")
             hook([self._modality_scope(self._src_modality) + "/"])
             # whatever is still waiting ("end": everything in one launch; "side": the front dense layer's 20 tiles)

@@ -90,6 +90,9 @@ class GradientReducer(object):
         wire = {"fp32": None, "float32": None, None: None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
                 "fp16": torch.float16, "float16": torch.float16}[wire]
         self.wire_dtype = wire
+        # fp16 wire: the rank-local gradients are scaled by 1/world BEFORE the cast (a sum of N fp16 values can overflow to inf
+        # where the average is representable; bf16 has the range of fp32 and keeps sum-then-scale, i.e. one rounding less)
+        self.prescale = wire == torch.float16
         self._wire_buf = None
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
         # streams (besides the current one) whose queued work writes gradients: the exchange waits for them on the
@@ -103,6 +106,10 @@ class GradientReducer(object):
         # graph capture of the train step (training/train_step.py): instead of issuing a bucket, the reducer hands its
         # range to this callback, which cuts the capture there and replays the exchange eagerly between two graph launches
         self.capture_cut = None
+        if self.wire_dtype is not None and self.active and not self.host_staged:
+            # staging buffer of the 16-bit wire, as long as the gradient buffer: every in-flight message owns its own region.
+            # Allocated here, not inside the first step (a step that is being captured into a HIP graph must not allocate it)
+            self._wire_buf = torch.empty(store.total, dtype=self.wire_dtype, device=store.grad.device)
 
     # ---- parameter ranges -------------------------------------------------------------------------------------
     def range_of(self, prefixes):
@@ -149,12 +156,13 @@ class GradientReducer(object):
                 # 16-bit wire: the staging buffer is as long as the gradient buffer, so every in-flight message owns its own
                 # region (no reuse hazard between asynchronous collectives); the add-back is queued on the same stream
                 # behind the collective (Work.wait() orders the current stream after it without blocking the host)
-                if self._wire_buf is None or self._wire_buf.dtype != self.wire_dtype:
-                    self._wire_buf = torch.empty(self.store.total, dtype=self.wire_dtype, device=g.device)
                 w = self._wire_buf[s:e]
-                w.copy_(g[s:e])
+                if self.prescale:
+                    w.copy_(g[s:e] * (1.0 / self.world))
+                else:
+                    w.copy_(g[s:e])
                 h = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                h.wait()
+                h.wait()          # stream-ordered: the add-back below is queued behind the collective, the host does not block
                 g[s:e].copy_(w)
                 continue
             h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -214,7 +222,7 @@ class GradientReducer(object):
         if self.capture_cut is None:   # while capturing, the waits belong to the replay (wait_issued)
             self.wait_issued()
         self.last_messages, self.messages = self.messages, 0
-        return 1.0 / self.world
+        return 1.0 if (self.prescale and not self.host_staged) else 1.0 / self.world
 
     def wait_issued(self):
         """The current stream waits for every exchange issued so far."""

@@ -21,6 +21,8 @@ import warnings
 
 import torch
 
+from neurst_amd import _lib
+
 
 class _Segment(object):
     """One slice of a captured step: a graph of compute-stream work, optionally followed by a graph of the weight-gradient
@@ -56,6 +58,7 @@ class _StepCapture(object):
         # captures -- in the default (global) mode such a call from ANOTHER thread invalidates the capture and aborts the
         # process (seen once in five forced-exchange runs of bench.py, round 3)
         self.cur.main.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self._calls_at_begin = _lib.CALLS[0]
 
     def _close(self):
         """Ends the compute graph of the current segment and captures its weight-gradient graph from the recorded calls."""
@@ -65,11 +68,16 @@ class _StepCapture(object):
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             seg.main.capture_end()
-        if any("Graph is empty" in str(w.message) for w in caught):
-            seg.main = None
+        empty = any("Graph is empty" in str(w.message) for w in caught)
+        queued = _lib.CALLS[0] - self._calls_at_begin     # library calls issued on this thread since begin()
+        if empty and queued == 0:
+            seg.main = None       # our own bookkeeping agrees: nothing was queued between two cuts
         else:
             for w in caught:
                 warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            if empty:             # kernels were queued but none was captured: wrong stream or device -- never skip that silently
+                raise RuntimeError(f"captured segment is empty although {queued} library calls were issued while it was "
+                                   "open: they ran on another stream or device than the one being captured")
         if self.deferred:
             calls, self.deferred = self.deferred, []
             self.side_stream.wait_stream(self.main_stream)

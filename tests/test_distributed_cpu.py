@@ -230,7 +230,15 @@ def _wire_worker(rank, world, port, q):
     # (b) no slice of a few hundred elements travels alone: output_ln was part of its top layer's report
     ln = [red.range_of([f"{s}/output_ln/"]) for s in ("TransformerDecoder", "TransformerEncoder")]
     alone = [r for r in issued if r in ln]
-    q.put((rank, ok_wire, rel, scale, alone, len(issued)))
+    # (c) fp16 wire: gradients are scaled by 1/world BEFORE the cast, so values whose SUM leaves the fp16 range (but whose
+    # average does not) survive, and finish() hands the optimizer a factor of 1 instead of 1/world
+    red16 = GradientReducer(st, bucket_bytes=4096, wire_dtype="fp16")
+    big = torch.full((st.total,), 40000.0) + rank          # 2 x 40000 > 65504 = fp16 max
+    st.grad.copy_(big)
+    scale16 = red16.finish()
+    want16 = torch.full((st.total,), 40000.0) + (world - 1) / 2.0
+    fp16_ok = bool(torch.isfinite(st.grad).all()) and float((st.grad * scale16 - want16).abs().max()) <= 40000.0 * 2e-3
+    q.put((rank, ok_wire, rel, scale, alone, len(issued), fp16_ok, scale16))
     dist.destroy_process_group()
 
 
@@ -247,7 +255,8 @@ def test_bf16_wire_and_no_standalone_output_ln_message_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok_wire, rel, scale, alone, n in res:
+    for rank, ok_wire, rel, scale, alone, n, fp16_ok, scale16 in res:
         assert ok_wire, "the 16-bit wire must carry bf16-rounded slices and widen the bf16 sum"
         assert rel < 1e-2 and scale == 0.5
         assert alone == [] and n >= 4
+        assert fp16_ok and scale16 == 1.0, "fp16 wire: pre-scaled by 1/world, no overflow of the sum"

@@ -125,7 +125,40 @@ def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
     assert float(model.store.grad[~used].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("at", ["end", "stack", "side"])
+def test_grouped_cross_attention_projection_equals_per_layer_and_leaves_nothing_behind(cpu_kernels, monkeypatch):
+    """TransformerDecoder's grouped k|v projection (one GEMM over the packed kv_transform kernels, NST_DEC_KV_GROUP) against the
+    per-layer projections: same logits and gradients; and the per-layer hand-over attributes (_kv_pre / _dkv_out) never survive
+    a call -- a training forward that dies inside the decoder must not feed its k|v to the next (teacher-forced, not grouped)
+    evaluation forward of a DIFFERENT batch."""
+    from neurst_amd.criterions import build_criterion
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    outs = []
+    for grouped in ("1", "0"):
+        monkeypatch.setenv("NST_DEC_KV_GROUP", grouped)
+        model, cfg, shape = _speech_model("small")
+        assert (model._decoder._kv_group is not None) == (grouped == "1")
+        inputs = _speech_inputs(shape)
+        logits = model(inputs, is_training=True)
+        crit.reduce_loss(inputs, logits)
+        model.backward(crit.backward())
+        outs.append((logits.double(), model.store.grad.clone().double()))
+        assert all(getattr(a, "_kv_pre", None) is None and getattr(a, "_dkv_out", None) is None for a in model._decoder._kv_atts)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-5
+    monkeypatch.setenv("NST_DEC_KV_GROUP", "1")
+    model, cfg, shape = _speech_model("small")
+    inputs, other = _speech_inputs(shape), _speech_inputs(shape, seed=99)
+    want = model(other, is_training=False).double()
+    last = model._decoder._stacking_layers[-1]
+    real = last.forward
+    monkeypatch.setattr(last, "forward", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected")))
+    with pytest.raises(RuntimeError, match="injected"):
+        model(inputs, is_training=True)
+    monkeypatch.setattr(last, "forward", real)
+    assert all(getattr(a, "_kv_pre", None) is None for a in model._decoder._kv_atts)
+    assert rel_err(model(other, is_training=False).double(), want) < 1e-6
+
+
+@pytest.mark.parametrize("at", ["end", "stack", "side", "encoder"])
 def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_follow_the_launch(cpu_kernels, monkeypatch, at):
     """Runtime.wgrad_group / launch_wgrad_group: with the group on, Dense.backward_params only queues its product; the model
     launches the queue once per stack (or once at the end).  Same gradients as the per-product schedule (bit-identical over
@@ -157,7 +190,7 @@ def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_fol
             assert all(pending == 0 for _, pending in seen), "a report ran while its weight gradients were still queued"
             # 2 encoder layers x (qkv, out, ffn1, ffn2) + 2 decoder layers x (qkv, out, q, out, ffn1, ffn2); the cross-attention
             # k|v projections and the front dense layer (long, few tiles) stay on the per-product path
-            assert len(launches) == {"end": 1, "stack": 2, "side": 2}[at] and sum(launches) == 2 * 4 + 2 * 6, launches
+            assert len(launches) == {"end": 1, "stack": 2, "side": 2, "encoder": 1}[at] and sum(launches) == 2 * 4 + 2 * 6, launches
     assert torch.equal(grads[0], grads[1])
     assert reports[0] == reports[1]
 
