@@ -164,11 +164,13 @@ class NstError(RuntimeError):
     pass
 
 
-CALLS = [0]     # library calls checked so far (training/train_step.py: did a captured segment queue any kernel?)
+CALLS = [0]     # kernel-launching library calls so far (training/train_step.py: did a captured segment queue any kernel?)
 
 
-def check(rc, what=""):
-    CALLS[0] += 1
+def check(rc, what="", launches=True):
+    """launches=False: a host-only entry point (it queues nothing on a stream)."""
+    if launches:
+        CALLS[0] += 1
     if rc != 0:
         msg = lib.nst_last_error_string()
         raise NstError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -105,7 +105,7 @@ PROBE = _KernelProbe()
 # ------------------------------------------------------------------------------------------------ dropout seed offset
 def dropout_seed_offset_bind(scalar):
     """scalar: 1-element int64 device tensor that the following launches use as the dropout seed offset (None: the library's)."""
-    check(lib.nst_dropout_seed_offset_bind(_p(scalar)), "dropout_seed_offset_bind")
+    check(lib.nst_dropout_seed_offset_bind(_p(scalar)), "dropout_seed_offset_bind", launches=False)
 
 
 def dropout_seed_offset_set(value):

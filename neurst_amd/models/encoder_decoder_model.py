@@ -74,7 +74,9 @@ class _DecodeSession(object):
 # "encoder" = one launch behind the encoder stack (decoder + encoder products), the rest at the end.
 # Measured (profiles/r04_history/c3..c5_ab_step.log): end 14.46, stack 15.18, side 14.75 ms per step with every product in the
 # group -- a group that cannot fill the chip, or fills it 1.06 times, wastes more than the launch saves
-_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "encoder")
+# ("encoder" 14.07 vs "end" 13.91 ms on one GPU, c8_ab_step.log: behind the encoder the group shares the chip with the
+# weight-gradient stream's leftovers; what it would buy with N > 1 -- an earlier start of the exchange -- is unmeasured)
+_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "end")
 
 
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
