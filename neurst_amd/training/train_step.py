@@ -86,9 +86,22 @@ class _StepCapture(object):
                 try:
                     seg.wgrad = torch.cuda.CUDAGraph()
                     seg.wgrad.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                    calls0 = _lib.CALLS[0]
                     for fn in calls:
                         fn()
-                    seg.wgrad.capture_end()
+                    # recorded calls that turned out to have nothing to launch (a flush of an empty batch): same rule as above
+                    with warnings.catch_warnings(record=True) as caught_w:
+                        warnings.simplefilter("always")
+                        seg.wgrad.capture_end()
+                    empty_w = any("Graph is empty" in str(w.message) for w in caught_w)
+                    if empty_w and _lib.CALLS[0] == calls0:
+                        seg.wgrad = None
+                    else:
+                        for w in caught_w:
+                            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+                        if empty_w:
+                            raise RuntimeError(f"weight-gradient graph is empty although {_lib.CALLS[0] - calls0} library calls "
+                                               "were issued for it: they ran on another stream than the one being captured")
                 finally:
                     self.rt.capture = cap
             self.main_stream.wait_stream(self.side_stream)
