@@ -14,6 +14,7 @@ from oracle import neurst_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = {"float32": 1e-3, "bfloat16": 1e-2}
 REPORT = {}
 
@@ -156,7 +157,7 @@ def test_frontend_matches_reference_neurst_pt_hip(tag):
 
 
 # ------------------------------------------------------------------------------------------------ model fwd/bwd vs oracle
-def _speech_case(name, dtype, device=None, batch=None, **extra):
+def _speech_case(name, dtype, device=None, batch=None, ragged_batch=None, **extra):
     cases = {
         # d, H, enc, dec, ffn, C, B, T, F, L, V, ragged
         "toy": (8, 2, 2, 2, 10, 5, 2, 11, 80, 3, 5, False),
@@ -169,6 +170,8 @@ def _speech_case(name, dtype, device=None, batch=None, **extra):
     d, H, ne, nd, ffn, C, B, T, F, L, V, ragged = cases[name]
     if batch is not None:
         B, ragged = batch, False
+    if ragged_batch is not None:      # the case's architecture at another batch size, lengths ragged as in the case itself
+        B, ragged = ragged_batch, True
     from neurst_amd.models import build_model
     from neurst_amd.utils.hparams_sets import get_hyper_parameters
     hp = get_hyper_parameters("speech_transformer_toy")
@@ -326,6 +329,63 @@ def test_speech_transformer_s_real_configuration_parity(dtype):
     assert own[2] <= 3e-2, f"global gradient rel-L2 vs the oracle {own[2]:.3e}"
     # with the discrete gate flips taken out, the bf16 path meets the north-star tolerance on the whole gradient
     assert gated[2] <= 1e-2 and gated[0] <= 1e-2, (gated, own)
+
+
+@pytest.mark.parametrize("batch", [32, 128])
+def test_speech_transformer_s_bf16_step_against_the_oracle_fixture(batch):
+    """The bf16 HIP step of the real speech_transformer_s at a batch of 32 / 128 (the benchmark's) ragged 900-frame utterances
+    against the float64 ORACLE -- not against another HIP path.  The oracle at these batches runs on the build host
+    (tests/golden/make_oracle_b32.py, minutes and tens of GB); what travels is, per gradient tensor and for the logits, the L2
+    norm and 64 fixed +-1 projections (oracle/projections.py: the relative L2 distance of two projection sets estimates the
+    relative L2 distance of the tensors), for the oracle and for the float64 emulation of the kernels with the same bf16
+    rounding points.  Asserted: loss and logits at the north-star bf16 bar of 1e-2; gradients (a) no farther from the oracle
+    than 1.3 x what exact kernels with bf16 rounding points are, globally, and within 2 x per tensor, (b) the measured level
+    itself.  Round 4 on MI355X (profiles/r04_model_parity_report.json): global rel-L2 of the gradients against the ORACLE
+    1.87e-2 at 32 utterances (emulation 1.71e-2 exact / 1.80e-2 by projections) and 1.03e-2 at 128 (emulation 1.02e-2 / 1.10e-2);
+    logits 6.7e-3, loss 2.9e-4 at both.  At the benchmark batch the bf16 step therefore sits AT the north star's 1e-2 against the
+    oracle, and exactly where exact kernels with the same rounding points sit: the remaining distance is the rounding of
+    activations to bf16 between kernels, not kernel error (per tensor the median ratio HIP / emulation is 0.94 - 1.03)."""
+    from neurst_amd.criterions import build_criterion
+    from oracle.projections import sign_projections
+    fx = np.load(os.path.join(GOLDEN, f"oracle_s_real_b{batch}.npz"))
+    assert int(fx["batch"]) == batch
+    model, inputs, cfg = _speech_case("s_real", "bfloat16", ragged_batch=batch)
+    dinp = {k: v.to(DEV) for k, v in inputs.items()}
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    logits = model(dinp, is_training=True)
+    loss = float(crit.reduce_loss(dinp, logits))
+    model.backward(crit.backward())
+    torch.cuda.synchronize()
+    names = [str(n) for n in fx["names"]]
+    assert names == sorted(model.store.params)
+    lp = sign_projections(logits.float().cpu(), "logits").numpy()
+    gp = np.stack([sign_projections(model.store.params[n].grad.float().cpu(), n).numpy() for n in names])
+    gn = np.array([float(model.store.params[n].grad.float().norm()) for n in names])
+    ref, emu = fx["grad_proj_ref"], fx["grad_proj_emu"]
+    tag = f"st[s_real,bfloat16,B{batch}].oracle_fixture"
+    rep = {
+        "loss_abs_err": abs(loss - float(fx["loss_ref"])),
+        "logits_rel_l2": float(np.linalg.norm(lp - fx["logits_proj_ref"]) / np.linalg.norm(fx["logits_proj_ref"])),
+        "logits_rel_l2_emulation": float(np.linalg.norm(fx["logits_proj_emu"] - fx["logits_proj_ref"]) / np.linalg.norm(fx["logits_proj_ref"])),
+        "grad_global_rel_l2": float(np.linalg.norm(gp - ref) / np.linalg.norm(ref)),
+        "grad_global_rel_l2_emulation": float(np.linalg.norm(emu - ref) / np.linalg.norm(ref)),
+        "grad_global_rel_l2_emulation_exact": float(fx["grad_global_rel_l2_emu"]),
+        "grad_norm_rel_err_worst": float(np.max(np.abs(gn - fx["grad_norm_ref"]) / np.maximum(fx["grad_norm_ref"], 1e-12))),
+    }
+    per_hip = np.linalg.norm(gp - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-12)
+    per_emu = np.linalg.norm(emu - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-12)
+    rep["grad_worst_tensor_rel_l2"], rep["grad_worst_tensor_rel_l2_emulation"] = float(per_hip.max()), float(per_emu.max())
+    rep["tensors_above_1e-2"], rep["tensors_above_1e-2_emulation"] = int((per_hip > 1e-2).sum()), int((per_emu > 1e-2).sum())
+    rep["ratio_median"] = float(np.median(per_hip / np.maximum(per_emu, 1e-12)))
+    for k, v in rep.items():
+        REPORT[f"{tag}.{k}"] = v
+    assert rep["loss_abs_err"] <= 1e-2 and rep["logits_rel_l2"] <= 1e-2, rep
+    assert rep["grad_global_rel_l2"] <= 1.3 * rep["grad_global_rel_l2_emulation"] + 1e-3, rep
+    # per tensor: 64 projections estimate a tensor's error to ~ +-12 %; 2 x the emulation + a small absolute term as in the B = 3 test
+    bad = [(n, float(h), float(e)) for n, h, e in zip(names, per_hip, per_emu) if h > 2.0 * e + 4e-3]
+    assert not bad, f"{len(bad)} gradient tensors farther from the oracle than bf16 rounding explains: {bad[:6]}"
+    assert rep["grad_norm_rel_err_worst"] <= 5e-2, rep
+    assert rep["grad_global_rel_l2"] <= (1.2e-2 if batch >= 128 else 2.2e-2), rep     # measured 1.03e-2 / 1.87e-2
 
 
 def _grad_errors(grads, grads_ref):
