@@ -157,11 +157,6 @@ typedef struct NstSplitkJob {
 } NstSplitkJob;
 
 int nst_gemm(const NstGemmDesc* desc, const void* A, const void* B, void* C, void* stream);
-/* Edge of the output tile nst_gemm will cut desc's product into: 256 for the bf16 weight gradients (trans_a, f32 output, M and
- * N >= 256, plain epilogue) that run on the phase-staggered 256 x 256 kernel, 128 otherwise.  Only M, N, the dtypes, the
- * transposes and the epilogue fields are read.  The host sizes split_k with it (tiles * split_k workgroups; a multiple of 8
- * keeps every K slice on one XCD).  ABI 7. */
-int nst_gemm_tile(const NstGemmDesc* desc);
 /* n weight gradients dW_i[M_i, N_i] (+)= X_i^T . dZ_i in ONE launch (ABI 7): descs[i] describes product i exactly as for
  * nst_gemm (trans_a = 1, trans_b = 0, bf16 in, f32 out, plain epilogue; accumulate, colsum / colsum_accumulate honoured;
  * split_k must be <= 1), A[i] / B[i] / C[i] are its operands.  Every 256 x 256 output tile of every product is one workgroup of

@@ -102,7 +102,6 @@ SIGNATURES = {
     "nst_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_ln_finalize_multi": [_P, _I, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
-    "nst_gemm_tile": [C.POINTER(NstGemmDesc)],
     "nst_gemm_wgrad_group": [_P, _P, _P, _P, _I, _P, _L, _P],
     "nst_splitk_reduce_multi": [_P, _I, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],

@@ -725,35 +725,41 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_from_ds_kernel(AttnParams p) 
 }
 
 // =============================================================================================
-// backward, fused (bf16, Tq <= 256 and Tk <= 256, round 3): ONE workgroup per (batch, head) computes dK, dV AND dQ.
+// backward, one workgroup per (batch, head) (bf16, Tq <= 256 and Tk <= 256; round 4): dK, dV AND dQ from one kernel, EIGHT waves.
 //
-// The two-kernel path above moves dS^T through HBM (B*H*Tk'*Tq' bf16 written by the dK/dV kernel, read by the dQ kernel: 134 MB
-// of the ~240 MB an encoder layer's attention backward touches at the benchmark shape) and re-reads Q / dO once per 64-key
-// workgroup.  At these sequence lengths a whole head fits in LDS:
-//   * Q, dO and K of the (batch, head) are staged ONCE (<= 4 tiles of 64 rows each, 108 KB), next to lse / delta / key bias of
-//     its <= 256 positions and the head's dropout keep bits (<= 8 KB);
-//   * the workgroup walks the key blocks of 64 (wave w: keys 16 w .. 16 w + 15, K / V fragments in registers -- V straight
-//     from HBM in fragment layout, prefetched one block ahead) and, inside, the query tiles: S and dP, the element-wise part
-//     and the dV / dK products exactly as in attn_bwd_dkdv_kernel;
-//   * dS^T of a step (64 keys x 64 queries) goes into a double-buffered LDS tile instead of the workspace; behind ONE barrier
-//     per step wave w adds K^T . dS^T for queries 16 w .. 16 w + 15 of the tile to its dQ accumulators, which stay in
-//     registers for all four query tiles until the end (64 registers).
-// 140 KB of LDS: one workgroup (4 waves) per CU; B*H workgroups.
+// The two-kernel path above moves the scaled dS^T through HBM (B*H*Tk'*Tq' bf16 written by the dK/dV kernel, read by the dQ
+// kernel: 134 MB of the ~240 MB an encoder layer's attention backward touches at the benchmark shape -- the launch pair runs at
+// 5.7 TB/s, it is HBM-bound on traffic the algorithm does not need) and re-reads Q / dO once per key block.  Round 3's first
+// fused form (four waves, one per SIMD, Q / dO / K resident in 140 KB of LDS) removed the traffic but walked its 16 dependent
+// steps with nothing to hide their latency behind (82 us against 86).  This form:
+//   * wave w of 8 owns keys [32 w, 32 w + 32) for the whole kernel -- K and V fragments, the key bias and the dK / dV
+//     accumulators of those keys live in its registers (two waves per SIMD: one computes while the other waits);
+//   * K of the head stays in LDS (the A operand of dQ = dS . K for EVERY wave), Q and dO stream through it in tiles of 32
+//     queries: one 16-byte chunk per thread and tile (threads 0..255 Q, 256..511 dO), loaded a tile ahead into a register,
+//     written to the other half of a double buffer before the tile's single barrier;
+//   * per tile and wave: S and dP (8 + 8 MFMAs), the element-wise part, dV += P^T dO and dK += dS^T Q (8 + 8), the scaled
+//     dS^T of its 32 keys x 32 queries into a double-buffered LDS tile, BARRIER, then its 16 x 16 block of
+//     dQ^T = K^T . dS^T over all 256 keys (8 MFMAs) -- stored at once, no accumulator survives the tile.
+// 40 MFMAs per wave and tile, one barrier per tile, ~100 KB of LDS, B*H workgroups.
 // =============================================================================================
-constexpr int FB_MAXT = 256, FB_NT = FB_MAXT / TR;
-constexpr int FB_TB = AT<bf16_t>::TILE_BYTES;
-constexpr int FB_Q = 0, FB_G = FB_NT * FB_TB, FB_K = 2 * FB_NT * FB_TB, FB_D = 3 * FB_NT * FB_TB, FB_STAT = FB_D + 2 * FB_TB;
-constexpr int FB_MASK = FB_STAT + 3 * FB_MAXT * 4;
-constexpr int FB_LDS_BYTES = FB_MASK + (FB_MAXT / 16) * FB_NT * 64 * 2;
+constexpr int HB_MAXT = 256, HB_QT = 32;
+constexpr int HB_RS = AT<bf16_t>::RS;                    // 144: row stride of the K / Q / dO images (bf16, 64 head dims + 16)
+constexpr int HB_RSD = HB_QT * 2 + 16;                   // 80: row stride of a dS^T image (32 queries + 16)
+constexpr int HB_K = 0;                                  // K image [256][144]
+constexpr int HB_QG = HB_K + HB_MAXT * HB_RS;            // two buffers of { Q tile [32][144] | dO tile [32][144] }
+constexpr int HB_QG_BUF = 2 * HB_QT * HB_RS;
+constexpr int HB_D = HB_QG + 2 * HB_QG_BUF;              // two dS^T images [256][80]
+constexpr int HB_D_BUF = HB_MAXT * HB_RSD;
+constexpr int HB_STAT = HB_D + 2 * HB_D_BUF;             // lse * log2(e) [256], delta [256]
+constexpr int HB_LDS_BYTES = HB_STAT + 2 * HB_MAXT * 4;
 
-__global__ void __launch_bounds__(256, 1) attn_bwd_fused_kernel(AttnParams p) {
+__global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
   typedef bf16_t T;
   typedef FragT<T>::type Frag;
-  extern __shared__ __attribute__((aligned(16))) char fsm[];
-  float* lss = reinterpret_cast<float*>(fsm + FB_STAT);   // lse * log2(e) of the queries (inf beyond Tq)
-  float* dls = lss + FB_MAXT;                             // delta
-  float* kbs = dls + FB_MAXT;                             // key term of the logits, log2 domain (-inf beyond Tk)
-  const uint16_t* mks = reinterpret_cast<const uint16_t*>(fsm + FB_MASK);
+  typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) char hsm[];
+  float* lss = reinterpret_cast<float*>(hsm + HB_STAT);
+  float* dls = lss + HB_MAXT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
   const int h = blockIdx.x, b = blockIdx.y;
@@ -762,173 +768,214 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_fused_kernel(AttnParams p) {
   const T* vb = (const T*)p.v + (int64_t)b * p.bsv + h * p.dh;
   const T* gb = (const T*)p.dout + (int64_t)b * p.Tq * p.ldo + h * p.dh;
   const int64_t bh = (int64_t)b * p.H + h;
-  const int nqt = (p.Tq + TR - 1) / TR, nkt = (p.Tk + TR - 1) / TR;
+  const int nqt = (p.Tq + HB_QT - 1) / HB_QT;
+  const int kw0 = wave * 32;                     // this wave's first key
 
-  // ---------------------------------------------------------------- prologue: the whole head into LDS
-  {
-    TileRegs<T> r0, r1;
-    for (int t = 0; t < nqt; ++t) {
-      tile_load<T, true>(r0, qb, p.ldq, t * TR, p.Tq, p.dh, tid);
-      tile_load<T, true>(r1, gb, p.ldo, t * TR, p.Tq, p.dh, tid);
-      tile_store<T>(fsm + FB_Q + t * FB_TB, r0, tid);
-      tile_store<T>(fsm + FB_G + t * FB_TB, r1, tid);
-    }
-    for (int t = 0; t < nkt; ++t) {
-      tile_load<T, true>(r0, kb, p.ldk, t * TR, p.Tk, p.dh, tid);
-      tile_store<T>(fsm + FB_K + t * FB_TB, r0, tid);
-    }
-    {
-      const int i = tid;   // 256 threads = FB_MAXT positions
-      const bool okq = i < p.Tq;
-      lss[i] = okq ? p.lse[bh * p.Tq + i] * LOG2E : INFINITY;
-      dls[i] = okq ? p.delta[bh * p.Tq + i] : 0.f;
-      kbs[i] = key_bias2(p, b, i);
-    }
-    if (p.drop_thresh) {
-      const int nwords = p.nqb * p.nkt * 32;   // u32 words of the head's keep bits
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(p.mask + bh * p.nqb * (int64_t)p.nkt * 64);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(fsm + FB_MASK);
-      for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
-    }
+  // Q / dO tile t: thread -> (which operand, row, 16-byte chunk); one chunk per thread
+  const int which = tid >> 8, crow = (tid & 255) >> 3, cchunk = tid & 7;
+  const T* qg_src = which ? gb : qb;
+  const int64_t qg_ld = which ? p.ldo : p.ldq;
+  auto qg_load = [&](int t) -> uint4 {
+    const int row = t * HB_QT + crow;
+    const bool ok = row < p.Tq && cchunk * 8 < p.dh;
+    const uint4 v = *reinterpret_cast<const uint4*>(ok ? qg_src + (int64_t)row * qg_ld + cchunk * 8 : qg_src);
+    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto qg_store = [&](int buf, const uint4& v) {
+    *reinterpret_cast<uint4*>(hsm + HB_QG + buf * HB_QG_BUF + which * (HB_QT * HB_RS) + crow * HB_RS + cchunk * 16) = v;
+  };
+
+  // ---------------------------------------------------------------- prologue
+  uint4 qg_next = qg_load(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {                  // K image: 256 rows x 8 chunks, 4 per thread (rows beyond Tk: zeros)
+    const int c = tid + s * 512, row = c >> 3, ch = c & 7;
+    const bool ok = row < p.Tk && ch * 8 < p.dh;
+    const uint4 v = *reinterpret_cast<const uint4*>(ok ? kb + (int64_t)row * p.ldk + ch * 8 : kb);
+    *reinterpret_cast<uint4*>(hsm + HB_K + row * HB_RS + ch * 16) = ok ? v : make_uint4(0u, 0u, 0u, 0u);
   }
-  // V fragments (B operand: column = key 16 w + lc, head dims s * 32 + g * 8 ..) straight from HBM, one key block ahead
-  auto load_vf = [&](int kbi, Frag (&dst)[2]) {
-    const int row = kbi * TR + wave * 16 + lc;
+  if (tid < HB_MAXT) {
+    lss[tid] = tid < p.Tq ? p.lse[bh * p.Tq + tid] * LOG2E : INFINITY;
+  } else {
+    const int i = tid - HB_MAXT;
+    dls[i] = i < p.Tq ? p.delta[bh * p.Tq + i] : 0.f;
+  }
+  Frag kf[2][2], vf[2][2];
+  float kb2[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {               // V fragments (B operand: column = key) straight from HBM
+    const int row = kw0 + mi * 16 + lc;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int col = s2 * 32 + g * 8;
       const bool ok = row < p.Tk && col < p.dh;
       const uint4 v = *reinterpret_cast<const uint4*>(ok ? vb + (int64_t)row * p.ldv + col : vb);
-      dst[s2] = __builtin_bit_cast(Frag, ok ? v : make_uint4(0u, 0u, 0u, 0u));
+      vf[mi][s2] = __builtin_bit_cast(Frag, ok ? v : make_uint4(0u, 0u, 0u, 0u));
     }
-  };
-  Frag vfn[2];
-  load_vf(0, vfn);
+    kb2[mi] = key_bias2(p, b, row);
+  }
+  qg_store(0, qg_next);
+  if (nqt > 1) qg_next = qg_load(1);
   __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) kf[mi][s2] = rc_frag<T>(hsm + HB_K, kw0 + mi * 16, s2 * AT<T>::KS, lane);
 
-  floatx4_t dq[FB_NT][4];
+  floatx4_t dk[2][4], dv[2][4];
 #pragma unroll
-  for (int t = 0; t < FB_NT; ++t)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) dq[t][f] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; ++f) { dk[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+
   const int mlane = g * 4 + 16 * (lc >> 2);
-  const int mbit = wave * 4 + (lc & 3);
-  const int roff = (g * 4 + (lc >> 2)) * AT<T>::RS + (lc & 3) * 8;   // transpose-read row / chunk of this lane
-  T* dkb = (T*)p.dk + (int64_t)b * p.bsk + h * p.dh;
-  T* dvb = (T*)p.dv + (int64_t)b * p.bsv + h * p.dh;
-  int buf = 0;
+  const int roff = g * 4 + (lc >> 2);            // transpose reads: this lane's row inside a 16-row half step ...
+  const int coff8 = (lc & 3) * 8;                // ... and its 8-byte chunk
+  const int fd_q = wave & 3, fq_q = wave >> 2;   // this wave's 16 x 16 block of dQ^T: head dims 16 fd_q .., queries 16 fq_q ..
+  T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
 
-  for (int kbi = 0; kbi < nkt; ++kbi) {
-    const int k0 = kbi * TR;
-    const char* Kt = fsm + FB_K + kbi * FB_TB;
-    Frag kf[1][2], vf[1][2];
+  // dropout keep words of tile t (two 16-query blocks x this wave's two 16-key blocks), loaded a tile ahead
+  uint2 mwn[2][2];
+  auto mask_load = [&](int t) {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      kf[0][s2] = rc_frag<T>(Kt, wave * 16, s2 * AT<T>::KS, lane);
-      vf[0][s2] = vfn[s2];
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        mwn[mi][f] = make_uint2(0xffffffffu, 0xffffffffu);
+        const int qblk = t * 2 + f, ktile = (kw0 + mi * 16) >> 6;
+        if (p.drop_thresh && qblk < p.nqb && ktile < p.nkt)
+          mwn[mi][f] = *reinterpret_cast<const uint2*>(p.mask + ((bh * p.nqb + qblk) * p.nkt + ktile) * 64 + mlane);
+      }
+  };
+  mask_load(0);
+
+  for (int t = 0; t < nqt; ++t) {
+    const int q0 = t * HB_QT, buf = t & 1;
+    const char* Qt = hsm + HB_QG + buf * HB_QG_BUF;
+    const char* Gt = Qt + HB_QT * HB_RS;
+    char* Dt = hsm + HB_D + buf * HB_D_BUF;
+    uint2 mwc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) mwc[mi][f] = mwn[mi][f];
+    if (t + 1 < nqt) mask_load(t + 1);
+    floatx4_t ls4[2], dl4[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      ls4[f] = *reinterpret_cast<const floatx4_t*>(lss + q0 + f * 16 + g * 4);
+      dl4[f] = *reinterpret_cast<const floatx4_t*>(dls + q0 + f * 16 + g * 4);
     }
-    if (kbi + 1 < nkt) load_vf(kbi + 1, vfn);
-    const int kblk0 = k0 + wave * 16, kg = kblk0 + lc;
-    const float kb2 = kbs[kg];
-    floatx4_t dk[1][4], dv[1][4];
+    // ---- S[q][key] = Q K^T and dP[q][key] = dO V^T for 32 queries x this wave's 32 keys
+    floatx4_t st[2][2], dp[2][2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { dk[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dv[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
-    const int qt_first = (p.causal && k0 > p.coff) ? (k0 - p.coff) / TR : 0;   // queries before the block's first key never see it
-
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int qt = 0; qt < FB_NT; ++qt) {
-      if (qt < nqt && qt >= qt_first) {   // workgroup-uniform
-        const int q0 = qt * TR;
-        const char* Qt = fsm + FB_Q + qt * FB_TB;
-        const char* Gt = fsm + FB_G + qt * FB_TB;
-        uint2 mwc[4];
+      for (int f = 0; f < 2; ++f) { st[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          mwc[f] = make_uint2(0xffffffffu, 0xffffffffu);
-          if (p.drop_thresh && (q0 >> 4) + f < p.nqb)
-            mwc[f] = *reinterpret_cast<const uint2*>(mks + (((q0 >> 4) + f) * p.nkt + kbi) * 64 + mlane);
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const Frag aq = rc_frag<T>(Qt, f * 16, s2 * AT<T>::KS, lane);
+        const Frag ag = rc_frag<T>(Gt, f * 16, s2 * AT<T>::KS, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          st[mi][f] = Mma<T>::run(aq, kf[mi][s2], st[mi][f]);
+          dp[mi][f] = Mma<T>::run(ag, vf[mi][s2], dp[mi][f]);
         }
-        floatx4_t ls4[4], dl4[4];
+      }
+    // ---- P, dropped P, scaled dS; dS^T of the wave's keys into the exchange image
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          ls4[f] = *reinterpret_cast<const floatx4_t*>(lss + q0 + f * 16 + g * 4);
-          dl4[f] = *reinterpret_cast<const floatx4_t*>(dls + q0 + f * 16 + g * 4);
-        }
-        floatx4_t st[1][4], dp[1][4];
+    for (int mi = 0; mi < 2; ++mi) {
+      const int kblk0 = kw0 + mi * 16, kg = kblk0 + lc;
+      const int mbit = ((kblk0 >> 4) & 3) * 4 + (lc & 3);
+      const bool diag = p.causal && (kblk0 + 15 > q0 + p.coff);
+      auto elems = [&](auto DIAG, auto DROP) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { st[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; dp[0][f] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int f = 0; f < 2; ++f) {
+          const uint2 mw = mwc[mi][f];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            const Frag aq = rc_frag<T>(Qt, f * 16, s2 * AT<T>::KS, lane);
-            const Frag ag = rc_frag<T>(Gt, f * 16, s2 * AT<T>::KS, lane);
-            st[0][f] = Mma<T>::run(aq, kf[0][s2], st[0][f]);
-            dp[0][f] = Mma<T>::run(ag, vf[0][s2], dp[0][f]);
-          }
-        const bool diag = p.causal && (kblk0 + 15 > q0 + p.coff);
-        auto elems = [&](auto DIAG, auto DROP) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            const uint2 mw = mwc[f];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pv = prob_exp2(fmaf(st[0][f][r], p.scale2, kb2 - ls4[f][r]));
-              if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r + p.coff)) pv = 0.f;
-              float keep = 1.f;
-              if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
-              st[0][f][r] = pv * keep;                                          // dropped P, feeds dV
-              dp[0][f][r] = pv * (keep * dp[0][f][r] - dl4[f][r]) * p.scale;      // dS (scaled), feeds dK and dQ
-            }
-          }
-        };
-        if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
-        else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
-        // dS^T[key][q] of this step: the lane's key row, 4 consecutive queries per 16-query block
-        char* Dt = fsm + FB_D + buf * FB_TB;
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-          *reinterpret_cast<uint2*>(Dt + (wave * 16 + lc) * AT<T>::RS + (f * 16 + g * 4) * 2) =
-              make_uint2(pack_bf16x2(dp[0][f][0], dp[0][f][1]), pack_bf16x2(dp[0][f][2], dp[0][f][3]));
-        tmul_acc<T, 1>(dv, st, Gt, lane);
-        tmul_acc<T, 1>(dk, dp, Qt, lane);
-        __syncthreads();   // every wave's key rows of dS^T are in the tile (the other buffer is free again two steps on)
-        {
-          typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            union { short4_t hh[2]; bf16x8_t f; } bfr;
-            const char* pb = Dt + roff + s2 * 32 * AT<T>::RS + wave * 32;
-            bfr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb));
-            bfr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pb + 16 * AT<T>::RS));
-#pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-              union { short4_t hh[2]; bf16x8_t f; } afr;
-              const char* pa = Kt + roff + s2 * 32 * AT<T>::RS + fd * 32;
-              afr.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa));
-              afr.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(pa + 16 * AT<T>::RS));
-              dq[qt][fd] = Mma<T>::run(afr.f, bfr.f, dq[qt][fd]);
-            }
+          for (int r = 0; r < 4; ++r) {
+            float pv = prob_exp2(fmaf(st[mi][f][r], p.scale2, kb2[mi] - ls4[f][r]));
+            if (decltype(DIAG)::value && (kg > q0 + f * 16 + g * 4 + r + p.coff)) pv = 0.f;
+            float keep = 1.f;
+            if (decltype(DROP)::value) keep = keep_mul(r < 2 ? mw.x : mw.y, (r & 1) * 16 + mbit, p.drop_inv_keep);
+            st[mi][f][r] = pv * keep;                                           // dropped P, feeds dV
+            dp[mi][f][r] = pv * (keep * dp[mi][f][r] - dl4[f][r]) * p.scale;     // dS (scaled), feeds dK and dQ
           }
         }
-        buf ^= 1;
+      };
+      if (p.drop_thresh) { if (diag) elems(std::true_type{}, std::true_type{}); else elems(std::false_type{}, std::true_type{}); }
+      else { if (diag) elems(std::true_type{}, std::false_type{}); else elems(std::false_type{}, std::false_type{}); }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        *reinterpret_cast<uint2*>(Dt + (kblk0 + lc) * HB_RSD + (f * 16 + g * 4) * 2) =
+            make_uint2(pack_bf16x2(dp[mi][f][0], dp[mi][f][1]), pack_bf16x2(dp[mi][f][2], dp[mi][f][3]));
+    }
+    // ---- dV^T[d][key] += dO^T[d][q] . P[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (one 32-query step)
+    {
+      bf16x8_t bp[2], bs[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        union { uint32_t u[4]; bf16x8_t f; } u0, u1;
+        u0.u[0] = pack_bf16x2(st[mi][0][0], st[mi][0][1]); u0.u[1] = pack_bf16x2(st[mi][0][2], st[mi][0][3]);
+        u0.u[2] = pack_bf16x2(st[mi][1][0], st[mi][1][1]); u0.u[3] = pack_bf16x2(st[mi][1][2], st[mi][1][3]);
+        u1.u[0] = pack_bf16x2(dp[mi][0][0], dp[mi][0][1]); u1.u[1] = pack_bf16x2(dp[mi][0][2], dp[mi][0][3]);
+        u1.u[2] = pack_bf16x2(dp[mi][1][0], dp[mi][1][1]); u1.u[3] = pack_bf16x2(dp[mi][1][2], dp[mi][1][3]);
+        bp[mi] = u0.f; bs[mi] = u1.f;
+      }
+      const char* gbase = Gt + roff * HB_RS + coff8;
+      const char* qbase = Qt + roff * HB_RS + coff8;
+#pragma unroll
+      for (int fd = 0; fd < 4; ++fd) {
+        union { short4_t hh[2]; bf16x8_t f; } ag, aq;
+        ag.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(gbase + fd * 32));
+        ag.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(gbase + fd * 32 + 16 * HB_RS));
+        aq.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(qbase + fd * 32));
+        aq.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(qbase + fd * 32 + 16 * HB_RS));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          dv[mi][fd] = Mma<T>::run(ag.f, bp[mi], dv[mi][fd]);
+          dk[mi][fd] = Mma<T>::run(aq.f, bs[mi], dk[mi][fd]);
+        }
       }
     }
+    // ---- the next tile's Q / dO go to the other buffer (every wave finished reading it before the previous barrier)
+    if (t + 1 < nqt) {
+      qg_store(buf ^ 1, qg_next);
+      if (t + 2 < nqt) qg_next = qg_load(t + 2);
+    }
+    __syncthreads();   // dS^T of all 256 keys (and the next Q / dO tile) are in LDS
+    // ---- dQ^T[d][q] = K^T[d][key] . dS^T[key][q] over the 256 keys: this wave's 16 head dims x 16 queries
+    {
+      floatx4_t dq = floatx4_t{0.f, 0.f, 0.f, 0.f};
+      const char* ka = hsm + HB_K + roff * HB_RS + coff8 + fd_q * 32;
+      const char* da = Dt + roff * HB_RSD + coff8 + fq_q * 32;
+#pragma unroll
+      for (int ks = 0; ks < HB_MAXT / 32; ++ks) {
+        union { short4_t hh[2]; bf16x8_t f; } af, bf;
+        af.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(ka + ks * 32 * HB_RS));
+        af.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(ka + ks * 32 * HB_RS + 16 * HB_RS));
+        bf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(da + ks * 32 * HB_RSD));
+        bf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(da + ks * 32 * HB_RSD + 16 * HB_RSD));
+        dq = Mma<T>::run(af.f, bf.f, dq);
+      }
+      const int qg = q0 + fq_q * 16 + lc;
+      if (qg < p.Tq) store_row4<T, true>(dqb + (int64_t)qg * p.ldq, fd_q * 16 + g * 4, p.dh, dq, 1.f);
+    }
+  }
+
+  T* dkb = (T*)p.dk + (int64_t)b * p.bsk + h * p.dh;
+  T* dvb = (T*)p.dv + (int64_t)b * p.bsv + h * p.dh;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int kg = kw0 + mi * 16 + lc;
     if (kg < p.Tk) {
 #pragma unroll
       for (int fd = 0; fd < 4; ++fd) {
-        store_row4<T, true>(dkb + (int64_t)kg * p.ldk, fd * 16 + g * 4, p.dh, dk[0][fd], 1.f);
-        store_row4<T, true>(dvb + (int64_t)kg * p.ldv, fd * 16 + g * 4, p.dh, dv[0][fd], 1.f);
+        store_row4<T, true>(dkb + (int64_t)kg * p.ldk, fd * 16 + g * 4, p.dh, dk[mi][fd], 1.f);
+        store_row4<T, true>(dvb + (int64_t)kg * p.ldv, fd * 16 + g * 4, p.dh, dv[mi][fd], 1.f);
       }
-    }
-  }
-  T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
-#pragma unroll
-  for (int qt = 0; qt < FB_NT; ++qt) {
-    const int qg = qt * TR + wave * 16 + lc;
-    if (qg < p.Tq) {
-#pragma unroll
-      for (int fd = 0; fd < 4; ++fd) store_row4<T, true>(dqb + (int64_t)qg * p.ldq, fd * 16 + g * 4, p.dh, dq[qt][fd], 1.f);
     }
   }
 }
@@ -1180,19 +1227,16 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
     }
     NST_CHECK_LAUNCH("attention_bwd(delta)");
   }
-  // short sequences in bf16: the whole head in LDS, dK / dV / dQ from one kernel, no dS^T round trip through HBM.
-  // NST_ATTN_FUSED_BWD=1 selects it; OFF by default: stand-alone it is 4 % faster than the two kernels (encoder shape 82.6 vs
-  // 86.1 us, scripts/attn_bench.py), but its 140 KB of LDS keep the weight-gradient stream's workgroups off its CUs and the
-  // step gets SLOWER (15.15 -> 15.30 ms, gpurun_out/r03_ab_attn_fused_bwd.log).  One wave per SIMD walking 16 dependent
-  // steps is latency-bound; the next thing to try is two wave groups per workgroup on alternate query tiles.
-  if (d->dtype == NST_BF16 && vec && d->Tq <= FB_MAXT && d->Tk <= FB_MAXT && env_int("NST_ATTN_FUSED_BWD", 0) != 0) {
+  // sequences up to 256 in bf16: one 8-wave workgroup per (batch, head) -- dK / dV / dQ from one kernel, no dS^T round trip
+  // through HBM (attn_bwd_head8_kernel).  NST_ATTN_FUSED_BWD=0: the two-kernel path (the test matrix runs both)
+  if (d->dtype == NST_BF16 && vec && d->Tq <= HB_MAXT && d->Tk <= HB_MAXT && env_int("NST_ATTN_FUSED_BWD", 1) != 0) {
     static bool lds_ok = false;
     if (!lds_ok) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_head8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS_BYTES);
       lds_ok = true;
     }
-    attn_bwd_fused_kernel<<<dim3(d->H, d->B), 256, FB_LDS_BYTES, st>>>(p);
-    NST_CHECK_LAUNCH("attention_bwd(fused)");
+    attn_bwd_head8_kernel<<<dim3(d->H, d->B), 512, HB_LDS_BYTES, st>>>(p);
+    NST_CHECK_LAUNCH("attention_bwd(head8)");
     return NST_OK;
   }
   const int mik = pick_mi("NST_ATTN_MI_DKDV", d->Tk, (int64_t)d->B * d->H, false);

@@ -2240,7 +2240,7 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
     ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
     ga.rowmap = IdentityRowMap();
     ga.z_per_xcd = zx ? 1 : 0;
-    ga.split_issue = 0;
+    ga.reserved0 = 0;
     const int units = ntiles * split;
     auto kfn = conv2_wgrad_kernel_v3<T>;
     conv_allow_big_lds(kfn, V3_LDS_BYTES);

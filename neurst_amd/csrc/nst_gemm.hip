@@ -44,20 +44,13 @@ dense_gemm_kernel_v3ks(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, 
 }
 
 
-// 256 x 256 tile, eight waves in two phase-staggered groups (nst_gemm256.h)
-template <typename OutT, int AMODE, int BMODE, bool CS, int EF, int DBG = 0>
-__global__ void __launch_bounds__(G256_THREADS, 2)
-dense_gemm256_kernel(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  (void)args;
-  gemm256_block<OutT, AMODE, BMODE, IdentityRowMap, CS, EF, DBG>(smem_dyn);
-}
-
-template <int DBG>
+// 256 x 256 tiles, eight waves in two phase-staggered groups (nst_gemm256.h): nst_gemm_wgrad_group.  A SINGLE weight gradient
+// stays on the 128 x 128 stream kernel: alone it needs 32 K slices to fill the chip with 256 x 256 tiles, and their slabs cost
+// more than the tile saves (ffn1: 68 us against 53; profiles/r04_history/c1_g256_new.json / c1_g256_old.json).
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_group_kernel(G256GroupArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   (void)args;
-  gemm256_group_block<DBG>(smem_dyn);
+  gemm256_group_block(smem_dyn);
 }
 
 // copies a by-value chunk of the product table into device memory (tables of more than G256_MAX_PROBLEMS products)
@@ -66,66 +59,6 @@ __global__ void __launch_bounds__(256) g256_table_write_kernel(G256GroupArgs chu
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&chunk.p[0]);
   uint32_t* d = reinterpret_cast<uint32_t*>(dst);
   for (int i = threadIdx.x; i < nw; i += blockDim.x) d[i] = src[i];
-}
-
-// NST_GEMM256: 0 (default) = a single nst_gemm weight gradient stays on the 128 x 128 stream kernel -- stand-alone it needs
-// 32 K slices to fill the chip with 256 x 256 tiles and the slabs cost more than the tile saves (profiles/r04_g256_*.json);
-// the 256 x 256 kernel is reached through nst_gemm_wgrad_group (many products, no split).  1 = also single weight gradients of
-// at least 256 x 256 outputs (the measurement above); 11 / 12 / 14 = timing ablations of the kernel (results wrong)
-int g256_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM256"); v = e ? atoi(e) : 0; }
-  return v;
-}
-// the shapes nst_gemm sends to the 256 x 256 kernel (operand alignment is checked again at launch)
-bool g256_shape(const NstGemmDesc* d) {
-  return g256_mode() != 0 && d->in_dtype == NST_BF16 && d->out_dtype == NST_F32 && d->trans_a && !d->trans_b && d->M >= 256 &&
-         d->N >= 256 && d->alpha == 1.0f && !d->bias && !d->relu && d->dropout_p == 0.f && !d->residual && !d->gate_src &&
-         !d->posenc && !d->rowdot_dst;
-}
-
-// NST_GEMM_KS=1 (opt-in): the weight gradients of at most one workgroup per CU (units <= CUs, >= 4 K steps per unit) on the
-// eight-wave form.  Measured: ffn weight gradients 59.2 -> 55.5 us stand-alone, the step 14.90 -> 15.00 ms (worse): all eight
-// waves still issue their loads FIRST and multiply AFTER every barrier, so the two phases do not overlap any better than with
-// four waves (the decoder's 150-unit GEMMs and the logits' input gradient did not move at all when this form was tried on
-// them: 27.0 / 100.2 us either way) -- profiles/r03_history/r03_small_experiments.log.
-bool ks_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_KS"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
-  }
-  return cus;
-}
-
-// the weight-gradient form (reduction-major bf16 operands, f32 output): five half-step slots in the same 80 KB
-template <bool CS, int EF, int SLOTS = 5, int DBG = 0>
-__global__ void __launch_bounds__(THREADS, 2)
-dense_wgrad_ring_kernel(GemmArgs<float, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  (void)args;
-  gemm_stream_v3_ring<float, IdentityRowMap, CS, EF, SLOTS, DBG>(smem_dyn);
-}
-
-// NST_GEMM_RING=5 (3, 4): the weight gradients on the ring of five (three, four) half-step slots; 5x: its timing ablations.
-// Default 0 = the two-stage stream kernel: the ring measured SLOWER (ffn1 weight gradient 59.5 -> 81 us, step +0.2 ms,
-// profiles/r03_history/r03_wgrad_ring_ablation.log) -- a deeper ring does not buy what the issue of the loads costs.
-int wgrad_ring() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_RING"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
-bool specialised_epilogues() {   // NST_GEMM_GENERIC_EPI=1: the runtime-flag kernels only (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_GENERIC_EPI"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
 }
 
 // the stages an Epilogue asks for, as an EF_* mask; -1 when a stage has no compile-time form (alpha, atomics, scalar stores)
@@ -259,22 +192,10 @@ DenseLoader<T> make_loader(const void* base, int64_t ld, int mode, int out_exten
   return l;
 }
 
-bool zxcd_enabled() {  // split-K slices pinned to XCDs (gemm_stream_v3 unit_of)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_ZXCD"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-
 bool use_tr() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
   return v == 1;
-}
-
-// g256_shape + what the LDS-DMA loaders need of the operands (16-byte aligned rows, 8-element granular extents)
-bool g256_launchable(const NstGemmDesc* d, const void* A, const void* B) {
-  return g256_shape(d) && use_v2() && use_tr() && nst_aligned16(A) && nst_aligned16(B) && (d->lda * 2) % 16 == 0 &&
-         (d->ldb * 2) % 16 == 0 && d->M % 8 == 0 && d->N % 8 == 0;
 }
 
 template <typename T, typename OutT>
@@ -290,37 +211,6 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   if (split > kt_total) split = kt_total;
   if (split < 1) split = 1;
   const bool tr = use_tr();
-  if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
-    // weight gradients (both operands reduction-major, f32 slabs or in place) on 256 x 256 tiles
-    const int em256 = epilogue_mask(ep);
-    if (g256_launchable(d, A, B) && (em256 == 0 || em256 == EF_ACCUM)) {
-      const int t_m = (d->M + 255) / 256, t_n = (d->N + 255) / 256, nt = t_m * t_n;
-      const int kt_per_split = (kt_total + split - 1) / split;   // (unused by the kernel: it cuts kt_total into `split` even slices)
-      GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
-      ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
-      ga.tiles_n = t_n; ga.ntiles = nt; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
-      ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0) ? 1 : 0;
-      ga.split_issue = 0;
-      dim3 g(nt * split, 1, 1);
-#define NST_G256(CS_, EF_, DBG_)                                                                                       \
-  do {                                                                                                               \
-    auto kfn = dense_gemm256_kernel<OutT, MODE_OC, MODE_OC, CS_, EF_, DBG_>;                                          \
-    allow_big_lds(kfn, G256_LDS_BYTES);                                                                              \
-    kfn<<<g, G256_THREADS, G256_LDS_BYTES, st>>>(ga);                                                                \
-  } while (0)
-      const int mode = g256_mode();
-      if (mode == 11 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 1); return 0; }
-      if (mode == 12 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 2); return 0; }
-      if (mode == 14 && em256 == 0 && ep.colsum_dst) { NST_G256(true, 0, 4); return 0; }
-      if (ep.colsum_dst) {
-        if (em256 == 0) NST_G256(true, 0, 0); else NST_G256(true, EF_ACCUM, 0);
-      } else {
-        if (em256 == 0) NST_G256(false, 0, 0); else NST_G256(false, EF_ACCUM, 0);
-      }
-#undef NST_G256
-      return 0;
-    }
-  }
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
@@ -330,11 +220,8 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
     GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
     ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
     ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
-    ga.z_per_xcd = (zxcd_enabled() && split >= 8 && split % 8 == 0 && g3.x % 8 == 0) ? 1 : 0;
-    // NST_GEMM_SPLIT_ISSUE=1: next step's DMA in two halves between the MFMA groups.  Measured WORSE here (two workgroups per
-    // CU already cover each other's issue time): ffn2 forward 37.2 -> 40.3 us, step +0.15 ms (r03_ab_split_issue.log); off.
-    { static int si = -1; if (si < 0) { const char* e = getenv("NST_GEMM_SPLIT_ISSUE"); si = (e && e[0] == '1') ? 1 : 0; } ga.split_issue = si; }
-    const bool use_ks = sizeof(T) == 2 && ks_enabled() && units <= device_cus() && kt_per_split >= 4;
+    ga.z_per_xcd = (split >= 8 && split % 8 == 0 && g3.x % 8 == 0) ? 1 : 0;
+    ga.reserved0 = 0;
 #define NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_)                                                                          \
   do {                                                                                                               \
     auto kfn = dense_gemm_kernel_v3<T, OutT, AM, BMO, CS_, EF_>;                                                      \
@@ -344,7 +231,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
 #define NST_GEMM_LAUNCH3(AM, BMO, CS_) NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_GENERIC)
     // Specialised instantiations: the epilogue configurations a training step of the Transformer models actually issues
     // (enumerated by tracing a step; everything else takes the generic kernel below).
-    const int em = (sizeof(T) == 2 && specialised_epilogues()) ? epilogue_mask(ep) : -1;
+    const int em = sizeof(T) == 2 ? epilogue_mask(ep) : -1;
     if (em >= 0) {
       if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
         if (amode == MODE_RC && bmode == MODE_OC && !ep.colsum_dst) {   // forward projections: x [M,K] . W [K,N]
@@ -372,43 +259,6 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
         }
       }
       if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
-#define NST_GEMM_LAUNCH_RING(CS_, EF_)                                                                                 \
-  do {                                                                                                               \
-    auto kfn = dense_wgrad_ring_kernel<CS_, EF_>;                                                                     \
-    allow_big_lds(kfn, V3_LDS_BYTES);                                                                                 \
-    kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga);                                                                       \
-  } while (0)
-        if (amode == MODE_OC && bmode == MODE_OC && wgrad_ring() != 0 && kt_per_split >= 4) {
-          if (ep.colsum_dst) {
-#define NST_RING_DBG(V, D) if (em == 0 && wgrad_ring() == V) { auto kfn = dense_wgrad_ring_kernel<true, 0, 5, D>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
-            NST_RING_DBG(51, 1) NST_RING_DBG(52, 2) NST_RING_DBG(54, 4) NST_RING_DBG(58, 8) NST_RING_DBG(53, 3) NST_RING_DBG(55, 5) NST_RING_DBG(57, 7) NST_RING_DBG(515, 15)
-#undef NST_RING_DBG
-            if (em == 0 && wgrad_ring() == 3) { auto kfn = dense_wgrad_ring_kernel<true, 0, 3>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
-            if (em == 0 && wgrad_ring() == 4) { auto kfn = dense_wgrad_ring_kernel<true, 0, 4>; allow_big_lds(kfn, V3_LDS_BYTES); kfn<<<g3, THREADS, V3_LDS_BYTES, st>>>(ga); return 0; }
-            if (em == 0) { NST_GEMM_LAUNCH_RING(true, 0); return 0; }
-            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_RING(true, EF_ACCUM); return 0; }
-          } else {
-            if (em == 0) { NST_GEMM_LAUNCH_RING(false, 0); return 0; }
-            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_RING(false, EF_ACCUM); return 0; }
-          }
-        }
-#undef NST_GEMM_LAUNCH_RING
-#define NST_GEMM_LAUNCH_KS(AM, BMO, CS_, EF_)                                                                          \
-  do {                                                                                                               \
-    auto kfn8 = dense_gemm_kernel_v3ks<OutT, AM, BMO, CS_, EF_>;                                                       \
-    allow_big_lds(kfn8, V3_LDS_BYTES);                                                                                 \
-    kfn8<<<g3, 512, V3_LDS_BYTES, st>>>(ga);                                                                           \
-  } while (0)
-        if (amode == MODE_OC && bmode == MODE_OC && use_ks) {           // (opt-in) eight-wave form of the weight gradients
-          if (ep.colsum_dst) {
-            if (em == 0) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, true, 0); return 0; }
-            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, true, EF_ACCUM); return 0; }
-          } else {
-            if (em == 0) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, false, 0); return 0; }
-            if (em == EF_ACCUM) { NST_GEMM_LAUNCH_KS(MODE_OC, MODE_OC, false, EF_ACCUM); return 0; }
-          }
-        }
-#undef NST_GEMM_LAUNCH_KS
         if (amode == MODE_OC && bmode == MODE_OC) {                     // weight gradients: x^T . dz, slabs or in place
           if (ep.colsum_dst) {
             if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, 0); return 0; }
@@ -525,19 +375,10 @@ extern "C" int nst_gemm_wgrad_group(const NstGemmDesc* descs, const void* const*
   ga.nunits = units;
   ga.ext = ext ? (const G256Problem*)workspace : nullptr;
   const int grid = (units + 63) / 64 * 64;
-  const int mode = g256_mode();
-#define NST_G256G(DBG_) do { auto kfn = gemm256_group_kernel<DBG_>; allow_big_lds(kfn, G256_LDS_BYTES); kfn<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(ga); } while (0)
-  if (mode == 11) NST_G256G(1);
-  else if (mode == 12) NST_G256G(2);
-  else if (mode == 14) NST_G256G(4);
-  else NST_G256G(0);
-#undef NST_G256G
+  allow_big_lds(gemm256_group_kernel, G256_LDS_BYTES);
+  gemm256_group_kernel<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(ga);
   NST_CHECK_LAUNCH("gemm_wgrad_group");
   return NST_OK;
-}
-
-extern "C" int nst_gemm_tile(const NstGemmDesc* d) {
-  return (d && g256_shape(d) && use_v2() && use_tr()) ? G256_TILE : BM;
 }
 
 extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void* C, void* stream) {
@@ -622,10 +463,8 @@ extern "C" int nst_gemm(const NstGemmDesc* d, const void* A, const void* B, void
                   "gemm: split_k supports only the plain alpha*A*B (+accumulate) epilogue");
     const int kt_total = (d->K + (d->in_dtype == NST_BF16 ? 64 : 32) - 1) / (d->in_dtype == NST_BF16 ? 64 : 32);
     if (split > kt_total) split = kt_total;
-    if (!g256_launchable(d, A, B)) {   // (the 256 x 256 kernel cuts the K steps into exactly `split` even slices)
-      const int kps = (kt_total + split - 1) / split;
-      split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
-    }
+    const int kps = (kt_total + split - 1) / split;
+    split = (kt_total + kps - 1) / kps;  // the split count launch() will actually use
     const int64_t need = (int64_t)split * d->M * d->N * 4 + (cs_fused ? (int64_t)split * d->N * 4 : 0);
     const bool slab = split > 1 && d->workspace && d->workspace_bytes >= need && nst_aligned16(d->workspace) &&
                       (d->N % 4 == 0) && ((d->ldc * 4) % 16 == 0) && nst_aligned16(C);

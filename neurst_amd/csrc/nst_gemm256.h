@@ -346,58 +346,6 @@ __device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int
 
 }
 
-// One product per launch (nst_gemm): unit = (K slice z, tile) of GemmArgs.
-template <typename OutT, int AMODE, int BMODE, typename RowMap, bool CS, int EF, int DBG = 0>
-__device__ __forceinline__ void gemm256_block(char* smem) {
-  typedef bf16_t T;
-  typedef DenseLoader<T> Loader;
-  typedef GemmArgs<OutT, Loader, Loader, RowMap> Args;
-  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  int z, tile;
-  splitk_unit(blockIdx.x, ka->ntiles, ka->z_per_xcd, z, tile);
-  const int tiles_n = ka->tiles_n;
-  const int tm = tile / tiles_n;
-  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
-  // K slice z of `split`: steps [kt_total * z / split, kt_total * (z + 1) / split) -- every slice holds floor or ceil of the
-  // mean, so ANY split <= kt_total yields exactly `split` non-empty slices (the 128 x 128 kernels round the count instead)
-  const int kt_total = (ka->K + 63) >> 6, split = ka->split;
-  const int kt_first = (int)(((int64_t)kt_total * z) / split);
-  const int nk = (int)(((int64_t)kt_total * (z + 1)) / split) - kt_first;
-  const bool do_cs = CS && ka->ep.colsum_dst != nullptr && m0 == 0 && wr == 0;   // wave-uniform
-  floatx4_t acc[2][4][4], cs[4];
-  {
-    const Loader la = kload(&ka->la), lb = kload(&ka->lb);
-    Dma256<AMODE> da;
-    Dma256<BMODE> db;
-    da.init(la, m0, kt_first * 64, wave, lane);
-    db.init(lb, n0, kt_first * 64, wave, lane);
-    gemm256_mainloop<AMODE, BMODE, CS, DBG>(smem, da, db, nk, do_cs, acc, cs);
-  }
-
-  // ---- epilogue: each 64 x 64 quarter through the v3 epilogue (4 KB wave-private staging in the dead stage buffers)
-  const NST_AS4 Args* k2 = launder(ka);
-  Epilogue ep = kload(&k2->ep);
-  if (ef_on<EF, EF_DROP>(ep.drop_thresh != 0)) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);
-  const RowMap rowmap = kload(&k2->rowmap);
-  const int M = k2->M, N = k2->N;
-  if (CS && do_cs && lane < 16) {   // every row of cs holds the column sums; lane = column within the 16-block
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + lane;
-      if (col < N) {
-        float* dst = ep.colsum_dst + (int64_t)z * ep.colsum_zstride + col;
-        *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
-      }
-    }
-  }
-  float* epi = reinterpret_cast<float*>(smem + wave * V3_EPI_BYTES_PER_WAVE);
-  OutT* Cz = k2->C + (int64_t)z * ep.slab_stride;
-  epilogue_v3<OutT, RowMap, EF>(acc[0], epi, Cz, k2->ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
-  epilogue_v3<OutT, RowMap, EF>(acc[1], epi, Cz, k2->ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
-}
-
 // -----------------------------------------------------------------------------------------------------------------------
 // Grouped weight gradients: MANY products dW_p[M_p, N_p] (+)= X_p^T . dZ_p (both operands reduction-major bf16, f32 output)
 // in ONE launch.  The weight gradients of a layer stack do not feed the backward chain, so they can all wait until the stack
@@ -429,7 +377,6 @@ struct G256GroupArgs {
   G256Problem p[G256_MAX_PROBLEMS];
 };
 
-template <int DBG = 0>
 __device__ __forceinline__ void gemm256_group_block(char* smem) {
   typedef bf16_t T;
   typedef DenseLoader<T> Loader;
@@ -466,7 +413,7 @@ __device__ __forceinline__ void gemm256_group_block(char* smem) {
     Dma256<MODE_OC> da, db;
     da.init(la, m0, 0, wave, lane);
     db.init(lb, n0, 0, wave, lane);
-    gemm256_mainloop<MODE_OC, MODE_OC, true, DBG>(smem, da, db, (Kd + 63) >> 6, do_cs, acc, cs);
+    gemm256_mainloop<MODE_OC, MODE_OC, true>(smem, da, db, (Kd + 63) >> 6, do_cs, acc, cs);
   }
   asm volatile("" ::: "memory");
   const NST_AS4 G256Problem* p2 = launder(pp);

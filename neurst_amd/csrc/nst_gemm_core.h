@@ -613,72 +613,6 @@ struct DenseDma {
     }
     ++t_next;
   }
-  // Half of a K step (OC tiles only: reduction rows [32 h, 32 h + 32) of the step are pieces s = 2h, 2h + 1 of every wave,
-  // i.e. one contiguous half of the stage image).  half_lds_addr = LDS address of THAT half (8 KB); the wave's two pieces go
-  // to half + wave * 1 KB and + 4 KB.  The cursors advance after the second half.
-  template <int h>
-  __device__ __forceinline__ void next_half(uint32_t half_lds_addr, int wave) {
-    static_assert(MODE == MODE_OC || sizeof(T) == 0, "half steps are contiguous for reduction-major tiles only");
-    if (t_next < n_fast) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_add_u32 m0, m0, 0x1000\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(h ? p[2] : p[0]), "v"(h ? p[3] : p[1]), "s"(half_lds_addr + (uint32_t)wave * 1024u)
-          : "memory", "scc");
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int s = 2 * h + q;
-        const bool ok = ovalid[s] && (kvalid_base[s] + t_next * Tile<T>::BK) < k_limit;
-        const void* src = ok ? (const void*)p[s] : (const void*)g_nst_zero16;
-        glds16(src, __builtin_amdgcn_readfirstlane(half_lds_addr + (uint32_t)((q * 4 + wave) * 64) * 16u));
-      }
-    }
-    if (h) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) p[s] += step_bytes;
-      ++t_next;
-    }
-  }
-  // Eight-wave form of next(): the wave issues pieces 2h, 2h + 1 of the step (the other wave group issues the other two) and
-  // advances ONLY those cursors.  tile_lds_addr = LDS address of the operand tile (16 KB); `wave` = wave & 3.
-  template <int h>
-  __device__ __forceinline__ void next_mine(uint32_t tile_lds_addr, int wave) {
-    if (t_next < n_fast) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_add_u32 m0, m0, 0x1000\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %2, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(p[2 * h]), "v"(p[2 * h + 1]), "s"(tile_lds_addr + (uint32_t)(h * 8192) + (uint32_t)wave * 1024u)
-          : "memory", "scc");
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int s = 2 * h + q;
-        const bool ok = ovalid[s] && (kvalid_base[s] + t_next * Tile<T>::BK) < k_limit;
-        const void* src = ok ? (const void*)p[s] : (const void*)g_nst_zero16;
-        glds16(src, __builtin_amdgcn_readfirstlane(tile_lds_addr + (uint32_t)((s * 4 + wave) * 64) * 16u));
-      }
-    }
-    p[2 * h] += step_bytes;
-    p[2 * h + 1] += step_bytes;
-    ++t_next;
-  }
   // issue the DMA of K step `t` (relative to the r0 given to init) into the stage at tile_lds_addr
   __device__ __forceinline__ void issue(int t, uint32_t tile_lds_addr, int wave) const {
 #pragma unroll
@@ -1203,7 +1137,7 @@ struct GemmArgs {
   int64_t ldc;
   int M, N, K, tiles_n, ntiles, split, kt_per_split;
   int z_per_xcd;   // != 0 (needs split % 8 == 0, grid % 8 == 0): K slice z lives on XCD z % 8, see unit_of
-  int split_issue; // != 0: the next step's DMA is issued in two halves between the MFMA groups (0: in front of the step; A/B switch)
+  int reserved0;
   Epilogue ep;
   RowMap rowmap;
 };
@@ -1326,10 +1260,7 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
     wait_vmcnt<0>();                 // the K step about to be multiplied has landed (and older stores have retired)
     __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is also done reading the other stage
     asm volatile("" ::: "memory");
-    const bool split_issue = (BK / KS == 2) && ka->split_issue != 0;
-    const bool more_now = iu < units;
-    if (!split_issue && more_now) issue_next(stage ^ 1);
-    const bool more = split_issue && more_now;
+    if (iu < units) issue_next(stage ^ 1);
     const char* As = smem + stage * V2_STAGE_BYTES;
     const char* Bs = As + BM * KBYTES;
     const bool do_cs = has_cs && cq.m0 == 0 && wm == 0;  // wave-uniform
@@ -1346,8 +1277,6 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1[i] = RA::read(As, wm + i * 16, KS, lane);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) issue_a(stage ^ 1);     // the next step's A tile: its issue runs under the fragment reads' latency
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1356,9 +1285,6 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b0[j], cs[j]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) issue_b(stage ^ 1);     // ... and its B tile behind the first 16 MFMAs (they run while the wave issues the DMA)
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1405,378 +1331,6 @@ __device__ __forceinline__ void gemm_stream_v3(char* smem) {
       }
       epilogue_v3<OutT, RowMap, EF>(acc, reinterpret_cast<float*>(smem + 2 * V2_STAGE_BYTES + wave * V3_EPI_BYTES_PER_WAVE),
                                 k2->C + (int64_t)cq.z * ep.slab_stride, k2->ldc, M, N, cq.m0 + wm, cq.n0 + wn, ep, rowmap, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-      cu += gridDim.x;
-      if (cu >= units) break;
-      cq = unit_of(cu);
-      ckt = 0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Weight-gradient form of the stream kernel (both operands reduction-major, bf16): a ring of FIVE half steps.
-//
-// dW = x^T . dz reduces over tens of thousands of rows that come from HBM, and the two-stage kernel above has ONE K step
-// (32 KB) in flight per workgroup: a step cannot start before the load issued one step earlier has crossed the fabric, so a
-// step takes the memory latency (1.6 us per 64 rows stand-alone on qkv / 288 units) however little MFMA work it holds
-// (0.2 us of a CU).  With reduction-major tiles the two 32-row halves of a stage are contiguous, so the same 80 KB hold five
-// half-step slots of 16 KB ([A half 8 KB | B half 8 KB]): four half steps (64 KB per workgroup, 128 KB per CU) are in
-// flight while the fifth is multiplied, and a load has four multiply phases to arrive.  One barrier per half step (16
-// MFMAs per wave); the unit's epilogue stages through the slot it just finished reading (one more barrier per unit).
-// DBG (timing ablations, results are wrong): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no barriers
-template <typename OutT, typename RowMap, bool CS, int EF, int SLOTS = 5, int DBG = 0>
-__device__ __forceinline__ void gemm_stream_v3_ring(char* smem) {
-  typedef bf16_t T;
-  typedef DenseLoader<T> Loader;
-  typedef GemmArgs<OutT, Loader, Loader, RowMap> Args;
-  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
-  typedef SwzFrag<T, MODE_OC> RF;
-  constexpr int BK = Tile<T>::BK;
-  constexpr int SLOT_BYTES = V2_STAGE_BYTES / 2, HALF_BYTES = SLOT_BYTES / 2;
-  static_assert(SLOTS * SLOT_BYTES <= V3_LDS_BYTES && 4 * V3_EPI_BYTES_PER_WAVE <= SLOT_BYTES, "ring fits the v3 allocation");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int ntiles = ka->ntiles, tiles_n = ka->tiles_n, kt_per_split = ka->kt_per_split;
-  const int kt_total = (ka->K + BK - 1) / BK;
-  const int units = ntiles * ka->split;
-  const bool has_cs = CS && ka->ep.colsum_dst != nullptr;
-  const int zx = ka->z_per_xcd;
-  struct Unit { int m0, n0, z, kt_first, kt_count; };
-  auto unit_of = [&](int u) {   // as gemm_stream_v3
-    Unit q;
-    int tile;
-    if (zx) {
-      const int idx = u >> 3, sl = idx / ntiles;
-      q.z = (u & 7) + 8 * sl;
-      tile = idx - sl * ntiles;
-    } else {
-      q.z = u / ntiles;
-      tile = xcd_remap(u - q.z * ntiles, ntiles);
-    }
-    const int tm = tile / tiles_n;
-    q.m0 = tm * BM;
-    q.n0 = (tile - tm * tiles_n) * BN;
-    q.kt_first = q.z * kt_per_split;
-    q.kt_count = kt_total - q.kt_first;
-    if (q.kt_count > kt_per_split) q.kt_count = kt_per_split;
-    return q;
-  };
-
-  floatx4_t acc[4][4], cs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-  const typename RF::Frag ones = ones_frag<T>();
-
-  // ---- issue side: unit iu, K step ikt, half ih; slot islot
-  int iu = blockIdx.x;
-  if (iu >= units) return;
-  int ikt = 0, ikt_count, ih = 0, islot = 0;
-  DenseDma<T, MODE_OC> da, db;
-  auto cursor_init = [&](int u) {
-    const NST_AS4 Args* k2 = launder(ka);
-    const Loader la_cur = kload(&k2->la), lb_cur = kload(&k2->lb);
-    const Unit q = unit_of(u);
-    ikt_count = q.kt_count;
-    da.init(la_cur, q.m0, q.kt_first * BK, wave, lane);
-    db.init(lb_cur, q.n0, q.kt_first * BK, wave, lane);
-    da.begin(q.kt_count);
-    db.begin(q.kt_count);
-  };
-  cursor_init(iu);
-  bool prologue_done = false;
-  auto issue_half = [&]() {   // (iu < units)
-    const uint32_t base = smem_addr + (uint32_t)islot * SLOT_BYTES;
-    islot = islot + 1 == SLOTS ? 0 : islot + 1;
-    const bool dma = (DBG & 2) == 0 || !prologue_done;
-    if (ih == 0) {   // (wave-uniform; the half is a template argument: a runtime index would put the cursors in scratch)
-      if (dma) {
-        da.template next_half<0>(base, wave);
-        db.template next_half<0>(base + HALF_BYTES, wave);
-      }
-      ih = 1;
-    } else {
-      if (dma) {
-        da.template next_half<1>(base, wave);
-        db.template next_half<1>(base + HALF_BYTES, wave);
-      }
-      ih = 0;
-      if (++ikt == ikt_count) {
-        iu += gridDim.x;
-        ikt = 0;
-        if (iu < units) cursor_init(iu);
-      }
-    }
-  };
-  int inflight = 0;   // half steps issued and not yet multiplied (wave-uniform)
-#pragma unroll 1
-  for (int s = 0; s < SLOTS - 1 && iu < units; ++s) { issue_half(); ++inflight; }
-  prologue_done = true;
-
-  // ---- multiply side
-  int cu = blockIdx.x;
-  Unit cq = unit_of(cu);
-  int chalf = 0, cslot = 0;   // half steps of cu multiplied so far
-  while (true) {
-    // the oldest half step in flight has landed: every issue is 4 DMA instructions per wave, completed in order
-    if (inflight >= 4) wait_vmcnt<12>();
-    else if (inflight == 3) wait_vmcnt<8>();
-    else if (inflight == 2) wait_vmcnt<4>();
-    else wait_vmcnt<0>();
-    if constexpr ((DBG & 8) == 0) __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is also done reading the slot refilled below
-    asm volatile("" ::: "memory");
-    const char* As = smem + cslot * SLOT_BYTES;
-    const char* Bs = As + HALF_BYTES;
-    typename RF::Frag a[4], b[4];
-    if constexpr ((DBG & 4) != 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { b[j] = ones; a[j] = ones; }
-    } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = RF::read(Bs, wn + j * 16, 0, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = RF::read(As, wm + i * 16, 0, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (iu < units) issue_half(); else --inflight;   // refills the slot multiplied in the previous iteration
-    __builtin_amdgcn_sched_barrier(0);
-    const bool do_cs = has_cs && cq.m0 == 0 && wm == 0;  // wave-uniform
-    if constexpr ((DBG & 1) != 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(a[j])); asm volatile("" ::"v"(b[j])); }
-    } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
-    }
-    if (CS && do_cs && (DBG & 1) == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b[j], cs[j]);
-    }
-    const int eslot = cslot;
-    cslot = cslot + 1 == SLOTS ? 0 : cslot + 1;
-    if (++chalf == 2 * cq.kt_count) {
-      const NST_AS4 Args* k2 = launder(ka);
-      Epilogue ep = kload(&k2->ep);
-      const RowMap rowmap = kload(&k2->rowmap);
-      const int M = k2->M, N = k2->N;
-      if (CS && do_cs && lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = cq.n0 + wn + j * 16 + lane;
-          if (col < N) {
-            float* dst = ep.colsum_dst + (int64_t)cq.z * ep.colsum_zstride + col;
-            *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
-          }
-        }
-      }
-      __builtin_amdgcn_s_barrier();   // every wave has read its fragments of slot eslot: it becomes the store staging area
-      asm volatile("" ::: "memory");
-      epilogue_v3<OutT, RowMap, EF>(acc, reinterpret_cast<float*>(smem + eslot * SLOT_BYTES + wave * V3_EPI_BYTES_PER_WAVE),
-                                    k2->C + (int64_t)cq.z * ep.slab_stride, k2->ldc, M, N, cq.m0 + wm, cq.n0 + wn, ep, rowmap, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-      cu += gridDim.x;
-      if (cu >= units) break;
-      cq = unit_of(cu);
-      chalf = 0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Eight-wave form of the stream kernel for launches that cannot fill the chip with two workgroups per CU (units <= CUs: the
-// feed-forward weight gradients, the decoder's 9600-row GEMMs, the front dense layer, the logits' input gradient).
-//
-// A wave issues in order: with ONE 4-wave workgroup on a CU every K step is the SUM of its 8 DMA instructions (~1100 cycles),
-// its 16 fragment reads and its 32 MFMAs (512 cycles), and nothing else runs meanwhile.  Here the same 128 x 128
-// tile is worked by EIGHT waves: the two wave groups split the K step (group h multiplies the 32 reduction indices [32 h, +32)
-// and issues half of the DMA pieces), so a wave's chain per step is 4 DMA instructions + 8 fragment reads + 16 MFMAs, and a
-// SIMD holds two waves that interleave.  The price: the groups hold partial sums of the same outputs -- at the end of a unit
-// group 1 hands its accumulators to group 0 through the stage buffer the unit just finished reading (two rounds of 32 KB),
-// which then runs the ordinary epilogue.  Same LDS (80 KB), same registers per wave, no additional split-K slabs.
-template <typename OutT, int AMODE, int BMODE, typename RowMap, bool CS, int EF>
-__device__ __forceinline__ void gemm_stream_v3_ks(char* smem) {
-  typedef bf16_t T;
-  typedef DenseLoader<T> Loader;
-  typedef GemmArgs<OutT, Loader, Loader, RowMap> Args;
-  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
-  typedef SwzFrag<T, AMODE> RA;
-  typedef SwzFrag<T, BMODE> RB;
-  constexpr int BK = Tile<T>::BK;
-  constexpr int KS = Mma<T>::KS;
-  static_assert(BK == 2 * KS, "the two wave groups split a K step in halves");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
-  const int wm = (w4 >> 1) * 64, wn = (w4 & 1) * 64;
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int ntiles = ka->ntiles, tiles_n = ka->tiles_n, kt_per_split = ka->kt_per_split;
-  const int kt_total = (ka->K + BK - 1) / BK;
-  const int units = ntiles * ka->split;
-  const bool has_cs = CS && ka->ep.colsum_dst != nullptr;
-  const int zx = ka->z_per_xcd;
-  struct Unit { int m0, n0, z, kt_first, kt_count; };
-  auto unit_of = [&](int u) {   // as gemm_stream_v3
-    Unit q;
-    int tile;
-    if (zx) {
-      const int idx = u >> 3, sl = idx / ntiles;
-      q.z = (u & 7) + 8 * sl;
-      tile = idx - sl * ntiles;
-    } else {
-      q.z = u / ntiles;
-      tile = xcd_remap(u - q.z * ntiles, ntiles);
-    }
-    const int tm = tile / tiles_n;
-    q.m0 = tm * BM;
-    q.n0 = (tile - tm * tiles_n) * BN;
-    q.kt_first = q.z * kt_per_split;
-    q.kt_count = kt_total - q.kt_first;
-    if (q.kt_count > kt_per_split) q.kt_count = kt_per_split;
-    return q;
-  };
-
-  floatx4_t acc[4][4], cs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cs[j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-  const typename RA::Frag ones = ones_frag<T>();
-
-  int iu = blockIdx.x;
-  if (iu >= units) return;
-  int ikt = 0, ikt_count;
-  DenseDma<T, AMODE> da;
-  DenseDma<T, BMODE> db;
-  auto cursor_init = [&](int u) {
-    const NST_AS4 Args* k2 = launder(ka);
-    const Loader la_cur = kload(&k2->la), lb_cur = kload(&k2->lb);
-    const Unit q = unit_of(u);
-    ikt_count = q.kt_count;
-    da.init(la_cur, q.m0, q.kt_first * BK, w4, lane);
-    db.init(lb_cur, q.n0, q.kt_first * BK, w4, lane);
-    da.begin(q.kt_count);
-    db.begin(q.kt_count);
-  };
-  cursor_init(iu);
-  auto issue_next = [&](int stage) {
-    const uint32_t sa = smem_addr + stage * V2_STAGE_BYTES;
-    if (grp == 0) {
-      da.template next_mine<0>(sa, w4);
-      db.template next_mine<0>(sa + BM * KBYTES, w4);
-    } else {
-      da.template next_mine<1>(sa, w4);
-      db.template next_mine<1>(sa + BM * KBYTES, w4);
-    }
-    if (++ikt == ikt_count) {
-      iu += gridDim.x;
-      ikt = 0;
-      if (iu < units) cursor_init(iu);
-    }
-  };
-  int cu = blockIdx.x;
-  Unit cq = unit_of(cu);
-  int ckt = 0;
-  issue_next(0);
-  int stage = 0;
-  const int kk = grp * KS;
-  while (true) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (iu < units) issue_next(stage ^ 1);
-    const char* As = smem + stage * V2_STAGE_BYTES;
-    const char* Bs = As + BM * KBYTES;
-    const bool do_cs = has_cs && cq.m0 == 0 && wm == 0;  // wave-uniform
-    typename RA::Frag a[4];
-    typename RB::Frag b[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = RB::read(Bs, wn + j * 16, kk, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = RA::read(As, wm + i * 16, kk, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
-    if (CS && do_cs) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cs[j] = Mma<T>::run(ones, b[j], cs[j]);
-    }
-    const int done_stage = stage;
-    stage ^= 1;
-    if (++ckt == cq.kt_count) {
-      // ---- group 1 -> group 0: partial sums through the stage buffer just read (free until the next step refills it)
-      floatx4_t* xb = reinterpret_cast<floatx4_t*>(smem + done_stage * V2_STAGE_BYTES) + w4 * 512 + lane;   // 8 KB per wave pair
-      floatx4_t* xc = reinterpret_cast<floatx4_t*>(smem + 2 * V2_STAGE_BYTES) + w4 * 256 + lane;           // column sums: 4 KB
-      __builtin_amdgcn_s_barrier();    // every wave has read its fragments of this stage
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (grp == 1) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xb[(i * 4 + j) * 64] = acc[2 * r + i][j];
-          if (CS && r == 0 && do_cs) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xc[j * 64] = cs[j];
-          }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (grp == 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[2 * r + i][j] += xb[(i * 4 + j) * 64];
-          if (CS && r == 0 && do_cs) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cs[j] += xc[j * 64];
-          }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      if (grp == 0) {
-        const NST_AS4 Args* k2 = launder(ka);
-        Epilogue ep = kload(&k2->ep);
-        if (ef_on<EF, EF_DROP>(ep.drop_thresh != 0)) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
-        const RowMap rowmap = kload(&k2->rowmap);
-        const int M = k2->M, N = k2->N;
-        if (CS && do_cs && lane < 16) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int col = cq.n0 + wn + j * 16 + lane;
-            if (col < N) {
-              float* dst = ep.colsum_dst + (int64_t)cq.z * ep.colsum_zstride + col;
-              *dst = ep.colsum_acc ? *dst + cs[j][0] : cs[j][0];
-            }
-          }
-        }
-        epilogue_v3<OutT, RowMap, EF>(acc, reinterpret_cast<float*>(smem + 2 * V2_STAGE_BYTES + w4 * V3_EPI_BYTES_PER_WAVE),
-                                      k2->C + (int64_t)cq.z * ep.slab_stride, k2->ldc, M, N, cq.m0 + wm, cq.n0 + wn, ep, rowmap, lane);
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -228,18 +228,6 @@ class SplitkBatch(object):
         self.ln_n = 0
 
 
-def wgrad_tile(k_in, n_out, dtype):
-    """Edge of the output tile nst_gemm cuts the weight gradient dW[k_in, n_out] = X^T dY into (nst_gemm_tile): 256 on the
-    phase-staggered bf16 kernel, 128 otherwise.  A host-side query (no device work)."""
-    d = NstGemmDesc()
-    d.M, d.N, d.K = k_in, n_out, 64
-    d.trans_a, d.trans_b = 1, 0
-    d.in_dtype = NST_BF16 if dtype == torch.bfloat16 else NST_F32
-    d.out_dtype = NST_F32
-    d.alpha = 1.0
-    return int(lib.nst_gemm_tile(C.byref(d)))
-
-
 class WgradGroup(object):
     """Weight-gradient products dW (+)= X^T dZ waiting for ONE nst_gemm_wgrad_group launch: every 256 x 256 output tile of every
     product becomes a workgroup of the same grid, so the gradients of a whole layer stack fill the chip without split-K slabs.

@@ -45,26 +45,8 @@ _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
 _FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "1") != "0"
 
 
-# 256 x 256 kernel (K.wgrad_tile == 256): one 8-wave workgroup per CU, tiles * split ~ this many workgroups
-_WGRAD256_UNITS = int(os.environ.get("NST_WGRAD256_UNITS", "256"))
-
-
-def _wgrad_split256(rows, k_in, n_out, units=None):
-    """split-K factor on the 256 x 256 kernel: the library cuts the K steps into exactly `split` even slices (any count up
-    to the number of steps), so only two rules remain: a multiple of 8 (slice z then runs on XCD z % 8 and its tiles share the
-    slice's rows in that L2) and at least 4 K steps per slice (prologue + epilogue of a unit cost about two steps)."""
-    tiles = ((k_in + 255) // 256) * ((n_out + 255) // 256)
-    kt = (rows + 63) // 64
-    split = max(1, min((units or _WGRAD256_UNITS) // max(tiles, 1), kt // 4))
-    if split >= 8:
-        split = split // 8 * 8
-    return split
-
-
 def _wgrad_split(rows, k_in, n_out, dtype, units=None):
     """split-K factor for dW[k_in, n_out] = X^T dY reduced over `rows`: tiles*split ~ _WGRAD_UNITS workgroups."""
-    if K.wgrad_tile(k_in, n_out, dtype) == 256:
-        return _wgrad_split256(rows, k_in, n_out, units)
     tiles = ((k_in + 127) // 128) * ((n_out + 127) // 128)
     bk = 64 if dtype == torch.bfloat16 else 32
     kt = (rows + bk - 1) // bk

@@ -498,12 +498,7 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
           "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi",
-          "gemm_wgrad_group", "wgrad_tile"]
-
-
-def wgrad_tile(k_in, n_out, dtype):
-    """nst_gemm_tile: the emulated gemm has no tiles; 128 keeps the host on the split rules of the 128 x 128 kernel."""
-    return 128
+          "gemm_wgrad_group"]
 
 
 def gemm_wgrad_group(items, table=None):

@@ -331,25 +331,6 @@ def test_gemm_wgrad_group(K, nprob):
     assert float(items[0][2]._base[:, -8:].min()) == 3.0 and float(items[0][2]._base[:, -8:].max()) == 3.0
 
 
-@pytest.mark.parametrize("switch", ["NST_GEMM_RING=5", "NST_GEMM_KS=1"])
-def test_gemm_wgrad_on_the_opt_in_kernels(switch):
-    """NST_GEMM_RING=5 routes the bf16 weight gradients (slabs, fused column sums, accumulate) to gemm_stream_v3_ring (five
-    half-step slots), NST_GEMM_KS=1 to gemm_stream_v3_ks (eight waves, the two wave groups split every K step and exchange their
-    partial sums through LDS) -- both opt-in, neither faster in the step.  The switches are read once per
-    process: the weight-gradient cases above run again in a child interpreter, where a wrong slot order or a wrong exchange would
-    show as a wrong dW / db."""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    name, value = switch.split("=")
-    env = dict(os.environ, **{name: value})
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"), "-q", "-x", "-k",
-                          "test_gemm_wgrad_fused_colsum or test_gemm_splitk_wgrad", "-p", "no:cacheprovider"],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dropout_epilogue(K, dtype):
     M, N, K_ = 256, 256, 64
