@@ -740,11 +740,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_from_ds_kernel(AttnParams p) 
 //   * per tile and wave: S and dP (8 + 8 MFMAs), the element-wise part, dV += P^T dO and dK += dS^T Q (8 + 8), the scaled
 //     dS^T of its 32 keys x 32 queries into a double-buffered LDS tile, BARRIER, then its 16 x 16 block of
 //     dQ^T = K^T . dS^T over all 256 keys (8 MFMAs) -- stored at once, no accumulator survives the tile.
-// 40 MFMAs per wave and tile, one barrier per tile, ~100 KB of LDS, B*H workgroups.
+// 40 MFMAs per wave and tile, one barrier per tile, ~113 KB of LDS, B*H workgroups.
+// Encoder shape (B = 128, H = 4, T = 225): 52.7 us against 87 us for the two kernels.  Timing ablations (profiles/r04_history/
+// c13 / c14_attn_ablation.log): loads + staging + barriers alone 18.5 us, + stores 28 us (the 107 MB a launch moves at ~4.5 TB/s:
+// one workgroup per CU, so a workgroup's loads, compute and stores do not overlap with a neighbour's), element-wise part ~9 us,
+// the five products ~12 us -- the compute part is VALU-issue bound (16 probabilities per lane and tile, ~11 instructions each).
 // =============================================================================================
 constexpr int HB_MAXT = 256, HB_QT = 32;
-constexpr int HB_RS = AT<bf16_t>::RS;                    // 144: row stride of the K / Q / dO images (bf16, 64 head dims + 16)
-constexpr int HB_RSD = HB_QT * 2 + 16;                   // 80: row stride of a dS^T image (32 queries + 16)
+// Row strides chosen for the TRANSPOSE reads, which outnumber the row reads 6 : 1 here: a ds_read_b64_tr_b16 serves 32 lanes
+// per pass = 8 rows x 32 bytes, so a stride of 8 dwords mod 64 (160 B, 96 B) spreads them over all 64 banks; with the
+// 144-byte rows of the other kernels two of the eight rows share four banks (PMC: 45 % of the LDS cycles were conflicts)
+constexpr int HB_RS = 160;                               // K / Q / dO images: 64 head dims (128 B) + 32
+constexpr int HB_RSD = HB_QT * 2 + 32;                   // 96: dS^T image rows (32 queries + 32)
 constexpr int HB_K = 0;                                  // K image [256][144]
 constexpr int HB_QG = HB_K + HB_MAXT * HB_RS;            // two buffers of { Q tile [32][144] | dO tile [32][144] }
 constexpr int HB_QG_BUF = 2 * HB_QT * HB_RS;
@@ -752,6 +759,10 @@ constexpr int HB_D = HB_QG + 2 * HB_QG_BUF;              // two dS^T images [256
 constexpr int HB_D_BUF = HB_MAXT * HB_RSD;
 constexpr int HB_STAT = HB_D + 2 * HB_D_BUF;             // lse * log2(e) [256], delta [256]
 constexpr int HB_LDS_BYTES = HB_STAT + 2 * HB_MAXT * 4;
+
+__device__ __forceinline__ bf16x8_t hb_frag(const char* tile, int row0, int kk, int lane) {   // rc_frag on HB_RS rows
+  return *reinterpret_cast<const bf16x8_t*>(tile + (row0 + (lane & 15)) * HB_RS + (kk + (lane >> 4) * 8) * 2);
+}
 
 __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
   typedef bf16_t T;
@@ -775,11 +786,15 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
   const int which = tid >> 8, crow = (tid & 255) >> 3, cchunk = tid & 7;
   const T* qg_src = which ? gb : qb;
   const int64_t qg_ld = which ? p.ldo : p.ldq;
+  // every global load below is UNCONDITIONAL at a clamped (always valid) address, out-of-range pieces are zeroed by a select on
+  // the VALUE: a load under a branch makes hipcc wait vmcnt(0) right behind it (prologue: eight serialized memory round trips)
+  // and again at the loop's back edge (a full round trip per query tile) -- MI355X guide, "three .s-level traps" (c)
+  const int ccol = cchunk * 8 < p.dh ? cchunk * 8 : 0;
   auto qg_load = [&](int t) -> uint4 {
-    const int row = t * HB_QT + crow;
+    const int row = t * HB_QT + crow, rr = row < p.Tq ? row : p.Tq - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(qg_src + (int64_t)rr * qg_ld + ccol);
     const bool ok = row < p.Tq && cchunk * 8 < p.dh;
-    const uint4 v = *reinterpret_cast<const uint4*>(ok ? qg_src + (int64_t)row * qg_ld + cchunk * 8 : qg_src);
-    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
   };
   auto qg_store = [&](int buf, const uint4& v) {
     *reinterpret_cast<uint4*>(hsm + HB_QG + buf * HB_QG_BUF + which * (HB_QT * HB_RS) + crow * HB_RS + cchunk * 16) = v;
@@ -787,40 +802,56 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
 
   // ---------------------------------------------------------------- prologue
   uint4 qg_next = qg_load(0);
+  uint4 kv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {                  // K image: 256 rows x 8 chunks, 4 per thread (rows beyond Tk: zeros)
     const int c = tid + s * 512, row = c >> 3, ch = c & 7;
-    const bool ok = row < p.Tk && ch * 8 < p.dh;
-    const uint4 v = *reinterpret_cast<const uint4*>(ok ? kb + (int64_t)row * p.ldk + ch * 8 : kb);
-    *reinterpret_cast<uint4*>(hsm + HB_K + row * HB_RS + ch * 16) = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-  }
-  if (tid < HB_MAXT) {
-    lss[tid] = tid < p.Tq ? p.lse[bh * p.Tq + tid] * LOG2E : INFINITY;
-  } else {
-    const int i = tid - HB_MAXT;
-    dls[i] = i < p.Tq ? p.delta[bh * p.Tq + i] : 0.f;
+    const int rr = row < p.Tk ? row : p.Tk - 1, cc = ch * 8 < p.dh ? ch * 8 : 0;
+    kv[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)rr * p.ldk + cc);
   }
   Frag kf[2][2], vf[2][2];
   float kb2[2];
+  uint4 vraw[2][2];
+  float kbraw[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {               // V fragments (B operand: column = key) straight from HBM
-    const int row = kw0 + mi * 16 + lc;
+    const int row = kw0 + mi * 16 + lc, rr = row < p.Tk ? row : p.Tk - 1;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int col = s2 * 32 + g * 8;
-      const bool ok = row < p.Tk && col < p.dh;
-      const uint4 v = *reinterpret_cast<const uint4*>(ok ? vb + (int64_t)row * p.ldv + col : vb);
-      vf[mi][s2] = __builtin_bit_cast(Frag, ok ? v : make_uint4(0u, 0u, 0u, 0u));
+      vraw[mi][s2] = *reinterpret_cast<const uint4*>(vb + (int64_t)rr * p.ldv + (col < p.dh ? col : 0));
     }
-    kb2[mi] = key_bias2(p, b, row);
+    const float* kbp = p.key_bias ? p.key_bias + (int64_t)b * p.Tk + rr : p.lse;     // (any readable float when there is no bias)
+    kbraw[mi] = *kbp;
+  }
+  const int sidx = tid & (HB_MAXT - 1), sq = sidx < p.Tq ? sidx : p.Tq - 1;
+  const float sraw = tid < HB_MAXT ? p.lse[bh * p.Tq + sq] : p.delta[bh * p.Tq + sq];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = tid + s * 512, row = c >> 3, ch = c & 7;
+    const bool ok = row < p.Tk && ch * 8 < p.dh;
+    *reinterpret_cast<uint4*>(hsm + HB_K + row * HB_RS + ch * 16) =
+        make_uint4(ok ? kv[s].x : 0u, ok ? kv[s].y : 0u, ok ? kv[s].z : 0u, ok ? kv[s].w : 0u);
+  }
+  if (tid < HB_MAXT) lss[sidx] = sidx < p.Tq ? sraw * LOG2E : INFINITY;
+  else dls[sidx] = sidx < p.Tq ? sraw : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row = kw0 + mi * 16 + lc;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bool ok = row < p.Tk && s2 * 32 + g * 8 < p.dh;
+      const uint4 v = vraw[mi][s2];
+      vf[mi][s2] = __builtin_bit_cast(Frag, make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u));
+    }
+    kb2[mi] = row >= p.Tk ? -INFINITY : (p.key_bias ? fmaxf(kbraw[mi] * LOG2E, -3.0e38f) : 0.f);
   }
   qg_store(0, qg_next);
-  if (nqt > 1) qg_next = qg_load(1);
   __syncthreads();
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) kf[mi][s2] = rc_frag<T>(hsm + HB_K, kw0 + mi * 16, s2 * AT<T>::KS, lane);
+    for (int s2 = 0; s2 < 2; ++s2) kf[mi][s2] = hb_frag(hsm + HB_K, kw0 + mi * 16, s2 * AT<T>::KS, lane);
 
   floatx4_t dk[2][4], dv[2][4];
 #pragma unroll
@@ -835,31 +866,36 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
   T* dqb = (T*)p.dq + (int64_t)b * p.Tq * p.ldq + h * p.dh;
 
   // dropout keep words of tile t (two 16-query blocks x this wave's two 16-key blocks), loaded a tile ahead
-  uint2 mwn[2][2];
+  uint2 mwn[2][2], mwc[2][2];
+  const bool mask_off = p.drop_thresh == 0;
+  const uint16_t* mbase = mask_off ? reinterpret_cast<const uint16_t*>(p.lse)      // (no dropout: 8 readable bytes, unused)
+                                   : p.mask + bh * p.nqb * (int64_t)p.nkt * 64 + mlane;
   auto mask_load = [&](int t) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        mwn[mi][f] = make_uint2(0xffffffffu, 0xffffffffu);
-        const int qblk = t * 2 + f, ktile = (kw0 + mi * 16) >> 6;
-        if (p.drop_thresh && qblk < p.nqb && ktile < p.nkt)
-          mwn[mi][f] = *reinterpret_cast<const uint2*>(p.mask + ((bh * p.nqb + qblk) * p.nkt + ktile) * 64 + mlane);
+        int qblk = t * 2 + f, ktile = (kw0 + mi * 16) >> 6;
+        qblk = qblk < p.nqb ? qblk : p.nqb - 1;
+        ktile = ktile < p.nkt ? ktile : p.nkt - 1;
+        mwn[mi][f] = *reinterpret_cast<const uint2*>(mbase + (mask_off ? 0 : (qblk * p.nkt + ktile) * 64));
       }
   };
   mask_load(0);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) mwc[mi][f] = mwn[mi][f];
 
   for (int t = 0; t < nqt; ++t) {
     const int q0 = t * HB_QT, buf = t & 1;
     const char* Qt = hsm + HB_QG + buf * HB_QG_BUF;
     const char* Gt = Qt + HB_QT * HB_RS;
     char* Dt = hsm + HB_D + buf * HB_D_BUF;
-    uint2 mwc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) mwc[mi][f] = mwn[mi][f];
-    if (t + 1 < nqt) mask_load(t + 1);
+    // the next tile's Q / dO chunk and dropout words: issued here, consumed at the END of this iteration -- no load is pending
+    // across the loop's back edge (where hipcc would drain vmcnt(0), the dQ stores included)
+    qg_next = qg_load(t + 1 < nqt ? t + 1 : t);
+    mask_load(t + 1 < nqt ? t + 1 : t);
     floatx4_t ls4[2], dl4[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -876,8 +912,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        const Frag aq = rc_frag<T>(Qt, f * 16, s2 * AT<T>::KS, lane);
-        const Frag ag = rc_frag<T>(Gt, f * 16, s2 * AT<T>::KS, lane);
+        const Frag aq = hb_frag(Qt, f * 16, s2 * AT<T>::KS, lane);
+        const Frag ag = hb_frag(Gt, f * 16, s2 * AT<T>::KS, lane);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           st[mi][f] = Mma<T>::run(aq, kf[mi][s2], st[mi][f]);
@@ -941,11 +977,20 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_head8_kernel(AttnParams p) {
       }
     }
     // ---- the next tile's Q / dO go to the other buffer (every wave finished reading it before the previous barrier)
-    if (t + 1 < nqt) {
-      qg_store(buf ^ 1, qg_next);
-      if (t + 2 < nqt) qg_next = qg_load(t + 2);
-    }
-    __syncthreads();   // dS^T of all 256 keys (and the next Q / dO tile) are in LDS
+    qg_store(buf ^ 1, qg_next);                         // (behind the last tile: a copy nobody reads)
+    // dS^T of all 256 keys (and the next Q / dO tile) are in LDS.  A raw barrier behind lgkmcnt(0) only: __syncthreads() also
+    // drains vmcnt, i.e. waits at EVERY tile for the Q / dO prefetch issued a moment ago and for the dQ stores of the previous
+    // tile to be acknowledged -- a full memory round trip per tile (the ablation: 22 of 54 us were this skeleton, 12 the stores)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the next tile's dropout words become current HERE, in front of the dQ stores: behind them the copy would wait for the
+    // stores' acknowledgement as well (a store under `if (row < Tq)` makes hipcc's count conservative: vmcnt(0))
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) { mwc[mi][f] = mwn[mi][f]; asm volatile("" : "+v"(mwc[mi][f].x), "+v"(mwc[mi][f].y)); }
     // ---- dQ^T[d][q] = K^T[d][key] . dS^T[key][q] over the 256 keys: this wave's 16 head dims x 16 queries
     {
       floatx4_t dq = floatx4_t{0.f, 0.f, 0.f, 0.f};

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04
-timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "attention or gemm" > $O/c11_attn_tests.log 2>&1
+timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "attention" > $O/c11_attn_tests.log 2>&1
 echo "attention tests rc=$? $(tail -n 1 $O/c11_attn_tests.log)"; grep -E "^FAILED|^ERROR|^E  " $O/c11_attn_tests.log | head
 for v in 1 0 1 0; do
   NST_ATTN_FUSED_BWD=$v timeout 300 python scripts/attn_bench.py 2>/dev/null | tail -n 1
