@@ -1236,6 +1236,9 @@ extern "C" int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void
   const bool vec = vec_legal(q, d->ldq, d->dh, esz) && vec_legal(k, d->ldk, d->dh, esz) && vec_legal(v, d->ldv, d->dh, esz) &&
                    vec_legal(out, d->ldo, d->dh, esz);
   hipStream_t st = (hipStream_t)stream;
+  // (round 4: a one-workgroup-per-head forward with K / V staged once -- the backward's structure -- was built, bit-identical and
+  // NOT faster: encoder shape 39.1 vs 41.2 us, decoder shapes slower, step 13.10 vs 13.02 ms; the forward is bound by its
+  // element-wise / Philox work, not by the K / V re-reads.  Removed; profiles/r04_history/c15_attn_bench.log)
   // one query block per wave (140 registers, three waves per SIMD) measured 0.07 ms per step faster than two (236
   // registers, two waves) at the benchmark shape: the kernel is latency-bound, occupancy beats reuse (NST_ATTN_MI_FWD=2)
   const int mi = pick_mi("NST_ATTN_MI_FWD", d->Tq, (int64_t)d->B * d->H, false);

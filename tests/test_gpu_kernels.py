@@ -384,8 +384,9 @@ ATTN_CASES = [  # B, H, Tq, Tk, dh, causal, key-padding
 
 @pytest.fixture(params=[1, 2, "fused_bwd"])
 def attn_mi(request, monkeypatch):
-    """Force the number of 16-row blocks per wave (64*MI rows per workgroup) in all three attention kernels; "fused_bwd": the
-    one-workgroup-per-head backward (attn_bwd_fused_kernel: bf16, sequences <= 256; other cases fall back by themselves)."""
+    """Force the number of 16-row blocks per wave (64*MI rows per workgroup) in the three tiled attention kernels; "fused_bwd":
+    the one-workgroup-per-head backward (attn_bwd_head8_kernel: bf16, sequences <= 256 -- the library's default for such
+    shapes; other cases fall back to the tiled kernels by themselves)."""
     mi = 1 if request.param == "fused_bwd" else request.param
     for k in ("NST_ATTN_MI_FWD", "NST_ATTN_MI_DKDV", "NST_ATTN_MI_DQ"):
         monkeypatch.setenv(k, str(mi))
