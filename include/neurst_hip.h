@@ -171,6 +171,18 @@ int nst_gemm_wgrad_group(const NstGemmDesc* descs, const void* const* A, const v
 /* C (+)= sum of the slabs (and the column sums) of up to 8 deferred split-K products, one launch. */
 int nst_splitk_reduce_multi(const NstSplitkJob* jobs_host, int njobs, void* stream);
 
+/* Sequence masks from lengths (ABI 7): out[b][t] = t < len'(b) ? on_token : on_padding with len' = `halvings` times
+ * ceil(len / stride) -- model_utils.py:44-75 (sequence_mask and 1 - sequence_mask), layer_utils.py:19-32 (padding * FLOAT_MIN:
+ * on_padding = -1e9) and the conv-subsampled lengths of speech_transformer.py:179-189 (halvings = 2, stride = 2) in one launch.
+ * lengths [B] int64 (device), out [B, T] f32. */
+int nst_seq_mask(const int64_t* lengths, float* out, int B, int T, int halvings, int stride, float on_token, float on_padding,
+                 void* stream);
+/* Reductions of LabelSmoothedCrossEntropy (label_smoothed_cross_entropy.py:46-53, 141-157) in one launch (ABI 7):
+ * nll_sum[b] = sum_t xent[b][t], n_tokens[b] = sum_t weights[b][t], loss = sum(nll_sum) / sum(n_tokens),
+ * inv_tokens = 1 / sum(n_tokens) (the device scalar nst_ls_xent_bwd reads).  xent, weights [B, L] f32 dense. */
+int nst_xent_reduce(const float* xent, const float* weights, int B, int L, float* nll_sum, float* n_tokens, float* loss,
+                    float* inv_tokens, void* stream);
+
 /* Column sums: out[N] (f32) (+)= sum_rows x[rows,N] -- bias gradients.  workspace (nullable, >= 256*N*4 bytes):
  * two-stage reduction without atomics, as for nst_layernorm_bwd. */
 int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate, void* workspace,

@@ -105,6 +105,8 @@ SIGNATURES = {
     "nst_gemm_wgrad_group": [_P, _P, _P, _P, _I, _P, _L, _P],
     "nst_splitk_reduce_multi": [_P, _I, _P],
     "nst_colsum": [_P, _P, _L, _I, _L, _I, _I, _P, _L, _P],
+    "nst_seq_mask": [_P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "nst_xent_reduce": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     "nst_attention_dropout_mask_bytes": [C.POINTER(NstAttnDesc)],
     "nst_attention_fwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P],
     "nst_attention_bwd": [C.POINTER(NstAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -23,6 +23,7 @@ class LabelSmoothedCrossEntropy(Criterion):
         super().__init__()
         self._label_smoothing = float((args or {}).get("label_smoothing", 0.) or 0.)
         self._saved = None
+        self._n_samples = {}
 
     @staticmethod
     def class_or_method_args():
@@ -53,23 +54,25 @@ class LabelSmoothedCrossEntropy(Criterion):
         weights = self._weights(model_inp, labels).contiguous()
         l2 = logits.reshape(B * L, V)
         xent, lse = K.ls_xent_fwd(l2, labels.view(-1), weights.view(-1), self._label_smoothing)
-        nll_sum = xent.view(B, L).sum(dim=1)
-        n_tokens = weights.sum(dim=1)
-        n_samples = torch.full((1,), float(B), dtype=torch.float32, device=logits.device)
-        self._saved = (l2, labels.view(-1), weights.view(-1), lse, n_tokens, (B, L, V))
-        return nll_sum, n_samples, n_tokens
+        # the four reductions (per-sample sums, the batch loss, 1 / tokens for the backward kernel) in one launch
+        nll_sum, n_tokens, loss, inv_tokens = K.xent_reduce(xent, weights)
+        key = (B, str(logits.device))
+        if key not in self._n_samples:
+            self._n_samples[key] = torch.full((1,), float(B), dtype=torch.float32, device=logits.device)
+        self._saved = (l2, labels.view(-1), weights.view(-1), lse, inv_tokens, (B, L, V))
+        self._loss = loss
+        return nll_sum, self._n_samples[key], n_tokens
 
     def reduce_loss(self, model_inp, model_out):
         """sum(nll_sum) / sum(n_tokens)  (label_smoothed_cross_entropy.py:46-53), a device scalar."""
-        nll_sum, _, n_tokens = self(model_inp, model_out)
-        return nll_sum.sum() / n_tokens.sum()
+        self(model_inp, model_out)
+        return self._loss[0]
 
     def backward(self, loss_scale=1.0, loss_scale_dev=None):
         """d(reduce_loss * loss_scale)/d(logits) for the logits of the last __call__; [B, L, V] in the logits dtype.
         loss_scale_dev: an additional factor held in a device scalar (the dynamic loss scale)."""
-        l2, labels, weights, lse, n_tokens, (B, L, V) = self._saved
+        l2, labels, weights, lse, inv, (B, L, V) = self._saved
         self._saved = None
-        inv = (1.0 / n_tokens.sum()).reshape(1)
         if loss_scale_dev is not None:
             inv = inv * loss_scale_dev.reshape(1)
         inv = inv.contiguous()

@@ -540,6 +540,74 @@ extern "C" int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const 
   return NST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sequence masks from lengths in ONE launch (model_utils.py:44-75 sequence_mask / 1 - sequence_mask, layer_utils.py:19-32
+// padding * FLOAT_MIN, speech_transformer.py:179-189 the length after the two stride-2 convolutions): the host path built them
+// from arange / compare / cast / arithmetic launches (11 of the ~30 torch-native launches of a step).
+//   out[b][t] = t < len'(b) ? on_token : on_padding,   len' = `halvings` times ceil(len / stride)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) seq_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ out, int B, int T,
+                                                      int halvings, int stride, float on_token, float on_padding) {
+  const int64_t n = (int64_t)B * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+    int64_t len = lengths[b];
+    for (int h = 0; h < halvings; ++h) len = (len + stride - 1) / stride;
+    out[i] = t < len ? on_token : on_padding;
+  }
+}
+
+extern "C" int nst_seq_mask(const int64_t* lengths, float* out, int B, int T, int halvings, int stride, float on_token,
+                            float on_padding, void* stream) {
+  NST_CHECK_ARG(lengths && out && B >= 0 && T >= 0 && halvings >= 0 && stride >= 1, "seq_mask: bad arguments");
+  if (B == 0 || T == 0) return NST_OK;
+  const int64_t n = (int64_t)B * T;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  seq_mask_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(lengths, out, B, T, halvings, stride, on_token, on_padding);
+  NST_CHECK_LAUNCH("seq_mask");
+  return NST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reductions of the criterion in ONE launch (label_smoothed_cross_entropy.py:46-53, 141-157): per sample nll_sum[b] = sum_t
+// xent[b][t] and n_tokens[b] = sum_t weights[b][t], the batch loss sum(nll_sum) / sum(n_tokens) and 1 / sum(n_tokens) (the
+// factor the backward kernel reads from the device) -- eight torch reductions / element-wise launches before.  One workgroup;
+// sums in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xent_reduce_kernel(const float* __restrict__ xent, const float* __restrict__ weights, int B, int L,
+                                                         float* __restrict__ nll_sum, float* __restrict__ n_tokens,
+                                                         float* __restrict__ loss, float* __restrict__ inv_tokens) {
+  __shared__ float s_nll[256], s_tok[256];
+  float a_nll = 0.f, a_tok = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float n = 0.f, w = 0.f;
+    for (int t = 0; t < L; ++t) { n += xent[(int64_t)b * L + t]; w += weights[(int64_t)b * L + t]; }
+    nll_sum[b] = n;
+    n_tokens[b] = w;
+    a_nll += n;
+    a_tok += w;
+  }
+  s_nll[threadIdx.x] = a_nll;
+  s_tok[threadIdx.x] = a_tok;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s_nll[threadIdx.x] += s_nll[threadIdx.x + o]; s_tok[threadIdx.x] += s_tok[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = s_nll[0] / s_tok[0];
+    inv_tokens[0] = 1.0f / s_tok[0];
+  }
+}
+
+extern "C" int nst_xent_reduce(const float* xent, const float* weights, int B, int L, float* nll_sum, float* n_tokens, float* loss,
+                               float* inv_tokens, void* stream) {
+  NST_CHECK_ARG(xent && weights && nll_sum && n_tokens && loss && inv_tokens && B > 0 && L > 0, "xent_reduce: bad arguments");
+  xent_reduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(xent, weights, B, L, nll_sum, n_tokens, loss, inv_tokens);
+  NST_CHECK_LAUNCH("xent_reduce");
+  return NST_OK;
+}
+
 extern "C" int nst_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int dtype, int accumulate,
                           void* workspace, int64_t workspace_bytes, void* stream) {
   NST_CHECK_ARG(x && out, "colsum: null pointer");

@@ -647,6 +647,26 @@ def ls_xent_bwd(logits, labels, weights, lse, label_smoothing, gscale, out=None,
     return dlogits
 
 
+def seq_mask(lengths, max_len, on_token, on_padding, halvings=0, stride=2):
+    """[B, max_len] f32: on_token where t < len', on_padding elsewhere; len' = `halvings` times ceil(len / stride) (one launch)."""
+    lengths = lengths.to(torch.int64).contiguous()
+    out = torch.empty(lengths.shape[0], int(max_len), dtype=torch.float32, device=lengths.device)
+    check(lib.nst_seq_mask(_p(lengths), _p(out), lengths.shape[0], int(max_len), int(halvings), int(stride), float(on_token),
+                           float(on_padding), _stream()), "seq_mask")
+    return out
+
+
+def xent_reduce(xent, weights):
+    """xent, weights [B, L] f32 -> (nll_sum [B], n_tokens [B], loss [1], inv_tokens [1]) in one launch."""
+    B, L = weights.shape
+    assert xent.numel() == B * L and xent.is_contiguous() and weights.is_contiguous()
+    assert xent.dtype == torch.float32 and weights.dtype == torch.float32
+    o = torch.empty(2 * B + 2, dtype=torch.float32, device=xent.device)
+    check(lib.nst_xent_reduce(_p(xent), _p(weights), B, L, o.data_ptr(), o.data_ptr() + 4 * B, o.data_ptr() + 8 * B,
+                              o.data_ptr() + 8 * B + 4, _stream()), "xent_reduce")
+    return o[:B], o[B:2 * B], o[2 * B:2 * B + 1], o[2 * B + 1:]
+
+
 def adam_update(p, m, v, g, shadow, lr_t, beta1, beta2, eps, grad_scale=1.0, loss_scale_state=None):
     """lr_t: float, or a 1-element float32 DEVICE tensor read when the kernel runs (graph replay).  loss_scale_state: the
     4-float device state of loss_scale_update (skip on overflow, unscale otherwise)."""

@@ -8,7 +8,11 @@ from neurst_amd.kernels import FLOAT_MIN
 
 
 def input_padding_to_bias(input_padding):
-    """layer_utils.py:19-32: bias = padding * FLOAT_MIN, shape [batch, max_length], float32."""
+    """layer_utils.py:19-32: bias = padding * FLOAT_MIN, shape [batch, max_length], float32.  A padding tensor built on the
+    device from lengths (model_utils.input_length_to_padding) already carries it."""
+    bias = getattr(input_padding, "_nst_bias", None)
+    if bias is not None and bias.shape == input_padding.shape:
+        return bias
     return (input_padding.float() * FLOAT_MIN).contiguous()
 
 

@@ -90,6 +90,9 @@ class SpeechTransformer(EncoderDecoderModel):
         def _length_after_conv(_l):
             return ((_l + strides - 1) // strides + strides - 1) // strides
 
+        if strides >= 1:      # the two ceil-divisions of the lengths ride inside the mask kernel
+            return input_length_to_padding(inputs["src_length"], _length_after_conv(inputs["src"].shape[1]), halvings=2,
+                                           stride=strides)
         return input_length_to_padding(_length_after_conv(inputs["src_length"]),
                                        _length_after_conv(inputs["src"].shape[1]))
 

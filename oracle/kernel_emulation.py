@@ -498,7 +498,21 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "atte
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
           "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi",
-          "gemm_wgrad_group"]
+          "gemm_wgrad_group", "seq_mask", "xent_reduce"]
+
+
+def seq_mask(lengths, max_len, on_token, on_padding, halvings=0, stride=2):
+    ln = lengths.to(torch.int64)
+    for _ in range(int(halvings)):
+        ln = (ln + stride - 1) // stride
+    inside = torch.arange(int(max_len))[None, :] < ln[:, None]
+    return torch.where(inside, torch.tensor(float(on_token)), torch.tensor(float(on_padding))).float()
+
+
+def xent_reduce(xent, weights):
+    B, L = weights.shape
+    nll, tok = xent.reshape(B, L).to(F64).sum(1), weights.to(F64).sum(1)
+    return nll.float(), tok.float(), (nll.sum() / tok.sum()).float().reshape(1), (1.0 / tok.sum()).float().reshape(1)
 
 
 def gemm_wgrad_group(items, table=None):

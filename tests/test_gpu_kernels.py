@@ -770,6 +770,34 @@ def test_ls_xent(K, dtype, rows, V, ls):
     close(tag + ".dlogits", dl, lr.grad.reshape(rows, V), dtype)
 
 
+def test_seq_mask_and_xent_reduce(K):
+    """nst_seq_mask (padding / non-padding / attention-bias masks from lengths, with the conv-subsampled lengths of
+    speech_transformer.py:179-189 folded in) and nst_xent_reduce (the criterion's reductions) against the torch expressions of
+    the reference functions (model_utils.py:44-75, layer_utils.py:19-32, label_smoothed_cross_entropy.py:46-53)."""
+    lens = torch.tensor([900, 1, 0, 37, 451, 899, 2, 450])
+    for T, halv in ((900, 0), (225, 2), (5, 0), (57, 1)):
+        ln = lens.clone()
+        for _ in range(halv):
+            ln = (ln + 1) // 2
+        inside = torch.arange(T)[None, :] < ln[:, None]
+        for tok, pad in ((1.0, 0.0), (0.0, 1.0), (0.0, float(K.FLOAT_MIN))):
+            got = K.seq_mask(lens.to(DEV), T, tok, pad, halvings=halv).cpu()
+            want = torch.where(inside, torch.tensor(tok), torch.tensor(pad))
+            assert torch.equal(got, want), (T, halv, tok, pad)
+    from neurst_amd.layers import layer_utils
+    from neurst_amd.models.model_utils import input_length_to_padding
+    padding = input_length_to_padding(lens.to(DEV), 225, halvings=2)
+    assert torch.equal(layer_utils.input_padding_to_bias(padding).cpu(), padding.cpu() * float(K.FLOAT_MIN))
+    for B, L in ((128, 75), (3, 1), (300, 7)):
+        xent, w = rnd(B, L, seed=4).abs(), (rnd(B, L, seed=5) > 0).float()
+        w[:, 0] = 1.0
+        nll, tok, loss, inv = K.xent_reduce(xent.to(DEV), w.to(DEV))
+        close(f"xent_reduce[{B}x{L}].nll", nll, xent.double().sum(1), torch.float32)
+        assert torch.equal(tok.cpu(), w.sum(1))
+        want = float(xent.double().sum() / w.double().sum())
+        assert abs(float(loss) - want) <= 1e-5 * abs(want) and abs(float(inv) - 1.0 / float(w.sum())) <= 1e-6 / float(w.sum())
+
+
 def test_adam_and_cast(K):
     n = 10007
     p, g = rnd(n, seed=1), rnd(n, seed=2)
