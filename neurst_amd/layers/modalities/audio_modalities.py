@@ -37,7 +37,7 @@ class AudioConv2dSubsamplingLayer(Layer):
         self._dense_layer = Dense(rt, name + "/output_dense", f2 * C, embedding_dim, gen)
         # 20 long tiles (K = every encoder row): behind the encoder stack's 240 they would start a second round of the grouped
         # launch (1.05 -> 1.59 ms stand-alone, step 14.08 -> 14.36 ms: profiles/r04_history/c3_group_bench_0.json, c5_ab_step.log); its weight gradient keeps the split-K path on the weight-gradient stream
-        self._dense_layer.wgrad_grouped = False
+        self._dense_layer.wgrad_grouped = False   # (as a small group of their own on the weight-gradient stream: 13.0 -> 13.8 ms, c17_ab_side_group.log)
         # (its weight gradient runs at the very end of the backward next to the conv kernels; 512 units measured no better)
         self._dense_layer.wgrad_units = int(os.environ.get("NST_FRONT_WGRAD_UNITS", "256"))
 
