@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 7
+#define NST_ABI_VERSION 8
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -482,6 +482,31 @@ typedef struct {
   int block0, nblocks;
 } NstPack2dJob;
 int nst_pack2d(const NstPack2dJob* jobs_dev, int njobs, int total_blocks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL (one process per GPU; ABI v8).  Replaces the Horovod calls of the reference's data-parallel
+ * step: the averaged all-reduce of every gradient (neurst/training/hvd_utils.py:46-62, hvd.DistributedOptimizer /
+ * hvd.Average; optional fp16 wire training_utils.py:381-384) and the broadcast of rank 0's variables
+ * (neurst/exps/trainer.py:285).  The host moves the 128-byte unique id from rank 0 to the other ranks by whatever channel it
+ * has (the reference: MPI under Horovod; here: the launcher's TCP store).  RCCL is bound at run time (librccl.so.1 of the
+ * process, else of the loader path; NST_RCCL_PATH overrides): NST_ERR_UNSUPPORTED when there is none.
+ *
+ * A communicator owns a communication stream and its event fences; every call is asynchronous for the host:
+ *   nst_comm_allreduce_bucket  the communication stream waits for everything queued so far on the `producers` streams (the
+ *                              compute stream, the weight-gradient stream), then SUMS buf[0:count) over the ranks in place.
+ *                              Buckets issued in the same order on every rank.  No 1/N: nst_adam_update's grad_scale does it.
+ *   nst_comm_fence             `consumer` (the stream of the optimizer step) waits for every bucket issued so far.
+ *   nst_comm_broadcast         buf[0:count) of `root` to all ranks, ordered with `stream` on both sides.
+ * dtype: NST_F32, NST_BF16, NST_COMM_F16, NST_COMM_U8.  All ranks of a communicator call init / destroy collectively. */
+#define NST_COMM_UNIQUE_ID_BYTES 128
+enum { NST_COMM_F16 = 2, NST_COMM_U8 = 3 };
+int nst_comm_unique_id(void* id, size_t id_bytes);
+int nst_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);
+int nst_comm_info(void* comm, int* rank, int* world, int64_t* buckets_since_fence, int64_t* bytes_since_fence);
+int nst_comm_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, void* const* producers, int nproducers);
+int nst_comm_fence(void* comm, void* consumer);
+int nst_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* stream);
+int nst_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 7
+NST_ABI_VERSION = 8
+NST_COMM_F16, NST_COMM_U8 = 2, 3
+NST_COMM_UNIQUE_ID_BYTES = 128
 
 
 class NstGemmDesc(C.Structure):
@@ -137,6 +139,13 @@ SIGNATURES = {
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
     "nst_pack2d": [_P, _I, _I, _P],
+    "nst_comm_unique_id": [_P, C.c_size_t],
+    "nst_comm_init": [_P, C.c_size_t, _I, _I, C.POINTER(C.c_void_p)],
+    "nst_comm_info": [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "nst_comm_allreduce_bucket": [_P, _P, _L, _I, C.POINTER(C.c_void_p), _I],
+    "nst_comm_fence": [_P, _P],
+    "nst_comm_broadcast": [_P, _P, _L, _I, _I, _P],
+    "nst_comm_destroy": [_P],
 }
 
 

@@ -2104,11 +2104,180 @@ bool conv2_dgrad_patch(const void* dy, const void* w2, void* dx, int B, int T1, 
   return true;
 }
 
+// =============================================================================================
+// conv2 data gradient on the phase-staggered 256 x 256 tile kernel (bf16, C == 256, even T1 and F1; round 4).
+//
+// Same decomposition as the patch kernel above -- a workgroup owns 256 consecutive dy pixels and produces the four parity
+// classes of their 2 x 2 dx pixels one after the other (4 + 2 + 2 + 1 taps, 36 K steps of 64 output channels) -- but nothing is
+// LDS-resident: both operands stream through the two K-step buffers of gemm256_mainloop.
+//   A (RC images, 128 dy pixels x 64 co): the lane keeps the address of ITS pixel's dy row and a 4-bit mask of the shifts
+//     (du, dv) that stay inside the image; a K step adds the wave-uniform ((du * F2 + dv) * C + co0) offset, a shift that
+//     leaves the image reads the zero block.  A dy row crosses the L2 interface 9 times (once per tap; the patch kernel: once)
+//     -- all but the first are hits, the taps of one class and the classes of one tile follow each other within microseconds.
+//   B (RC images, 128 ci x 64 co): w2[tap][ci][co] rows, 288 KB per class set, L2-resident.
+// The next class's first loads are issued BEFORE the current class's store epilogue (whose transposition scratch lives in
+// buffer 1's A images, the one region those loads do not touch), so only the first class of a tile pays the load latency.
+// =============================================================================================
+struct DyTapDma256 {
+  const char* base;         // &dy[m0 + row][kchunk * 8]: piece s of half h sits (h * 128 + s * 64) rows further (same chunk swizzle)
+  uint32_t mask[2];         // [piece]: bits 0..3 = shifts (du * 2 + dv) of half 0's pixel that stay inside, bits 16..19 of half 1's
+  int F2, C, pf;
+  int tp[2], c0[2];         // per half (wave-uniform): the (tap of the class, first channel) of the K step issued next
+  __device__ __forceinline__ void init(const bf16_t* dy, int M, int T2, int F2_, int C_, const FastDiv& dF2, const FastDiv& dT2, int m0,
+                                       int wave, int lane) {
+    F2 = F2_; C = C_;
+    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int kchunk = slot ^ ((row >> 1) & 7);
+    base = reinterpret_cast<const char*>(dy + (int64_t)(m0 + row) * C + kchunk * 8);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pixel = m0 + h * 128 + s * 64 + row;
+        uint32_t q, v, b, u;
+        dF2.divmod((uint32_t)pixel, q, v);
+        dT2.divmod(q, b, u);
+        uint32_t mm = 0;
+        if (pixel < M) {
+          const bool un = (int)u + 1 < T2, vn = (int)v + 1 < F2;
+          mm = 1u | (vn ? 2u : 0u) | (un ? 4u : 0u) | ((un && vn) ? 8u : 0u);
+        }
+        m |= mm << (16 * h);
+      }
+      mask[s] = m;
+    }
+  }
+  __device__ __forceinline__ void begin(int /*pt*/, int pf_) { pf = pf_; tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
+  template <int H>
+  __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
+    const uint32_t dst = img + (uint32_t)wave * 1024u;
+    const int du = tp[H] >> pf, dv = tp[H] & pf;          // taps of a class: dv fastest (pf == 0: dv == 0, du == tp)
+    const int64_t off = ((int64_t)(du * F2 + dv + H * 128) * C + c0[H]) * 2;   // wave-uniform
+    const int bit = 16 * H + du * 2 + dv;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bool ok = (mask[s] >> bit) & 1u;
+      const void* src = ok ? (const void*)(base + (off + (int64_t)s * 64 * C * 2)) : (const void*)g_nst_zero16;
+      glds16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)s * 8192u));
+    }
+    c0[H] += 64;
+    if (c0[H] == C) { c0[H] = 0; ++tp[H]; }
+  }
+};
+
+struct W2TapDma256 {
+  const char* base;         // &w2[0][row][kchunk * 8]: piece s of half h sits (h * 128 + s * 64) rows (input channels) further
+  int C, pt, pf;
+  int tp[2], c0[2];
+  __device__ __forceinline__ void init(const bf16_t* w2, int C_, int wave, int lane) {
+    C = C_;
+    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int kchunk = slot ^ ((row >> 1) & 7);
+    base = reinterpret_cast<const char*>(w2 + (int64_t)row * C + kchunk * 8);
+  }
+  __device__ __forceinline__ void begin(int pt_, int pf_) { pt = pt_; pf = pf_; tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
+  template <int H>
+  __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
+    const uint32_t dst = img + (uint32_t)wave * 1024u;
+    const int du = tp[H] >> pf, dv = tp[H] & pf;
+    // dx row ti = 2u + pt takes dy row u + du through tap kh = ti + 1 - 2 (u + du): even rows kh = 1, odd rows kh = 2 - 2 du
+    const int kh = pt ? 2 - 2 * du : 1, kw = pf ? 2 - 2 * dv : 1;
+    const int64_t off = (((int64_t)(kh * 3 + kw) * C + H * 128) * C + c0[H]) * 2;   // wave-uniform
+    const char* s0 = base + off;
+    const char* s1 = s0 + (int64_t)64 * C * 2;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(s0), "v"(s1), "s"(dst)
+        : "memory", "scc");
+    c0[H] += 64;
+    if (c0[H] == C) { c0[H] = 0; ++tp[H]; }
+  }
+};
+
+struct Conv2Dgrad256Args {
+  const bf16_t* dy;
+  const bf16_t* w2;
+  bf16_t* dx;
+  int M, T1, F1, T2, F2, C;
+  FastDiv dF2, dT2;
+};
+
+__global__ void __launch_bounds__(G256_THREADS) conv2_dgrad256_kernel(Conv2Dgrad256Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = blockIdx.x * G256_TILE;
+  const int C = a.C;
+  DyTapDma256 da;
+  da.init(a.dy, a.M, a.T2, a.F2, C, a.dF2, a.dT2, m0, wave, lane);
+  W2TapDma256 db;
+  db.init(a.w2, C, wave, lane);
+  DgradRowMap rm;
+  rm.T1 = a.T1; rm.F1 = a.F1; rm.ct = a.T2; rm.cf = a.F2; rm.dcf = a.dF2; rm.dct = a.dT2;
+  Epilogue ep{};
+  ep.vec = 1;
+  // transposition scratch of the store epilogue: buffer 1's A images (see the header comment)
+  float* epi = reinterpret_cast<float*>(smem_dyn + G256_KT_BYTES + wave * V3_EPI_BYTES_PER_WAVE);
+  floatx4_t acc[2][4][4], cs[4];
+  // heaviest class first: (odd, odd) 4 taps, then 2, 2, 1
+  da.begin(1, 1);
+  db.begin(1, 1);
+  gemm256_prologue(smem_dyn, da, db, 16);
+#pragma unroll 1
+  for (int cls = 3; cls >= 0; --cls) {
+    const int pt = cls >> 1, pf = cls & 1;
+    const int nk = 4 << (pt + pf);
+    gemm256_mainloop<MODE_RC, MODE_RC, false, 0, true>(smem_dyn, da, db, nk, false, acc, cs);
+    asm volatile("" ::: "memory");
+    if (cls > 0) {
+      const int npt = (cls - 1) >> 1, npf = (cls - 1) & 1;
+      da.begin(npt, npf);
+      db.begin(npt, npf);
+      gemm256_prologue(smem_dyn, da, db, 4 << (npt + npf));
+    }
+    rm.pt = pt; rm.pf = pf;
+    epilogue_v3<bf16_t, DgradRowMap, 0>(acc[0], epi, a.dx, (int64_t)C, a.M, C, m0 + wr * 128, wc * 64, ep, rm, lane);
+    epilogue_v3<bf16_t, DgradRowMap, 0>(acc[1], epi, a.dx, (int64_t)C, a.M, C, m0 + wr * 128 + 64, wc * 64, ep, rm, lane);
+  }
+}
+
+// returns true when the 256 x 256 kernel handled the call (NST_CONV2_DGRAD_G256=0: the patch kernel, A/B switch of round 4)
+bool conv2_dgrad_g256(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("NST_CONV2_DGRAD_G256"); enabled = (e && e[0] == '0') ? 0 : 1; }
+  const int T2 = T1 / 2, F2 = F1 / 2;
+  if (!enabled || C != 256 || (T1 & 1) || (F1 & 1) || T1 < 2 || F1 < 2 || !nst_aligned16(dy) || !nst_aligned16(w2) || !nst_aligned16(dx))
+    return false;
+  const int64_t M = (int64_t)B * T2 * F2;
+  if (M >= (1ll << 30) || M < 256) return false;
+  Conv2Dgrad256Args a;
+  a.dy = (const bf16_t*)dy; a.w2 = (const bf16_t*)w2; a.dx = (bf16_t*)dx;
+  a.M = (int)M; a.T1 = T1; a.F1 = F1; a.T2 = T2; a.F2 = F2; a.C = C;
+  a.dF2.init(F2); a.dT2.init(T2);
+  const int grid = (int)((M + G256_TILE - 1) / G256_TILE);
+  conv_allow_big_lds(conv2_dgrad256_kernel, G256_LDS_BYTES);
+  conv2_dgrad256_kernel<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(a);
+  return true;
+}
+
 template <typename T>
 int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   if constexpr (sizeof(T) == 2)
+  {
+    if (conv2_dgrad_g256(dy, w2, dx, B, T1, F1, C, st)) return 0;
     if (conv2_dgrad_patch(dy, w2, dx, B, T1, F1, C, st)) return 0;
+  }
   for (int pt = 0; pt < 2; ++pt)
     for (int pf = 0; pf < 2; ++pf) {
       const int ct = (T1 - pt + 1) / 2, cf = (F1 - pf + 1) / 2;  // rows / cols of this parity

@@ -153,7 +153,24 @@ __device__ __forceinline__ void g256_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0
 // da / db: DMA cursors of the two operands, positioned on the unit's first K step; cursor.issue<H>(t, image, wave) stages
 // half-tile H of the unit's K step t (called with t = 0, 1, 2, ... in order for either half).  AMODE / BMODE: layout of their
 // half-tile images (fragment readers).
-template <int AMODE, int BMODE, bool CS, int DBG = 0, typename DA, typename DB>
+// The loads a unit starts with: K step 0 entirely, B of K step 1 (also callable ahead of the main loop -- PRE -- while the
+// previous unit's epilogue runs, provided that epilogue keeps out of buffer 0 and of buffer 1's B images).
+template <typename DA, typename DB>
+__device__ __forceinline__ void gemm256_prologue(char* smem, DA& da, DB& db, int nk) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  da.template issue<0>(0, smem_addr + 0 * G256_HALF_BYTES, wave);
+  da.template issue<1>(0, smem_addr + 1 * G256_HALF_BYTES, wave);
+  db.template issue<0>(0, smem_addr + 2 * G256_HALF_BYTES, wave);
+  db.template issue<1>(0, smem_addr + 3 * G256_HALF_BYTES, wave);
+  if (nk > 1) {
+    db.template issue<0>(1, smem_addr + G256_KT_BYTES + 2 * G256_HALF_BYTES, wave);
+    db.template issue<1>(1, smem_addr + G256_KT_BYTES + 3 * G256_HALF_BYTES, wave);
+  }
+}
+
+template <int AMODE, int BMODE, bool CS, int DBG = 0, bool PRE = false, typename DA, typename DB>
 __device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int nk, bool do_cs, floatx4_t (&acc)[2][4][4],
                                                  floatx4_t (&cs)[4]) {
   typedef bf16_t T;
@@ -177,16 +194,15 @@ __device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int
   const bf16x8_t ones = ones_frag<T>();
 
   // ---- prologue: K step 0 entirely, B of K step 1
-  da.template issue<0>(0, smem_addr + 0 * G256_HALF_BYTES, wave);
-  da.template issue<1>(0, smem_addr + 1 * G256_HALF_BYTES, wave);
-  db.template issue<0>(0, smem_addr + 2 * G256_HALF_BYTES, wave);
-  db.template issue<1>(0, smem_addr + 3 * G256_HALF_BYTES, wave);
-  if (nk > 1) {
-    db.template issue<0>(1, smem_addr + G256_KT_BYTES + 2 * G256_HALF_BYTES, wave);
-    db.template issue<1>(1, smem_addr + G256_KT_BYTES + 3 * G256_HALF_BYTES, wave);
-    wait_vmcnt<4>();
-  } else {
+  if constexpr (PRE) {
+    // issued by the caller in front of the previous unit's epilogue, whose stores sit between those loads and this point in
+    // the counter: drain it (and this wave's epilogue scratch reads, before anybody restages buffer 1's A images)
     wait_vmcnt<0>();
+    g256_wait_lgkm0();
+  } else {
+    gemm256_prologue(smem, da, db, nk);
+    if (nk > 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs half a phase behind from here on

@@ -76,7 +76,17 @@ class _DecodeSession(object):
 # group -- a group that cannot fill the chip, or fills it 1.06 times, wastes more than the launch saves
 # ("encoder" 14.07 vs "end" 13.91 ms on one GPU, c8_ab_step.log: behind the encoder the group shares the chip with the
 # weight-gradient stream's leftovers; what it would buy with N > 1 -- an earlier start of the exchange -- is unmeasured)
-_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT", "end")
+# Default: "end" on one GPU; "encoder" when gradients are exchanged (the reducer then gets 94 % of the parameters while the front
+# end's backward still runs; forced one-rank exchange over RCCL, profiles/r04_history/c18_ab_exchange.log: 13.05-13.08 ms vs
+# 13.11-13.19 with the launch at the end -- with real peers the exchange is longer and the difference with it)
+_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT")
+
+
+def _wgrad_group_at():
+    if _WGRAD_GROUP_AT is not None:
+        return _WGRAD_GROUP_AT
+    import torch.distributed as dist
+    return "encoder" if (dist.is_available() and dist.is_initialized()) else "end"
 
 
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
@@ -258,19 +268,20 @@ class EncoderDecoderModel(BaseModel):
             self._trg_modality.backward(ddec_in, mode="embedding")
             if not shared:
                 hook([self._modality_scope(self._trg_modality) + "/"])
-            if _WGRAD_GROUP_AT in ("stack", "side"):
+            at = _wgrad_group_at()
+            if at in ("stack", "side"):
                 # the decoder's weight gradients (+ the cross-attention k|v projections over the encoder output): one launch
-                self.rt.launch_wgrad_group(side=_WGRAD_GROUP_AT == "side")
+                self.rt.launch_wgrad_group(side=at == "side")
             denc_in = self._encoder.backward(dmemory, layer_done=hook)
             hook([self._encoder.name + "/"])
-            if _WGRAD_GROUP_AT in ("stack", "side", "encoder"):
+            if at in ("stack", "side", "encoder"):
                 # "encoder": decoder + encoder stacks in ONE full-chip launch here, in front of the front end's backward -- their
                 # gradients (94 % of the parameters) are then reported to the data-parallel reducer ~2.5 ms before the step ends
                 self.rt.launch_wgrad_group()
             self._src_modality.backward(denc_in, mode="embedding")
             hook([self._modality_scope(self._src_modality) + "/"])
             # whatever is still waiting ("end": everything in one launch; "side": the front dense layer's 20 tiles)
-            self.rt.launch_wgrad_group(side=_WGRAD_GROUP_AT == "side")
+            self.rt.launch_wgrad_group(side=at == "side")
             self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here

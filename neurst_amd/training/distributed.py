@@ -12,12 +12,18 @@ MI355X-first differences:
   * the model's backward reports every finished LAYER (decoder 5..0, embedding, encoder 11..0, front end); adjacent
     reports are merged into >= 8 MiB slices that are all-reduced on a side HIP stream while the remaining backward
     keeps the compute stream busy; the side stream -- not the compute stream -- waits for the weight-gradient stream;
-  * slices are cut into <= bucket_bytes pieces (default 32 MiB): on the fully connected 8-GPU xGMI mesh a ring is
-    bound by one ~153 GB/s link, so few large messages beat many small ones;
+  * slices are cut into <= bucket_bytes pieces (default 256 MiB, i.e. one message per report): on the fully connected 8-GPU
+    xGMI mesh a ring is bound by one ~153 GB/s link, so few large messages beat many small ones;
   * the 1/N of the average is folded into the fused Adam kernel instead of a separate scaling pass;
   * optional 16-bit wire (wire_dtype="bf16" / NST_DIST_WIRE=bf16): the reference casts gradients to fp16 on the wire in fp16
     mode (neurst/training/training_utils.py:381-384, hvd.Compression.fp16); here a slice is cast to bf16 into a staging
     buffer on the communication stream, all-reduced at half the bytes and added back as fp32.
+
+Native exchange (native=True / NST_DIST_NATIVE=1): the buckets go through the library's own RCCL entry points
+(include/neurst_hip.h: nst_comm_init / nst_comm_allreduce_bucket / nst_comm_fence / nst_comm_broadcast -- the boundary a
+non-Python host binds) instead of torch.distributed's ProcessGroupNCCL: same RCCL underneath, but the communication stream and
+its event fences are the library's, and the producers (compute stream, weight-gradient stream) are handed over per bucket.
+torch.distributed then only carries the 128-byte unique id from rank 0 to the others.
 
 Rehearsal mode (NOT the product path): NST_DIST_BACKEND=gloo with device tensors runs the same control flow -- hooks,
 bucket order, finish(), 1/N -- on a box with fewer GPUs than ranks; the exchange is then staged through the host
@@ -67,14 +73,80 @@ def init_distributed(backend=None):
 _DEBUG = os.environ.get("NST_DIST_DEBUG", "0") == "1"   # trace every exchange on stderr
 
 
+class NativeComm(object):
+    """One rank of the library's RCCL communicator (csrc/nst_comm.cpp).  The 128-byte unique id travels from rank 0 to the other
+    ranks through the existing torch.distributed group (any backend); everything after that is the C ABI."""
+
+    _DTYPES = None
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from neurst_amd import _lib
+        self._C, self._lib = C, _lib
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = C.create_string_buffer(_lib.NST_COMM_UNIQUE_ID_BYTES)
+        if rank == 0:
+            _lib.check(_lib.lib.nst_comm_unique_id(buf, len(buf)), "nst_comm_unique_id", launches=False)
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            buf = C.create_string_buffer(box[0], _lib.NST_COMM_UNIQUE_ID_BYTES)
+        handle = C.c_void_p()
+        _lib.check(_lib.lib.nst_comm_init(buf, len(buf), rank, world, C.byref(handle)), "nst_comm_init", launches=False)
+        self.handle, self.rank, self.world = handle, rank, world
+        NativeComm._DTYPES = {torch.float32: _lib.NST_F32, torch.bfloat16: _lib.NST_BF16, torch.float16: _lib.NST_COMM_F16,
+                              torch.uint8: _lib.NST_COMM_U8}
+
+    def _streams(self, streams):
+        arr = (self._C.c_void_p * max(len(streams), 1))()
+        for i, st in enumerate(streams):
+            arr[i] = st.cuda_stream
+        return arr, len(streams)
+
+    def allreduce_bucket(self, t, producers):
+        """Sums the contiguous tensor t over the ranks in place on the library's communication stream, behind everything queued
+        so far on the `producers` streams."""
+        assert t.is_contiguous()
+        arr, n = self._streams(producers)
+        self._lib.check(self._lib.lib.nst_comm_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), self._DTYPES[t.dtype], arr, n),
+                        "nst_comm_allreduce_bucket")
+
+    def fence(self, stream):
+        self._lib.check(self._lib.lib.nst_comm_fence(self.handle, stream.cuda_stream), "nst_comm_fence", launches=False)
+
+    def broadcast(self, t, root=0):
+        assert t.is_contiguous()
+        self._lib.check(self._lib.lib.nst_comm_broadcast(self.handle, t.data_ptr(), t.numel(), self._DTYPES[t.dtype], root,
+                                                         torch.cuda.current_stream().cuda_stream), "nst_comm_broadcast")
+
+    def info(self):
+        C = self._C
+        r, w, nb, by = C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
+        self._lib.check(self._lib.lib.nst_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(nb), C.byref(by)),
+                        "nst_comm_info", launches=False)
+        return {"rank": r.value, "world": w.value, "buckets_since_fence": nb.value, "bytes_since_fence": by.value}
+
+    def destroy(self):
+        if self.handle is not None and self.handle.value:
+            self._lib.check(self._lib.lib.nst_comm_destroy(self.handle), "nst_comm_destroy", launches=False)
+        self.handle = None
+
+
 class GradientReducer(object):
     """bucket_bytes: upper bound of one all-reduce message; min_bucket_bytes: ranges reported by the backward pass are
     coalesced (they arrive in reverse registration order, i.e. adjacent) until at least this much is ready, so a
     12-layer encoder becomes a handful of 8-16 MiB collectives that start while the earlier layers still
     back-propagate, instead of one 63 MiB exchange after the whole encoder."""
 
-    def __init__(self, store, bucket_bytes=32 << 20, group=None, overlap=True, min_bucket_bytes=8 << 20, extra_streams=(),
-                 force=False, wire_dtype=None):
+    def __init__(self, store, bucket_bytes=None, group=None, overlap=True, min_bucket_bytes=None, extra_streams=(),
+                 force=False, wire_dtype=None, native=None):
+        if bucket_bytes is None:
+            # (a report of the grouped weight gradients covers 110 MB at once: nothing to pipeline by cutting it, one message
+            # has the least launch overhead -- 13.05-13.08 vs 13.10 ms with 32 MiB pieces, profiles/r04_history/c18_ab_exchange.log)
+            bucket_bytes = int(float(os.environ.get("NST_DIST_BUCKET_MB", "256")) * (1 << 20))
+        if min_bucket_bytes is None:
+            min_bucket_bytes = int(float(os.environ.get("NST_DIST_MIN_BUCKET_MB", "8")) * (1 << 20))
         self.store, self.group = store, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # exchanges are issued when there is someone to exchange with -- or on request with an initialised one-rank group
@@ -106,6 +178,13 @@ class GradientReducer(object):
         # graph capture of the train step (training/train_step.py): instead of issuing a bucket, the reducer hands its
         # range to this callback, which cuts the capture there and replays the exchange eagerly between two graph launches
         self.capture_cut = None
+        # the library's own RCCL communicator instead of torch.distributed's (module docstring)
+        if native is None:
+            native = os.environ.get("NST_DIST_NATIVE", "0") == "1"
+        self.native = bool(native and self.active and self.on_gpu and not self.host_staged)
+        self._comm = None
+        if self.native:
+            self._comm = NativeComm(group)
         if self.wire_dtype is not None and self.active and not self.host_staged:
             # staging buffer of the 16-bit wire, as long as the gradient buffer: every in-flight message owns its own region.
             # Allocated here, not inside the first step (a step that is being captured into a HIP graph must not allocate it)
@@ -152,6 +231,9 @@ class GradientReducer(object):
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 g[s:e].copy_(host)
                 continue
+            if self.native:
+                self._allreduce_native(g, s, e)
+                continue
             if self.wire_dtype is not None:
                 # 16-bit wire: the staging buffer is as long as the gradient buffer, so every in-flight message owns its own
                 # region (no reuse hazard between asynchronous collectives); the add-back is queued on the same stream
@@ -168,6 +250,19 @@ class GradientReducer(object):
             h = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append(h)
 
+    def _allreduce_native(self, g, s, e):
+        """16-bit wire through the library's communicator (the fp32 wire needs no staging: issue() hands the slice over as is).
+        The casts run on the current stream (the reducer's side stream), the collective on the library's behind them."""
+        cur = torch.cuda.current_stream()
+        w = self._wire_buf[s:e]
+        if self.prescale:
+            w.copy_(g[s:e] * (1.0 / self.world))
+        else:
+            w.copy_(g[s:e])
+        self._comm.allreduce_bucket(w, [cur])
+        self._comm.fence(cur)          # the add-back below is queued behind the collective
+        g[s:e].copy_(w)
+
     def _issue(self, start, end):
         if not self.active or end <= start:
             return
@@ -178,7 +273,14 @@ class GradientReducer(object):
 
     def issue(self, start, end):
         """The exchange of grad[start:end] itself (asynchronous on the communication stream when there is one)."""
-        if self.overlap:
+        if self.native and self.wire_dtype is None:
+            # producers = the current stream + the weight-gradient stream; neither waits for the bucket
+            cur = torch.cuda.current_stream()
+            for s0 in range(start, end, self.bucket_elems):
+                e0 = min(end, s0 + self.bucket_elems)
+                self.messages += 1
+                self._comm.allreduce_bucket(self.store.grad[s0:e0], [cur] + self.extra_streams)
+        elif self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for s in self.extra_streams:
                 self.comm_stream.wait_stream(s)
@@ -233,16 +335,24 @@ class GradientReducer(object):
         self._pending = []
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.native:
+            self._comm.fence(torch.cuda.current_stream())
 
     def broadcast_parameters(self, src=0):
         """BroadcastGlobalVariablesCallback(0) (exps/trainer.py:285)."""
-        if self.active:
+        if self.native:
+            self._comm.broadcast(self.store.master, src)
+            self.store.refresh_shadow()
+        elif self.active:
             dist.broadcast(self.store.master, src=src, group=self.group)
             self.store.refresh_shadow()
 
     def broadcast_tensors(self, tensors, src=0):
         """Other replicated state that must start identical on every rank (optimizer moments after a resume)."""
-        if self.active:
+        if self.native:
+            for t in tensors:
+                self._comm.broadcast(t, src)
+        elif self.active:
             for t in tensors:
                 dist.broadcast(t, src=src, group=self.group)
 

@@ -167,10 +167,6 @@ class TrainStep(object):
         # does not need it; it is available for every dtype: loss_scale="dynamic" or a dict of its three constants.
         self.loss_scale = None
         if loss_scale:
-            if self.clip_value or self.clip_norm:
-                # the clip kernel takes its pre-scale by value; un-scaling by the device-resident loss scale in front of it
-                # is not built (the path computes in bf16, which needs no loss scale) -- refused here, not at the first step
-                raise NotImplementedError("loss scaling together with gradient clipping")
             import inspect
             if "loss_scale_dev" not in inspect.signature(criterion.backward).parameters:
                 raise TypeError(f"{type(criterion).__name__}.backward() must accept loss_scale_dev for dynamic loss scaling "
@@ -182,6 +178,10 @@ class TrainStep(object):
             self.loss_scale = cfg
             self._ls_state = torch.tensor([cfg["initial_loss_scale"], 0.0, 1.0, cfg["initial_loss_scale"]], dtype=torch.float32).to(dev)
             self._ls_counter = torch.zeros(4, dtype=torch.int32, device=dev)
+            # together with clipping (gradaccum_keras_model.py:224-233: aggregate -> get_unscaled_gradients -> clip -> apply):
+            # the factor that un-scales and averages, and the state the optimizer sees afterwards (same finite flag, scale 1)
+            self._ls_factor = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._ls_apply = self._ls_state.clone()
         if use_graph is None:
             use_graph = os.environ.get("NST_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and model.rt.device.type == "cuda"
@@ -214,17 +214,31 @@ class TrainStep(object):
             self.model.backward(dlogits, accumulate=(i > 0))
             loss_sum = loss if loss_sum is None else loss_sum + loss
         scale = self.reducer.finish() if self.reducer is not None else 1.0
-        if self.clip_value or self.clip_norm:
-            from neurst_amd import kernels as K
+        from neurst_amd import kernels as K
+        clip = bool(self.clip_value or self.clip_norm)
+        ls_state = None
+        if self.loss_scale:
+            # the finite check runs on the exchanged, still SCALED gradients (the reference aggregates before it unscales)
+            K.loss_scale_update(self.model.store.grad, self._ls_state, self.loss_scale["growth_steps"], self.loss_scale["multiplier"],
+                                self._ls_counter)
+            ls_state = self._ls_state
+            if clip:
+                # clipping acts on UNSCALED gradients: divide by the scale they carry (state[3], device-resident: the step may
+                # be a graph replay) and average in one pass; the optimizer then only needs the finite flag.  An overflow step
+                # clips inf / nan into garbage that the flag keeps out of the weights.
+                torch.div(torch.full_like(self._ls_factor, float(scale)), self._ls_state[3:4], out=self._ls_factor)
+                self.model.store.grad.mul_(self._ls_factor)
+                scale = 1.0
+                self._ls_apply.copy_(self._ls_state)
+                self._ls_apply[3:4].fill_(1.0)
+                ls_state = self._ls_apply
+        if clip:
             table, nentries, seg_first, nseg = self.model.store.clip_tables()
             K.grad_clip(self.model.store.grad, table, nentries, seg_first, nseg, pre_scale=scale,
                         clip_value=self.clip_value, clip_norm=self.clip_norm)
             scale = 1.0   # the average is already applied
-        if self.loss_scale:
-            from neurst_amd import kernels as K
-            K.loss_scale_update(self.model.store.grad, self._ls_state, self.loss_scale["growth_steps"], self.loss_scale["multiplier"],
-                                self._ls_counter)
-            self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev, loss_scale_state=self._ls_state)
+        if ls_state is not None:
+            self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev, loss_scale_state=ls_state)
         else:
             self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev)
         return loss_sum / n

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _setup(dtype, dropout, use_graph, reducer_factory=None, lr=1e-2, seed=11):
+def _setup(dtype, dropout, use_graph, reducer_factory=None, lr=1e-2, seed=11, **step_kwargs):
     from neurst_amd.criterions import build_criterion
     from neurst_amd.models import build_model
     from neurst_amd.optimizers.adam import Adam
@@ -30,7 +30,7 @@ def _setup(dtype, dropout, use_graph, reducer_factory=None, lr=1e-2, seed=11):
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     opt = Adam(model.store, learning_rate=(lambda it: lr * (1.0 + 0.1 * it)), beta_1=0.9, beta_2=0.98, epsilon=1e-9)
     red = reducer_factory(model.store) if reducer_factory else None
-    return model, TrainStep(model, crit, opt, red, use_graph=use_graph), opt
+    return model, TrainStep(model, crit, opt, red, use_graph=use_graph, **step_kwargs), opt
 
 
 def _solid(v, rel=1e-8):
@@ -74,6 +74,30 @@ def test_graph_replay_equals_eager_steps(dtype, dropout):
         # can take one Adam step of the opposite sign in one of the runs: lr = 1e-2 .. 1.6e-2 here, seen at 3.6e-3 on an MI355X)
         d = (we - wg).abs() * _solid(ve, 1e-4)
         assert float(d.max()) <= 2e-2 and float((d > 1e-3).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("clip", [{"clip_value": 2e-3}, {"clip_norm": 5e-2}])
+def test_loss_scale_with_clipping_eager_and_replayed(clip):
+    """Dynamic loss scale + clipping in one step (gradaccum_keras_model.py:224-233: aggregate -> unscale -> clip -> apply): the
+    scaled step lands on the weights of the unscaled clipped step, eagerly and as a graph replay (the un-scaling factor is
+    read from the device-resident loss-scale state when the kernels run); the scale doubles on schedule."""
+    batches = [_batch(300 + i) for i in range(5)]
+    ls = {"initial_loss_scale": 1024.0, "growth_steps": 2, "multiplier": 2.0}
+    res = {}
+    for tag, use_graph, kw in (("plain", False, dict(clip)), ("eager", False, dict(clip, loss_scale=ls)),
+                               ("graph", True, dict(clip, loss_scale=ls)), ("free", False, {})):
+        model, step, opt = _setup("float32", 0.0, use_graph, **kw)
+        for b in batches:
+            step(b)
+        torch.cuda.synchronize()
+        res[tag] = (model.store.master.clone(), opt.v.clone(), step)
+    want, v, _ = res["plain"]
+    for tag in ("eager", "graph"):
+        got, _, step = res[tag]
+        assert float(((got - want).abs() * _solid(v)).max()) <= 5e-5, tag
+        assert [float(x) for x in step._ls_state[:3]] == [4096.0, 1.0, 1.0], tag      # 5 good steps: x2 after 2 and 4
+    assert res["graph"][2].replays == len(batches) - 1
+    assert float(((res["free"][0] - want).abs() * _solid(v)).max()) > 1e-3       # the clip bites at these thresholds
 
 
 def test_graph_replay_draws_new_dropout_masks_and_new_step_sizes():

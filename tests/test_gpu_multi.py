@@ -37,7 +37,7 @@ def _inputs(inputs, seed):
     return out
 
 
-def _worker(rank, world, port, q, graph):
+def _worker(rank, world, port, q, graph, native=False, wire=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NST_DIST_FORCE="1")
@@ -49,8 +49,9 @@ def _worker(rank, world, port, q, graph):
     r, lr, w = init_distributed()
     dev = f"cuda:{lr}"
     model, inputs, cfg = _build(dev)
-    red = GradientReducer(model.store, bucket_bytes=64 << 10, min_bucket_bytes=16 << 10, force=True)   # several messages per step
-    assert red.overlap and red.active and red.world == world
+    red = GradientReducer(model.store, bucket_bytes=64 << 10, min_bucket_bytes=16 << 10, force=True, native=native,
+                          wire_dtype=wire)   # several messages per step
+    assert red.overlap and red.active and red.world == world and red.native == native
     red.broadcast_parameters(0)
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
@@ -62,6 +63,9 @@ def _worker(rank, world, port, q, graph):
     torch.cuda.synchronize()
     m = red.reduce_metrics({"loss": losses[-1], "ranks": 1.0})
     q.put((rank, model.store.master.cpu().numpy().copy(), losses, red.last_messages, m))
+    if native:
+        assert red._comm.info()["world"] == world
+        red._comm.destroy()
     dist.destroy_process_group()
 
 
@@ -90,12 +94,66 @@ def test_exchange_path_over_rccl_with_one_forced_rank(graph):
     _run_data_parallel(1, graph)
 
 
-def _run_data_parallel(world, graph):
+@pytest.mark.parametrize("graph", [False, True])
+def test_exchange_through_the_native_comm_entry_points_with_one_forced_rank(graph):
+    """The same step with the buckets going through nst_comm_allreduce_bucket / nst_comm_fence / nst_comm_broadcast
+    (csrc/nst_comm.cpp: the library's own RCCL communicator and communication stream) instead of torch.distributed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device: No HIP GPUs are available")
+    _run_data_parallel(1, graph, native=True)
+
+
+def test_native_comm_two_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device: No HIP GPUs are available")
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"2-rank native RCCL exchange NOT exercised: {torch.cuda.device_count()} GPU visible")
+    _run_data_parallel(2, True, native=True)
+
+
+def test_native_comm_one_rank_collectives_are_identities():
+    """nst_comm_* directly: unique id, a one-rank communicator, all-reduce (fp32 / bf16 / fp16) and broadcast leave the data
+    as it is, ordered behind a producer stream that is still writing it; info counts buckets and bytes; destroy."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device: No HIP GPUs are available")
+    from neurst_amd.training.distributed import NativeComm
+    comm = NativeComm()
+    assert comm.info() == {"rank": 0, "world": 1, "buckets_since_fence": 0, "bytes_since_fence": 0}
+    side = torch.cuda.Stream()
+    n = 1 << 20
+    total = 0
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        x = torch.zeros(n, device="cuda", dtype=dtype)
+        ref = torch.arange(n, device="cuda").remainder(251).to(dtype)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):          # the producer is still busy when the bucket is issued
+                x.copy_(ref * 0)
+            x.copy_(ref)
+        comm.allreduce_bucket(x, [side])
+        total += n * x.element_size()
+        comm.fence(torch.cuda.current_stream())
+        y = x.clone()                    # consumer: ordered behind the bucket by the fence
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    assert comm.info()["buckets_since_fence"] == 0
+    x = torch.randn(4096, device="cuda")
+    keep = x.clone()
+    comm.allreduce_bucket(x, [torch.cuda.current_stream()])
+    comm.allreduce_bucket(x[:8], [])
+    assert comm.info()["buckets_since_fence"] == 2 and comm.info()["bytes_since_fence"] == 4096 * 4 + 32
+    comm.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, keep)
+    comm.destroy()
+
+
+def _run_data_parallel(world, graph, native=False):
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph, native)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])

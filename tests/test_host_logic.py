@@ -27,10 +27,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, s), f"{s} declared in include/neurst_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 7
+    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 8
     out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (nst_[a-z0-9_]+)", out))
     assert exported == set(syms)
+
+
+def test_comm_entry_points_validate_their_arguments_without_a_device():
+    """nst_comm_* (include/neurst_hip.h, ABI v8): argument errors are reported before RCCL or the device is touched."""
+    from neurst_amd import _lib
+    L = _lib.lib
+    small = ctypes.create_string_buffer(16)
+    assert L.nst_comm_unique_id(small, len(small)) == -1 and b"128" in L.nst_last_error_string()
+    handle = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(_lib.NST_COMM_UNIQUE_ID_BYTES)
+    assert L.nst_comm_init(ident, len(ident), 2, 2, ctypes.byref(handle)) == -1 and handle.value is None
+    assert b"rank 2 of 2" in L.nst_last_error_string()
+    assert L.nst_comm_init(ident, 8, 0, 1, ctypes.byref(handle)) == -1
+    fake = ctypes.create_string_buffer(256)      # not a communicator: the magic number is missing
+    assert L.nst_comm_allreduce_bucket(fake, None, 0, _lib.NST_F32, None, 0) == -1
+    assert b"not a communicator" in L.nst_last_error_string()
+    assert L.nst_comm_fence(fake, None) == -1 and L.nst_comm_broadcast(fake, None, 0, _lib.NST_F32, 0, None) == -1
+    assert L.nst_comm_destroy(fake) == -1 and L.nst_comm_destroy(None) == 0
 
 
 def test_struct_layouts_match_header_sizes():

@@ -1030,3 +1030,38 @@ def test_dynamic_loss_scale_skips_overflow_steps_and_follows_the_reference_sched
     assert torch.equal(model.store.master, before) and torch.equal(opt.m, m_before)      # the step was skipped
     step(_speech_inputs(shape, 100))
     assert float(step._ls_state[2]) == 1.0 and not torch.equal(model.store.master, before)
+
+
+@pytest.mark.parametrize("clip", [{"clip_value": 2e-3}, {"clip_norm": 5e-2}])
+def test_dynamic_loss_scale_together_with_clipping(cpu_kernels, clip):
+    """gradaccum_keras_model.py:224-233 with a LossScaleOptimizer: aggregate -> get_unscaled_gradients -> clip -> apply.  The
+    scaled-and-clipped step must land on the weights of the unscaled clipped step (the clip acts on UNSCALED gradients: with
+    a scale of 1024 a clip applied first would cut everything), and an overflow step is still skipped."""
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.training.train_step import TrainStep
+    mk = lambda: build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    model, cfg, shape = _speech_model("toy")
+    ref_model, _, _ = _speech_model("toy")
+    free_model, _, _ = _speech_model("toy")
+    opt, ref_opt, free_opt = (Adam(m.store, learning_rate=1e-2) for m in (model, ref_model, free_model))
+    step = TrainStep(model, mk(), opt, loss_scale={"initial_loss_scale": 1024.0, "growth_steps": 2, "multiplier": 2.0}, **clip)
+    ref_step = TrainStep(ref_model, mk(), ref_opt, **clip)
+    free_step = TrainStep(free_model, mk(), free_opt)
+    for i in range(3):
+        b = _speech_inputs(shape, 70 + i)
+        step(b), ref_step(b), free_step(b)
+    assert [float(step._ls_state[0]), float(step._ls_state[2])] == [2048.0, 1.0]
+    assert rel_err(model.store.master, ref_model.store.master) < 1e-4
+    # the clip bites at these thresholds (otherwise the comparison above would not tell the order of the two apart)
+    assert rel_err(free_model.store.master, ref_model.store.master) > 1e-3
+    before = model.store.master.clone()
+    orig = model.backward
+
+    def poisoned(dlogits, accumulate=False):
+        orig(dlogits, accumulate=accumulate)
+        model.store.grad[7] = float("nan")
+    model.backward = poisoned
+    step(_speech_inputs(shape, 99))
+    model.backward = orig
+    assert float(step._ls_state[2]) == 0.0 and torch.equal(model.store.master, before)
