@@ -19,9 +19,10 @@ import os
 import sys
 import time
 
-# before the HIP runtime initialises: enough hardware queues for compute + weight-gradient + communication + RCCL streams
-# (neurst_amd/__init__.py has the measurement; with the default of 4 two of them share a queue and serialise)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# before the HIP runtime initialises: ONE hardware queue per stream-priority class (the step, its weight-gradient stream and the
+# exchange live in three classes; more queues per class made the step time depend on stream-creation history, 13 vs 21-31 ms:
+# neurst_amd/__init__.py has the measurements)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 
 import torch  # noqa: E402
 

@@ -2,17 +2,19 @@
 
 Process-wide HIP setting, applied before the HIP runtime initialises (it reads the variable once, at its first call):
 
-GPU_MAX_HW_QUEUES.  ROCm multiplexes a process's HIP streams onto at most this many hardware queues per device
-(default 4); streams that share a queue run strictly one after the other.  A data-parallel rank owns the compute stream,
-the weight-gradient stream, the communication stream of the gradient exchange and RCCL's own stream(s): with 4 queues the
-weight-gradient stream lands on the compute stream's queue and the two stop overlapping -- measured on one MI355X with
-the exchange path active: 20.2 ms per step against 16.4 ms with 8 queues (the kernels then run back to back: kernel-time
-sum == busy time in the rocprofv3 trace).  Worse, packets of two streams in one queue execute in SUBMISSION order, so a
-cross-stream wait can become a cycle: in a two-rank rehearsal over gloo (whose CUDA path takes a fresh pool stream per
-collective, 13 per step) the second step deadlocked with 8 queues -- a copy waiting for the compute stream sat in front of
-the weight-gradient GEMMs the compute stream was waiting for -- and ran with 32.  16 leaves headroom over the 4-6 streams
-of an RCCL rank and measured the same step time as 8.  An explicit setting in the environment wins.
+GPU_MAX_HW_QUEUES = 1.  ROCm multiplexes the HIP streams of ONE priority class onto at most this many hardware queues (default
+4).  A training step here has three concurrent activities and keeps each in a priority class of its own (runtime.make_stream:
+the step on a high-priority stream, its weight-gradient stream on a low-priority one, the gradient exchange in the default
+class), so one queue per class is all the concurrency it needs -- and MORE queues are what hurts: with 16 per class (rounds 2-3,
+chosen when the step's streams still shared a class) the same step ran at 13.0 ms or at 21-31 ms depending only on how many
+streams other libraries had touched before the first step (a second RCCL communicator, a few idle pool streams; even a
+single-stream eager step: 31 ms).  In the slow runs every kernel is stretched by 30-45 us (rocprofv3 kernel trace), as if the
+scheduler time-sliced the process's queues once their number passes a threshold.  With 1 or 2 queues per class all 14
+configurations tried run at 12.96-13.22 ms (profiles/r04_history/c26_order.log, c27_streams.log, c28_hwq.log).
+Streams that share a queue execute in submission order; with one submitting host thread and record-before-wait events that
+order cannot close a wait cycle (round 2's deadlock needed gloo's worker threads submitting copies of their own; that
+rehearsal path is host-staged since round 3).  An explicit setting in the environment wins.
 """
 import os
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")

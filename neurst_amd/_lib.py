@@ -139,6 +139,8 @@ SIGNATURES = {
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
     "nst_pack2d": [_P, _I, _I, _P],
+    "nst_stream_create": [_I, C.POINTER(C.c_void_p)],
+    "nst_stream_destroy": [_P],
     "nst_comm_unique_id": [_P, C.c_size_t],
     "nst_comm_init": [_P, C.c_size_t, _I, _I, C.POINTER(C.c_void_p)],
     "nst_comm_info": [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],

@@ -53,6 +53,33 @@ extern "C" int nst_dropout_seed_offset_add(uint64_t delta, void* stream) { retur
 extern "C" const char* nst_last_error_string(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
+// Streams of a given priority class.  The HIP runtime multiplexes the streams of ONE class onto a few hardware queues (least
+// used first), and two busy streams that end up in one queue run in turns; the three concurrent activities of a training step
+// -- the step itself, its weight-gradient stream, the gradient exchange -- are therefore kept in three different classes.
+// ---------------------------------------------------------------------------------------------
+extern "C" int nst_stream_create(int priority_class, void** stream_out) {
+  NST_CHECK_ARG(stream_out != nullptr, "nst_stream_create: NULL output");
+  *stream_out = nullptr;
+  NST_CHECK_ARG(priority_class >= -1 && priority_class <= 1, "nst_stream_create: priority class %d (-1 high, 0 default, 1 low)",
+                priority_class);
+  int least = 0, greatest = 0;
+  NST_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int prio = priority_class < 0 ? greatest : priority_class > 0 ? least : 0;
+  if ((priority_class < 0 && greatest >= 0) || (priority_class > 0 && least <= 0)) {
+    nst_set_error("nst_stream_create: the device has no priority class %d (range %d .. %d)", priority_class, greatest, least);
+    return NST_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = nullptr;
+  NST_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  *stream_out = s;
+  return NST_OK;
+}
+extern "C" int nst_stream_destroy(void* stream) {
+  if (stream) NST_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return NST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host helper of the data feed: CRC-32C (Castagnoli) of TFRecord frames, slicing-by-8 (the Python table walk in
 // neurst_amd/data/tfrecord.py does ~2 MB/s; a 900-frame utterance is 288 KB).
 // ---------------------------------------------------------------------------------------------

@@ -70,6 +70,10 @@ const RcclApi* rccl() {
     nst_set_error("nst_comm: librccl.so.1 lacks an entry point (%s)", dlerror());
     return nullptr;
   }
+  if (getenv("NST_COMM_DEBUG")) {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(a.AllReduce), &info) && info.dli_fname) fprintf(stderr, "[nst_comm] RCCL bound from %s\n", info.dli_fname);
+  }
   g_rccl = a;
   return &g_rccl;
 }
@@ -148,6 +152,9 @@ extern "C" int nst_comm_init(const void* id, size_t id_bytes, int rank, int worl
     delete c;
     return rc;
   }
+  // the communication stream stays in the DEFAULT priority class: the host runs the step on a high-priority stream and its
+  // weight-gradient stream on a low-priority one (nst_stream_create), so this stream -- whose waits for those two must never
+  // sit in front of their kernels in a shared hardware queue -- cannot meet either of them in a queue
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {

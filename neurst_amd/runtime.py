@@ -255,6 +255,26 @@ class ParamStore(object):
         return sum(p.numel for p in self.params.values())
 
 
+def make_stream(device, priority_class):
+    """A HIP stream of priority class -1 (high) / 0 (default) / 1 (low) as a torch stream.  Why classes: the HIP runtime
+    multiplexes the streams of ONE class onto a few hardware queues (the least used one at creation time), and two busy streams
+    that meet in a queue run in turns -- the same step took 13.0 or 22 ms depending on how many streams other libraries had
+    created before (profiles/r04_history/c26_order.log).  The step (high), its weight-gradient stream (low) and the gradient
+    exchange (default) are therefore kept in different classes.  torch.cuda.Stream reaches the default class and the higher
+    ones; the low class comes from the library (nst_stream_create) and is wrapped as an ExternalStream."""
+    device = torch.device(device)
+    if priority_class <= 0:
+        return torch.cuda.Stream(device, priority=priority_class)
+    import ctypes
+    from neurst_amd import _lib
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _lib.lib.nst_stream_create(priority_class, ctypes.byref(handle))
+    if rc != 0 or not handle.value:      # no such class on this device: the default class
+        return torch.cuda.Stream(device)
+    return torch.cuda.ExternalStream(handle.value, device=device)   # lives as long as the process
+
+
 class Runtime(object):
     """Per-process execution context shared by all layers of a model."""
 
@@ -280,7 +300,7 @@ class Runtime(object):
         self.wgrad_stream = None
         self.capture = None   # set by TrainStep while it captures a step (see run_wgrad)
         if self.device.type == "cuda" and os.environ.get("NST_WGRAD_STREAM", "1") != "0":
-            self.wgrad_stream = torch.cuda.Stream(self.device)
+            self.wgrad_stream = make_stream(self.device, int(os.environ.get("NST_WGRAD_PRIORITY", "1")))
 
     @contextlib.contextmanager
     def on_wgrad_stream(self, *tensors):

@@ -70,6 +70,7 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+
 _DEBUG = os.environ.get("NST_DIST_DEBUG", "0") == "1"   # trace every exchange on stderr
 
 

@@ -188,10 +188,20 @@ class TrainStep(object):
         self._seen, self._captured = set(), {}
         self._lr_dev = self._cap_stream = self._side_stream = None
         self.replays = 0
+        # The step runs on a HIGH-priority stream of its own (NST_STEP_PRIORITY=0: on the caller's stream): the runtime then
+        # keeps it on hardware queues apart from the weight-gradient stream (low class) and from the exchange (default class),
+        # whatever streams other libraries created before -- see runtime.make_stream.  The caller's stream is ordered before
+        # and after the step, so the step still behaves like work queued on the caller's stream.
+        self._step_stream = None
+        if model.rt.device.type == "cuda":
+            prio = int(os.environ.get("NST_STEP_PRIORITY", "-1"))
+            if prio != 0:
+                from neurst_amd.runtime import make_stream
+                self._step_stream = make_stream(model.rt.device, prio)
         if self.use_graph:
             model.rt.enable_device_step()
             self._lr_dev = torch.zeros(1, dtype=torch.float32, device=model.rt.device)
-            self._cap_stream = torch.cuda.Stream(model.rt.device)
+            self._cap_stream = self._step_stream if self._step_stream is not None else torch.cuda.Stream(model.rt.device)
 
     def _hook(self, prefixes):
         if self._last_micro and self.reducer is not None:
@@ -248,6 +258,18 @@ class TrainStep(object):
         the micro-batch gradients, GradientAccumulator semantics gradaccum_keras_model.py:62-109)."""
         if isinstance(batches, dict):
             batches = [batches]
+        if self._step_stream is None:
+            return self._call(batches)
+        cur = torch.cuda.current_stream(self.model.rt.device)
+        if cur == self._step_stream:
+            return self._call(batches)
+        self._step_stream.wait_stream(cur)
+        with torch.cuda.stream(self._step_stream):
+            loss = self._call(batches)
+        cur.wait_stream(self._step_stream)
+        return loss
+
+    def _call(self, batches):
         if self.use_graph:
             return self._graph_call(batches)
         loss = self._body(batches)
