@@ -1181,11 +1181,6 @@ __global__ void __launch_bounds__(V2W_THREADS) conv_gemm_kernel_v2w(AL la, BL lb
   gemm_block_v2w<T, OutT, AMODE, BMODE, AL, BL, RM>(la, lb, C, ldc, M, N, tm * BM, tn * 2 * BN, kt_total, ep, smem_dyn, rm);
 }
 
-bool conv_wide_dgrad() {  // measured slower than two 128-column tiles for the dgrad classes (short K): off unless asked for
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV_WIDE_DGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
 
 bool conv_use_wide() {
   static int v = -1;
@@ -1208,7 +1203,7 @@ conv2_wgrad_kernel_v3(GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityR
 // the MFMA work per K step, per DMA round trip and per barrier, and dy is read once per row panel (0.95 against 1.10 ms
 // stand-alone).  The same kernel for the DENSE weight gradients made the step slower (16.4 against 16.3 ms): a 96 KB
 // workgroup cannot share a CU with an 80 KB stream-GEMM workgroup of the dgrad chain, the conv2 weight gradient only
-// ever runs next to the 160 KB dgrad patch kernel.
+// ever runs next to the conv2 data gradient, which holds its CUs alone as well.
 template <typename T>
 __global__ void __launch_bounds__(V2W_THREADS)
 conv2_wgrad_wide_kernel(Im2colLoader<T> la, DenseLoader<T> lb, float* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_n,
@@ -1263,11 +1258,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
   }
 }
 
-int conv_nst() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_NST"); v = e ? atoi(e) : 2; }
-  return v;
-}
+int conv_nst() { return 2; }   // stages of the v2 ring (three measured no faster in round 2 and are gone)
 
 bool conv_use_v2() {
   static int v = -1;
@@ -1287,22 +1278,12 @@ void conv_allow_big_lds(KernelT kernel, int bytes) {
 
 #define NST_CONV_LAUNCH_V2(T_, OutT_, AM, BMO, AL, BL, RM, grid, ktps, ...)                                   \
   do {                                                                                                        \
-    if (conv_nst() >= 3 && (ktps) >= 3) {                                                                     \
-      auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 3, AL, BL, RM>;                                      \
-      conv_allow_big_lds(kfn, 3 * V2_STAGE_BYTES);                                                            \
-      kfn<<<grid, THREADS, 3 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                            \
-    } else {                                                                                                  \
-      auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 2, AL, BL, RM>;                                      \
-      conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);                                                            \
-      kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                            \
-    }                                                                                                         \
+    auto kfn = conv_gemm_kernel_v2<T_, OutT_, AM, BMO, 2, AL, BL, RM>;                                        \
+    conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);                                                              \
+    kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(__VA_ARGS__);                                              \
   } while (0)
 
-bool conv_use_tr() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+bool conv_use_tr() { return true; }   // (the fragment path without ds_read_b64_tr_b16 is no longer instantiated)
 
 Epilogue plain_epilogue() {
   Epilogue ep;
@@ -1316,399 +1297,6 @@ Epilogue plain_epilogue() {
 }
 
 
-// =============================================================================================
-// conv2 forward with an LDS-RESIDENT input patch (bf16, C == 256, even T1).
-//
-// The implicit-GEMM kernels above gather the A operand tap by tap, so every input pixel crosses the L2 / HBM interface
-// up to 2.25 times (measured 2.7 GB against 1.5 GB of algorithmic traffic).  Here a workgroup owns 128 consecutive
-// output pixels x all 256 output channels and, per 64-channel slice of the input, stages the BAND of input rows those
-// pixels touch ONCE (<= 17 rows x (F1+2) columns x 128 B, zero columns left and right stand for the padding); the nine
-// taps then read their A fragments from that patch at per-lane addresses (position = patch row (2*dr+kh), column
-// (2*fo+kw)), and only the 32 KB weight tile of each (tap, slice) streams through a double buffer.
-//   * with T1 == 2*T2 the band is contiguous in memory across images: input row of output row `orow` (global, over
-//     all images) and tap kh is 2*orow + kh - 1; only the top padding row (to == 0, kh == 0) needs a mask, which is a
-//     per-lane select of a zero block in LDS;
-//   * patch layout: pixel position `pos` lives at 128-byte slot pos ^ ((pos>>4)&1) with its eight 16-byte chunks
-//     XOR-ed by (pos>>1)&7 -- the 16 lanes of a fragment read walk positions two apart (same involution on the DMA
-//     source side); a ds_read_b128 of this layout costs 8-12 LDS cycles instead of 4, which the loop does not feel.
-// Variants measured and dropped (same shape, 983 us for this kernel): 32-channel slices with two workgroups per CU
-// (1070 us), a double-buffered 32-channel patch (1086 us), even/odd row regions reloaded under the multiply steps
-// (1008 us) -- the K loop, not the patch reload, is the limit: ~2100 cycles per K step for 1024 MFMA cycles per SIMD.
-// =============================================================================================
-// NST_CONV_ISSUE_LATE=1: the next weight tile's DMA behind this step's fragment reads instead of in front of them.  Measured
-// SLOWER in the step (15.12 -> 15.31 ms, gpurun_out/r03_conv_issue_late.log: the tile then has less than a step to land); off.
-static int conv_issue_late() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV_ISSUE_LATE"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v;
-}
-
-struct PatchArgs {
-  const bf16_t* x;
-  const bf16_t* w2;
-  bf16_t* y;
-  int T2, F1, F2, C, M, PW, in_rows, ntiles;
-  FastDiv dF2, dT2, dPW;
-  int issue_late;   // != 0: the next weight tile's DMA is issued BEHIND this step's fragment reads (its issue time then covers
-                    // their LDS latency; with one workgroup per CU both waves of a SIMD otherwise sit in the issue together)
-  Epilogue ep;
-};
-constexpr int CP_THREADS = 512;
-constexpr int CP_BBUF = 2 * BM * KBYTES;                      // one (tap, slice) weight tile: two 128-column images
-constexpr int CP_LDS_BYTES = 160 * 1024;
-constexpr int CP_ZERO_OFF = CP_LDS_BYTES - 2 * CP_BBUF - 1024;  // 128-byte zero block (1 KB slot) behind the patch
-constexpr int CP_PATCH_MAX = CP_ZERO_OFF;                      // 97280 B = 760 pixel positions
-constexpr int CP_B_OFF = CP_ZERO_OFF + 1024;
-constexpr int CP_NIT = (CP_PATCH_MAX / 1024 + 7) / 8;         // patch pieces (1 KB) per wave
-
-__global__ void __launch_bounds__(CP_THREADS) conv2_fwd_patch_kernel(PatchArgs a) {
-  typedef SwzFrag<bf16_t, MODE_OC> RB;
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  char* smem = smem_dyn;
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = wave >> 2, wq = wave & 3;
-  const int wm = quad * 64, wn = wq * 64;
-  const int tile = xcd_remap(blockIdx.x, a.ntiles);
-  const int m0 = tile * BM;
-  const int last_p = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
-  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
-  const int band_row0 = 2 * orow_first - 1;
-  const int npos = (2 * (orow_last - orow_first) + 3) * a.PW;
-  const int npieces = (npos + 7) >> 3;
-  if (tid < 32) reinterpret_cast<uint32_t*>(smem + CP_ZERO_OFF)[tid] = 0u;
-
-  // DMA sources of this wave's patch pieces (byte offsets into x for channel slice 0; ~0u = zero block)
-  uint32_t poff[CP_NIT];
-#pragma unroll
-  for (int it = 0; it < CP_NIT; ++it) {
-    const int P = (it * 8 + wave) * 8 + (lane >> 3);
-    const int pos = P ^ ((P >> 4) & 1);
-    const int prow = (int)a.dPW.div((uint32_t)pos), pc = pos - prow * a.PW;
-    const int grow = band_row0 + prow;
-    const bool ok = pos < npos && pc >= 1 && pc <= a.F1 && grow >= 0 && grow < a.in_rows;
-    const uint32_t chunk = (uint32_t)((lane & 7) ^ ((pos >> 1) & 7));
-    poff[it] = ok ? ((uint32_t)(grow * a.F1 + pc - 1) * (uint32_t)(a.C * 2) + chunk * 16u) : ~0u;
-  }
-  auto stage_patch = [&](int cc) {
-#pragma unroll
-    for (int it = 0; it < CP_NIT; ++it) {
-      const int piece = it * 8 + wave;
-      if (piece < npieces) {
-        const char* src = poff[it] != ~0u ? reinterpret_cast<const char*>(a.x) + poff[it] + cc * KBYTES
-                                          : reinterpret_cast<const char*>(g_nst_zero16);
-        glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
-      }
-    }
-  };
-  // weight tile (rows k0..k0+63 of w2 viewed as [9C, C], this wave's quarter of image `quad`)
-  uint32_t boff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int c = (s * 4 + wq) * 64 + lane;
-    const int r = c >> 4, c16 = c & 15;
-    const int g = (r & 3) | (((r >> 3) & 1) << 2);
-    boff[s] = (uint32_t)((r * a.C + quad * BM + (c16 ^ (g << 1)) * 8) * 2);
-  }
-  auto issue_b = [&](int k0, int buf) {
-    const char* wb = reinterpret_cast<const char*>(a.w2) + (int64_t)k0 * a.C * 2;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      glds16(wb + boff[s], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(CP_B_OFF + buf * CP_BBUF + quad * (BM * KBYTES) +
-                                                                               (s * 4 + wq) * 1024)));
-  };
-
-  // this lane's four A rows: patch position of tap (0, 0) and the top-padding flag
-  int pb[4];
-  bool top[4];
-  const int g = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = m0 + wm + i * 16 + (lane & 15);
-    const bool ok = p < a.M;
-    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
-    const int fo = (ok ? p : m0) - orow * a.F2;
-    const int to = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
-    pb[i] = ok ? 2 * (orow - orow_first) * a.PW + 2 * fo : 0;
-    top[i] = ok && to == 0;
-  }
-
-  floatx4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int ncc = a.C / 64;
-  stage_patch(0);
-  issue_b(0, 0);
-  int buf = 0;
-  for (int cc = 0; cc < ncc; ++cc) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap % 3;
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      auto issue_next_b = [&]() {
-        if (tap < 8) issue_b((tap + 1) * a.C + cc * 64, buf ^ 1);
-        else if (cc + 1 < ncc) issue_b((cc + 1) * 64, buf ^ 1);
-      };
-      if (!a.issue_late) issue_next_b();
-      const char* Bs = smem + CP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
-      const int wnl = wn & 127;
-      const int toff = kh * a.PW + kw;
-      bf16x8_t a0[4], a1[4];
-      typename RB::Frag b0[4], b1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wnl + j * 16, 0, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pos = pb[i] + toff;
-        int ad = ((pos ^ ((pos >> 4) & 1)) << 7) + ((g ^ ((pos >> 1) & 7)) << 4);
-        if (kh == 0) ad = top[i] ? CP_ZERO_OFF + (g << 4) : ad;
-        a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
-        a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + (ad ^ 64));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      if (a.issue_late) issue_next_b();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a0[i], b0[j], acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a1[i], b1[j], acc[i][j]);
-      buf ^= 1;
-    }
-    if (cc + 1 < ncc) {
-      __builtin_amdgcn_s_barrier();  // every wave has read its last fragment of this slice's patch
-      asm volatile("" ::: "memory");
-      stage_patch(cc + 1);
-    }
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  gemm_epilogue<bf16_t, IdentityRowMap, 4>(acc, a.y, (int64_t)a.C, a.M, a.C, m0, 0, a.ep, smem, IdentityRowMap());
-}
-
-// =============================================================================================
-// conv2 forward, 256 output pixels per workgroup (round 3).
-//
-// The kernel above is bound by what its waves have to ISSUE per MFMA: every K step a wave issues 4 weight-tile
-// DMA instructions (and 1.3 of the patch) next to 32 MFMAs.  Here a workgroup owns 256 consecutive output pixels: the patch is
-// staged per 32-channel slice (64-byte positions: 29 band rows x 42 columns = 76 KB) so that it still fits, a wave owns
-// 128 pixels x 64 channels (128 accumulators), and the weight tile of a (tap, slice) step is 32 rows x 256 channels = 16 KB:
-// 2 DMA instructions per wave and step for the same 32 MFMAs, and half as many workgroups re-fetch the weights.
-//   * patch layout: position pos lives in 64-byte slot pos ^ ((pos >> 2) & 1), its four 16-byte chunks XOR-ed by (pos >> 3) & 3
-//     (the 16 lanes of a fragment read walk positions two apart); the DMA applies the same involutions on the source side;
-//   * pixels of a wave: quad q = wave >> 2 takes rows [64 q, 64 q + 64) of BOTH 128-pixel halves of the tile, so that the two
-//     halves of its accumulators are two ordinary 128 x 256 epilogues (gemm_epilogue with four waves side by side);
-//   * four weight tiles in LDS (three steps ahead, counted vmcnt): with one tile ahead the kernel took 1025 us.
-// Measured (B = 128): 914 us stand-alone -- the SAME as the 128-pixel kernel, i.e. the step time (~3450 cycles at the nominal
-// clock, 30 % MFMA) is set by neither the DMA count nor the DMA latency but by the barrier-synchronised sequence
-// "issue, read 12 fragments, 32 MFMAs shared with the SIMD's other wave"; in the training step it is worth 0.07 ms (half as
-// many workgroups pull the weights while the other stream runs).  NST_CONV2_PATCH256=0 selects the 128-pixel kernel.
-// =============================================================================================
-constexpr int CQ_PX = 256;
-constexpr int CQ_WBUF = 2 * 32 * 256;                             // one (tap, 32-channel slice) weight tile: two 128-column images of 8 KB
-constexpr int CQ_NBUF = 4;                                          // weight tiles in LDS: three steps ahead of the one being multiplied
-constexpr int CQ_B_OFF = CP_LDS_BYTES - CQ_NBUF * CQ_WBUF;
-constexpr int CQ_ZERO_OFF = CQ_B_OFF - 1024;                       // 64-byte zero block (1 KB slot) behind the patch
-constexpr int CQ_PATCH_MAX = CQ_ZERO_OFF;                          // 97280 B = 1520 positions
-constexpr int CQ_MAXPOS = 1408;                                    // positions staged at most (88 pieces of 16 = 11 per wave)
-constexpr int CQ_NIT = CQ_MAXPOS / 16 / 8;
-
-__global__ void __launch_bounds__(CP_THREADS, 2) conv2_fwd_patch256_kernel(PatchArgs a) {
-  typedef SwzFrag<bf16_t, MODE_OC> RB;
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  char* smem = smem_dyn;
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = wave >> 2, wq = wave & 3;
-  const int wn = wq * 64;
-  const int tile = xcd_remap(blockIdx.x, a.ntiles);
-  const int m0 = tile * CQ_PX;
-  const int last_p = (m0 + CQ_PX - 1 < a.M) ? m0 + CQ_PX - 1 : a.M - 1;
-  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
-  const int band_row0 = 2 * orow_first - 1;
-  const int npos = (2 * (orow_last - orow_first) + 3) * a.PW;
-  const int npieces = (npos + 15) >> 4;
-  if (tid < 16) reinterpret_cast<uint32_t*>(smem + CQ_ZERO_OFF)[tid] = 0u;
-
-  // a patch piece = 16 positions x 64 bytes; the source address of a lane is re-derived at every staging (eight per workgroup:
-  // the 11 offsets would cost registers the 128 accumulators need)
-  auto stage_patch = [&](int cc) {
-#pragma unroll 1
-    for (int it = 0; it < CQ_NIT; ++it) {
-      const int piece = it * 8 + wave;
-      if (piece < npieces) {
-        const int S = piece * 16 + (lane >> 2);                  // LDS slot this lane fills
-        const int pos = S ^ ((S >> 2) & 1);                      // the position that lives there
-        const int prow = (int)a.dPW.div((uint32_t)pos), pc = pos - prow * a.PW;
-        const int grow = band_row0 + prow;
-        const bool ok = pos < npos && pc >= 1 && pc <= a.F1 && grow >= 0 && grow < a.in_rows;
-        const uint32_t chunk = (uint32_t)((lane & 3) ^ ((pos >> 3) & 3));
-        const char* src = ok ? reinterpret_cast<const char*>(a.x) + ((uint32_t)(grow * a.F1 + pc - 1) * (uint32_t)(a.C * 2) + chunk * 16u) +
-                                   cc * 64
-                             : reinterpret_cast<const char*>(g_nst_zero16);
-        glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
-      }
-    }
-  };
-  // weight tile (rows k0 .. k0 + 31 of w2 viewed as [9C, C]; this wave's quarter of image `quad`)
-  uint32_t boff[2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int c = (s2 * 4 + wq) * 64 + lane;
-    const int r = c >> 4, c16 = c & 15;
-    const int g = (r & 3) | (((r >> 3) & 1) << 2);
-    boff[s2] = (uint32_t)((r * a.C + quad * BM + (c16 ^ (g << 1)) * 8) * 2);
-  }
-  auto issue_b = [&](int k0, int buf) {
-    const char* wb = reinterpret_cast<const char*>(a.w2) + (int64_t)k0 * a.C * 2;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-      glds16(wb + boff[s2], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(CQ_B_OFF + buf * CQ_WBUF + quad * 8192 +
-                                                                                (s2 * 4 + wq) * 1024)));
-  };
-
-  // this lane's eight A rows: patch position of tap (0, 0) and the top-padding flag
-  int pb[8];
-  uint32_t topmask = 0;
-  const int g = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = m0 + (i >> 2) * 128 + quad * 64 + (i & 3) * 16 + (lane & 15);
-    const bool ok = p < a.M;
-    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
-    const int fo = (ok ? p : m0) - orow * a.F2;
-    const int to = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
-    pb[i] = ok ? 2 * (orow - orow_first) * a.PW + 2 * fo : 0;
-    topmask |= (ok && to == 0) ? (1u << i) : 0u;
-  }
-
-  floatx4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-
-  // Step t = 9 cc + tap multiplies weight tile t out of ring slot t % 4; the tiles of steps t + 1 .. t + 3 are in flight (two
-  // DMA instructions per wave each).  With ONE tile ahead a step took as long as a tile needs to land (~3500 cycles whatever
-  // the step holds: the first build of this kernel was slower than the 128-pixel one for that reason).
-  const int ncc = a.C / 32;
-  const int nsteps = ncc * 9;
-  stage_patch(0);
-  issue_b(0, 0);
-  issue_b(a.C, 1);
-  issue_b(2 * a.C, 2);
-  int buf = 0;
-  for (int cc = 0; cc < ncc; ++cc) {
-    // the 72 fragment addresses (8 pixels x 9 taps) do not depend on the slice: laundering the positions once per slice keeps the
-    // compiler from holding all of them in registers next to the 128 accumulators (it spilled 62 of them)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pb[i]));
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap % 3;
-      const int t = cc * 9 + tap;
-      // tile t has landed; behind it only tiles t + 1, t + 2 (4 instructions) may be pending -- except at the first tap of a
-      // slice, where the patch pieces issued at the end of the previous slice are younger than those and must have landed too
-      if (tap == 0 || t + 2 >= nsteps) wait_vmcnt<0>(); else wait_vmcnt<4>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      {
-        const int tap3 = (tap + 3) % 9, dcc = (tap + 3) / 9;   // (constants once the tap loop is unrolled)
-        if (t + 3 < nsteps) issue_b(tap3 * a.C + (cc + dcc) * 32, (buf + 3) & 3);
-      }
-      const char* Bs = smem + CQ_B_OFF + buf * CQ_WBUF + (wn >> 7) * 8192;
-      const int wnl = wn & 127;
-      const int toff = kh * a.PW + kw;
-      bf16x8_t af[8];
-      typename RB::Frag bfr[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = RB::read(Bs, wnl + j * 16, 0, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int pos = pb[i] + toff;
-        int ad = ((pos ^ ((pos >> 2) & 1)) << 6) + ((g ^ ((pos >> 3) & 3)) << 4);
-        if (kh == 0) ad = ((topmask >> i) & 1u) ? CQ_ZERO_OFF + (g << 4) : ad;
-        af[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i][j] = Mma<bf16_t>::run(af[i], bfr[j], acc[i][j]);
-      buf = (buf + 1) & 3;
-    }
-    if (cc + 1 < ncc) {
-      __builtin_amdgcn_s_barrier();  // every wave has read its last fragment of this slice's patch
-      asm volatile("" ::: "memory");
-      stage_patch(cc + 1);
-    }
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  // two 128 x 256 epilogues: accumulators 0..3 are rows [64 quad, +64) of the first 128 pixels, 4..7 of the second
-  gemm_epilogue<bf16_t, IdentityRowMap, 4>(reinterpret_cast<floatx4_t(&)[4][4]>(acc[0]), a.y, (int64_t)a.C, a.M, a.C, m0, 0, a.ep, smem,
-                                           IdentityRowMap());
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (m0 + 128 < a.M)
-    gemm_epilogue<bf16_t, IdentityRowMap, 4>(reinterpret_cast<floatx4_t(&)[4][4]>(acc[4]), a.y, (int64_t)a.C, a.M, a.C, m0 + 128, 0, a.ep,
-                                             smem, IdentityRowMap());
-}
-
-bool conv2_use_patch() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV2_PATCH"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-
-// returns true when the patch kernel handled the call
-bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
-  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
-  if (!conv2_use_patch() || C != 256 || (T1 & 1) || !nst_aligned16(x) || !nst_aligned16(w2) || !nst_aligned16(y)) return false;
-  const int64_t M = (int64_t)B * T2 * F2;
-  if ((int64_t)B * T1 * F1 * C * 2 >= (int64_t)0xFFFFFFFFll || M >= (1ll << 30)) return false;
-  const int PW = F1 + 2;
-  const int rows_out = (F2 - 1 + BM - 1) / F2 + 1;  // output rows a 128-pixel run can touch
-  const int npos_max = (2 * (rows_out - 1) + 3) * PW;
-  if (((npos_max + 15) & ~15) * 128 > CP_PATCH_MAX) return false;
-  PatchArgs a;
-  a.x = (const bf16_t*)x; a.w2 = (const bf16_t*)w2; a.y = (bf16_t*)y;
-  a.T2 = T2; a.F1 = F1; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.in_rows = B * T1;
-  a.ntiles = (int)((M + BM - 1) / BM);
-  a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
-  a.issue_late = conv_issue_late();
-  a.ep = plain_epilogue();
-  a.ep.bias = b2; a.ep.relu = relu; a.ep.vec = 1;
-  static int p256 = -1;   // NST_CONV2_PATCH256=0: the 128-pixel tile (A/B switch)
-  if (p256 < 0) { const char* e = getenv("NST_CONV2_PATCH256"); p256 = (e && e[0] == '0') ? 0 : 1; }
-  {
-    const int rows_out2 = (F2 - 1 + CQ_PX - 1) / F2 + 1;          // output rows a 256-pixel run can touch
-    const int npos_max2 = (2 * (rows_out2 - 1) + 3) * PW;
-    if (p256 && npos_max2 <= CQ_MAXPOS && M >= 4 * CQ_PX) {
-      a.ntiles = (int)((M + CQ_PX - 1) / CQ_PX);
-      conv_allow_big_lds(conv2_fwd_patch256_kernel, CP_LDS_BYTES);
-      conv2_fwd_patch256_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
-      return true;
-    }
-  }
-  conv_allow_big_lds(conv2_fwd_patch_kernel, CP_LDS_BYTES);
-  conv2_fwd_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
-  return true;
-}
-
 
 // =============================================================================================
 // conv2 on the phase-staggered 256 x 256 tile kernel (nst_gemm256.h), bf16, C == 256 (round 4).
@@ -1718,7 +1306,7 @@ bool conv2_fwd_patch(const void* x, const void* w2, const float* b2, void* y, in
 // half-tile images (128 pixels x 64 channels, 128-byte rows) are gathered by LDS-DMA straight from the NHWC input: per
 // (half, piece) a lane keeps the address of its pixel's tap (0, 0) and a 9-bit mask of the taps that fall inside the image;
 // a K step adds a wave-uniform (tap, slice) offset, padding taps read the zero block.  Every input element crosses the L2
-// interface 2.25 times this way (the patch kernels above fetch it once) -- but the loop runs at ~60 % of the MFMA peak
+// interface 2.25 times this way (the LDS-resident patch kernels of rounds 2-3 fetched it once) -- but the loop runs at ~60 % of the MFMA peak
 // instead of ~30 %, and the re-reads hit the L2: neighbouring taps of neighbouring pixels a few K steps apart.
 // =============================================================================================
 struct Im2colDma256 {
@@ -1810,7 +1398,8 @@ __global__ void __launch_bounds__(G256_THREADS, 2) conv2_fwd256_kernel(Conv2Fwd2
   epilogue_v3<bf16_t, IdentityRowMap, EF>(acc[1], epi, a.y, (int64_t)C, a.M, C, m0 + wr * 128 + 64, wc * 64, ep, rowmap, lane);
 }
 
-// NST_CONV2_G256=0: the patch kernels (A/B switch of round 4)
+// NST_CONV2_G256=0: the generic implicit-GEMM kernels (A/B switch; the LDS-resident patch kernels of rounds 2-3 -- 967 us forward,
+// 887 us data gradient on the benchmark shape against 788 / 787 here -- were removed in round 4)
 bool conv2_use_g256() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NST_CONV2_G256"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1848,7 +1437,6 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   const int M = B * T2 * F2, N = C, K = 9 * C;
   if constexpr (sizeof(T) == 2) {
     if (conv2_fwd_g256(x, w2, b2, y, B, T1, F1, C, relu, st)) return 0;
-    if (conv2_fwd_patch(x, w2, b2, y, B, T1, F1, C, relu, st)) return 0;
   }
   Im2colLoader<T> la;
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
@@ -1873,246 +1461,22 @@ int conv2_fwd_t(const void* x, const void* w2, const float* b2, void* y, int B, 
   } else if (conv_use_v2() && conv_use_tr() && la.vec && lb.vec)
     NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_total, la, lb, (T*)y,
                        (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
-  else if (conv_use_tr())
-    conv_gemm_kernel<T, T, MODE_RC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
   else
-    conv_gemm_kernel<T, T, MODE_RC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
+    conv_gemm_kernel<T, T, MODE_RC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, (T*)y, C, M, N, K, tiles_n, ntiles, kt_total, ep, IdentityRowMap());
   return 0;
-}
-
-// =============================================================================================
-// conv2 data gradient with an LDS-RESIDENT dy patch (bf16, C == 256, even T1 and F1).
-//
-// dx[b, ti, fi, :] = sum over the taps (kh, kw) that reach it:  dy[b, (ti+1-kh)/2, (fi+1-kw)/2, :] . w2[kh, kw]^T.
-// With even T1 / F1 each of the four parity classes (ti & 1, fi & 1) of dx has exactly the T2 x F2 grid of dy, and class
-// pixel (u, v) needs dy at (u + du, v + dv), du / dv in {0, 1} (1, 2, 2 and 4 taps).  The per-class implicit GEMMs
-// above run four launches with K = 256 ... 1024 (a handful of K steps per tile, 280 TFLOP/s on the benchmark shape).
-// Here a workgroup owns 128 consecutive dy pixels and produces ALL FOUR classes of their 2 x 2 dx pixels:
-//   * the dy patch -- those pixels plus one halo row, rows of F2 + 1 positions whose last column is the zero right
-//     border -- is staged ONCE with all 256 channels (<= 190 positions x 512 B); the bottom border of an image
-//     (u == T2 - 1, du == 1) is a per-lane select of the zero block;
-//   * the classes run one after the other over that patch: 9 (class, tap) groups x 4 channel slices = 36 K steps,
-//     the same MFMA work as the forward tile; only the 32 KB w2^T tile of each step streams through a double buffer
-//     (rows = input channel ci, contiguous along co: the RC layout);
-//   * every class ends with its own store epilogue (the patch has to survive, so the transposition scratch is the weight
-//     double buffer: no weight prefetch across a class boundary);
-//   * patch layout: position pos at byte pos * 512, its 128-byte channel slice cc at slot cc ^ ((pos>>3)&1) and the
-//     16-byte chunks of a slice XOR-ed with pos & 7 (consecutive class pixels are consecutive positions).
-// =============================================================================================
-struct DgradPatchArgs {
-  const bf16_t* dy;
-  const bf16_t* w2;
-  bf16_t* dx;
-  int T1, F1, T2, F2, C, M, PW, dy_rows, ntiles;
-  FastDiv dF2, dT2, dPW;
-  int issue_late;   // see PatchArgs
-};
-constexpr int DP_ZERO_OFF = CP_LDS_BYTES - 2 * CP_BBUF - 1024;   // patch bytes available: 97280 = 190 positions
-constexpr int DP_B_OFF = DP_ZERO_OFF + 1024;
-constexpr int DP_MAX_POS = DP_ZERO_OFF / 512;
-constexpr int DP_NIT = (DP_MAX_POS / 2 + 7) / 8;                // 1 KB pieces (2 positions) per wave
-constexpr int DP_EPI_LD = 68;
-
-// the nine (class, tap) groups: class = (pt << 1) | pf, shift (du, dv) into the patch, tap index kh * 3 + kw
-__device__ constexpr int DP_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
-__device__ constexpr int DP_DU[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0};
-__device__ constexpr int DP_DV[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0};
-__device__ constexpr int DP_TAP[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
-
-__global__ void __launch_bounds__(CP_THREADS) conv2_dgrad_patch_kernel(DgradPatchArgs a) {
-  typedef SwzFrag<bf16_t, MODE_RC> RB;
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  char* smem = smem_dyn;
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = wave >> 2, wq = wave & 3;
-  const int wm = quad * 64, wn = wq * 64;
-  const int tile = xcd_remap(blockIdx.x, a.ntiles);
-  const int m0 = tile * BM;
-  const int last_p = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
-  const int orow_first = (int)a.dF2.div((uint32_t)m0), orow_last = (int)a.dF2.div((uint32_t)last_p);
-  const int npos = (orow_last - orow_first + 2) * a.PW;   // the tile's rows + one halo row
-  const int npieces = (npos + 1) >> 1;
-  if (tid < 32) reinterpret_cast<uint32_t*>(smem + DP_ZERO_OFF)[tid] = 0u;
-
-  // the whole patch, all channels: piece = two positions of 512 bytes
-#pragma unroll
-  for (int it = 0; it < DP_NIT; ++it) {
-    const int piece = it * 8 + wave;
-    if (piece < npieces) {
-      const int pos = piece * 2 + (lane >> 5);
-      const int r = (int)a.dPW.div((uint32_t)pos), c = pos - r * a.PW;
-      const int grow = orow_first + r;
-      const bool ok = pos < npos && c < a.F2 && grow < a.dy_rows;
-      const int slice = ((lane & 31) >> 3) ^ ((pos >> 3) & 1), chunk = (lane & 7) ^ (pos & 7);
-      const char* src = ok ? reinterpret_cast<const char*>(a.dy) + ((int64_t)grow * a.F2 + c) * (a.C * 2) + slice * KBYTES + chunk * 16
-                           : reinterpret_cast<const char*>(g_nst_zero16);
-      glds16(src, __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)piece * 1024u));
-    }
-  }
-  // weight tile of (tap, slice): w2[tap][ci][co-slice] -- image `quad` holds input channels quad*128 .. +127
-  uint32_t boff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int c = (s * 4 + wq) * 64 + lane;
-    const int row = c >> 3, slot = c & 7;
-    const int kchunk = slot ^ ((row >> 1) & 7);
-    boff[s] = (uint32_t)(((quad * BM + row) * a.C + kchunk * 8) * 2);
-  }
-  auto issue_b = [&](int tap, int cc, int buf) {
-    const char* wb = reinterpret_cast<const char*>(a.w2) + ((int64_t)tap * a.C * a.C + cc * 64) * 2;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      glds16(wb + boff[s], __builtin_amdgcn_readfirstlane(smem_addr + (uint32_t)(DP_B_OFF + buf * CP_BBUF + quad * (BM * KBYTES) +
-                                                                               (s * 4 + wq) * 1024)));
-  };
-
-  // this lane's four A rows: patch position of (du, dv) = (0, 0) and the bottom-border flag
-  int pb[4];
-  bool bot[4];
-  const int g = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = m0 + wm + i * 16 + (lane & 15);
-    const bool ok = p < a.M;
-    const int orow = (int)a.dF2.div((uint32_t)(ok ? p : m0));
-    const int v = (ok ? p : m0) - orow * a.F2;
-    const int u = orow - (int)a.dT2.div((uint32_t)orow) * a.T2;
-    pb[i] = ok ? (orow - orow_first) * a.PW + v : 0;
-    bot[i] = ok && u == a.T2 - 1;
-  }
-
-  floatx4_t acc[4][4];
-  issue_b(DP_TAP[0], 0, 0);
-  int buf = 0;
-#pragma unroll
-  for (int e = 0; e < 9; ++e) {
-    const bool first = e == 0 || DP_CLS[e] != DP_CLS[e - 1], last = e == 8 || DP_CLS[e] != DP_CLS[e + 1];
-    if (first) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    const int toff = DP_DU[e] * a.PW + DP_DV[e];
-    for (int cc = 0; cc < 4; ++cc) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      auto issue_next_b = [&]() {
-        if (cc < 3) issue_b(DP_TAP[e], cc + 1, buf ^ 1);
-        else if (!last) issue_b(DP_TAP[e + 1], 0, buf ^ 1);
-      };
-      if (!a.issue_late) issue_next_b();
-      const char* Bs = smem + DP_B_OFF + buf * CP_BBUF + (wn >> 7) * (BM * KBYTES);
-      const int wnl = wn & 127;
-      bf16x8_t a0[4], a1[4];
-      typename RB::Frag b0[4], b1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b0[j] = RB::read(Bs, wnl + j * 16, 0, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pos = pb[i] + toff;
-        int ad = (pos << 9) + ((cc ^ ((pos >> 3) & 1)) << 7) + ((g ^ (pos & 7)) << 4);
-        if (DP_DU[e]) ad = bot[i] ? DP_ZERO_OFF + (g << 4) : ad;
-        a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad);
-        a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + (ad ^ 64));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b1[j] = RB::read(Bs, wnl + j * 16, 32, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      if (a.issue_late) issue_next_b();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a0[i], b0[j], acc[i][j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = Mma<bf16_t>::run(a1[i], b1[j], acc[i][j]);
-      buf ^= 1;
-    }
-    if (last) {
-      // class epilogue: 16-row quarters of the wave's 64 x 64 tile through the (now idle) weight buffers
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int pt = DP_CLS[e] >> 1, pf = DP_CLS[e] & 1;
-      float* epi = reinterpret_cast<float*>(smem + DP_B_OFF) + wave * (16 * DP_EPI_LD);
-      const int lr = (lane >> 4) * 4, lc = lane & 15;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const floatx4_t v4 = acc[q][j];
-          epi[(lr + 0) * DP_EPI_LD + j * 16 + lc] = v4[0];
-          epi[(lr + 1) * DP_EPI_LD + j * 16 + lc] = v4[1];
-          epi[(lr + 2) * DP_EPI_LD + j * 16 + lc] = v4[2];
-          epi[(lr + 3) * DP_EPI_LD + j * 16 + lc] = v4[3];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int rl = lane >> 2, cseg = (lane & 3) * 16;
-        const int p = m0 + wm + q * 16 + rl;
-        if (p < a.M) {
-          const int orow = (int)a.dF2.div((uint32_t)p), v = p - orow * a.F2;
-          const int b = (int)a.dT2.div((uint32_t)orow), u = orow - b * a.T2;
-          const int64_t pix = ((int64_t)b * a.T1 + 2 * u + pt) * a.F1 + 2 * v + pf;
-          const float* srow = epi + rl * DP_EPI_LD + cseg;
-          uint32_t w[8];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float4 x = *reinterpret_cast<const float4*>(srow + k * 4);
-            w[k * 2] = pack_bf16x2(x.x, x.y);
-            w[k * 2 + 1] = pack_bf16x2(x.z, x.w);
-          }
-          uint4* dst = reinterpret_cast<uint4*>(a.dx + pix * a.C + wn + cseg);
-          dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-          dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (e < 8) {
-        __builtin_amdgcn_s_barrier();  // every wave is done with the scratch before the next class's first weight tile lands
-        asm volatile("" ::: "memory");
-        issue_b(DP_TAP[e + 1], 0, buf);
-      }
-    }
-  }
-}
-
-bool conv2_dgrad_patch(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("NST_CONV2_DGRAD_PATCH"); enabled = (e && e[0] == '0') ? 0 : 1; }
-  const int T2 = T1 / 2, F2 = F1 / 2;
-  if (!enabled || C != 256 || (T1 & 1) || (F1 & 1) || T1 < 2 || F1 < 2 || !nst_aligned16(dy) || !nst_aligned16(w2) || !nst_aligned16(dx))
-    return false;
-  const int64_t M = (int64_t)B * T2 * F2;
-  if (M >= (1ll << 30)) return false;
-  const int PW = F2 + 1;
-  const int rows_out = (F2 - 1 + BM - 1) / F2 + 1;
-  if ((rows_out + 1) * PW > DP_MAX_POS) return false;
-  DgradPatchArgs a;
-  a.dy = (const bf16_t*)dy; a.w2 = (const bf16_t*)w2; a.dx = (bf16_t*)dx;
-  a.T1 = T1; a.F1 = F1; a.T2 = T2; a.F2 = F2; a.C = C; a.M = (int)M; a.PW = PW; a.dy_rows = B * T2;
-  a.ntiles = (int)((M + BM - 1) / BM);
-  a.dF2.init(F2); a.dT2.init(T2); a.dPW.init(PW);
-  a.issue_late = conv_issue_late();
-  conv_allow_big_lds(conv2_dgrad_patch_kernel, CP_LDS_BYTES);
-  conv2_dgrad_patch_kernel<<<a.ntiles, CP_THREADS, CP_LDS_BYTES, st>>>(a);
-  return true;
 }
 
 // =============================================================================================
 // conv2 data gradient on the phase-staggered 256 x 256 tile kernel (bf16, C == 256, even T1 and F1; round 4).
 //
-// Same decomposition as the patch kernel above -- a workgroup owns 256 consecutive dy pixels and produces the four parity
-// classes of their 2 x 2 dx pixels one after the other (4 + 2 + 2 + 1 taps, 36 K steps of 64 output channels) -- but nothing is
-// LDS-resident: both operands stream through the two K-step buffers of gemm256_mainloop.
+// dx[b, ti, fi, :] = sum over the taps (kh, kw) that reach it:  dy[b, (ti+1-kh)/2, (fi+1-kw)/2, :] . w2[kh, kw]^T.  With even
+// T1 / F1 each of the four parity classes (ti & 1, fi & 1) of dx has exactly the T2 x F2 grid of dy, and class pixel (u, v)
+// needs dy at (u + du, v + dv), du / dv in {0, 1} (1, 2, 2 and 4 taps).  A workgroup owns 256 consecutive dy pixels and
+// produces the four classes of their 2 x 2 dx pixels one after the other (4 + 2 + 2 + 1 taps, 36 K steps of 64 output
+// channels); both operands stream through the two K-step buffers of gemm256_mainloop:
 //   A (RC images, 128 dy pixels x 64 co): the lane keeps the address of ITS pixel's dy row and a 4-bit mask of the shifts
 //     (du, dv) that stay inside the image; a K step adds the wave-uniform ((du * F2 + dv) * C + co0) offset, a shift that
-//     leaves the image reads the zero block.  A dy row crosses the L2 interface 9 times (once per tap; the patch kernel: once)
+//     leaves the image reads the zero block.  A dy row crosses the L2 interface 9 times (once per tap)
 //     -- all but the first are hits, the taps of one class and the classes of one tile follow each other within microseconds.
 //   B (RC images, 128 ci x 64 co): w2[tap][ci][co] rows, 288 KB per class set, L2-resident.
 // The next class's first loads are issued BEFORE the current class's store epilogue (whose transposition scratch lives in
@@ -2251,7 +1615,7 @@ __global__ void __launch_bounds__(G256_THREADS) conv2_dgrad256_kernel(Conv2Dgrad
   }
 }
 
-// returns true when the 256 x 256 kernel handled the call (NST_CONV2_DGRAD_G256=0: the patch kernel, A/B switch of round 4)
+// returns true when the 256 x 256 kernel handled the call (NST_CONV2_DGRAD_G256=0: the per-class implicit GEMMs below)
 bool conv2_dgrad_g256(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("NST_CONV2_DGRAD_G256"); enabled = (e && e[0] == '0') ? 0 : 1; }
@@ -2276,7 +1640,6 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
   if constexpr (sizeof(T) == 2)
   {
     if (conv2_dgrad_g256(dy, w2, dx, B, T1, F1, C, st)) return 0;
-    if (conv2_dgrad_patch(dy, w2, dx, B, T1, F1, C, st)) return 0;
   }
   for (int pt = 0; pt < 2; ++pt)
     for (int pf = 0; pf < 2; ++pf) {
@@ -2300,12 +1663,7 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
       const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
       const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
       dim3 grid(ntiles, 1, 1);
-      if (conv_use_v2() && conv_wide_dgrad() && la.vec && lb.vec && N > BN) {
-        const int tiles_nw = (N + 2 * BN - 1) / (2 * BN), ntw = tiles_m * tiles_nw;
-        auto kfn = conv_gemm_kernel_v2w<T, T, MODE_RC, MODE_RC, DgradALoader<T>, DgradBLoader<T>, DgradRowMap>;
-        conv_allow_big_lds(kfn, V2W_LDS_BYTES);
-        kfn<<<ntw, V2W_THREADS, V2W_LDS_BYTES, st>>>(la, lb, (T*)dx, (int64_t)C, M, N, K, tiles_nw, ntw, ep, rm);
-      } else if (conv_use_v2() && la.vec && lb.vec)
+      if (conv_use_v2() && la.vec && lb.vec)
         NST_CONV_LAUNCH_V2(T, T, MODE_RC, MODE_RC, DgradALoader<T>, DgradBLoader<T>, DgradRowMap, grid, kt_total, la, lb, (T*)dx,
                            (int64_t)C, M, N, K, tiles_n, ntiles, kt_total, ep, rm);
       else
@@ -2423,10 +1781,8 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   } else if (dma)
     NST_CONV_LAUNCH_V2(T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, grid, kt_per_split, la, lb, out,
                        (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
-  else if (conv_use_tr())
-    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, out, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
   else
-    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, false, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, out, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
+    conv_gemm_kernel<T, float, MODE_OC, MODE_OC, true, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap><<<grid, THREADS, 0, st>>>(la, lb, out, N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());
   if (slab) {
     const int64_t total4 = (int64_t)M * N / 4;
     int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
@@ -2515,9 +1871,7 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
     kfn<<<mb, C1M_WAVES * 64, sizeof(C1mLds<NCB>), st>>>(src, w1, b1, gamma, beta, mean, rstd, (const bf16_t*)dout, dw1, \
                                                         db1, dgamma, dbeta, T, F, T1, F1, npix, dF1, dT1);             \
   } while (0)
-    static int v2 = -1;   // NST_CONV1_BWD_V2=0: the first form (one wave per SIMD) for C = 256 too
-    if (v2 < 0) { const char* e = getenv("NST_CONV1_BWD_V2"); v2 = (e && e[0] == '0') ? 0 : 1; }
-    if (v2 && C == 256) {
+    if (C == 256) {   // eight waves, two per SIMD (the one-wave-per-SIMD form below serves C = 64 / 128)
       typedef C1mLds<16, 8, 1> Lds2;
       const int mb2 = (int)((ngroups + 7) / 8 > cus ? cus : (ngroups + 7) / 8);
       if (layer_norm) {
@@ -2534,8 +1888,8 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
       NST_CHECK_LAUNCH("conv1_bwd(mfma, v2)");
       return NST_OK;
     }
-    if (layer_norm) { if (C == 256) NST_C1M(16, true); else if (C == 128) NST_C1M(8, true); else NST_C1M(4, true); }
-    else { if (C == 256) NST_C1M(16, false); else if (C == 128) NST_C1M(8, false); else NST_C1M(4, false); }
+    if (layer_norm) { if (C == 128) NST_C1M(8, true); else NST_C1M(4, true); }
+    else { if (C == 128) NST_C1M(8, false); else NST_C1M(4, false); }
 #undef NST_C1M
     NST_CHECK_LAUNCH("conv1_bwd(mfma)");
     return NST_OK;

@@ -1037,23 +1037,6 @@ int launch_pair(const FfnArgs& a, hipStream_t st) {
     return full ? launch_one<MODE, NW, 0, true>(a, st) : launch_one<MODE, NW, 0, false>(a, st);
   } else {
     const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
-    if constexpr (NW == 4) {
-      const char* e = getenv("NST_FFN_DBG");
-      const int dbg = e ? atoi(e) : 0;
-      if (dbg && full) {
-        switch (dbg) {
-          case 1: return launch_one<MODE, NW, 0, true, 1>(a, st);
-          case 2: return launch_one<MODE, NW, 0, true, 2>(a, st);
-          case 3: return launch_one<MODE, NW, 0, true, 3>(a, st);
-          case 4: return launch_one<MODE, NW, 0, true, 4>(a, st);
-          case 7: return launch_one<MODE, NW, 0, true, 7>(a, st);
-          case 8: return launch_one<MODE, NW, 0, true, 8>(a, st);
-          case 12: return launch_one<MODE, NW, 0, true, 12>(a, st);
-          case 16: return launch_one<MODE, NW, 0, true, 16>(a, st);
-          default: break;
-        }
-      }
-    }
     if (full && drop == 3) return launch_one<MODE, NW, 3, true>(a, st);
     if (full && drop == 0) return launch_one<MODE, NW, 0, true>(a, st);
     return launch_one<MODE, NW, 3, false>(a, st);
@@ -1068,10 +1051,11 @@ bool use_v2_fwd(const FfnArgs& a) {
   return v == 1 && a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
 }
 
-template <int DROP, bool FULL, int DBG = 0>
+template <int DROP, bool FULL>
 int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
+  constexpr int DBG = 0;   // (the ablation builds of rounds 2-3 -- ffn_pair8_kernel's DBG bits -- are not instantiated any more)
   const int lds = V2_BIAS + a.F * 4;
-  if (DBG == 0 && a.gate_bits) {
+  if (a.gate_bits) {
     auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true>;
     allow_lds(k, lds);
     k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
@@ -1122,22 +1106,6 @@ int launch_pair_v2_fwd(const FfnArgs& a_in, hipStream_t st) {
   { static int m = -1; if (m < 0) { const char* e = getenv("NST_FFN_ROT"); m = e ? atoi(e) : 0; } a.rot_mode = m; }
   const bool full = a.M % V2_ROWS == 0;
   const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
-  const char* e = getenv("NST_FFN_DBG");
-  if (e && full && drop == 0) {   // ablation builds (benchmark shape, no dropout): see the DBG bits of ffn_pair8_kernel
-    switch (atoi(e)) {
-      case 1: return launch_v2_fwd<0, true, 1>(a, st);
-      case 2: return launch_v2_fwd<0, true, 2>(a, st);
-      case 4: return launch_v2_fwd<0, true, 4>(a, st);
-      case 8: return launch_v2_fwd<0, true, 8>(a, st);
-      case 16: return launch_v2_fwd<0, true, 16>(a, st);
-      case 32: return launch_v2_fwd<0, true, 32>(a, st);
-      case 12: return launch_v2_fwd<0, true, 12>(a, st);
-      case 31: return launch_v2_fwd<0, true, 31>(a, st);
-      case 64: return launch_v2_fwd<0, true, 64>(a, st);
-      default: break;
-    }
-  }
-  if (e && full && drop == 3 && atoi(e) == 116) return launch_v2_fwd<3, true, 16>(a, st);
   if (full && drop == 3) return launch_v2_fwd<3, true>(a, st);
   if (full && drop == 0) return launch_v2_fwd<0, true>(a, st);
   return launch_v2_fwd<3, false>(a, st);

@@ -192,11 +192,7 @@ DenseLoader<T> make_loader(const void* base, int64_t ld, int mode, int out_exten
   return l;
 }
 
-bool use_tr() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+bool use_tr() { return true; }   // (the fragment path without ds_read_b64_tr_b16 is no longer instantiated)
 
 template <typename T, typename OutT>
 int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Epilogue& ep, int split, hipStream_t st) {
@@ -285,9 +281,9 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   dense_gemm_kernel<T, OutT, AM, BMO, TR><<<grid, THREADS, 0, st>>>(la, lb, (OutT*)C, d->ldc, d->M, d->N, d->K, tiles_n, \
                                                                    ntiles, kt_per_split, ep)
   if (amode == MODE_RC && bmode == MODE_RC) NST_GEMM_LAUNCH(MODE_RC, MODE_RC, true);
-  else if (amode == MODE_RC && bmode == MODE_OC) { if (tr) NST_GEMM_LAUNCH(MODE_RC, MODE_OC, true); else NST_GEMM_LAUNCH(MODE_RC, MODE_OC, false); }
-  else if (amode == MODE_OC && bmode == MODE_RC) { if (tr) NST_GEMM_LAUNCH(MODE_OC, MODE_RC, true); else NST_GEMM_LAUNCH(MODE_OC, MODE_RC, false); }
-  else { if (tr) NST_GEMM_LAUNCH(MODE_OC, MODE_OC, true); else NST_GEMM_LAUNCH(MODE_OC, MODE_OC, false); }
+  else if (amode == MODE_RC && bmode == MODE_OC) NST_GEMM_LAUNCH(MODE_RC, MODE_OC, true);
+  else if (amode == MODE_OC && bmode == MODE_RC) NST_GEMM_LAUNCH(MODE_OC, MODE_RC, true);
+  else NST_GEMM_LAUNCH(MODE_OC, MODE_OC, true);
 #undef NST_GEMM_LAUNCH
   return 0;
 }

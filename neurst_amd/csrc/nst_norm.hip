@@ -482,12 +482,6 @@ __global__ void __launch_bounds__(1024) ln_bwd_finalize_kernel(const float* __re
   ln_finalize_body(partial, dgamma, dbeta, blocks, d, accumulate, sh);
 }
 
-template <typename T>
-bool vec_ok(const void* a, const void* b, const void* c, int d) {
-  const uintptr_t al = sizeof(T) == 2 ? 7 : 15;
-  return d % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & al) == 0;
-}
-
 // 8 elements per lane access: d multiple of 8 (rows then stay 16-byte aligned for bf16, 32 for f32), aligned bases
 template <typename T>
 bool wide_ok(int d, const void* a, const void* b, const void* c, const void* e) {
@@ -499,13 +493,11 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
                int d, float eps, hipStream_t st) {
   if (wide_ok<T>(d, x, y, gamma, beta)) {
     const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
-    static int u_env = -1;
-    if (u_env < 0) { const char* e = getenv("NST_LN_FWD_U"); u_env = (e && e[0] == '2') ? 2 : 4; }
-    const int U_ = (lpr == 32 && d <= 256) ? u_env : 4;
+    const int U_ = 4;   // rows in flight per lane group
     int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
     if (wb > 65535) wb = 65535;
 #define NST_LN_FWDW(L, S, UU) ln_fwd_wide_kernel<T, L, S, RELU, UU><<<(int)wb, 256, 0, st>>>((const T*)x, gamma, beta, (T*)y, mean, rstd, rows, d, eps)
-    if (lpr == 16) NST_LN_FWDW(16, 1, 4); else if (lpr == 32) { if (U_ == 2) NST_LN_FWDW(32, 1, 2); else NST_LN_FWDW(32, 1, 4); }
+    if (lpr == 16) NST_LN_FWDW(16, 1, 4); else if (lpr == 32) NST_LN_FWDW(32, 1, 4);
     else if (d <= 512) NST_LN_FWDW(64, 1, 4); else NST_LN_FWDW(64, 2, 4);
 #undef NST_LN_FWDW
     return 0;
@@ -514,11 +506,8 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
 #define NST_LN_FWD(V, S) ln_fwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)x, gamma, beta, (T*)y, mean, rstd, rows, d, eps)
-  if (vec_ok<T>(x, y, nullptr, d)) {
-    if (d <= 256) NST_LN_FWD(4, 4); else if (d <= 512) NST_LN_FWD(4, 8); else NST_LN_FWD(4, 16);
-  } else {
-    if (d <= 256) NST_LN_FWD(1, 4); else if (d <= 512) NST_LN_FWD(1, 8); else NST_LN_FWD(1, 16);
-  }
+  // the fallback (d not a multiple of 8, d > 1024's neighbours, unaligned rows): ONE scalar-access variant for every width
+  NST_LN_FWD(1, 16);
 #undef NST_LN_FWD
   return 0;
 }
@@ -529,17 +518,15 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
                hipStream_t st, void* dz, uint32_t dz_thresh, float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid, bool* dz_done) {
   if (partial && wide_ok<T>(d, x, dy, dx, RELU ? y : dres) && wide_ok<T>(d, gamma, nullptr, nullptr, nullptr)) {
     const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
-    static int u_env = -1;
-    if (u_env < 0) { const char* e = getenv("NST_LN_BWD_U"); u_env = (e && e[0] == '2') ? 2 : 1; }
     // rows in flight per lane group.  d_model = 256: one row (fewer registers, 4 waves per SIMD) measured 0.05 ms per step
-    // faster than two (NST_LN_BWD_U=2)
-    const int U_ = (lpr == 32 && d <= 256) ? u_env : 2;
+    // faster than two
+    const int U_ = (lpr == 32 && d <= 256) ? 1 : 2;
     int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
     if (wb > 512) wb = 512;
     *nblocks = (int)wb;
 #define NST_LN_BWDW(L, S, UU) ln_bwd_wide_kernel<T, L, S, RELU, UU><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr())
     *dz_done = true;
-    if (lpr == 16) NST_LN_BWDW(16, 1, 2); else if (lpr == 32) { if (U_ == 1) NST_LN_BWDW(32, 1, 1); else NST_LN_BWDW(32, 1, 2); }
+    if (lpr == 16) NST_LN_BWDW(16, 1, 2); else if (lpr == 32) NST_LN_BWDW(32, 1, 1);
     else if (d <= 512) NST_LN_BWDW(64, 1, 2); else NST_LN_BWDW(64, 2, 2);
 #undef NST_LN_BWDW
     return 0;
@@ -550,11 +537,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
   if (blocks < 1) blocks = 1;
   *nblocks = (int)blocks;
 #define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d, partial)
-  if (vec_ok<T>(x, dy, dx, d) && vec_ok<T>(y, dres, nullptr, d)) {
-    if (d <= 256) NST_LN_BWD(4, 4); else if (d <= 512) NST_LN_BWD(4, 8); else NST_LN_BWD(4, 16);
-  } else {
-    if (d <= 256) NST_LN_BWD(1, 4); else if (d <= 512) NST_LN_BWD(1, 8); else NST_LN_BWD(1, 16);
-  }
+  NST_LN_BWD(1, 16);   // see launch_fwd
 #undef NST_LN_BWD
   return 0;
 }

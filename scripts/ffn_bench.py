@@ -31,8 +31,6 @@ def main():
     ap.add_argument("--ffn", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--ablate", action="store_true")
-    ap.add_argument("--rounds", type=int, default=7)
     args = ap.parse_args()
     from neurst_amd import kernels as K
     dev, d, F = "cuda:0", 256, args.ffn
@@ -64,22 +62,6 @@ def main():
             t_fb = timeit(fused_fwd_bits, args.iters)
             row[f"fwd_p{p}_gate_bits"] = {"fused_us": t_fb}
             row[f"fwd_p{p}"] = {"fused_us": t_f, "two_gemm_us": t_2, "fused_tflops": flop / t_f / 1e6, "fused_mfma_frac": flop / t_f / 1e6 / 2500.0}
-        if args.ablate and M % 128 == 0 and M >= 20480:   # ablation builds of the forward (NST_FFN_DBG is read per call)
-            # interleaved rounds, median per variant: single runs move by +-10 % with the clock state of the chip
-            variants = [(0, "default"), (16, "plain_stores"), (1, "no_hidden_store"), (2, "no_dma"), (3, "no_store_no_dma"),
-                        (4, "no_mfma"), (8, "no_frag_reads"), (12, "no_mfma_no_reads"), (7, "reads_epilogue_only")]
-            samples = {v: [] for v, _ in variants}
-            for _ in range(args.rounds):
-                for dbg, _w in variants:
-                    if dbg:
-                        os.environ["NST_FFN_DBG"] = str(dbg)
-                    else:
-                        os.environ.pop("NST_FFN_DBG", None)
-                    samples[dbg].append(timeit(lambda: K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r), 10, warm=2))
-            os.environ.pop("NST_FFN_DBG", None)
-            for dbg, what in variants:
-                v = sorted(samples[dbg])
-                row[f"fwd_p0_dbg{dbg}_{what}"] = {"median_us": v[len(v) // 2], "min_us": v[0], "max_us": v[-1]}
         _, h, bits = K.ffn_fwd(x, w1t, b1, w2t, b2, residual=r, hidden_p=0.1, hidden_seed=1, hidden_site=1, save_gate_bits=True)
 
         def fused_bwd():

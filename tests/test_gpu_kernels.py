@@ -33,7 +33,7 @@ def _dump_report():
     yield
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    tag = "notr" if os.environ.get("NST_GEMM_NO_TR") == "1" else "tr"
+    tag = "tr"
     path = os.path.join(out, f"kernel_report_{tag}.json")
     merged = {}
     if os.path.exists(path):
