@@ -1189,38 +1189,6 @@ bool conv_use_wide() {
 }
 
 // dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output);  db2[j] (+)= sum_z cs_parts[z][j] when cs_parts != NULL
-// conv2 weight gradient on the persistent v3 stream (same main loop, register-resident epilogue and unit walk as the
-// dense weight gradients; A = im2col gather with the incremental OC cursor above, B = dy, fused column sums = db2)
-template <typename T>
-__global__ void __launch_bounds__(THREADS, 2)
-conv2_wgrad_kernel_v3(GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap> args) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  (void)args;  // read through the kernarg segment, see gemm_stream_v3
-  gemm_stream_v3<T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>(smem_dyn);
-}
-
-// ... and, the default, on a wide (128 x 256 tile, 8 waves, one workgroup per CU) one-unit-per-workgroup split-K kernel: twice
-// the MFMA work per K step, per DMA round trip and per barrier, and dy is read once per row panel (0.95 against 1.10 ms
-// stand-alone).  The same kernel for the DENSE weight gradients made the step slower (16.4 against 16.3 ms): a 96 KB
-// workgroup cannot share a CU with an 80 KB stream-GEMM workgroup of the dgrad chain, the conv2 weight gradient only
-// ever runs next to the conv2 data gradient, which holds its CUs alone as well.
-template <typename T>
-__global__ void __launch_bounds__(V2W_THREADS)
-conv2_wgrad_wide_kernel(Im2colLoader<T> la, DenseLoader<T> lb, float* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_n,
-                        int ntiles, int kt_per_split, int zx, Epilogue ep) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  int z, tile;
-  splitk_unit(blockIdx.x, ntiles, zx, z, tile);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
-  const int kt_first = z * kt_per_split;
-  int kt_count = kt_total - kt_first;
-  if (kt_count > kt_per_split) kt_count = kt_per_split;
-  if (kt_count <= 0) return;
-  gemm_block_v2w<T, float, MODE_OC, MODE_OC, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>(
-      la, lb, C + (int64_t)z * ep.slab_stride, ldc, M, N, tm * BM, tn * 2 * BN, kt_count, ep, smem_dyn, IdentityRowMap(), kt_first, z);
-}
-
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int64_t total4, int split, int accumulate,
                                                                 const float* __restrict__ cs_parts, float* __restrict__ cs_out,
@@ -1672,22 +1640,149 @@ int conv2_dgrad_t(const void* dy, const void* w2, void* dx, int B, int T1, int F
   return 0;
 }
 
-bool conv2_wgrad_v3() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV2_WGRAD_V3"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+// =============================================================================================
+// conv2 weight gradient on the phase-staggered 256 x 256 tile kernel (bf16, C == 256; round 4).
+//
+// dw2[(tap, ci), co] = sum over output pixels p of x[pixel(p, tap), ci] . dy[p, co]: nine products (one per tap) of 256 x 256
+// outputs over a reduction of P = B * T2 * F2 pixels -- far too few tiles for the chip, so the reduction is cut into S slices
+// (9 S <= CUs units, each >= 32 K steps) whose partial sums go to slabs and through conv_splitk_reduce_kernel (66 MB next to
+// 1.5 GB of operands on the benchmark shape).  Both operands are reduction-major:
+//   A (OC images, 64 pixels x 128 ci): the rows of a K step are 64 consecutive output pixels; a lane decomposes ITS pixel
+//     into (b, to, fo) with two fast divisions per K step and piece, adds the unit's tap and reads the 16-byte chunk of that
+//     input pixel (the zero block for padding taps and past the last pixel);
+//   B (OC images, 64 pixels x 128 co): dy rows, the dense cursor of the grouped weight gradients.
+// The nine taps of a slice read the same dy rows and neighbouring x rows: they are dealt to ONE XCD (workgroup b runs on XCD
+// b % 8).  db2 = column sums of dy from the ones-row MFMA of the tap-0 units.
+// =============================================================================================
+struct Im2colOcDma256 {
+  const bf16_t* x;
+  int T1, F1, C, P, kh, kw, k0;
+  FastDiv dF2, dT2;
+  int r[2];       // K-step row (0..63) of piece s
+  int col[2];     // first channel of the lane's 16-byte chunk inside a half (swizzled by the row, see Dma256<MODE_OC>)
+  __device__ __forceinline__ void init(const bf16_t* x_, int T1_, int F1_, int C_, int P_, const FastDiv& dF2_, const FastDiv& dT2_,
+                                       int tap, int k0_, int wave, int lane) {
+    x = x_; T1 = T1_; F1 = F1_; C = C_; P = P_; dF2 = dF2_; dT2 = dT2_; k0 = k0_;
+    kh = (tap * 11) >> 5; kw = tap - kh * 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = (s * 8 + wave) * 64 + lane;
+      const int rr = c >> 4, c16 = c & 15;
+      const int g = (rr & 3) | (((rr >> 3) & 1) << 2);
+      r[s] = rr;
+      col[s] = (c16 ^ (g << 1)) * 8;
+    }
+  }
+  template <int H>
+  __device__ __forceinline__ void issue(int t, uint32_t img, int wave) {
+    const uint32_t dst = img + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int p = k0 + t * 64 + r[s];
+      uint32_t q, fo, b, to;
+      dF2.divmod((uint32_t)p, q, fo);
+      dT2.divmod(q, b, to);
+      const int ti = 2 * (int)to + kh - 1, fi = 2 * (int)fo + kw - 1;
+      const bool ok = p < P && ti >= 0 && ti < T1 && fi >= 0 && fi < F1;
+      const bf16_t* src = x + (((int64_t)b * T1 + ti) * F1 + fi) * C + H * 128 + col[s];
+      glds16(ok ? (const void*)src : (const void*)g_nst_zero16, __builtin_amdgcn_readfirstlane(dst + (uint32_t)s * 8192u));
+    }
+  }
+};
+
+struct Conv2Wgrad256Args {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* slabs;      // [nsplit][9 C][C]
+  float* cs_parts;   // [nsplit][C] or NULL
+  int P, T1, F1, C, KT, kps, nsplit;
+  FastDiv dF2, dT2;
+};
+
+__global__ void __launch_bounds__(G256_THREADS) conv2_wgrad256_kernel(Conv2Wgrad256Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // workgroup -> (K slice, tap): the nine taps of a slice on one XCD; slices beyond a multiple of 8 are spread over the XCDs
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s8 = a.nsplit >> 3;
+  int split, tap;
+  if (j < 9 * s8) {
+    const int jj = (j * 57) >> 9;   // j / 9 for j < 512
+    split = xcd + 8 * jj; tap = j - 9 * jj;
+  } else {
+    const int e = (j - 9 * s8) * 8 + xcd;
+    if (e >= 9 * (a.nsplit & 7)) return;
+    const int ee = (e * 57) >> 9;
+    split = 8 * s8 + ee; tap = e - 9 * ee;
+  }
+  const int t0 = split * a.kps;
+  int nk = a.KT - t0;
+  if (nk > a.kps) nk = a.kps;
+  const int C = a.C;
+  const bool do_cs = a.cs_parts != nullptr && tap == 0 && wr == 0;   // wave-uniform
+  floatx4_t acc[2][4][4], cs[4];
+  {
+    Im2colOcDma256 da;
+    da.init(a.x, a.T1, a.F1, C, a.P, a.dF2, a.dT2, tap, t0 * 64, wave, lane);
+    DenseLoader<bf16_t> lb;   // dy [P rows][C]: reduction-major, output columns = co
+    lb.base = a.dy; lb.ld = C; lb.outer_limit = a.P; lb.contig_limit = C; lb.vec = 1;
+    Dma256<MODE_OC> db;
+    db.init(lb, 0, t0 * 64, wave, lane);
+    gemm256_mainloop<MODE_OC, MODE_OC, true>(smem_dyn, da, db, nk, do_cs, acc, cs);
+  }
+  asm volatile("" ::: "memory");
+  if (do_cs && lane < 16) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) a.cs_parts[(int64_t)split * C + wc * 64 + jn * 16 + lane] = cs[jn][0];
+  }
+  Epilogue ep{};
+  ep.vec = 1;
+  float* epi = reinterpret_cast<float*>(smem_dyn + wave * V3_EPI_BYTES_PER_WAVE);
+  float* Ct = a.slabs + ((int64_t)split * 9 + tap) * C * C;   // the unit's 256 x 256 tile of its slab
+  const IdentityRowMap rowmap;
+  epilogue_v3<float, IdentityRowMap, 0>(acc[0], epi, Ct, (int64_t)C, 256, C, wr * 128, wc * 64, ep, rowmap, lane);
+  epilogue_v3<float, IdentityRowMap, 0>(acc[1], epi, Ct, (int64_t)C, 256, C, wr * 128 + 64, wc * 64, ep, rowmap, lane);
 }
 
-bool conv2_wgrad_wide() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV2_WGRAD_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-
-bool conv2_wgrad_zxcd() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_ZXCD"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+// returns true when the 256 x 256 kernel handled the call (slabs + reduce included); NST_CONV2_WGRAD_G256=0: the generic kernels
+bool conv2_wgrad_g256(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int accumulate, void* ws,
+                      int64_t ws_bytes, hipStream_t st, bool* db2_done) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("NST_CONV2_WGRAD_G256"); enabled = (e && e[0] == '0') ? 0 : 1; }
+  const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
+  const int64_t P = (int64_t)B * T2 * F2;
+  if (!enabled || C != 256 || !ws || !nst_aligned16(x) || !nst_aligned16(dy) || !nst_aligned16(dw2) || !nst_aligned16(ws) ||
+      P >= (1ll << 30))
+    return false;
+  const int KT = (int)((P + 63) / 64);
+  int cus = 256;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+  }
+  int nsplit = cus / 9;                       // one unit per CU
+  if (nsplit > KT / 32) nsplit = KT / 32;     // slices of >= 32 K steps
+  if (nsplit > 56) nsplit = 56;
+  if (nsplit < 8) return false;               // too little work to fill the chip this way
+  const int kps = (KT + nsplit - 1) / nsplit;
+  nsplit = (KT + kps - 1) / kps;              // every slice non-empty
+  const int64_t M = 9 * (int64_t)C;
+  if (ws_bytes < (int64_t)nsplit * (M + 1) * C * 4) return false;
+  Conv2Wgrad256Args a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slabs = (float*)ws;
+  a.cs_parts = db2 ? (float*)ws + (int64_t)nsplit * M * C : nullptr;
+  a.P = (int)P; a.T1 = T1; a.F1 = F1; a.C = C; a.KT = KT; a.kps = kps; a.nsplit = nsplit;
+  a.dF2.init(F2); a.dT2.init(T2);
+  const int s8 = nsplit >> 3, rest = 9 * (nsplit & 7);
+  const int grid = 8 * (9 * s8 + (rest + 7) / 8);
+  conv_allow_big_lds(conv2_wgrad256_kernel, G256_LDS_BYTES);
+  conv2_wgrad256_kernel<<<grid, G256_THREADS, G256_LDS_BYTES, st>>>(a);
+  const int64_t total4 = M * C / 4;
+  const int blocks = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  conv_splitk_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)ws, dw2, total4, nsplit, accumulate, a.cs_parts, db2, C, accumulate);
+  if (db2) *db2_done = true;
+  return true;
 }
 
 template <typename T>
@@ -1696,6 +1791,8 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int P = B * T2 * F2;          // reduction: pixels
   const int M = 9 * C, N = C, K = P;  // dw2[kk][co] = sum_p im2col[p][kk] * dy[p][co]
+  if constexpr (sizeof(T) == 2)
+    if (conv2_wgrad_g256(x, dy, dw2, db2, B, T1, F1, C, accumulate, ws, ws_bytes, st, db2_done)) return 0;
   Im2colLoader<T> la;                 // OC: outer = pixel (reduction), contig = kk (output row)
   la.x = (const T*)x; la.B = B; la.T1 = T1; la.F1 = F1; la.C = C; la.T2 = T2; la.F2 = F2;
   la.outer_limit = P; la.contig_limit = M;
@@ -1710,30 +1807,10 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   const int kt_total = (K + Tile<T>::BK - 1) / Tile<T>::BK;
   int split = (512 + ntiles - 1) / ntiles;  // ~2 workgroups per CU
   const bool dma = conv_use_v2() && conv_use_tr() && la.vec && lb.vec;
-  // stream kernel: K slices pinned to XCDs (split = 8 S).  An XCD then owns ntiles * S units for its 64 resident
-  // workgroups; take the S (slices of >= 32 K steps, slabs inside the workspace) that wastes the fewest workgroup rounds.
-  bool zx = false;
-  const bool wide = dma && sizeof(T) == 2 && conv2_wgrad_wide() && N % (2 * BN) == 0;
-  const int tiles_nw = wide ? N / (2 * BN) : tiles_n, ntw = wide ? tiles_m * tiles_nw : ntiles;
-  if (dma && (wide || conv2_wgrad_v3()) && conv2_wgrad_zxcd() && ws) {
-    int best = 0;
-    double best_eff = 0.0;
-    const int slots = wide ? 32 : 64;   // resident workgroups of one XCD
-    for (int S = 1; S <= 16; ++S) {
-      if (kt_total / (8 * S) < 32 || (int64_t)8 * S * (M + 1) * N * 4 > ws_bytes) break;
-      const int kps = (kt_total + 8 * S - 1) / (8 * S);
-      if ((kt_total + kps - 1) / kps != 8 * S) continue;  // the slice count has to survive the rounding below
-      const int per_xcd = ntw * S, rounds = (per_xcd + slots - 1) / slots;
-      const double eff = (double)per_xcd / ((double)slots * rounds);
-      if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
-    }
-    if (best) { split = 8 * best; zx = true; }
-  }
   if (split > kt_total) split = kt_total;
   if (split < 1) split = 1;
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
-  zx = zx && split % 8 == 0;
   dim3 grid(ntiles, 1, split);
   const bool slab = ws && nst_aligned16(ws) && ws_bytes >= (int64_t)split * (M + 1) * N * 4 && (N % 8 == 0) && nst_aligned16(dw2);
   float* out = dw2;
@@ -1753,27 +1830,7 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
       if (hipMemsetAsync(dw2, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) return -1;
     }
   }
-  if (slab && wide) {
-    if constexpr (sizeof(T) == 2) {
-      auto kfn = conv2_wgrad_wide_kernel<T>;
-      conv_allow_big_lds(kfn, V2W_LDS_BYTES);
-      kfn<<<ntw * split, V2W_THREADS, V2W_LDS_BYTES, st>>>(la, lb, out, (int64_t)N, M, N, K, tiles_nw, ntw, kt_per_split, zx ? 1 : 0, ep);
-      if (cs_parts) *db2_done = true;
-    }
-  } else if (slab && dma && conv2_wgrad_v3()) {
-    // persistent workgroups, two resident per CU; every workgroup walks the same number of (tile, K slice) units
-    GemmArgs<float, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap> ga;
-    ga.la = la; ga.lb = lb; ga.C = out; ga.ldc = N; ga.M = M; ga.N = N; ga.K = K;
-    ga.tiles_n = tiles_n; ga.ntiles = ntiles; ga.split = split; ga.kt_per_split = kt_per_split; ga.ep = ep;
-    ga.rowmap = IdentityRowMap();
-    ga.z_per_xcd = zx ? 1 : 0;
-    ga.reserved0 = 0;
-    const int units = ntiles * split;
-    auto kfn = conv2_wgrad_kernel_v3<T>;
-    conv_allow_big_lds(kfn, V3_LDS_BYTES);
-    kfn<<<units < 512 ? units : 512, THREADS, V3_LDS_BYTES, st>>>(ga);
-    if (cs_parts) *db2_done = true;
-  } else if (cs_parts) {
+  if (cs_parts) {
     auto kfn = conv_gemm_kernel_v2<T, float, MODE_OC, MODE_OC, 2, Im2colLoader<T>, DenseLoader<T>, IdentityRowMap, true>;
     conv_allow_big_lds(kfn, 2 * V2_STAGE_BYTES);
     kfn<<<grid, THREADS, 2 * V2_STAGE_BYTES, st>>>(la, lb, out, (int64_t)N, M, N, K, tiles_n, ntiles, kt_per_split, ep, IdentityRowMap());

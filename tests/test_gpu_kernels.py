@@ -650,10 +650,13 @@ def test_conv2(K, dtype, B, T1, F1, C):
 
 
 @pytest.mark.parametrize("relu", [False, True])
-@pytest.mark.parametrize("B,T1,F1", [(2, 8, 6), (3, 50, 40), (5, 34, 7), (2, 128, 41), (4, 2, 2), (1, 450, 40), (9, 450, 40)])
-def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
-    """bf16, C == 256, even T1: the LDS-resident input-patch kernel (nst_conv.hip conv2_fwd_patch_kernel) -- images that
-    share a tile, ragged last tiles, odd / even widths, the top padding row of every image, > 256 tiles."""
+@pytest.mark.parametrize("B,T1,F1", [(2, 8, 6), (3, 50, 40), (5, 34, 7), (2, 128, 41), (4, 2, 2), (1, 450, 40), (9, 450, 40),
+                                     (7, 300, 41)])
+def test_conv2_c256_kernels(K, B, T1, F1, relu):
+    """bf16, C == 256: the conv2 kernels on the 256 x 256 tile core (nst_conv.hip conv2_fwd256 / conv2_dgrad256 /
+    conv2_wgrad256 kernels) and their fallbacks for small or odd grids -- images that share a tile, ragged last tiles, odd /
+    even widths, the top padding row of every image, > 256 tiles, reductions cut into 19 and 13 slices with a ragged last
+    K step."""
     C, dtype = 256, torch.bfloat16
     x = rnd(B, T1, F1, C, dtype=dtype, seed=11)
     w2 = (rnd(3, 3, C, C, seed=12) * (1.0 / math.sqrt(9 * C))).to(dtype)
@@ -663,29 +666,37 @@ def test_conv2_fwd_patch_kernel(K, B, T1, F1, relu):
     if relu:
         ref = ref.relu()
     y = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV), relu=relu)
-    close(f"conv2_patch[B{B}T{T1}F{F1}relu{int(relu)}].y", y, ref, dtype)
+    close(f"conv2_c256[B{B}T{T1}F{F1}relu{int(relu)}].y", y, ref, dtype)
     y2 = K.conv2_fwd(x.to(DEV), w2.to(DEV), b2.to(DEV), relu=relu)
     assert torch.equal(y, y2), "conv2 forward is not deterministic"
     if not relu:
-        # data gradient: even T1 and F1 take conv2_dgrad_patch_kernel (all four parity classes from one dy patch), the
-        # odd width falls back to the per-class implicit GEMMs -- both against autograd of the same convolution
+        # data gradient: even T1 and F1 (>= 256 output pixels) take conv2_dgrad256_kernel (all four parity classes from one
+        # workgroup), the odd width falls back to the per-class implicit GEMMs -- both against autograd of the same convolution
         T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
         dy = rnd(B, T2, F2, C, dtype=dtype, seed=14)
         xr = x.double().requires_grad_(True)
         torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), w2.double().permute(3, 2, 0, 1), None, stride=2,
                                    padding=1).permute(0, 2, 3, 1).backward(dy.double())
         dx = K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1)
-        close(f"conv2_patch[B{B}T{T1}F{F1}].dx", dx, xr.grad, dtype, scale=2.0)
+        close(f"conv2_c256[B{B}T{T1}F{F1}].dx", dx, xr.grad, dtype, scale=2.0)
         assert torch.equal(dx, K.conv2_dgrad(dy.to(DEV), w2.to(DEV), T1, F1))
-        # weight gradient: the persistent stream kernel with the incremental im2col cursor (pixels advance 64 per K step:
-        # image wraps, the top padding row, ragged last K step, widths smaller than a K step)
+        # weight gradient: conv2_wgrad256_kernel when the reduction fills the chip in slices of >= 32 K steps (the two
+        # largest grids), the generic split-K kernels otherwise (pixels advance 64 per K step: image wraps, the top padding
+        # row, ragged last K step, widths smaller than a K step)
         wr = w2.double().requires_grad_(True)
         torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), None, stride=2,
                                    padding=1).permute(0, 2, 3, 1).backward(dy.double())
         dw2, db2 = torch.full((3, 3, C, C), 2.0, device=DEV), torch.full((C,), 2.0, device=DEV)
         K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, db2=db2)
-        close(f"conv2_patch[B{B}T{T1}F{F1}].dw2", dw2, wr.grad, dtype, scale=2.0)
-        close(f"conv2_patch[B{B}T{T1}F{F1}].db2", db2, dy.double().sum((0, 1, 2)), torch.float32)
+        close(f"conv2_c256[B{B}T{T1}F{F1}].dw2", dw2, wr.grad, dtype, scale=2.0)
+        close(f"conv2_c256[B{B}T{T1}F{F1}].db2", db2, dy.double().sum((0, 1, 2)), torch.float32)
+        first = dw2.clone()
+        K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw2, db2=db2, accumulate=True)     # += : deterministic, so exactly twice
+        assert torch.equal(dw2, 2 * first)
+        close(f"conv2_c256[B{B}T{T1}F{F1}].db2_acc", db2, 2 * dy.double().sum((0, 1, 2)), torch.float32)
+        dw3 = torch.full((3, 3, C, C), 7.0, device=DEV)
+        K.conv2_wgrad(x.to(DEV), dy.to(DEV), dw3)                               # without the bias gradient
+        assert torch.equal(dw3, first)
 
 
 def test_conv2_kernels_at_the_benchmark_grid(K):
