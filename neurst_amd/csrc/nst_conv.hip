@@ -366,6 +366,113 @@ __device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lan
   v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
   return v;
 }
+// ---------------------------------------------------------------------------------------------
+// Layer 1 forward, bf16 output, C == 256: TWO output pixels per wavefront pass (round 4).  The one-pixel-per-wave kernel at the
+// top of this file spends ~75 vector instructions per pixel, 16 of them the two all-lane reductions with their v_readlane
+// tails (423-495 us on the benchmark shape).  Here a half wave owns a pixel --
+// lane l: pixel 2 j + (l >> 5), channels 8 (l & 31) .. + 7 -- so one instruction stream serves two pixels: the 9-tap
+// products are the same 36 packed FMAs, a LayerNorm reduction is 4 DPP steps + one v_permlane16_swap for BOTH pixels and
+// leaves the sum in every lane, and a lane stores its 8 channels as one 16-byte piece.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1_fwd_pair_kernel(const float* __restrict__ src, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
+                                                            int T_, int F, int T1, int F1, int layer_norm, float eps) {
+  typedef floatx2_hw_t f2;
+  constexpr int C = 256;
+  __shared__ float xs_all[4][3][C1_MAXF + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, c0 = (lane & 31) * 8;
+  float(*xs)[C1_MAXF + 2] = xs_all[wave];
+  f2 w[4][9], bias[4], g[4], be[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + 2 * q;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[q][t] = f2{w1[t * C + c], w1[t * C + c + 1]};
+    bias[q] = f2{b1[c], b1[c + 1]};
+    g[q] = layer_norm ? f2{gamma[c], gamma[c + 1]} : f2{1.f, 1.f};
+    be[q] = layer_norm ? f2{beta[c], beta[c + 1]} : f2{0.f, 0.f};
+  }
+  const int nrows = B * T1;
+  const float inv_c = 1.f / (float)C;
+  // the three source rows of the NEXT output row travel in registers while this one is computed (a wave is alone with its
+  // row: without the prefetch every row starts with an exposed global-load round trip)
+  constexpr int NF = (C1_MAXF + 2 + 63) / 64;
+  float pre[3][NF];
+  auto fetch = [&](int row) {
+    const int b = row / T1, to = row - b * T1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ti = 2 * to + r - 1;
+      const bool rok = ti >= 0 && ti < T_;
+      const float* p = src + ((int64_t)b * T_ + (rok ? ti : 0)) * F;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int f = lane + k * 64;
+        pre[r][k] = (rok && f >= 1 && f <= F) ? p[f - 1] : 0.f;
+      }
+    }
+  };
+  int row = blockIdx.x * 4 + wave;
+  if (row < nrows) fetch(row);
+  for (; row < nrows; row += gridDim.x * 4) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int f = lane + k * 64;
+        if (f < F + 2) xs[r][f] = pre[r][k];
+      }
+    __builtin_amdgcn_wave_barrier();
+    if (row + (int)gridDim.x * 4 < nrows) fetch(row + gridDim.x * 4);
+    for (int fo2 = 0; fo2 < F1; fo2 += 2) {
+      const int fo = fo2 + half;
+      const bool valid = fo < F1;
+      const int foc = valid ? fo : F1 - 1;   // (an odd F1: the second half repeats the last pixel and does not store)
+      f2 z[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) z[q] = bias[q];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = xs[kh][2 * foc + kw];
+          const f2 x2 = f2{xv, xv};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = __builtin_elementwise_fma(w[q][kh * 3 + kw], x2, z[q]);
+        }
+      const int64_t pix = (int64_t)row * F1 + foc;
+      if (layer_norm) {
+        const f2 s2 = (z[0] + z[1]) + (z[2] + z[3]);
+        const float mean = c1_swap16_add(c1_row16_sum(s2.x + s2.y)) * inv_c;
+        const f2 m2 = f2{mean, mean};
+        f2 sq = f2{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          z[q] = z[q] - m2;
+          sq = __builtin_elementwise_fma(z[q], z[q], sq);
+        }
+        const float rstd = rsqrtf(c1_swap16_add(c1_row16_sum(sq.x + sq.y)) * inv_c + eps);
+        const f2 r2 = f2{rstd, rstd};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = __builtin_elementwise_fma(z[q] * r2, g[q], be[q]);
+        if ((lane & 31) == 0 && valid) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
+      }
+      if (valid) {
+        uint4 raw;
+        raw.x = pack_bf16x2(fmaxf(z[0].x, 0.f), fmaxf(z[0].y, 0.f));
+        raw.y = pack_bf16x2(fmaxf(z[1].x, 0.f), fmaxf(z[1].y, 0.f));
+        raw.z = pack_bf16x2(fmaxf(z[2].x, 0.f), fmaxf(z[2].y, 0.f));
+        raw.w = pack_bf16x2(fmaxf(z[3].x, 0.f), fmaxf(z[3].y, 0.f));
+        *reinterpret_cast<uint4*>(out + pix * C + c0) = raw;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __device__ __forceinline__ void c1_split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   hi = f32_to_bf16(x);
   lo = f32_to_bf16(x - bf16_to_f32(hi));
@@ -1874,6 +1981,8 @@ extern "C" int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const fl
   if (out_dtype == NST_F32) {
     if (vec) { if (C <= 256) NST_C1F(float, 4, true); else NST_C1F(float, 8, true); }
     else { if (C <= 256) NST_C1F(float, 4, false); else NST_C1F(float, 8, false); }
+  } else if (vec && C == 256) {   // 495 -> 410 us on the benchmark shape (2.9 TB/s of stores: what LayerNorm's write side reaches too)
+    conv1_fwd_pair_kernel<<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, (bf16_t*)out, mean, rstd, B, T, F, T1, F1, layer_norm, eps);
   } else {
     if (vec) { if (C <= 256) NST_C1F(bf16_t, 4, true); else NST_C1F(bf16_t, 8, true); }
     else { if (C <= 256) NST_C1F(bf16_t, 4, false); else NST_C1F(bf16_t, 8, false); }

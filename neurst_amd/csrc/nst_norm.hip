@@ -520,6 +520,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
     // rows in flight per lane group.  d_model = 256: one row (fewer registers, 4 waves per SIMD) measured 0.05 ms per step
     // faster than two
+    // (also for the front end's 576 000-row call: 256 us with one row, 267 with two, profiles/r04_history/c32_conv_bench_u*.json)
     const int U_ = (lpr == 32 && d <= 256) ? 1 : 2;
     int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
     if (wb > 512) wb = 512;

@@ -65,6 +65,16 @@ def main():
         us = timed(fn, a.iters)
         res[name] = {"us": us, "activation_tb_per_s": nbytes / us / 1e6}
         print(name, res[name])
+    # the LayerNorm + ReLU behind conv2 (576 000 rows x 256 channels): one long HBM stream each way
+    y2 = (torch.randn(B, T2, F2, C, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    yn, mean2, rstd2 = K.layernorm_fwd(y2, gam, bet, 1e-6, relu=True)
+    dg2, db2n = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    for name, fn, nb in (("conv2_ln_relu_fwd", lambda: K.layernorm_fwd(y2, gam, bet, 1e-6, relu=True), 2 * y2.numel() * 2),
+                         ("conv2_ln_relu_bwd", lambda: K.layernorm_bwd(dy, y2, gam, mean2, rstd2, dg2, db2n, y=yn), 4 * y2.numel() * 2)):
+        us = timed(fn, a.iters)
+        res[name] = {"us": us, "tb_per_s": nb / us / 1e6}
+        print(name, res[name])
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 
