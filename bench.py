@@ -35,11 +35,12 @@ FAMILY_KERNELS = {
             "and weight gradients incl. split-K reduce; work = sum 2MNK)",
     "gemm_wgrad_group": "gemm256_group_kernel (nst_gemm_wgrad_group: the weight gradients of a layer stack as ONE launch of "
                         "256 x 256 phase-staggered tiles, no split-K; work = sum 2MNK)",
-    "ffn_fwd": "ffn_fwd_fused_kernel (dense1 + ReLU + dropout + dense2 in one launch; work = 4*M*d*ffn)",
-    "ffn_bwd": "ffn_bwd_fused_kernel (d hidden + gate + d input in one launch; work = 4*M*d*ffn)",
-    "conv2_fwd": "conv2_fwd_patch_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C; LDS-resident input patch)",
-    "conv2_dgrad": "conv2_dgrad_patch_kernel", "conv2_wgrad": "conv2 weight gradient (implicit GEMM, K = pixels)",
-    "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd dK/dV + dQ kernels",
+    "ffn_fwd": "ffn_pair8_kernel<fwd> (dense1 + ReLU + dropout + dense2 in one launch; work = 4*M*d*ffn)",
+    "ffn_bwd": "ffn_pair8_kernel<bwd> (d hidden + gate + d input in one launch; work = 4*M*d*ffn)",
+    "conv2_fwd": "conv2_fwd256_kernel (conv2 forward as GEMM M=B*T2*F2, N=C, K=9C on the 256 x 256 phase-staggered tile core)",
+    "conv2_dgrad": "conv2_dgrad256_kernel (four stride-parity classes per 256-pixel tile, same core)",
+    "conv2_wgrad": "conv2_wgrad256_kernel + conv_splitk_reduce_kernel (nine tap products, reduction in slices, same core)",
+    "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_head8_kernel (one workgroup per (batch, head))",
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak

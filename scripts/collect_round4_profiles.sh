@@ -14,7 +14,7 @@ cp $G/${T}_pmc_ffn_fused.json $P/${T}_pmc_ffn_fused_raw.json
 cp $G/${T}_pmc_gemm.json $P/${T}_pmc_gemm_raw.json
 tail -1 $G/${T}_bench_final.json > $P/${T}_bench_bf16_final.json
 tail -1 $G/${T}_bench_eager.json > $P/${T}_bench_bf16_eager_final.json
-for f in bench_fp32 bench_bf16_ragged bench_bf16_speech_transformer_m bench_text_transformer_base_bf16 bench_text_transformer_big_bf16 bench_decode_bf16 bench_forced_exchange; do
+for f in bench_fp32 bench_bf16_ragged bench_bf16_speech_transformer_m bench_text_transformer_base_bf16 bench_text_transformer_big_bf16 bench_decode_bf16 bench_forced_exchange bench_forced_exchange_native; do
   [ -s $G/${T}_$f.json ] && grep '^{' $G/${T}_$f.json | tail -1 > $P/${T}_$f.json
 done
 [ -s $G/model_report.json ] && cp $G/model_report.json $P/${T}_model_parity_report.json
@@ -23,8 +23,10 @@ done
 python scripts/summarise_pmc.py --tag $T ${2:+--commit $2} > /dev/null
 python scripts/kernel_resources.py $T > /dev/null 2>&1
 ls -la $P | grep ${T}_ | wc -l
-for f in pmc_group256 pmc_attn attn_bench wgrad_group_bench pmc_whole_step kernel_bench_vs_hipblaslt; do
+for f in pmc_group256 pmc_attn attn_bench wgrad_group_bench pmc_whole_step pmc_conv2 hbm_probe; do
   [ -s $G/${T}_$f.json ] && cp $G/${T}_$f.json $P/${T}_$f.json
 done
 [ -s $G/${T}_two_rank_rehearsal_graph.log ] && cp $G/${T}_two_rank_rehearsal_graph.log $P/${T}_two_rank_rehearsal_graph_final.log
-[ -s $G/r04/c16_gpu_tests.log ] && cp $G/r04/c16_gpu_tests.log $P/${T}_gpu_pytest_final.log
+[ -s $G/${T}_kernel_bench_vs_hipblaslt.txt ] && cp $G/${T}_kernel_bench_vs_hipblaslt.txt $P/${T}_kernel_bench_vs_hipblaslt.txt
+[ -s $G/${T}_graph_rccl_soak.log ] && cp $G/${T}_graph_rccl_soak.log $P/${T}_graph_rccl_soak.log
+[ -s $G/${T}_gpu_tests_final.log ] && cp $G/${T}_gpu_tests_final.log $P/${T}_gpu_pytest_final.log

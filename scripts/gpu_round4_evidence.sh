@@ -16,12 +16,15 @@ PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUS
   scripts/pmc_kernel.sh $O/${T}_pmc_group256.json gemm256_group scripts/wgrad_group_bench.py > $O/${T}_pmc_group256.log 2>&1
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" \
   scripts/pmc_kernel.sh $O/${T}_pmc_attn.json attn_ scripts/attn_bench.py > $O/${T}_pmc_attn.log 2>&1
+PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+  scripts/pmc_kernel.sh $O/${T}_pmc_conv2.json conv2_ scripts/conv_bench.py --iters 3 > $O/${T}_pmc_conv2.log 2>&1
+timeout 120 python scripts/hbm_probe.py --out $O/${T}_hbm_probe.json > $O/${T}_hbm_probe.log 2>&1; tail -1 $O/${T}_hbm_probe.log | cut -c1-400
 timeout 300 python scripts/ffn_bench.py --rows 28800,9600 --out $O/${T}_ffn_bench.json > $O/${T}_ffn_bench.log 2>&1
 timeout 300 python scripts/conv_bench.py --out $O/${T}_conv_bench.json > $O/${T}_conv_bench.log 2>&1
 timeout 300 python scripts/gemm_iso.py > $O/${T}_gemm_iso.json 2>/dev/null
 timeout 300 python scripts/attn_bench.py > $O/${T}_attn_bench.json 2>/dev/null
 timeout 300 python scripts/wgrad_group_bench.py > $O/${T}_wgrad_group_bench.json 2>/dev/null
-timeout 400 python scripts/kernel_bench.py --only blas,gemm > $O/${T}_kernel_bench_vs_hipblaslt.json 2>/dev/null
+timeout 400 python scripts/kernel_bench.py --only blas,gemm > $O/${T}_kernel_bench_vs_hipblaslt.txt 2>/dev/null
 timeout 400 python bench.py > $O/${T}_bench_final.json 2> $O/${T}_bench_final.err
 tail -1 $O/${T}_bench_final.json | cut -c1-400
 STEP_MS=$(tail -1 $O/${T}_bench_final.json | python -c 'import sys,json; print(round(json.loads(sys.stdin.read())["ms_per_step"],2))')

@@ -12,3 +12,9 @@ timeout 300 python scripts/bench_text.py --model transformer_base --batch 256 > 
 timeout 300 python scripts/bench_text.py --model transformer_big --batch 256 > $O/${T}_bench_text_transformer_big_bf16.json 2>/dev/null; tail -1 $O/${T}_bench_text_transformer_big_bf16.json | cut -c1-300
 timeout 300 python scripts/bench_decode.py --graphs > $O/${T}_bench_decode_bf16.json 2>/dev/null; tail -1 $O/${T}_bench_decode_bf16.json | cut -c1-300
 NST_DIST_FORCE=1 timeout 300 python bench.py --no-cpu-baseline --roofline-steps 0 > $O/${T}_bench_forced_exchange.json 2>/dev/null; tail -1 $O/${T}_bench_forced_exchange.json | cut -c1-200
+NST_DIST_FORCE=1 NST_DIST_NATIVE=1 timeout 300 python bench.py --no-cpu-baseline --roofline-steps 0 > $O/${T}_bench_forced_exchange_native.json 2>/dev/null; tail -1 $O/${T}_bench_forced_exchange_native.json | cut -c1-200
+# soak: 10 consecutive graph-mode runs of 200 steps with the exchange path over RCCL (one forced rank)
+for i in 1 2 3 4 5 6 7 8 9 10; do
+  NST_DIST_FORCE=1 timeout 300 python bench.py --no-cpu-baseline --roofline-steps 0 --steps 200 --warmup 5 > $O/${T}_soak_$i.json 2>$O/${T}_soak_$i.err
+  echo "soak run $i rc=$? $(grep '^{' $O/${T}_soak_$i.json | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],3), "ms/step,", d["reducer_messages_per_step"], "messages/step, graph", d["hip_graph"])')"
+done | tee $O/${T}_graph_rccl_soak.log
