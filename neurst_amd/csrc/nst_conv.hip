@@ -374,7 +374,7 @@ __device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lan
 // products are the same 36 packed FMAs, a LayerNorm reduction is 4 DPP steps + one v_permlane16_swap for BOTH pixels and
 // leaves the sum in every lane, and a lane stores its 8 channels as one 16-byte piece.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) conv1_fwd_pair_kernel(const float* __restrict__ src, const float* __restrict__ w1,
+__global__ void __launch_bounds__(256, 4) conv1_fwd_pair_kernel(const float* __restrict__ src, const float* __restrict__ w1,
                                                             const float* __restrict__ b1, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ out,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
@@ -397,36 +397,10 @@ __global__ void __launch_bounds__(256) conv1_fwd_pair_kernel(const float* __rest
   }
   const int nrows = B * T1;
   const float inv_c = 1.f / (float)C;
-  // the three source rows of the NEXT output row travel in registers while this one is computed (a wave is alone with its
-  // row: without the prefetch every row starts with an exposed global-load round trip)
-  constexpr int NF = (C1_MAXF + 2 + 63) / 64;
-  float pre[3][NF];
-  auto fetch = [&](int row) {
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
     const int b = row / T1, to = row - b * T1;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ti = 2 * to + r - 1;
-      const bool rok = ti >= 0 && ti < T_;
-      const float* p = src + ((int64_t)b * T_ + (rok ? ti : 0)) * F;
-#pragma unroll
-      for (int k = 0; k < NF; ++k) {
-        const int f = lane + k * 64;
-        pre[r][k] = (rok && f >= 1 && f <= F) ? p[f - 1] : 0.f;
-      }
-    }
-  };
-  int row = blockIdx.x * 4 + wave;
-  if (row < nrows) fetch(row);
-  for (; row < nrows; row += gridDim.x * 4) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int k = 0; k < NF; ++k) {
-        const int f = lane + k * 64;
-        if (f < F + 2) xs[r][f] = pre[r][k];
-      }
+    c1_stage_rows(xs, src, b, to, T_, F, lane);
     __builtin_amdgcn_wave_barrier();
-    if (row + (int)gridDim.x * 4 < nrows) fetch(row + gridDim.x * 4);
     for (int fo2 = 0; fo2 < F1; fo2 += 2) {
       const int fo = fo2 + half;
       const bool valid = fo < F1;

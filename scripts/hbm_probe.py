@@ -47,6 +47,11 @@ def main():
     nbytes = n * 2
     res = {"bytes": nbytes}
     res["fill_tb_per_s"] = nbytes / timed(lambda: x.zero_()) / 1e12
+    res["fill_nonzero_tb_per_s"] = nbytes / timed(lambda: x.fill_(1.5)) / 1e12
+    f32 = torch.empty(n // 2, dtype=torch.float32, device="cuda")
+    res["fill_nonzero_f32_tb_per_s"] = nbytes / timed(lambda: f32.fill_(1.5)) / 1e12
+    half = x[: n // 2]
+    res["cast_f32_to_bf16_write_tb_per_s"] = (n // 2) * 2 / timed(lambda: half.copy_(f32)) / 1e12   # reads 4 B, writes 2 B per element
     res["copy_tb_per_s_read_plus_write"] = 2 * nbytes / timed(lambda: y.copy_(x)) / 1e12
     res["sum_tb_per_s"] = nbytes / timed(lambda: x.view(torch.int16).sum()) / 1e12
     # shader clock under a matrix-bound load (hipBLASLt 8192^3 bf16), sampled from another thread
