@@ -90,14 +90,13 @@ class AudioConv2dSubsamplingLayer(Layer):
             dy2 = self._dense_layer.backward_input(dz, gate_src=a2_2d, gate_scale=1.0).view(B, T2, F2, C)
         acc2 = st.acc_flag(self.w2)
         assert st.acc_flag(self.b2) == acc2
-        import os
-        where = os.environ.get("NST_CONV2_WGRAD_AT", "side")   # side | after_dgrad | last  (main stream for the latter two)
-        if os.environ.get("NST_SKIP_WGRAD", "0") != "1" and where == "side":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
-            # overlaps the dgrad below and the conv1 backward
-            self.rt.run_wgrad(lambda: K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2), a1, dy2)
-            self.rt.sublayer_boundary(force=True)
         da1 = K.conv2_dgrad(dy2, self.w2.compute, a1.shape[1], a1.shape[2])
-        if where == "after_dgrad":
+        # The conv2 weight gradient runs on the COMPUTE stream, behind the data gradient: all three kernels of the front end's
+        # backward (conv2 dgrad / wgrad on the 256 x 256 tile core, conv1's backward) hold their CUs alone, so running the weight
+        # gradient beside them on the weight-gradient stream only made them take turns -- 2.38 ms for 2.04 ms of stand-alone
+        # work; one after the other: 13.10 -> 12.88 ms per step (profiles/r04_history/c36_ab_step.log)
+        import os
+        if os.environ.get("NST_SKIP_WGRAD", "0") != "1":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
             K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
         acc = st.acc_flag(self.w1)
         st.acc_flag(self.b1)
@@ -107,6 +106,4 @@ class AudioConv2dSubsamplingLayer(Layer):
         K.conv1_ln_relu_bwd(src, self.w1.data, self.b1.data, self.g1.data if ln else None,
                             self.be1.data if ln else None, mean1, rstd1, da1, self.w1.grad, self.b1.grad,
                             self.g1.grad if ln else None, self.be1.grad if ln else None, ln, 1e-6, accumulate=acc)
-        if where == "last":
-            K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
         return None  # the audio features are data, not a differentiable input
