@@ -335,20 +335,21 @@ int nst_ls_xent_bwd(const void* logits, const int64_t* labels, const float* weig
                     void* dlogits, int64_t rows, int V, int64_t ldl, float label_smoothing, float gscale,
                     const float* gscale_dev, int dtype, void* stream);
 
-/* ------------------------------------------------------------------ data-parallel exchange: NOT in this library
- * The library exports NO collective (no nst_comm_init / nst_comm_broadcast / nst_comm_allreduce_bucket / nst_comm_destroy
- * and no nst_workspace_query_*): the gradient exchange stays in the HOST framework, exactly where the reference keeps it
- * (Horovod's hvd.DistributedOptimizer / hvd.allreduce, neurst/training/hvd_utils.py:46-98; rank-0 broadcast
- * neurst/exps/trainer.py:285; metric reduce neurst/training/callbacks.py:149-207).  What this library guarantees to that
- * host instead:
+/* ------------------------------------------------------------------ data-parallel exchange: what the compute entry points guarantee
+ * The exchange itself is at the end of this header (nst_comm_*, ABI v8: the Horovod calls of the reference --
+ * hvd.DistributedOptimizer / hvd.allreduce, neurst/training/hvd_utils.py:46-98; rank-0 broadcast neurst/exps/trainer.py:285);
+ * a host may just as well keep it in its own framework (ours does by default: RCCL through torch.distributed; the metric
+ * reduce of neurst/training/callbacks.py:149-207 always stays there).  There is no nst_workspace_query_*: workspaces are
+ * sized by the caller from the formulas given at each entry point.  What the compute entry points guarantee to either kind
+ * of host:
  *   - all parameter gradients of a model are written into ONE flat fp32 buffer in forward registration order, so a
  *     bucket is a contiguous [start, end) slice the host can hand to RCCL (ncclAllReduce / torch.distributed) as is;
  *   - every entry point is asynchronous on the stream it is given and touches nothing outside its arguments: the host
  *     orders its communication stream after the compute and weight-gradient streams with plain HIP events;
  *   - the 1/world_size of hvd.Average is an ARGUMENT of the entry points that follow the exchange (grad_scale of
  *     nst_adam_update*, pre_scale of nst_grad_clip), nst_loss_scale_update runs on the already exchanged buffer.
- * Our host does this in neurst_amd/training/distributed.py (RCCL through torch.distributed, side stream, >= 8 MiB buckets,
- * optional 16-bit wire); workspaces are sized by the caller from the formulas given at each entry point.
+ * Our host does this in neurst_amd/training/distributed.py (side stream, buckets = the slices the backward pass reports,
+ * optional 16-bit wire).
  *
  * ------------------------------------------------------------------ optimizer
  * Keras Adam (neurst/models/speech_transformer.py:265-279, neurst/optimizers/__init__.py) over ONE flat buffer:
