@@ -68,17 +68,12 @@ class _DecodeSession(object):
         return static_logits
 
 
-# where the grouped weight-gradient launches go: "end" = one launch behind the whole backward; "stack" = one behind each
-# layer stack on the compute stream; "side" = like "stack", but the groups that cannot fill the chip (decoder, front dense
-# layer) go to the weight-gradient stream and only the encoder's 240 tiles run as a full-chip launch on the compute stream;
-# "encoder" = one launch behind the encoder stack (decoder + encoder products), the rest at the end.
-# Measured (profiles/r04_history/c3..c5_ab_step.log): end 14.46, stack 15.18, side 14.75 ms per step with every product in the
-# group -- a group that cannot fill the chip, or fills it 1.06 times, wastes more than the launch saves
-# ("encoder" 14.07 vs "end" 13.91 ms on one GPU, c8_ab_step.log: behind the encoder the group shares the chip with the
-# weight-gradient stream's leftovers; what it would buy with N > 1 -- an earlier start of the exchange -- is unmeasured)
-# Default: "end" on one GPU; "encoder" when gradients are exchanged (the reducer then gets 94 % of the parameters while the front
-# end's backward still runs; forced one-rank exchange over RCCL, profiles/r04_history/c18_ab_exchange.log: 13.05-13.08 ms vs
-# 13.11-13.19 with the launch at the end -- with real peers the exchange is longer and the difference with it)
+# where the grouped weight-gradient launch goes: "end" = behind the whole backward pass; "encoder" = behind the encoder stack
+# (decoder + encoder products in one launch, in front of the front end's backward).  One launch per stack, and the groups that
+# cannot fill the chip on the weight-gradient stream, were measured and lost (profiles/r04_history/c3..c5_ab_step.log: end 14.46,
+# per stack 15.18, small groups on the side stream 14.75 ms per step -- a group that cannot fill the chip, or fills it 1.06 times,
+# wastes more than the launch saves) and are gone.  "encoder" vs "end" on ONE GPU: 14.07 vs 13.91 and 13.79 vs 13.79 ms in two
+# sessions (behind the encoder the group shares the chip with the weight-gradient stream's leftovers).
 _WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT")
 
 
@@ -269,19 +264,15 @@ class EncoderDecoderModel(BaseModel):
             if not shared:
                 hook([self._modality_scope(self._trg_modality) + "/"])
             at = _wgrad_group_at()
-            if at in ("stack", "side"):
-                # the decoder's weight gradients (+ the cross-attention k|v projections over the encoder output): one launch
-                self.rt.launch_wgrad_group(side=at == "side")
             denc_in = self._encoder.backward(dmemory, layer_done=hook)
             hook([self._encoder.name + "/"])
-            if at in ("stack", "side", "encoder"):
-                # "encoder": decoder + encoder stacks in ONE full-chip launch here, in front of the front end's backward -- their
-                # gradients (94 % of the parameters) are then reported to the data-parallel reducer ~2.5 ms before the step ends
+            if at == "encoder":
+                # decoder + encoder stacks in ONE full-chip launch here, in front of the front end's backward -- their gradients
+                # (94 % of the parameters) are then reported to the data-parallel reducer ~2 ms before the step ends
                 self.rt.launch_wgrad_group()
             self._src_modality.backward(denc_in, mode="embedding")
             hook([self._modality_scope(self._src_modality) + "/"])
-            # whatever is still waiting ("end": everything in one launch; "side": the front dense layer's 20 tiles)
-            self.rt.launch_wgrad_group(side=at == "side")
+            self.rt.launch_wgrad_group()   # whatever is still waiting ("end": everything in one launch)
             self.rt.join_wgrad_stream()
 
     grad_ready_hook = None  # callable(list of variable-name prefixes): the data-parallel reducer plugs in here

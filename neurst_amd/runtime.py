@@ -359,20 +359,15 @@ class Runtime(object):
         else:
             report()
 
-    def launch_wgrad_group(self, side=False):
-        """One launch for every weight gradient queued since the last call, then the reports that waited for it.
-        side=False: on the current stream (a full-chip launch: the encoder stack's 240 tiles).  side=True: on the
-        weight-gradient stream next to what follows -- for groups that cannot fill the chip (the decoder's 144 tiles, the
-        front dense layer's 20): their workgroups take a few CUs for a while instead of the whole chip running half empty."""
+    def launch_wgrad_group(self):
+        """One launch, on the current stream, for every weight gradient queued since the last call, then the reports that
+        waited for it.  (Groups that cannot fill the chip on the weight-gradient stream, and one launch per stack, were measured
+        and lost: DESIGN 5e.)"""
         g = getattr(self, "_wgrad_group", None)
         if g is None:
             return
         if len(g):
-            if side and (self.wgrad_stream is not None or self.capture is not None):
-                launch, tensors = g.take()
-                self.run_wgrad(launch, *tensors)
-            else:
-                g.launch()
+            g.launch()
         reports, self._deferred_reports = self._deferred_reports, []
         for r in reports:
             r()
