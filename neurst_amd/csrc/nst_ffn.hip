@@ -210,8 +210,8 @@ struct Cfg {
 // DROP: bit 0 = hidden dropout on, bit 1 = output dropout on (forward); FULL: M is a multiple of the workgroup's rows.
 // Both are template parameters so that a phase is ONE basic block: the scheduler can then place the mid epilogue's
 // VALU work between the MFMAs of the second product.
-// DBG (ablation builds of the benchmark shape only, NST_FFN_DBG): 1 = no hidden-tile store, 2 = no DMA after the prologue
-// (stale LDS), 4 = no MFMA, 8 = no fragment reads.
+// DBG: always 0.  It selected the ablation builds of rounds 2-3 (no hidden-tile store / no DMA / no MFMAs / no fragment reads;
+// their timings: DESIGN 5c); the branches are gone, the parameter stays so that kernel names match the earlier profiles.
 template <int MODE, int NW, int DROP, bool FULL, int DBG = 0>
 __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   typedef Cfg<MODE, NW> C;
@@ -318,15 +318,13 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   auto open_phase = [&](int c, auto jtag) {
     constexpr int J = decltype(jtag)::value;
     if (c == nch - 1 && J > C::PPC - C::DEPTH) wait_vm<0>();   // fewer than DEPTH-1 younger pieces exist: drain
-    else if (c == 0 || !FULL || (DBG & 1)) wait_vm<C::WAITN>();   // no (or predicated) stores behind the pieces: conservative
+    else if (c == 0 || !FULL) wait_vm<C::WAITN>();   // no (or predicated) stores behind the pieces: conservative
     else wait_vm<C::waitn_exact(J)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr int JN = (J + C::DEPTH) % C::PPC;
     const int cn = c + (J + C::DEPTH) / C::PPC;
-    if constexpr ((DBG & 2) == 0) {
-      if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
-    }
+    if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
   };
 
   // The MFMAs of a chunk form a stream of 128 positions: s < 64: first product, phase pa = s >> 4, k-block kbl = (s >> 2) & 3,
@@ -340,9 +338,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   bf16x8_t wq[PD];
   auto read_frag = [&](auto stag) {
     constexpr int S = decltype(stag)::value & 127;
-    if constexpr ((DBG & 8) != 0) {
-      return;
-    } else if constexpr (S < 64) {
+    if constexpr (S < 64) {
       constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
       wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + pa * PIECE + nb * (32 * 128) + offA[kbl]);
     } else {
@@ -359,10 +355,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
   };
   auto mfma_at = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
-    if constexpr ((DBG & 4) != 0) {
-      const bf16x8_t keep_alive = wq[S % PD];   // keeps the fragment read alive
-      asm volatile("" ::"v"(keep_alive));
-    } else if constexpr (S < 64) {
+    if constexpr (S < 64) {
       constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
       if constexpr (pa == 0 && kbl == 0) {
         const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -422,7 +415,7 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) P[nb][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-    if constexpr ((DBG & 1) == 0) {
+    {
       uint4* w = reinterpret_cast<uint4*>(stage + m_l * 64 + h * 32);
       w[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
       w[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
@@ -433,13 +426,8 @@ __global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
       // non-temporal: the hidden tensor streams out (118 MB per launch at the benchmark shape) and must not push the 2 MB of
       // weights every CU re-reads out of the XCD's L2 (measured: -12 % kernel time against plain stores)
       typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-      if constexpr ((DBG & 16) != 0) {   // ablation: plain stores
-        if (st_ok0) *reinterpret_cast<uint4*>(o) = r0;
-        if (st_ok1) *reinterpret_cast<uint4*>(o + (int64_t)16 * F) = r1;
-      } else {
-        if (st_ok0) __builtin_nontemporal_store(u32x4_t{r0.x, r0.y, r0.z, r0.w}, reinterpret_cast<u32x4_t*>(o));
-        if (st_ok1) __builtin_nontemporal_store(u32x4_t{r1.x, r1.y, r1.z, r1.w}, reinterpret_cast<u32x4_t*>(o + (int64_t)16 * F));
-      }
+      if (st_ok0) __builtin_nontemporal_store(u32x4_t{r0.x, r0.y, r0.z, r0.w}, reinterpret_cast<u32x4_t*>(o));
+      if (st_ok1) __builtin_nontemporal_store(u32x4_t{r1.x, r1.y, r1.z, r1.w}, reinterpret_cast<u32x4_t*>(o + (int64_t)16 * F));
     }
   };
 
@@ -697,32 +685,11 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   // ---- first product of chunk c (logical): 16 dependent MFMAs (same accumulator: the matrix core forwards it)
   auto a_phase = [&](int c_logical) {
     const char* w1 = smem + V2_W1 + (c_logical & 1) * 32768;
-    if constexpr ((DBG & 64) != 0) {   // variant: two accumulators (even / odd k-blocks), summed at the end
-      floatx16_t acc1;
-#pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
-        const uint32_t o = (offA ^ (uint32_t)(((2 * kb) & 15) << 4)) + (uint32_t)((kb >> 3) * 256);
-        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(w1 + o);
-        const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (kb == 0) accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[0], zero, 0, 0, 0);
-        else if (kb == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[1], zero, 0, 0, 0);
-        else if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[kb], acc1, 0, 0, 0);
-        else accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[kb], accH, 0, 0, 0);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) accH[e] += acc1[e];
-      return;
-    }
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
       const uint32_t o = (offA ^ (uint32_t)(((2 * kb) & 15) << 4)) + (uint32_t)((kb >> 3) * 256);
-      bf16x8_t wf;
-      if constexpr ((DBG & 8) != 0) wf = xf[(kb + 1) & 15];   // ablation: no fragment reads
-      else wf = *reinterpret_cast<const bf16x8_t*>(w1 + o);
-      if constexpr ((DBG & 4) != 0) {                          // ablation: no MFMAs (the reads stay alive)
-        asm volatile("" ::"v"(wf));
-        if (kb == 0) { for (int e = 0; e < 16; ++e) accH[e] = 1.0f; }
-      } else if (kb == 0) {
+      const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(w1 + o);
+      if (kb == 0) {
         const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[0], zero, 0, 0, 0);
       } else {
@@ -737,11 +704,6 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     float v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = accH[e];
-    if constexpr ((DBG & 16) != 0) {   // ablation: no bias / ReLU / dropout work
-#pragma unroll
-      for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-      return;
-    }
     if constexpr (MODE == MODE_BWD) {
       // this lane's 16 gate values: row i_l of the wave's region (64-byte rows), bytes [32 h, +32)
       if constexpr (decltype(first_tag)::value || !FULL) wait_vm<0>(); else wait_vm<10>();   // (2 stores + 8 weight DMAs are younger than the gate copy)
@@ -815,20 +777,18 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   };
   // ---- the saved activation of chunk c, stored from the P tile in whole row pieces
   auto store_hidden = [&](int c_logical) {
-    if constexpr ((DBG & 1) == 0) {
-      const int c = phys(c_logical);
-      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    const int c = phys(c_logical);
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = st_r0 + 8 * q;
-        const uint4 d = *reinterpret_cast<const uint4*>(smem + V2_P + r * 128 + ((st_slot ^ ((r >> 1) & 7)) << 4));
-        bf16_t* o = a.mid_out + (int64_t)(m0 + r) * F + (c * CH2 + st_slot * 8);
-        if (q == 0 ? st_ok0 : st_ok1) __builtin_nontemporal_store(u32x4_t{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4_t*>(o));
-      }
+    for (int q = 0; q < 2; ++q) {
+      const int r = st_r0 + 8 * q;
+      const uint4 d = *reinterpret_cast<const uint4*>(smem + V2_P + r * 128 + ((st_slot ^ ((r >> 1) & 7)) << 4));
+      bf16_t* o = a.mid_out + (int64_t)(m0 + r) * F + (c * CH2 + st_slot * 8);
+      if (q == 0 ? st_ok0 : st_ok1) __builtin_nontemporal_store(u32x4_t{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4_t*>(o));
     }
   };
   auto barrier = [&]() {
-    if constexpr ((DBG & 32) == 0) __builtin_amdgcn_s_barrier();   // (ablation 32: no workgroup barriers -- timing only)
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
@@ -841,9 +801,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   bf16x8_t wq[PD], pf[4];
   auto read_frag = [&](auto stag, const char* w1, const char* w2) {
     constexpr int S = decltype(stag)::value;
-    if constexpr ((DBG & 8) != 0) {
-      wq[S % PD] = xf[S & 15];
-    } else if constexpr (S < 16) {
+    if constexpr (S < 16) {
       const uint32_t o = (offA ^ (uint32_t)(((2 * S) & 15) << 4)) + (uint32_t)((S >> 3) * 256);
       wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(w1 + o);
     } else {
@@ -853,11 +811,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   };
   auto mfma_at = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
-    if constexpr ((DBG & 4) != 0) {
-      const bf16x8_t keep_alive = wq[S % PD];
-      asm volatile("" ::"v"(keep_alive));
-      if constexpr (S == 0) { for (int e = 0; e < 16; ++e) accH[e] = 1.0f; }
-    } else if constexpr (S == 0) {
+    if constexpr (S == 0) {
       const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xf[0], zero, 0, 0, 0);
     } else if constexpr (S < 16) {
@@ -871,8 +825,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     const char* prow = smem + V2_P + offP;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if constexpr ((DBG & 8) != 0) pf[ks] = xf[ks];
-      else pf[ks] = *reinterpret_cast<const bf16x8_t*>(prow + ((((uint32_t)(2 * ks + h)) ^ pz) << 4));
+      pf[ks] = *reinterpret_cast<const bf16x8_t*>(prow + ((((uint32_t)(2 * ks + h)) ^ pz) << 4));
     }
   };
   // the first LOOK fragments of a span, issued right behind barrier X (the P write, barrier Y and the DMA issue cover their latency)
@@ -902,7 +855,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
       ([&] {
         constexpr int S = S0 + SS;
         mfma_at(std::integral_constant<int, S>());
-        if constexpr (HAS_A && (DBG & 2) == 0 && S >= 1 && S <= 8) {
+        if constexpr (HAS_A && S >= 1 && S <= 8) {
           if constexpr (S <= 4) glds_one(src1, voff1[S - 1], dst1 + (uint32_t)(S - 1) * 1024u);
           else glds_one(src2, voff2[S - 5], dst2 + (uint32_t)(S - 5) * 1024u);
         }
@@ -1053,7 +1006,7 @@ bool use_v2_fwd(const FfnArgs& a) {
 
 template <int DROP, bool FULL>
 int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
-  constexpr int DBG = 0;   // (the ablation builds of rounds 2-3 -- ffn_pair8_kernel's DBG bits -- are not instantiated any more)
+  constexpr int DBG = 0;
   const int lds = V2_BIAS + a.F * 4;
   if (a.gate_bits) {
     auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true>;
