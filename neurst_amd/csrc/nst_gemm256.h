@@ -149,7 +149,8 @@ struct Frag256<MODE_OC> {   // [64 k][128 cols] image, 32-byte pair ^= (r & 3) |
 __device__ __forceinline__ void g256_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
 
 // Main loop of one unit: acc (+)= A[m0.., k-range] . B[n0.., k-range]; cs = column sums of the B operand (do_cs, wave-uniform).
-// DBG (timing ablations, results wrong): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads
+// DBG: always 0 (it selected the timing ablations of DESIGN 5e -- no MFMAs / no DMA after the prologue / no fragment reads --
+// whose branches are gone; the parameter keeps the instantiation names of the earlier profiles).
 // da / db: DMA cursors of the two operands, positioned on the unit's first K step; cursor.issue<H>(t, image, wave) stages
 // half-tile H of the unit's K step t (called with t = 0, 1, 2, ... in order for either half).  AMODE / BMODE: layout of their
 // half-tile images (fragment readers).
@@ -214,113 +215,87 @@ __device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int
     const uint32_t cur = (uint32_t)(t & 1) * G256_KT_BYTES, nxt = G256_KT_BYTES - cur;
     const char* Ah = smem + cur + wr * G256_HALF_BYTES;
     const char* Bh = smem + cur + (2 + (wc >> 1)) * G256_HALF_BYTES;
-    const bool dma_on = (DBG & 2) == 0;
+    const bool dma_on = true;
     bf16x8_t blo[2][2], bhi[2][2], af[4][2];
 
     // ---------------- phase 0
-    if constexpr ((DBG & 4) == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) blo[j][kh] = fb.read(Bh, bip + j, kh);
+      for (int kh = 0; kh < 2; ++kh) blo[j][kh] = fb.read(Bh, bip + j, kh);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) af[i][kh] = fa.read(Ah, i, kh);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) blo[j][kh] = ones;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) af[i][kh] = ones;
-    }
+      for (int kh = 0; kh < 2; ++kh) af[i][kh] = fa.read(Ah, i, kh);
     __builtin_amdgcn_sched_barrier(0);
     if (dma_on && t + 1 < nk) da.template issue<0>(t + 1, smem_addr + nxt + 0 * G256_HALF_BYTES, wave);
     g256_wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((DBG & 1) == 0) {
-      __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0][i][j] = Mma<T>::run(af[i][kh], blo[j][kh], acc[0][i][j]);
+    if (CS && do_cs) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[0][i][j] = Mma<T>::run(af[i][kh], blo[j][kh], acc[0][i][j]);
-      if (CS && do_cs) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) cs[j] = Mma<T>::run(ones, blo[j][kh], cs[j]);
-      }
-      __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < 2; ++j) cs[j] = Mma<T>::run(ones, blo[j][kh], cs[j]);
     }
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- phase 1
-    if constexpr ((DBG & 4) == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) bhi[j][kh] = fb.read(Bh, bip + 2 + j, kh);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) bhi[j][kh] = ones;
-    }
+      for (int kh = 0; kh < 2; ++kh) bhi[j][kh] = fb.read(Bh, bip + 2 + j, kh);
     __builtin_amdgcn_sched_barrier(0);
     if (dma_on && t + 1 < nk) da.template issue<1>(t + 1, smem_addr + nxt + 1 * G256_HALF_BYTES, wave);
     g256_wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((DBG & 1) == 0) {
-      __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0][i][2 + j] = Mma<T>::run(af[i][kh], bhi[j][kh], acc[0][i][2 + j]);
+    if (CS && do_cs) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[0][i][2 + j] = Mma<T>::run(af[i][kh], bhi[j][kh], acc[0][i][2 + j]);
-      if (CS && do_cs) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) cs[2 + j] = Mma<T>::run(ones, bhi[j][kh], cs[2 + j]);
-      }
-      __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < 2; ++j) cs[2 + j] = Mma<T>::run(ones, bhi[j][kh], cs[2 + j]);
     }
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- phase 2
-    if constexpr ((DBG & 4) == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) af[i][kh] = fa.read(Ah, 4 + i, kh);
-    }
+      for (int kh = 0; kh < 2; ++kh) af[i][kh] = fa.read(Ah, 4 + i, kh);
     __builtin_amdgcn_sched_barrier(0);
     if (dma_on && t + 2 < nk) db.template issue<0>(t + 2, smem_addr + cur + 2 * G256_HALF_BYTES, wave);
     g256_wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((DBG & 1) == 0) {
-      __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[1][i][2 + j] = Mma<T>::run(af[i][kh], bhi[j][kh], acc[1][i][2 + j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
+        for (int i = 0; i < 4; ++i) acc[1][i][2 + j] = Mma<T>::run(af[i][kh], bhi[j][kh], acc[1][i][2 + j]);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -334,25 +309,14 @@ __device__ __forceinline__ void gemm256_mainloop(char* smem, DA& da, DB& db, int
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((DBG & 1) == 0) {
-      __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[1][i][j] = Mma<T>::run(af[i][kh], blo[j][kh], acc[1][i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) { asm volatile("" ::"v"(af[i][kh])); }
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) { asm volatile("" ::"v"(blo[j][kh])); asm volatile("" ::"v"(bhi[j][kh])); }
-    }
+        for (int i = 0; i < 4; ++i) acc[1][i][j] = Mma<T>::run(af[i][kh], blo[j][kh], acc[1][i][j]);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
