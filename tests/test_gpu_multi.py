@@ -111,6 +111,32 @@ def test_native_comm_two_ranks():
     _run_data_parallel(2, True, native=True)
 
 
+def test_streams_of_the_three_priority_classes():
+    """nst_stream_create: the step (high), the weight-gradient stream (low) and the exchange (default) live in three classes;
+    runtime.make_stream wraps them for torch, work queued on them runs and orders through events like on any stream."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device: No HIP GPUs are available")
+    from neurst_amd.runtime import make_stream
+    streams = {c: make_stream("cuda:0", c) for c in (-1, 0, 1)}
+    assert len({s.cuda_stream for s in streams.values()}) == 3
+    x = torch.zeros(1 << 20, device="cuda:0")
+    torch.cuda.synchronize()
+    prev = torch.cuda.current_stream()
+    for c in (1, 0, -1):          # a chain low -> default -> high, each adding one
+        st = streams[c]
+        st.wait_stream(prev)
+        with torch.cuda.stream(st):
+            x.add_(1.0)
+        prev = st
+    torch.cuda.current_stream().wait_stream(prev)
+    assert float(x.sum()) == 3.0 * x.numel()
+    from neurst_amd import _lib
+    import ctypes
+    h = ctypes.c_void_p()
+    assert _lib.lib.nst_stream_create(1, ctypes.byref(h)) == 0 and h.value
+    assert _lib.lib.nst_stream_destroy(h) == 0
+
+
 def test_native_comm_one_rank_collectives_are_identities():
     """nst_comm_* directly: unique id, a one-rank communicator, all-reduce (fp32 / bf16 / fp16) and broadcast leave the data
     as it is, ordered behind a producer stream that is still writing it; info counts buckets and bytes; destroy."""

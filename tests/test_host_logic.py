@@ -51,6 +51,15 @@ def test_comm_entry_points_validate_their_arguments_without_a_device():
     assert L.nst_comm_destroy(fake) == -1 and L.nst_comm_destroy(None) == 0
 
 
+def test_stream_create_rejects_unknown_priority_classes_without_a_device():
+    from neurst_amd import _lib
+    handle = ctypes.c_void_p()
+    assert _lib.lib.nst_stream_create(2, ctypes.byref(handle)) == -1 and handle.value is None
+    assert b"priority class 2" in _lib.lib.nst_last_error_string()
+    assert _lib.lib.nst_stream_create(0, None) == -1
+    assert _lib.lib.nst_stream_destroy(None) == 0
+
+
 def test_struct_layouts_match_header_sizes():
     from neurst_amd import _lib
     # field order/types mirror the header; sizes guard against silent drift (x86-64 SysV layout)
