@@ -190,11 +190,4 @@ static inline void nst_dropout_params16(float p, uint32_t* thresh16, float* inv_
   *thresh16 = (uint32_t)t;
   *inv_keep = (float)(65536.0 / (65536.0 - (double)*thresh16));
 }
-// attention probabilities keep full 32-bit words (one word per probability)
-static inline uint32_t nst_dropout_threshold(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t < 0) t = 0;
-  if (t > 4294967295.0) t = 4294967295.0;
-  return (uint32_t)t;
-}
 

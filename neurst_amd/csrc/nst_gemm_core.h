@@ -888,20 +888,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 
-// (K slice, tile) of workgroup b in a one-unit-per-workgroup split-K launch of ntiles * split workgroups.  zx != 0 (split a
-// multiple of 8): slice z lives on XCD z % 8 -- workgroup ids go round-robin over the XCDs, and all tiles of a slice read
-// the same rows of both operands, so their re-reads then hit one L2.
-__device__ __forceinline__ void splitk_unit(int b, int ntiles, int zx, int& z, int& tile) {
-  if (zx) {
-    const int idx = b >> 3, sl = idx / ntiles;
-    z = (b & 7) + 8 * sl;
-    tile = idx - sl * ntiles;
-  } else {
-    z = b / ntiles;
-    tile = xcd_remap(b - z * ntiles, ntiles);
-  }
-}
-
 // =============================================================================================
 // v3: persistent stream of (output tile, K step) work over the same LDS-DMA stage ring.
 //
