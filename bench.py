@@ -72,6 +72,12 @@ def parse():
     ap.add_argument("--wire", default=os.environ.get("NST_DIST_WIRE", "fp32"), choices=["fp32", "bf16", "fp16"],
                     help="gradient dtype on the wire (16-bit: the reference's fp16 compression, training_utils.py:381-384)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="extra un-timed steps with per-launch HIP events (0 = skip)")
+    ap.add_argument("--no-autotune", dest="autotune", action="store_false", default=True,
+                    help="N > 1 only: skip the short child runs that choose {hardware queues per class} x {RCCL channels} x "
+                         "{exchange carrier} before the timed run (the variables are read when HIP / RCCL initialise, so each "
+                         "candidate needs fresh processes; every candidate and the choice are reported under `autotune`)")
+    ap.add_argument("--autotune-budget", type=float, default=240.0, help="wall-clock cap of all autotune child runs, seconds")
+    ap.add_argument("--autotune-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -198,6 +204,117 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+AUTOTUNE_CANDIDATES = [
+    # (label, environment of the candidate) -- the first one is the default configuration; one factor changes at a time
+    ("hwq1_ch16_torch", {"GPU_MAX_HW_QUEUES": "1", "NCCL_MAX_NCHANNELS": "16", "NST_DIST_NATIVE": "0"}),
+    ("hwq2_ch16_torch", {"GPU_MAX_HW_QUEUES": "2", "NCCL_MAX_NCHANNELS": "16", "NST_DIST_NATIVE": "0"}),
+    ("hwq1_ch32_torch", {"GPU_MAX_HW_QUEUES": "1", "NCCL_MAX_NCHANNELS": "32", "NST_DIST_NATIVE": "0"}),
+    ("hwq1_ch16_native", {"GPU_MAX_HW_QUEUES": "1", "NCCL_MAX_NCHANNELS": "16", "NST_DIST_NATIVE": "1"}),
+]
+_LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                  "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def autotune(args, rank, world):
+    """N > 1, BEFORE this process touches HIP: rank 0 times each candidate as a short child job of its own (same N ranks on the
+    same GPUs -- the parent ranks hold nothing on them yet), picks the fastest and tells the other ranks through a file next
+    to the launcher's rendezvous port; every rank then applies the winner's environment and carries on into the timed run.
+    Explicit settings in the caller's environment are never overridden (such a variable is simply not a factor).  Any failure
+    -- a candidate that crashes, hangs past its share of --autotune-budget, or prints no JSON line -- is recorded and skipped;
+    with no usable candidate the defaults stay.  Returns the report that goes into the JSON line."""
+    import subprocess
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"nst_autotune_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.json")
+    fixed = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NCCL_MAX_NCHANNELS", "NST_DIST_NATIVE") if k in os.environ}
+    if rank != 0:
+        t_end = time.time() + args.autotune_budget + 90.0
+        while time.time() < t_end:
+            if os.path.exists(path):
+                try:
+                    report = json.load(open(path))
+                    break
+                except Exception:
+                    pass
+            time.sleep(0.2)
+        else:
+            report = {"chosen": None, "note": "rank 0 never published a choice: defaults"}
+        for k, v in (report.get("chosen_env") or {}).items():
+            os.environ[k] = v
+        return report
+    t0 = time.time()
+    report = {"fixed_by_caller": fixed, "candidates": [], "budget_s": args.autotune_budget}
+    passthrough = ["--gpus", str(world), "--steps", "6", "--warmup", "3", "--roofline-steps", "0", "--no-cpu-baseline",
+                   "--autotune-child", "--dtype", args.dtype, "--model", args.model, "--batch", str(args.batch),
+                   "--frames", str(args.frames), "--vocab", str(args.vocab), "--wire", args.wire]
+    if args.graph is not None:
+        passthrough.append("--graph" if args.graph else "--eager")
+    if args.ragged:
+        passthrough.append("--ragged")
+    if args.strong:
+        passthrough.append("--strong")
+    seen = set()
+    for label, cand in AUTOTUNE_CANDIDATES:
+        env_c = {k: v for k, v in cand.items() if k not in fixed}
+        key = tuple(sorted(env_c.items()))
+        if key in seen:                    # the caller fixed this candidate's factor: it collapses onto an earlier one
+            continue
+        seen.add(key)
+        left = args.autotune_budget - (time.time() - t0)
+        entry = {"label": label, "env": env_c}
+        report["candidates"].append(entry)
+        if left < 20.0:
+            entry["skipped"] = "autotune budget spent"
+            continue
+        env = {k: v for k, v in os.environ.items() if k not in _LAUNCHER_VARS and not k.startswith("TORCHELASTIC")}
+        env.update(env_c)
+        env["NST_BENCH_CHILD"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + passthrough
+        t1 = time.time()
+        try:
+            # own session: a candidate that hangs is killed with its whole process group (exact pgid, never by pattern)
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=min(100.0, left))
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                so, se = proc.communicate()
+                entry["error"] = "timed out"
+            line = next((ln for ln in reversed((so or "").strip().splitlines()) if ln.startswith("{")), None)
+            if line is not None and "error" not in entry:
+                d = json.loads(line)
+                entry["ms_per_step"] = d.get("ms_per_step")
+                entry["exchange"] = d.get("exchange")
+            elif "error" not in entry:
+                entry["error"] = "no JSON line (rc %s): %s" % (proc.returncode, ((se or "").strip().splitlines() or ["no stderr"])[-1][:200])
+        except Exception as e:      # never let the tuner take the measurement down
+            entry["error"] = f"{type(e).__name__}: {e}"[:200]
+        entry["seconds"] = round(time.time() - t1, 1)
+    ok = [c for c in report["candidates"] if c.get("ms_per_step")]
+    best = min(ok, key=lambda c: c["ms_per_step"]) if ok else None
+    # a candidate replaces the default only when it wins by more than the run-to-run noise of a 6-step sample
+    base = next((c for c in ok if c["label"] == AUTOTUNE_CANDIDATES[0][0]), None)
+    if best is not None and base is not None and best is not base and best["ms_per_step"] > 0.98 * base["ms_per_step"]:
+        best = base
+    report["chosen"] = best["label"] if best else None
+    report["chosen_env"] = dict(best["env"]) if best else {}
+    report["seconds"] = round(time.time() - t0, 1)
+    tmp = path + ".tmp"
+    json.dump(report, open(tmp, "w"))
+    os.replace(tmp, path)
+    for k, v in report["chosen_env"].items():
+        os.environ[k] = v
+    return report
+
+
 def main():
     if os.environ.get("NST_BENCH_HANG_DUMP_S"):   # debugging aid: dump every thread's stack and exit if the run takes longer
         import faulthandler
@@ -209,6 +326,12 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("NST_BENCH_CHILD") != "1":
         sys.exit(self_launch(args))
+    # process-wide settings first: nothing below may load the HIP library's code objects or touch the device before them
+    from neurst_amd.runtime import configure_training_process
+    tune = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.autotune and not args.autotune_child:
+        tune = autotune(args, int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"]))
+    configure_training_process()
     from neurst_amd import kernels as K
     from neurst_amd.criterions import build_criterion
     from neurst_amd.data.datasets.synthetic_speech import SyntheticSpeechDataset
@@ -284,6 +407,7 @@ def main():
             torch.cuda.synchronize()
             print(f"[bench] rank {rank}: warm-up step {i} done", file=sys.stderr, flush=True)
     barrier()
+    reducer.diag = bool(reducer.active)      # HIP events around the exchange of every timed step (three records per step)
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
@@ -291,6 +415,12 @@ def main():
     t_issued = time.perf_counter() - t0      # the host has queued every launch of the K steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
+    reducer.diag = False
+    exchange = reducer.exchange_report()     # this rank's: exposed wait, span, bytes, bus-rate bound (None without an exchange)
+    if exchange is not None and world > 1:   # the slowest rank's exposed wait is the one the step time contains
+        worst = torch.tensor([exchange["exchange_exposed_ms"], exchange["exchange_span_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        exchange["exchange_exposed_ms_max_over_ranks"], exchange["exchange_span_ms_max_over_ranks"] = worst.tolist()
     # roofline pass (un-timed, after the measurement): the same steps with HIP events around every launch of the MFMA kernel
     # families, on the stream each launch goes to -- durations are therefore IN-STEP durations (the weight-gradient stream
     # shares the CUs with the dgrad chain), the same thing `rocprofv3 --kernel-trace --stats` of this command reports
@@ -385,6 +515,12 @@ def main():
         "gradient_wire_dtype": args.wire,
         "exchange_path_active": bool(reducer.active),
         "reducer_messages_per_step": getattr(reducer, "last_messages", None),
+        "exchange": exchange,
+        "autotune": tune,
+        # every switch of the environment that can change what is measured (the library reads NST_*, HIP / RCCL the others)
+        "env": {k: v for k, v in sorted(os.environ.items())
+                if k.startswith(("NST_", "NCCL_", "RCCL_", "GPU_MAX_HW_QUEUES", "HSA_ENABLE", "HIP_VISIBLE", "ROCR_VISIBLE"))},
+        "hw_queues_note": configure_training_process(),
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, T, F, L, V)

@@ -37,7 +37,7 @@ class Trainer(BaseExperiment):
         self._update_cycle = args["update_cycle"] or 1
         self._optimizer_args = {"optimizer.class": args["optimizer.class"], "optimizer.params": args["optimizer.params"]}
         self._lr_args = {"lr_schedule.class": args["lr_schedule.class"], "lr_schedule.params": args["lr_schedule.params"]}
-        self._bucket_mb = args.get("allreduce_bucket_mb", 32) or 32
+        self._bucket_mb = args.get("allreduce_bucket_mb", None) or None   # None: the reducer's default (one message per report)
         self._clip_value, self._clip_norm = args.get("clip_value", None), args.get("clip_norm", None)
         self._validator = build_validator(args)
         self._max_to_keep = args.get("checkpoints_max_to_keep", 8) or 8
@@ -60,8 +60,9 @@ class Trainer(BaseExperiment):
             Flag("clip_norm", dtype=Flag.TYPE.FLOAT, default=None, help="Gradient clipping by norm."),
             Flag("pretrain_model", dtype=Flag.TYPE.STRING, default=None,
                  help="A checkpoint (directory or prefix, TensorFlow bundle format) to initialise the weights from."),
-            Flag("allreduce_bucket_mb", dtype=Flag.TYPE.INTEGER, default=32,
-                 help="Size of one RCCL all-reduce message of the flat gradient buffer."),
+            Flag("allreduce_bucket_mb", dtype=Flag.TYPE.INTEGER, default=None,
+                 help="Upper bound of one RCCL all-reduce message of the flat gradient buffer in MiB (default: the "
+                      "reducer's own, NST_DIST_BUCKET_MB or 256 -- the configuration bench.py measures)."),
         ]
 
     def _save(self, step):
@@ -94,7 +95,7 @@ class Trainer(BaseExperiment):
                 if self._ckpt_manager.restore() is not None:
                     start_step = optimizer.iterations
                     logging.info("resuming %s at step %d", self.model_dir, start_step)
-        reducer = GradientReducer(model.store, bucket_bytes=self._bucket_mb << 20)
+        reducer = GradientReducer(model.store, bucket_bytes=(self._bucket_mb << 20) if self._bucket_mb else None)
         reducer.broadcast_parameters(0)
         if world > 1:
             start_step = int(reducer.reduce_metrics({"start_step": float(start_step)})["start_step"])

@@ -255,6 +255,10 @@ class WgradGroup(object):
     def add(self, x, dz, out, accumulate=False, colsum_out=None, colsum_accumulate=False):
         self.items.append((x, dz, out, bool(accumulate), colsum_out, bool(colsum_accumulate)))
 
+    def pending_bytes(self):
+        """Activation bytes the queued products keep alive until the launch (x and dz of every product)."""
+        return sum(x.numel() * x.element_size() + dz.numel() * dz.element_size() for x, dz, *_ in self.items)
+
     def __len__(self):
         return len(self.items)
 

@@ -33,11 +33,11 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
 
 
 _WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
-_SKIP_WGRAD = os.environ.get("NST_SKIP_WGRAD", "0") == "1"
 _WGRAD_SPLIT8 = os.environ.get("NST_WGRAD_SPLIT8", "1") != "0"
 _WGRAD_UNITS_SMALL = int(os.environ.get("NST_WGRAD_UNITS_SMALL", "128"))   # gradients of fewer than 8 tiles (256 x 256 kernels)
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
+_WGRAD_GROUP_MAX_BYTES = 6 << 30    # activations a pending weight-gradient group may keep alive before it is launched early
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
 # the backward pair (NST_FFN_FUSED_BWD=0: two persistent GEMMs instead).  It holds all 160 KB of a CU's LDS, so no
 # weight-gradient workgroup shares its CUs, but at 97 us against 124 us for the two GEMMs it still wins in the step
@@ -140,14 +140,16 @@ class Dense(Layer):
         """dkernel (+)= x^T dz ; dbias (+)= colsum(dz)."""
         st = self.rt.store
         rows = x.shape[0]
-        if _SKIP_WGRAD:      # timing experiment only (NST_SKIP_WGRAD=1): the dgrad chain without the weight-gradient stream
-            return
         acc_k = st.acc_flag(self.kernel)
         grp = self.rt.wgrad_group()
         if grp is not None and self.wgrad_grouped and grp.accepts(x, dz, self.kernel.grad, None if self.bias is None else self.bias.grad):
             # waits for the stack's grouped launch (Runtime.launch_wgrad_group): no split-K, no slabs
             grp.add(x, dz, self.kernel.grad, acc_k, None if self.bias is None else self.bias.grad,
                     False if self.bias is None else st.acc_flag(self.bias))
+            # the group keeps x and dz of every queued product alive (benchmark shape: ~1.1 GB for 84 products); past the cap
+            # (long ragged batches, transformer_big) it is launched early instead of growing with batch x layers
+            if grp.pending_bytes() > _WGRAD_GROUP_MAX_BYTES:
+                self.rt.launch_wgrad_group()
             return
         bias_kw = {}
         if self.bias is not None:  # dbias rides on the same pass over dz (ones^T.dz inside the MFMA loop)

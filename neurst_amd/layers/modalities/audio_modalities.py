@@ -95,9 +95,7 @@ class AudioConv2dSubsamplingLayer(Layer):
         # backward (conv2 dgrad / wgrad on the 256 x 256 tile core, conv1's backward) hold their CUs alone, so running the weight
         # gradient beside them on the weight-gradient stream only made them take turns -- 2.38 ms for 2.04 ms of stand-alone
         # work; one after the other: 13.10 -> 12.88 ms per step (profiles/r04_history/c36_ab_step.log)
-        import os
-        if os.environ.get("NST_SKIP_WGRAD", "0") != "1":   # (timing experiment switch, see common_layers._SKIP_WGRAD)
-            K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
+        K.conv2_wgrad(a1, dy2, self.w2.grad, db2=self.b2.grad, accumulate=acc2)
         acc = st.acc_flag(self.w1)
         st.acc_flag(self.b1)
         if ln:

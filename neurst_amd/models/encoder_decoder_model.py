@@ -1,6 +1,5 @@
 """EncoderDecoderModel (neurst/models/encoder_decoder_model.py:27-279): modalities -> encoder -> decoder ->
 tied logits, training path, with an explicit backward pass."""
-import os
 
 import torch
 
@@ -74,14 +73,19 @@ class _DecodeSession(object):
 # per stack 15.18, small groups on the side stream 14.75 ms per step -- a group that cannot fill the chip, or fills it 1.06 times,
 # wastes more than the launch saves) and are gone.  "encoder" vs "end" on ONE GPU: 14.07 vs 13.91 and 13.79 vs 13.79 ms in two
 # sessions (behind the encoder the group shares the chip with the weight-gradient stream's leftovers).
-_WGRAD_GROUP_AT = os.environ.get("NST_WGRAD_GROUP_AT")
+_WGRAD_GROUP_AT = None      # tests pin it; None: "encoder" whenever there is an exchange to overlap, else "end"
 
 
 def _wgrad_group_at():
-    if _WGRAD_GROUP_AT is not None:
-        return _WGRAD_GROUP_AT
     import torch.distributed as dist
-    return "encoder" if (dist.is_available() and dist.is_initialized()) else "end"
+    exchanging = dist.is_available() and dist.is_initialized()
+    if _WGRAD_GROUP_AT is not None:
+        if _WGRAD_GROUP_AT == "end" and exchanging and dist.get_world_size() > 1:
+            import warnings
+            warnings.warn("grouped weight gradients at the END of the backward pass with more than one rank: every reducer report "
+                          "waits for that launch, so no gradient exchange overlaps compute")
+        return _WGRAD_GROUP_AT
+    return "encoder" if exchanging else "end"
 
 
 @register_model(["seq2seq", "sequence_to_sequence", "SequenceToSequence"])
@@ -238,6 +242,17 @@ class EncoderDecoderModel(BaseModel):
     def backward(self, dlogits, accumulate=False):
         """Back-propagates d(loss)/d(logits) through the whole model; parameter gradients land in the flat
         gradient buffer (rt.store.grad).  `accumulate`: add to existing gradients (update_cycle micro steps)."""
+        stale = self.rt.drop_pending_wgrads()      # left behind by a backward pass that aborted (see Runtime.drop_pending_wgrads)
+        if stale:
+            import warnings
+            warnings.warn(f"{stale} weight-gradient products / reducer reports of an aborted backward pass were dropped")
+        try:
+            self._backward(dlogits, accumulate)
+        except BaseException:
+            self.rt.drop_pending_wgrads()
+            raise
+
+    def _backward(self, dlogits, accumulate):
         with self.rt.bound():
             self.rt.store.begin_backward(accumulate)
             user_hook = self.grad_ready_hook or (lambda prefixes: None)

@@ -255,6 +255,40 @@ class ParamStore(object):
         return sum(p.numel for p in self.params.values())
 
 
+_HWQ_NOTE = [None]
+
+
+def configure_training_process():
+    """Process-wide HIP setting of the TRAINING entry points (init_distributed, bench.py, neurst-run); returns the line it logs.
+    Must run before the first HIP call of the process (the runtime reads the variable once, when it initialises).
+
+    GPU_MAX_HW_QUEUES = 1.  ROCm multiplexes the HIP streams of ONE priority class onto at most this many hardware queues
+    (default 4).  A training step here has three concurrent activities and keeps each in a priority class of its own
+    (make_stream: the step on a high-priority stream, its weight-gradient stream on a low-priority one, the gradient exchange
+    in the default class), so one queue per class is all the concurrency it needs -- and MORE queues are what hurt: with 16 per
+    class the same step ran at 13.0 ms or at 21-31 ms depending only on how many streams other libraries had touched before
+    the first step (a second RCCL communicator, a few idle pool streams); with 1 or 2 queues per class all 14 configurations
+    tried run at 12.96-13.22 ms (profiles/r04_history/c26_order.log, c27_streams.log, c28_hwq.log).  Streams that share a
+    queue execute in submission order; with one submitting host thread and record-before-wait events that order cannot close
+    a wait cycle.  An explicit setting in the environment wins.  The setting relies on the three streams landing in three
+    DISTINCT classes: make_stream warns when a class is missing and the stream falls back to the default one.
+    Importing neurst_amd alone (decoding, other libraries in the process) does not apply it."""
+    import logging
+    import torch
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        note = f"GPU_MAX_HW_QUEUES={cur} (taken from the environment)"
+    elif torch.cuda.is_initialized():
+        note = "GPU_MAX_HW_QUEUES not set and HIP is already initialised: the runtime default (4 queues per class) stays"
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = "1"
+        note = "GPU_MAX_HW_QUEUES=1 (training default: one hardware queue per stream-priority class)"
+    if _HWQ_NOTE[0] != note:
+        logging.getLogger("neurst_amd").info(note)
+        _HWQ_NOTE[0] = note
+    return note
+
+
 def make_stream(device, priority_class):
     """A HIP stream of priority class -1 (high) / 0 (default) / 1 (low) as a torch stream.  Why classes: the HIP runtime
     multiplexes the streams of ONE class onto a few hardware queues (the least used one at creation time), and two busy streams
@@ -271,6 +305,11 @@ def make_stream(device, priority_class):
     with torch.cuda.device(device):
         rc = _lib.lib.nst_stream_create(priority_class, ctypes.byref(handle))
     if rc != 0 or not handle.value:      # no such class on this device: the default class
+        import warnings
+        warnings.warn(f"no stream priority class {priority_class} on {device} (nst_stream_create rc={rc}): the stream shares the "
+                      "default class" + (" -- with GPU_MAX_HW_QUEUES=1 it then shares ONE hardware queue with the gradient "
+                                         "exchange and executes in submission order (no overlap)"
+                                         if os.environ.get("GPU_MAX_HW_QUEUES") == "1" else ""))
         return torch.cuda.Stream(device)
     return torch.cuda.ExternalStream(handle.value, device=device)   # lives as long as the process
 
@@ -358,6 +397,22 @@ class Runtime(object):
             self._deferred_reports.append(report)
         else:
             report()
+
+    def drop_pending_wgrads(self):
+        """Forgets weight gradients that were queued for the grouped launch, and the reducer reports waiting behind it, without
+        launching them; returns how many there were.  Called at the start of every backward pass and when one aborts (an
+        exception between Dense.backward_params and launch_wgrad_group, a failed capture): a dead batch's products must never
+        run inside the next step's launch (they would overwrite / accumulate into its gradients with stale accumulate flags),
+        and a stale report would make this rank issue one collective more than its peers."""
+        g = getattr(self, "_wgrad_group", None)
+        stale = 0
+        if g is not None and len(g):
+            stale += len(g)
+            g.items = []
+        if getattr(self, "_deferred_reports", None):
+            stale += len(self._deferred_reports)
+            self._deferred_reports = []
+        return stale
 
     def launch_wgrad_group(self):
         """One launch, on the current stream, for every weight gradient queued since the last call, then the reports that

@@ -42,6 +42,8 @@ def init_distributed(backend=None):
     """Reads the launcher environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pins the GPU and creates the
     process group.  Equivalent of training_utils.handle_distribution_strategy's horovod branch
     (neurst/training/training_utils.py:104-119).  Returns (rank, local_rank, world_size)."""
+    from neurst_amd.runtime import configure_training_process
+    configure_training_process()      # before the first HIP call of this process (logged; see its docstring)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,12 +89,15 @@ class NativeComm(object):
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         buf = C.create_string_buffer(_lib.NST_COMM_UNIQUE_ID_BYTES)
-        if rank == 0:
-            _lib.check(_lib.lib.nst_comm_unique_id(buf, len(buf)), "nst_comm_unique_id", launches=False)
+        rc = _lib.lib.nst_comm_unique_id(buf, len(buf)) if rank == 0 else 0
         if world > 1:
-            box = [bytes(buf.raw)]
+            # (status, id) travels together: if rank 0 cannot create the id (librccl not found -> NST_ERR_UNSUPPORTED) every rank
+            # raises here instead of waiting forever in the broadcast or in ncclCommInitRank
+            box = [(int(rc), bytes(buf.raw))]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            buf = C.create_string_buffer(box[0], _lib.NST_COMM_UNIQUE_ID_BYTES)
+            rc = box[0][0]
+            buf = C.create_string_buffer(box[0][1], _lib.NST_COMM_UNIQUE_ID_BYTES)
+        _lib.check(rc, "nst_comm_unique_id" + ("" if rank == 0 else " (on rank 0)"), launches=False)
         handle = C.c_void_p()
         _lib.check(_lib.lib.nst_comm_init(buf, len(buf), rank, world, C.byref(handle)), "nst_comm_init", launches=False)
         self.handle, self.rank, self.world = handle, rank, world
@@ -179,6 +184,11 @@ class GradientReducer(object):
         # graph capture of the train step (training/train_step.py): instead of issuing a bucket, the reducer hands its
         # range to this callback, which cuts the capture there and replays the exchange eagerly between two graph launches
         self.capture_cut = None
+        # measurement (bench.py): with diag on, every step records HIP events -- on the stream that issues the first bucket, and on
+        # the stream that waits for the exchange right before and right after that wait -- and counts the bytes it sends;
+        # exchange_report() turns them into the time the step stood still for the exchange ("exposed") and a bus-rate bound
+        self.diag = False
+        self._diag_steps, self._diag_first, self._diag_bytes = [], None, 0
         # the library's own RCCL communicator instead of torch.distributed's (module docstring)
         if native is None:
             native = os.environ.get("NST_DIST_NATIVE", "0") == "1"
@@ -190,6 +200,18 @@ class GradientReducer(object):
             # staging buffer of the 16-bit wire, as long as the gradient buffer: every in-flight message owns its own region.
             # Allocated here, not inside the first step (a step that is being captured into a HIP graph must not allocate it)
             self._wire_buf = torch.empty(store.total, dtype=self.wire_dtype, device=store.grad.device)
+
+    def close(self):
+        """Releases the library's communicator (ncclCommDestroy, its stream and events); idempotent."""
+        comm, self._comm = self._comm, None
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:      # interpreter shutdown: the library or the process group may be gone already
+                pass
+
+    def __del__(self):
+        self.close()
 
     # ---- parameter ranges -------------------------------------------------------------------------------------
     def range_of(self, prefixes):
@@ -241,7 +263,7 @@ class GradientReducer(object):
                 # behind the collective (Work.wait() orders the current stream after it without blocking the host)
                 w = self._wire_buf[s:e]
                 if self.prescale:
-                    w.copy_(g[s:e] * (1.0 / self.world))
+                    torch.mul(g[s:e], 1.0 / self.world, out=w)     # scale + cast in one pass, no fp32 temporary
                 else:
                     w.copy_(g[s:e])
                 h = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -257,7 +279,7 @@ class GradientReducer(object):
         cur = torch.cuda.current_stream()
         w = self._wire_buf[s:e]
         if self.prescale:
-            w.copy_(g[s:e] * (1.0 / self.world))
+            torch.mul(g[s:e], 1.0 / self.world, out=w)     # scale + cast in one pass, no fp32 temporary
         else:
             w.copy_(g[s:e])
         self._comm.allreduce_bucket(w, [cur])
@@ -274,6 +296,11 @@ class GradientReducer(object):
 
     def issue(self, start, end):
         """The exchange of grad[start:end] itself (asynchronous on the communication stream when there is one)."""
+        if self.diag and self.on_gpu:
+            if self._diag_first is None:
+                self._diag_first = torch.cuda.Event(enable_timing=True)
+                self._diag_first.record(torch.cuda.current_stream())     # the producers of the first bucket are queued up to here
+            self._diag_bytes += (end - start) * (4 if self.wire_dtype is None else 2)
         if self.native and self.wire_dtype is None:
             # producers = the current stream + the weight-gradient stream; neither waits for the bucket
             cur = torch.cuda.current_stream()
@@ -329,6 +356,10 @@ class GradientReducer(object):
 
     def wait_issued(self):
         """The current stream waits for every exchange issued so far."""
+        before = None
+        if self.diag and self.on_gpu and self._diag_first is not None:
+            before = torch.cuda.Event(enable_timing=True)
+            before.record(torch.cuda.current_stream())       # everything the step computed before it needs the exchanged gradients
         for i, h in enumerate(self._pending):
             h.wait()
             if _DEBUG:
@@ -338,6 +369,31 @@ class GradientReducer(object):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         if self.native:
             self._comm.fence(torch.cuda.current_stream())
+        if before is not None:
+            after = torch.cuda.Event(enable_timing=True)
+            after.record(torch.cuda.current_stream())        # completes when the last bucket's fence has cleared
+            self._diag_steps.append((self._diag_first, before, after, self._diag_bytes))
+            self._diag_first, self._diag_bytes = None, 0
+
+    def exchange_report(self):
+        """Per-step averages of the steps recorded with diag on (synchronises the device): exchange_exposed_ms = time between
+        the end of the step's own work in front of the wait and the clearing of the last bucket's fence on the same stream;
+        exchange_span_ms = first bucket issued -> last fence cleared (includes the time buckets wait for their producers, so
+        the bus rate derived from it -- 2(n-1)/n x bytes / span, the ring all-reduce's traffic per link -- is a LOWER bound)."""
+        if not self._diag_steps:
+            return None
+        torch.cuda.synchronize()
+        n = len(self._diag_steps)
+        exposed = sum(b.elapsed_time(a) for _, b, a, _ in self._diag_steps) / n
+        span = sum(f.elapsed_time(a) for f, _, a, _ in self._diag_steps) / n
+        nbytes = sum(x[3] for x in self._diag_steps) / n
+        w = max(self.world, 1)
+        self._diag_steps = []
+        return {"steps": n, "exchange_exposed_ms": exposed, "exchange_span_ms": span, "exchange_bytes": nbytes,
+                "bus_gbps_lower_bound": (2.0 * (w - 1) / w * nbytes / (span * 1e-3) / 1e9) if span > 0 else None,
+                "algo_gbps_lower_bound": (nbytes / (span * 1e-3) / 1e9) if span > 0 else None,
+                "carrier": "nst_comm" if self.native else ("host-staged gloo" if self.host_staged else "torch.distributed"),
+                "messages_per_step": self.last_messages}
 
     def broadcast_parameters(self, src=0):
         """BroadcastGlobalVariablesCallback(0) (exps/trainer.py:285)."""

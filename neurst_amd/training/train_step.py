@@ -360,6 +360,7 @@ class TrainStep(object):
                     sc.cur.main.capture_end()
                 except Exception:
                     pass
+                rt.drop_pending_wgrads()   # nothing of the aborted step may run inside the next one's grouped launch
         torch.cuda.current_stream(rt.device).wait_stream(stream)
         cap.segments, cap.keep = sc.segments, sc.keep
         return cap

@@ -11,6 +11,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    # the GPU tests run in the configuration of the training entry points (one hardware queue per stream-priority class);
+    # applied here, before any test touches the device -- importing neurst_amd does not do it
+    from neurst_amd.runtime import configure_training_process
+    configure_training_process()
 
 
 def load_golden(name):

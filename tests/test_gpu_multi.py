@@ -84,6 +84,15 @@ def test_data_parallel_train_step_over_rccl_two_ranks_matches_oracle_average(gra
     _run_data_parallel(2, graph)
 
 
+def test_native_comm_two_ranks():
+    """The 2-rank cases come FIRST in this file so that a `pytest -x` on a multi-GPU node reaches them before anything else."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device: No HIP GPUs are available")
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"2-rank native RCCL exchange NOT exercised: {torch.cuda.device_count()} GPU visible")
+    _run_data_parallel(2, True, native=True)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_exchange_path_over_rccl_with_one_forced_rank(graph):
     """ONE rank with a forced process group (NST_DIST_FORCE=1): the collectives are identities, but bucket coalescing, the
@@ -101,14 +110,6 @@ def test_exchange_through_the_native_comm_entry_points_with_one_forced_rank(grap
     if not torch.cuda.is_available():
         pytest.skip("needs the device: No HIP GPUs are available")
     _run_data_parallel(1, graph, native=True)
-
-
-def test_native_comm_two_ranks():
-    if not torch.cuda.is_available():
-        pytest.skip("needs the device: No HIP GPUs are available")
-    if torch.cuda.device_count() < 2:
-        pytest.skip(f"2-rank native RCCL exchange NOT exercised: {torch.cuda.device_count()} GPU visible")
-    _run_data_parallel(2, True, native=True)
 
 
 def test_streams_of_the_three_priority_classes():

@@ -195,6 +195,46 @@ def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_fol
     assert reports[0] == reports[1]
 
 
+def test_aborted_backward_leaves_no_weight_gradient_products_or_reports_for_the_next_step(cpu_kernels, monkeypatch):
+    """A backward pass that dies between Dense.backward_params (queued for the grouped launch) and launch_wgrad_group must not
+    leave its products or its deferred reducer reports behind: the next step's launch would run them on a dead batch's
+    activations with stale accumulate flags, and the stale reports would make this rank issue extra collectives."""
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    monkeypatch.setattr(K.WgradGroup, "MIN_OUTPUTS", 1)
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    model, cfg, shape = _speech_model("small", dtype="bfloat16")
+    model.rt._wgrad_group_on_cpu = True
+    inputs = _speech_inputs(shape)
+    seen = []
+    model.grad_ready_hook = lambda prefixes: seen.append(tuple(prefixes))
+    logits = model(inputs, is_training=True)
+    crit.reduce_loss(inputs, logits)
+    dlogits = crit.backward()
+    model.backward(dlogits)
+    want, want_reports = model.store.grad.clone(), list(seen)
+    # the same step again, but the encoder's backward dies after the decoder queued its products and deferred its reports
+    logits = model(inputs, is_training=True)
+    crit.reduce_loss(inputs, logits)
+    real = model._encoder.backward
+    monkeypatch.setattr(model._encoder, "backward", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected")))
+    del seen[:]
+    with pytest.raises(RuntimeError, match="injected"):
+        model.backward(crit.backward())
+    assert len(model.rt.wgrad_group()) == 0 and not model.rt._deferred_reports
+    monkeypatch.setattr(model._encoder, "backward", real)
+    # a survivor planted by hand (as if the clean-up of the failing pass itself had been skipped) is dropped with a warning
+    model.rt.wgrad_group().add(torch.ones(8, 8, dtype=torch.bfloat16), torch.ones(8, 8, dtype=torch.bfloat16),
+                               torch.zeros(8, 8), False)
+    model.rt._deferred_reports.append(lambda: seen.append("stale"))
+    del seen[:]
+    logits = model(inputs, is_training=True)
+    crit.reduce_loss(inputs, logits)
+    with pytest.warns(UserWarning, match="aborted backward"):
+        model.backward(crit.backward())
+    assert torch.equal(model.store.grad, want) and seen == want_reports
+
+
 @pytest.mark.parametrize("variant", ["post_norm", "post_norm_encoder_only", "untied_softmax", "post_norm_untied"])
 def test_post_norm_and_untied_softmax_host_schedule(cpu_kernels, variant):
     """post_normalize (common_layers.py:86-92; no output_ln, transformer_encoder.py:97-100) and the separate
@@ -476,16 +516,32 @@ def _dp_worker(rank, world, port, q):
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
     step = TrainStep(model, crit, opt, red)
-    losses = [float(step(_speech_inputs(shape, 100 + 10 * s + rank))) for s in range(2)]
+    losses = [float(step(_dp_inputs(shape, s, rank, world))) for s in range(2)]
     q.put((rank, model.store.master.numpy().copy(), losses, fired))   # numpy: no fd passing after exit
     dist.destroy_process_group()
 
 
-def test_data_parallel_train_step_world2_gloo_matches_oracle_average():
-    """Two ranks, different batches: after two steps both ranks hold the weights the oracle gets from the MEAN of the two
-    per-rank gradients (hvd.Average, hvd_utils.py:46-62) under Keras Adam; the component hooks fire in backward order."""
+def _dp_inputs(shape, step, rank, world):
+    """The batch of one rank.  With more than two ranks the ranks hold UNEQUAL numbers of target tokens (rank r keeps
+    max(1, L - r) tokens per utterance): the exchanged quantity is then the documented mean over ranks of per-rank
+    token-mean gradients (hvd.Average of each rank's own mean loss, hvd_utils.py:46-62 + label_smoothed_cross_entropy.py:
+    94-157), NOT the token mean over the global batch."""
+    inp = _speech_inputs(shape, 100 + 10 * step + rank)
+    if world > 2:
+        B, T, F, L, V, _ = shape
+        trg_len = torch.full((B,), max(1, L - rank))
+        trg = torch.where(torch.arange(L)[None] >= (trg_len[:, None] - 1), torch.full_like(inp["trg"], V - 1), inp["trg"])
+        inp.update(trg=trg, trg_length=trg_len, trg_input=torch.cat([torch.full((B, 1), V - 2), trg[:, :-1]], 1))
+    return inp
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_train_step_gloo_matches_oracle_average(world):
+    """N ranks, different batches (N = 4: unequal token counts per rank, _dp_inputs): after two steps every rank holds the
+    weights the oracle gets from the MEAN of the per-rank gradients (hvd.Average, hvd_utils.py:46-62) under Keras Adam; the
+    component hooks fire in backward order."""
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
@@ -496,10 +552,12 @@ def test_data_parallel_train_step_world2_gloo_matches_oracle_average():
         p.join(timeout=60)
         assert p.exitcode == 0
     res = [(r, torch.from_numpy(w), l, f) for r, w, l, f in res]
-    assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
+    assert all(torch.equal(res[0][1], r[1]) for r in res[1:]), "ranks diverged"
+    if world > 2:    # the ranks really hold different token counts (the toy case: L = 3 -> 3, 2, 1, 1 tokens per utterance)
+        assert len({int(_dp_inputs(_speech_model("toy")[2], 0, r, world)["trg_length"].sum()) for r in range(world)}) >= 3
     # per-layer reports (last layer first) followed by the component report that sweeps up output_ln
     comps = [f[0] for f in res[0][3] if "/layer_" not in f[0]]
-    assert res[0][3] == res[1][3] and comps[:4] == [
+    assert all(res[0][3] == r[3] for r in res[1:]) and comps[:4] == [
         "TransformerDecoder/", "target_symbol_modality/", "TransformerEncoder/", "input_audio_modality/"]
     first = [f[0] for f in res[0][3]]
     assert first[0].startswith("TransformerDecoder/layer_") and first.index("TransformerEncoder/") > first.index("TransformerEncoder/layer_0/")
@@ -515,7 +573,7 @@ def test_data_parallel_train_step_world2_gloo_matches_oracle_average():
     for s in range(2):
         per_rank = []
         for rank in range(world):
-            inp = _speech_inputs(shape, 100 + 10 * s + rank)
+            inp = _dp_inputs(shape, s, rank, world)
             loss, _, g = O.train_step_reference(W, {k: (t.double() if t.is_floating_point() else t) for k, t in inp.items()}, cfg, 0.1)
             per_rank.append(g)
             assert abs(float(loss) - res[rank][2][s]) < 1e-5
