@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 8
+#define NST_ABI_VERSION 9
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -297,6 +297,25 @@ int nst_layernorm_bwd_deferred(const void* dy, const void* x, const void* y, con
                                int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
                                void* stream);
 int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs_host, int njobs, void* stream);
+
+/* fp32 residual stream of the pre-norm path (ABI 9).  PrePostProcessingWrapper (neurst/layers/common_layers.py:73-85) computes
+ * inputs + dropout(layer(LN(inputs))) in float32; a bf16 path that rounds that sum to bf16 after every sub-layer carries 24
+ * roundings through a 12-layer encoder -- measured as the one rounding class that puts the bf16 gradients outside 1e-2 of
+ * the reference (profiles/r05_rounding_point_study_b32.json).  Here the sum stays f32: the sub-layer's last kernel writes
+ * its contribution `delta` = dropout(layer(..)) as bf16 WITHOUT the residual, and the NEXT LayerNorm adds it:
+ *     x_new = x + delta   (f32; written to x_out unless x_out == NULL)      y = LayerNorm(x_new)   (dtype, bf16)
+ * x is f32 (x_dtype = NST_F32) or, for the first sub-layer of a stack, the bf16 embedding output (x_dtype = NST_BF16).
+ * mean / rstd of x_new as in nst_layernorm_fwd.  Needs d % 8 == 0, d <= 1024, 16-byte aligned rows (NST_ERR_UNSUPPORTED
+ * otherwise: the host then keeps the bf16 stream). */
+int nst_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, void* x_out, const float* gamma, const float* beta,
+                          void* y, float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, void* stream);
+/* nst_layernorm_bwd / _bwd_dropout / _bwd_deferred in one entry for a saved input x of its own dtype (x_dtype = NST_F32 with
+ * dtype = NST_BF16: the x_new of nst_add_layernorm_fwd; x_dtype == dtype: same as the entries above).  dz == NULL: no dropped
+ * copy; job_out == NULL: the parameter gradients are finished by this call. */
+int nst_layernorm_bwd_mixed(const void* dy, const void* x, int x_dtype, const float* gamma, const float* mean,
+                            const float* rstd, const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed,
+                            uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d, int dtype, int accumulate,
+                            void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out, void* stream);
 
 /* ------------------------------------------------------------------ target embedding
  * WordEmbeddingSharedWeights._bottom + PositionEmbeddingWrapper.call

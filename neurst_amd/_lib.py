@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 8
+NST_ABI_VERSION = 9
 NST_COMM_F16, NST_COMM_U8 = 2, 3
 NST_COMM_UNIQUE_ID_BYTES = 128
 
@@ -103,6 +103,8 @@ SIGNATURES = {
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_ln_finalize_multi": [_P, _I, _P],
+    "nst_add_layernorm_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "nst_layernorm_bwd_mixed": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
     "nst_gemm_wgrad_group": [_P, _P, _P, _P, _I, _P, _L, _P],
     "nst_splitk_reduce_multi": [_P, _I, _P],

@@ -69,13 +69,17 @@ __device__ __forceinline__ typename FragT<T>::type rc_frag(const char* tile, int
 
 // acc[mi][fd] (+)= sum over the 64 rows of `tile` of  tile[row][fd*16 + i] (A operand, output row i)
 //                                                   x  pt[mi][f][r]        (B operand: row f*16 + g*4 + r, column l&15)
-template <typename T, int MI>
+// RSV: row stride of `tile` in bytes.  The forward stages V with 160-byte rows (VS_RS): a ds_read_b64_tr_b16 pass serves 32
+// lanes = 8 rows x 32 bytes, and a stride of 8 dwords mod 64 spreads them over all 64 banks (with the 144-byte rows that suit
+// the ds_read_b128 row reads of K and Q, rows r and r + 7 overlap: 36 % of the forward's LDS cycles were bank conflicts,
+// profiles/r04_pmc_attn.json); the backward kernels made the same choice in round 4 (HB_RS).
+template <typename T, int MI, int RSV = AT<T>::RS>
 __device__ __forceinline__ void tmul_acc(floatx4_t (&acc)[MI][4], const floatx4_t (&pt)[MI][4], const char* tile, int lane) {
   const int g = lane >> 4, lc = lane & 15;
   if constexpr (sizeof(T) == 2) {
     typedef short4_t __attribute__((address_space(3))) * lds_ptr_t;
     // transpose read: lane ii of a 16-lane group addresses row ii>>2, 8-byte chunk ii&3 and receives column ii
-    const char* base = tile + (g * 4 + (lc >> 2)) * AT<T>::RS + (lc & 3) * 8;
+    const char* base = tile + (g * 4 + (lc >> 2)) * RSV + (lc & 3) * 8;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       bf16x8_t b[MI];
@@ -89,9 +93,9 @@ __device__ __forceinline__ void tmul_acc(floatx4_t (&acc)[MI][4], const floatx4_
       }
 #pragma unroll
       for (int fd = 0; fd < 4; ++fd) {
-        const char* p = base + st * 32 * AT<T>::RS + fd * 32;
+        const char* p = base + st * 32 * RSV + fd * 32;
         const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
-        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p + 16 * AT<T>::RS));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p + 16 * RSV));
         union { short4_t h[2]; bf16x8_t f; } a;
         a.h[0] = lo; a.h[1] = hi;
 #pragma unroll
@@ -99,14 +103,14 @@ __device__ __forceinline__ void tmul_acc(floatx4_t (&acc)[MI][4], const floatx4_
       }
     }
   } else {
-    const char* base = tile + (g * 4) * AT<T>::RS + lc * 4;
+    const char* base = tile + (g * 4) * RSV + lc * 4;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) {
-          const float a = *reinterpret_cast<const float*>(base + (f * 16 + r) * AT<T>::RS + fd * 64);
+          const float a = *reinterpret_cast<const float*>(base + (f * 16 + r) * RSV + fd * 64);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) acc[mi][fd] = Mma<T>::run(a, pt[mi][f][r], acc[mi][fd]);
         }
@@ -147,12 +151,12 @@ __device__ __forceinline__ void tile_load(TileRegs<T>& regs, const T* __restrict
     }
   }
 }
-template <typename T>
+template <typename T, int RSV = AT<T>::RS>
 __device__ __forceinline__ void tile_store(char* lds, const TileRegs<T>& regs, int tid) {
 #pragma unroll
   for (int s = 0; s < AT<T>::NCH; ++s) {
     const int c = tid + s * 256;
-    *reinterpret_cast<uint4*>(lds + (c / AT<T>::CPR) * AT<T>::RS + (c % AT<T>::CPR) * 16) = regs.v[s];
+    *reinterpret_cast<uint4*>(lds + (c / AT<T>::CPR) * RSV + (c % AT<T>::CPR) * 16) = regs.v[s];
   }
 }
 
@@ -241,10 +245,11 @@ __device__ __forceinline__ void store_row4(T* row, int d, int dh, const floatx4_
 template <typename T, int MI, bool VEC>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   typedef typename FragT<T>::type Frag;
-  __shared__ __attribute__((aligned(16))) char smem[2 * AT<T>::TILE_BYTES + TR * 4];
+  constexpr int VS_RS = sizeof(T) == 2 ? 160 : AT<T>::RS;   // V rows: laid out for the transpose reads (see tmul_acc)
+  __shared__ __attribute__((aligned(16))) char smem[AT<T>::TILE_BYTES + TR * VS_RS + TR * 4];
   char* Ks = smem;
   char* Vs = smem + AT<T>::TILE_BYTES;
-  float* kbs = reinterpret_cast<float*>(smem + 2 * AT<T>::TILE_BYTES);
+  float* kbs = reinterpret_cast<float*>(smem + AT<T>::TILE_BYTES + TR * VS_RS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
   const int q0 = blockIdx.x * (TR * MI), h = blockIdx.y, b = blockIdx.z;
@@ -296,7 +301,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TR;
     tile_store<T>(Ks, kreg, tid);
-    tile_store<T>(Vs, vreg, tid);
+    tile_store<T, VS_RS>(Vs, vreg, tid);
     if (tid < TR) kbs[tid] = key_bias_fin(p, kbreg, k0 + tid);
     __syncthreads();
 #pragma unroll
@@ -377,7 +382,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[mi][f][r] *= alpha;
     }
-    tmul_acc<T, MI>(o, s, Vs, lane);
+    tmul_acc<T, MI, VS_RS>(o, s, Vs, lane);
     __syncthreads();
   }
 #pragma unroll

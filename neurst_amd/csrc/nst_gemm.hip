@@ -234,6 +234,7 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
           switch (em) {
             case 0: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, 0); return 0;
             case EF_BIAS: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS); return 0;
+            case EF_BIAS | EF_DROP: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_DROP); return 0;   // (fp32 residual stream: the next LayerNorm adds)
             case EF_BIAS | EF_DROP | EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_DROP | EF_RESID); return 0;
             case EF_BIAS | EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_RESID); return 0;
             case EF_BIAS | EF_RELU | EF_DROP: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, EF_BIAS | EF_RELU | EF_DROP); return 0;

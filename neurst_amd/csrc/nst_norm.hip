@@ -5,6 +5,8 @@
 //   audio_modalities.py:102-104.
 #include "nst_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int LN_MAX_PER_LANE = 16;  // d <= 64*16 = 1024
@@ -257,11 +259,15 @@ __device__ __forceinline__ void zero8(float (&v)[8]) {
   for (int j = 0; j < 8; ++j) v[j] = 0.f;
 }
 
-template <typename T, int LPR, int S, bool RELU, int U>
-__global__ void __launch_bounds__(256) ln_fwd_wide_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+// TX / ADD: the fp32 residual stream of the pre-norm bf16 path (nst_add_layernorm_fwd).  x is then read as TX (f32, or bf16
+// for the first sub-layer of a stack), the sub-layer contribution `delta` (type T) is added to it, the sum is written once as
+// f32 (xout, the value the backward normalises again and the next sub-layer adds to) and normalised into y (type T).
+template <typename T, int LPR, int S, bool RELU, int U, typename TX = T, bool ADD = false>
+__global__ void __launch_bounds__(256) ln_fwd_wide_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                         int64_t rows, int d, float eps) {
+                                                         int64_t rows, int d, float eps, const T* __restrict__ delta = nullptr,
+                                                         float* __restrict__ xout = nullptr) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, li = lane % LPR;
@@ -283,8 +289,30 @@ __global__ void __launch_bounds__(256) ln_fwd_wide_kernel(const T* __restrict__ 
       const int64_t row = base + u * RPW + sub;
 #pragma unroll
       for (int c = 0; c < S; ++c) {
-        if (row < rows && cok[c]) load8<T>(x + row * d + (li + c * LPR) * 8, v[u][c]);
+        if (row < rows && cok[c]) load8<TX>(x + row * d + (li + c * LPR) * 8, v[u][c]);
         else zero8(v[u][c]);
+      }
+    }
+    if constexpr (ADD) {
+      float dl[U][S][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = base + u * RPW + sub;
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+          if (row < rows && cok[c]) load8<T>(delta + row * d + (li + c * LPR) * 8, dl[u][c]);
+          else zero8(dl[u][c]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t row = base + u * RPW + sub;
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][c][j] += dl[u][c][j];
+          if (xout && row < rows && cok[c]) store8<float>(xout + row * d + (li + c * LPR) * 8, v[u][c]);
+        }
       }
     }
 #pragma unroll
@@ -323,8 +351,8 @@ __global__ void __launch_bounds__(256) ln_fwd_wide_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T, int LPR, int S, bool RELU, int U>
-__global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int LPR, int S, bool RELU, int U, typename TX = T>
+__global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ dy, const TX* __restrict__ x,
                                                          const T* __restrict__ yout, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const T* __restrict__ dres, T* __restrict__ dx, int64_t rows, int d,
@@ -361,7 +389,7 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
       for (int c = 0; c < S; ++c) {
         const int64_t off = row * d + (li + c * LPR) * 8;
         if (rok && cok[c]) {
-          load8<T>(x + off, xv[u][c]);
+          load8<TX>(x + off, xv[u][c]);
           load8<T>(dy + off, gv[u][c]);
           if (RELU) load8<T>(yout + off, rv[u][c]);
           else if (dres) load8<T>(dres + off, rv[u][c]);
@@ -512,7 +540,24 @@ int launch_fwd(const void* x, const float* gamma, const float* beta, void* y, fl
   return 0;
 }
 
-template <typename T, bool RELU>
+// the add + LayerNorm forward of the fp32 residual stream: wide shapes only (the host keeps the bf16 stream otherwise)
+template <typename TX>
+int launch_add_fwd(const void* x, const void* delta, float* xout, const float* gamma, const float* beta, void* y, float* mean,
+                   float* rstd, int64_t rows, int d, float eps, hipStream_t st) {
+  typedef bf16_t T;
+  const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
+  // rows in flight per lane group: two row operands per row here, so half of the plain forward's four
+  const int U_ = 2;
+  int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
+  if (wb > 65535) wb = 65535;
+#define NST_LN_ADDW(L, S) ln_fwd_wide_kernel<T, L, S, false, 2, TX, true><<<(int)wb, 256, 0, st>>>((const TX*)x, gamma, beta, (T*)y, mean, rstd, rows, d, eps, (const T*)delta, xout)
+  if (lpr == 16) NST_LN_ADDW(16, 1); else if (lpr == 32) NST_LN_ADDW(32, 1);
+  else if (d <= 512) NST_LN_ADDW(64, 1); else NST_LN_ADDW(64, 2);
+#undef NST_LN_ADDW
+  return 0;
+}
+
+template <typename T, bool RELU, typename TX = T>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
                hipStream_t st, void* dz, uint32_t dz_thresh, float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid, bool* dz_done) {
@@ -525,20 +570,21 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
     if (wb > 512) wb = 512;
     *nblocks = (int)wb;
-#define NST_LN_BWDW(L, S, UU) ln_bwd_wide_kernel<T, L, S, RELU, UU><<<(int)wb, 256, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr())
+#define NST_LN_BWDW(L, S, UU) ln_bwd_wide_kernel<T, L, S, RELU, UU, TX><<<(int)wb, 256, 0, st>>>((const T*)dy, (const TX*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr())
     *dz_done = true;
     if (lpr == 16) NST_LN_BWDW(16, 1, 2); else if (lpr == 32) NST_LN_BWDW(32, 1, 1);
     else if (d <= 512) NST_LN_BWDW(64, 1, 2); else NST_LN_BWDW(64, 2, 2);
 #undef NST_LN_BWDW
     return 0;
   }
+  if constexpr (!std::is_same<T, TX>::value) return -1;   // mixed input types exist on the wide path only (caller reports it)
   int64_t blocks = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
   const int64_t cap = partial ? 1024 : 512;  // atomics: one per column per block, keep the fan-in per address small
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   *nblocks = (int)blocks;
 #define NST_LN_BWD(V, S) ln_bwd_kernel<T, V, RELU, S><<<(int)blocks, LN_WAVES * 64, 0, st>>>((const T*)dy, (const T*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, d, partial)
-  NST_LN_BWD(1, 16);   // see launch_fwd
+  if constexpr (std::is_same<T, TX>::value) NST_LN_BWD(1, 16);   // see launch_fwd
 #undef NST_LN_BWD
   return 0;
 }
@@ -573,8 +619,12 @@ __global__ void __launch_bounds__(1024) ln_bwd_finalize_multi_kernel(LnJobs jobs
 int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
                   int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu, void* dz = nullptr, float dz_p = 0.f,
-                  uint64_t dz_seed = 0, uint64_t dz_sid = 0, NstLnFinalizeJob* job_out = nullptr) {
+                  uint64_t dz_seed = 0, uint64_t dz_sid = 0, NstLnFinalizeJob* job_out = nullptr, int x_dtype = -1) {
   if (job_out) memset(job_out, 0, sizeof(*job_out));
+  if (x_dtype < 0) x_dtype = dtype;
+  const bool x32 = x_dtype == NST_F32 && dtype == NST_BF16;   // the saved input of the fp32 residual stream
+  NST_CHECK_ARG(x_dtype == dtype || x32, "layernorm_bwd: x_dtype %d with dtype %d (only f32 x with bf16 gradients is mixed)", x_dtype, dtype);
+  NST_CHECK_ARG(!(x32 && relu), "layernorm_bwd: the ReLU variant has no mixed-type form");
   NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
   NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
@@ -592,7 +642,12 @@ int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gam
   }
   if (rows <= 0) return NST_OK;
   int nblocks = 0;
-  if (dtype == NST_F32) {
+  if (x32) {
+    if (!partial || launch_bwd<bf16_t, false, float>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done) != 0) {
+      nst_set_error("layernorm_bwd: f32 x with bf16 gradients needs d %% 8 == 0, d <= 1024, 16-byte aligned rows and a workspace");
+      return NST_ERR_UNSUPPORTED;
+    }
+  } else if (dtype == NST_F32) {
     if (relu) launch_bwd<float, true>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
     else launch_bwd<float, false>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done);
   } else {
@@ -651,6 +706,36 @@ extern "C" int nst_layernorm_bwd_deferred(const void* dy, const void* x, const v
   NST_CHECK_ARG(!(y && (dres || dz)), "layernorm_bwd_deferred: the ReLU variant takes neither dres nor dz");
   return ln_bwd_common(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
                        workspace_bytes, stream, y != nullptr, dz, dz ? dropout_p : 0.f, seed, stream_id, job_out);
+}
+// fp32 residual stream of the pre-norm bf16 path (PrePostProcessingWrapper, neurst/layers/common_layers.py:73-85):
+//   x_new = x + delta (f32 sum, written to x_out when it is not null) ;  y = LayerNorm(x_new) in bf16
+extern "C" int nst_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, void* x_out, const float* gamma,
+                                     const float* beta, void* y, float* mean, float* rstd, int64_t rows, int d, float eps,
+                                     int dtype, void* stream) {
+  NST_CHECK_ARG(x && delta && gamma && beta && y, "add_layernorm_fwd: null pointer");
+  NST_CHECK_ARG(dtype == NST_BF16 && (x_dtype == NST_F32 || x_dtype == NST_BF16), "add_layernorm_fwd: bf16 delta / y, f32 or bf16 x");
+  if (rows <= 0) return NST_OK;
+  const bool ok = d > 0 && d % 8 == 0 && d <= 1024 &&
+                  ((((uintptr_t)x | (uintptr_t)delta | (uintptr_t)x_out | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+  if (!ok) {
+    nst_set_error("add_layernorm_fwd: needs d %% 8 == 0, d <= 1024 and 16-byte aligned operands (d=%d)", d);
+    return NST_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == NST_F32) launch_add_fwd<float>(x, delta, (float*)x_out, gamma, beta, y, mean, rstd, rows, d, eps, st);
+  else launch_add_fwd<bf16_t>(x, delta, (float*)x_out, gamma, beta, y, mean, rstd, rows, d, eps, st);
+  NST_CHECK_LAUNCH("add_layernorm_fwd");
+  return NST_OK;
+}
+// LayerNorm backward whose saved input x has its own dtype (x_dtype = NST_F32 with dtype = NST_BF16: the fp32 residual stream);
+// dz / job_out optional as in nst_layernorm_bwd_dropout / nst_layernorm_bwd_deferred
+extern "C" int nst_layernorm_bwd_mixed(const void* dy, const void* x, int x_dtype, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed,
+                                       uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                                       int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
+                                       void* stream) {
+  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, false, dz, dz ? dropout_p : 0.f, seed, stream_id, job_out, x_dtype);
 }
 extern "C" int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs, int njobs, void* stream) {
   NST_CHECK_ARG(njobs >= 0 && njobs <= 16 && (njobs == 0 || jobs), "ln_finalize_multi: 0..16 jobs");

@@ -131,6 +131,27 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
     return y, mean, rstd
 
 
+def add_layernorm_fwd(x, delta, gamma, beta, eps, want_sum=True):
+    """The fp32 residual stream of the pre-norm bf16 path (nst_add_layernorm_fwd): x [.., d] f32 or bf16, delta bf16 or None.
+    -> (y bf16 = LayerNorm(x + delta), x_new f32 = x + delta (None unless want_sum; with delta None it is the f32 copy of x),
+        mean, rstd)."""
+    assert x.is_contiguous() and (delta is None or (delta.is_contiguous() and delta.dtype == torch.bfloat16 and delta.shape == x.shape))
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    xs = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.nst_add_layernorm_fwd(_p(x), _dt(x), _p(delta), _p(xs), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, d,
+                                    float(eps), NST_BF16, _stream()), "add_layernorm_fwd")
+    return y, xs, mean, rstd
+
+
+def add_layernorm_supported(d, dtype):
+    """Shapes the fp32 residual stream exists for (the wide LayerNorm kernels): bf16 models with d % 8 == 0, d <= 1024."""
+    return dtype == torch.bfloat16 and d % 8 == 0 and d <= 1024
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
     """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x)).
     emit_dropout=(p, seed, site): also returns dz = dropout_backward(dx) under that mask -> (dx, dz).
@@ -139,8 +160,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
     assert dy.is_contiguous() and x.is_contiguous()
     d = x.shape[-1]
     rows = x.numel() // d
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(dy)
     slot = batch.ln_slot(d) if batch is not None else None
+    if x.dtype != dy.dtype:       # saved input of the fp32 residual stream: f32 x, bf16 gradients
+        assert x.dtype == torch.float32 and dy.dtype == torch.bfloat16 and y is None
+        assert dres is None or (dres.is_contiguous() and dres.dtype == dy.dtype)
+        p, seed, site = emit_dropout if emit_dropout is not None else (0.0, 0, 0)
+        dz = torch.empty_like(dy) if emit_dropout is not None else None
+        if slot is not None:
+            ws_ptr, ws_bytes, job = slot
+        else:
+            ws = _workspace(64 << 20, x.device)
+            ws_ptr, ws_bytes, job = ws.data_ptr(), ws.numel(), None
+        check(lib.nst_layernorm_bwd_mixed(_p(dy), _p(x), NST_F32, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dz), p, seed,
+                                          site, _p(dgamma), _p(dbeta), rows, d, _dt(dy), int(accumulate), ws_ptr, ws_bytes, job,
+                                          _stream()), "layernorm_bwd_mixed")
+        return (dx, dz) if emit_dropout is not None else dx
     if slot is not None:
         assert dres is None or (dres.is_contiguous() and dres.dtype == x.dtype)
         assert not (y is not None and (dres is not None or emit_dropout is not None))

@@ -6,7 +6,7 @@ import torch
 
 from neurst_amd import kernels as K
 from neurst_amd.layers import layer_utils
-from neurst_amd.layers.common_layers import LayerNorm, dropped_grad
+from neurst_amd.layers.common_layers import LayerNorm, ResidualStream, dropped_grad
 from neurst_amd.layers.decoders.decoder import Decoder, register_decoder
 from neurst_amd.layers.transformer_layers import TransformerDecoderLayer
 
@@ -40,6 +40,7 @@ class TransformerDecoder(Decoder):
         self._output_norm_layer = None if p["post_normalize"] else LayerNorm(
             rt, f"{self.name}/output_ln", p["hidden_size"], p["layer_postprocess_epsilon"])
         self._site = rt.new_dropout_site()
+        self._stream32 = ResidualStream.supported(rt, p["hidden_size"], pre_norm=not p["post_normalize"])
         # Training: every layer's cross attention projects the SAME encoder output with its own kv_transform
         # (transformer_layers.py:213-234, multi_head_attention.py:166-223).  The kernels are kept side by side in a packed
         # copy [d, n * 2d] (refreshed once per optimizer step), so the projection is ONE GEMM whose output the layers read as
@@ -144,9 +145,17 @@ class TransformerDecoder(Decoder):
         if memory_bias is not None and not memory_bias.is_contiguous():
             memory_bias = memory_bias.contiguous()           # the kernel reads a dense [B, Tk] bias
         x = decoder_inputs
+        if self._stream32:
+            x = ResidualStream(x if x.is_contiguous() else x.contiguous())
         for i, layer in enumerate(self._stacking_layers):
             x = layer.forward(x, Bp, 1, mem2, Tm, memory_bias, is_training=False, cache=cache["decoding_states"][f"layer_{i}"])
-        return x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=False)
+        return self._finish(x, False)
+
+    def _finish(self, x, save):
+        """Output of the stack from the residual stream / tensor behind the last layer."""
+        if isinstance(x, ResidualStream):
+            return self._output_norm_layer.forward_stream(x, save=save, want_sum=False)[0]
+        return x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=save)
 
     def forward(self, decoder_inputs, cache, decode_lagging=None, is_training=True, decode_loop_step=None):
         """decoder_inputs [B,L,d]; cache from create_decoding_internal_cache -> [B,L,d]."""
@@ -169,13 +178,15 @@ class TransformerDecoder(Decoder):
         self._clear_kv_handoff()      # a forward / backward that aborted half way must not leave another batch's k|v behind
         if self._grouped:
             self._project_memory(mem2)
+        if self._stream32:
+            x = ResidualStream(x if x.is_contiguous() else x.contiguous())
         try:
             for layer in self._stacking_layers:
                 x = layer.forward(x, B, L, mem2, Tm, memory_bias, is_training=is_training, lagging=decode_lagging)
         finally:
             for a in getattr(self, "_kv_atts", ()):
                 a._kv_pre = None
-        out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
+        out = self._finish(x, is_training)
         self._shapes = (B, L, d, Tm)
         return out.view(B, L, d)
 

@@ -3,7 +3,7 @@ import torch
 
 from neurst_amd import kernels as K
 from neurst_amd.layers import layer_utils
-from neurst_amd.layers.common_layers import dropped_grad, LayerNorm
+from neurst_amd.layers.common_layers import LayerNorm, ResidualStream, dropped_grad
 from neurst_amd.layers.encoders.encoder import Encoder, register_encoder
 from neurst_amd.layers.transformer_layers import TransformerEncoderLayer
 
@@ -42,8 +42,15 @@ class TransformerEncoder(Encoder):
         self._output_norm_layer = None if p["post_normalize"] else LayerNorm(
             rt, f"{self.name}/output_ln", p["hidden_size"], p["layer_postprocess_epsilon"])
         self._site = rt.new_dropout_site()
+        self._stream32 = ResidualStream.supported(rt, p["hidden_size"], pre_norm=not p["post_normalize"])
         self._built = True
         return self
+
+    def _finish(self, x, save):
+        """Output of the stack from the residual stream / tensor behind the last layer."""
+        if isinstance(x, ResidualStream):
+            return self._output_norm_layer.forward_stream(x, save=save, want_sum=False)[0]
+        return x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=save)
 
     def forward(self, inputs, inputs_padding, is_training=True):
         """inputs [B,T,d] (device, compute dtype), inputs_padding [B,T] float (1.0 = pad) -> [B,T,d]."""
@@ -57,10 +64,11 @@ class TransformerEncoder(Encoder):
         # attention_monotonic (transformer_encoder.py:121-123): min(padding bias, lower-triangle bias) = the kernel's
         # key bias + causal flag together
         causal = bool(self._params["attention_monotonic"])
+        if self._stream32:
+            x = ResidualStream(x if x.is_contiguous() else x.contiguous())
         for layer in self._stacking_layers:
             x = layer.forward(x, B, T, bias, is_training=is_training, causal=causal)
-        out = x if self._output_norm_layer is None else self._output_norm_layer.forward(x, save=is_training)
-        return out.view(B, T, d)
+        return self._finish(x, is_training).view(B, T, d)
 
     __call__ = forward
 
@@ -88,11 +96,11 @@ class TransformerEncoder(Encoder):
         if time is not None and int(time) != filled:
             raise ValueError(f"incremental_encode: chunk starts at time {time} but {filled} positions are cached")
         x = x3.reshape(B * n, d).contiguous()
+        if self._stream32:
+            x = ResidualStream(x)
         for i, layer in enumerate(self._stacking_layers):
             x = layer.forward(x, B, n, None, is_training=False, cache=cache[f"layer_{i}"])
-        if self._output_norm_layer is not None:
-            x = self._output_norm_layer.forward(x, save=False)
-        return x.view(B, n, d), cache
+        return self._finish(x, False).view(B, n, d), cache
 
     def backward(self, dout, layer_done=None):
         """layer_done(prefixes): called after each layer's backward has been QUEUED (its gradients are complete once the

@@ -49,9 +49,27 @@ def layernorm_fwd(x, gamma, beta, eps, relu=False):
     return y.to(x.dtype).reshape(x.shape), mean.float(), rstd.float()
 
 
+def add_layernorm_supported(d, dtype):
+    return dtype == torch.bfloat16 and d % 8 == 0 and d <= 1024
+
+
+def add_layernorm_fwd(x, delta, gamma, beta, eps, want_sum=True):
+    """nst_add_layernorm_fwd: the float32 residual stream.  x f32 or bf16, delta bf16 -> y = LN(x + delta) in bf16, the sum in
+    f32 (exactly what the next call adds to and the backward normalises again), mean, rstd."""
+    assert x.is_contiguous() and delta is not None and delta.is_contiguous() and delta.dtype == torch.bfloat16
+    assert x.dtype in (torch.float32, torch.bfloat16) and delta.shape == x.shape
+    d = x.shape[-1]
+    assert add_layernorm_supported(d, delta.dtype)
+    xs = (x.reshape(-1, d).to(F64) + delta.reshape(-1, d).to(F64)).float()      # the device adds in f32 and stores f32
+    mean, rstd = _ln_stats(xs.to(F64), eps)
+    y = (xs.to(F64) - mean[:, None]) * rstd[:, None] * gamma.to(F64) + beta.to(F64)
+    return y.to(delta.dtype).reshape(x.shape), (xs.reshape(x.shape) if want_sum else None), mean.float(), rstd.float()
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
-    assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
-    assert dres is None or (dres.is_contiguous() and dres.dtype == x.dtype and y is None)
+    # (x.dtype != dy.dtype: the f32 sum saved by add_layernorm_fwd under bf16 gradients, nst_layernorm_bwd_mixed)
+    assert dy.is_contiguous() and x.is_contiguous() and (dy.dtype == x.dtype or (x.dtype == torch.float32 and y is None))
+    assert dres is None or (dres.is_contiguous() and dres.dtype == dy.dtype and y is None)
     d = x.shape[-1]
     g = dy.reshape(-1, d).to(F64)
     if y is not None:  # backward of relu(LN(x)): gate by the saved output
@@ -68,7 +86,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
     dx = (gh - gh.mean(1, keepdim=True) - xh * (gh * xh).mean(1, keepdim=True)) * rstd.to(F64)[:, None]
     if dres is not None:
         dx = dx + dres.reshape(-1, d).to(F64)
-    dx = dx.to(x.dtype).reshape(x.shape)
+    dx = dx.to(dy.dtype).reshape(x.shape)
     if emit_dropout is not None:
         p, seed, site = emit_dropout
         return dx, (dx.to(F64) * _keep(p, seed, site, dx.shape)).to(dx.dtype)
@@ -493,7 +511,7 @@ def cast_f32_to_bf16(src, dst):
     dst.copy_(src.to(torch.bfloat16))
 
 
-_NAMES = ["layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "grad_clip", "attention_fwd", "attention_bwd",
+_NAMES = ["layernorm_fwd", "layernorm_bwd", "add_layernorm_fwd", "add_layernorm_supported", "gemm", "colsum", "grad_clip", "attention_fwd", "attention_bwd",
           "conv1_ln_relu_fwd", "conv1_ln_relu_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "embedding_fwd",
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",

@@ -92,6 +92,69 @@ def test_lds_transpose_read_map(K):
     np.testing.assert_array_equal(got, expect)
 
 
+# ------------------------------------------------------------------------------------------------ fp32 residual stream
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(37, 8), (300, 256), (100, 512), (33, 1024), (1000, 128), (131, 64), (20001, 256), (77, 768),
+                                    (1, 256), (5, 16)])
+def test_add_layernorm_float32_residual_stream(K, x_dtype, rows, d):
+    """nst_add_layernorm_fwd / nst_layernorm_bwd_mixed against float64: the sum x + delta is formed and stored in f32 (exact for
+    a bf16 delta on an f32 or bf16 x up to one f32 rounding), normalised in the same pass; the backward reads the f32 sum."""
+    x = rnd(rows, d, dtype=x_dtype, seed=1, scale=3.0)
+    delta = rnd(rows, d, dtype=torch.bfloat16, seed=6)
+    gamma = rnd(d, seed=2) * 0.2 + 1.0
+    beta = rnd(d, seed=3) * 0.1
+    dy = rnd(rows, d, dtype=torch.bfloat16, seed=4)
+    dres = rnd(rows, d, dtype=torch.bfloat16, seed=5)
+    xs_ref = (x.double() + delta.double()).float()          # the device's f32 sum (one rounding, same on both sides)
+    xr = xs_ref.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br, 1e-6)
+    yr.backward(dy.double())
+    y, xs, mean, rstd = K.add_layernorm_fwd(x.to(DEV), delta.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    tag = f"add_ln[{x_dtype},{rows}x{d}]"
+    assert xs.dtype == torch.float32 and y.dtype == torch.bfloat16
+    assert torch.equal(xs.cpu(), xs_ref), tag + ": the f32 sum is not the correctly rounded x + delta"
+    close(tag + ".y", y, yr, torch.bfloat16)
+    close(tag + ".mean", mean, xs_ref.double().mean(1), torch.float32)
+    y2, none, _, _ = K.add_layernorm_fwd(x.to(DEV), delta.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, want_sum=False)
+    assert none is None and torch.equal(y2, y)
+    # same statistics as the plain f32 forward on the stored sum (another instantiation: the last bit of rstd may differ)
+    y3, mean3, rstd3 = K.layernorm_fwd(xs, gamma.to(DEV), beta.to(DEV), 1e-6) if torch.device(DEV).type == "cuda" else (None, mean, rstd)
+    if y3 is not None:
+        assert torch.allclose(mean3, mean, rtol=1e-6, atol=1e-7) and torch.allclose(rstd3, rstd, rtol=1e-6, atol=0)
+    dgamma, dbeta = torch.full((d,), 7.0, device=DEV), torch.full((d,), 7.0, device=DEV)
+    dx = K.layernorm_bwd(dy.to(DEV), xs, gamma.to(DEV), mean, rstd, dgamma, dbeta, dres=dres.to(DEV))
+    assert dx.dtype == torch.bfloat16
+    close(tag + ".dx", dx, xr.grad + dres.double(), torch.bfloat16, scale=2.0)
+    close(tag + ".dgamma", dgamma, gr.grad, torch.bfloat16, scale=2.0)
+    close(tag + ".dbeta", dbeta, br.grad, torch.bfloat16, scale=2.0)
+    dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dx2, dz2 = K.layernorm_bwd(dy.to(DEV), xs, gamma.to(DEV), mean, rstd, dg2, db2, dres=dres.to(DEV), emit_dropout=(0.3, 11, 5))
+    assert torch.equal(dx2, dx)
+    dz_ref = K.scale_dropout_bwd(dx2, 1.0, 0.3, 11, 5)
+    assert torch.equal(dz2 == 0, dz_ref == 0)
+    if torch.device(DEV).type != "cuda":
+        return
+    # deferred parameter gradients through the batch: bit-identical to the immediate second stage
+    batch = K.SplitkBatch(DEV)
+    g_k, b_k = torch.full((d,), 3.0, device=DEV), torch.full((d,), 3.0, device=DEV)
+    dx_k = K.layernorm_bwd(dy.to(DEV), xs, gamma.to(DEV), mean, rstd, g_k, b_k, dres=dres.to(DEV), batch=batch)
+    assert batch.ln_n == (1 if d <= 512 else 0) and torch.equal(dx_k, dx)
+    batch.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(g_k, dgamma) and torch.equal(b_k, dbeta)
+
+
+def test_add_layernorm_refuses_what_it_cannot_do(K):
+    if torch.device(DEV).type != "cuda":
+        pytest.skip("argument checks of the library")
+    x, delta = rnd(8, 12).to(DEV), rnd(8, 12, dtype=torch.bfloat16).to(DEV)
+    with pytest.raises(RuntimeError):
+        K.add_layernorm_fwd(x, delta, torch.ones(12, device=DEV), torch.zeros(12, device=DEV), 1e-6)
+    assert not K.add_layernorm_supported(12, torch.bfloat16) and not K.add_layernorm_supported(256, torch.float32)
+    assert K.add_layernorm_supported(256, torch.bfloat16)
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,d", [(7, 4), (37, 8), (300, 256), (100, 512), (33, 1024), (5, 250), (1000, 128), (131, 64),
