@@ -340,11 +340,11 @@ def test_speech_transformer_s_bf16_step_against_the_oracle_fixture(batch):
     relative L2 distance of the tensors), for the oracle and for the float64 emulation of the kernels with the same bf16
     rounding points.  Asserted: loss and logits at the north-star bf16 bar of 1e-2; gradients (a) no farther from the oracle
     than 1.3 x what exact kernels with bf16 rounding points are, globally, and within 2 x per tensor, (b) the measured level
-    itself.  Round 4 on MI355X (profiles/r04_model_parity_report.json): global rel-L2 of the gradients against the ORACLE
-    1.87e-2 at 32 utterances (emulation 1.71e-2 exact / 1.80e-2 by projections) and 1.03e-2 at 128 (emulation 1.02e-2 / 1.10e-2);
-    logits 6.7e-3, loss 2.9e-4 at both.  At the benchmark batch the bf16 step therefore sits AT the north star's 1e-2 against the
-    oracle, and exactly where exact kernels with the same rounding points sit: the remaining distance is the rounding of
-    activations to bf16 between kernels, not kernel error (per tensor the median ratio HIP / emulation is 0.94 - 1.03)."""
+    itself.  Round 4 on MI355X (profiles/r04_model_parity_report.json), residual stream rounded to bf16 after every sub-layer:
+    global rel-L2 of the gradients against the ORACLE 1.87e-2 at 32 utterances and 1.03e-2 at 128 -- AT the north star's 1e-2, and
+    exactly where exact kernels with the same rounding points sit.  Round 5 carries the residual stream in float32
+    (layers/common_layers.py: ResidualStream; scripts/rounding_point_study.py found it to be the one rounding class that
+    matters): 1.25e-2 at 32 utterances and 8.8e-3 at 128 (emulation 1.20e-2 / 7.6e-3 exact), logits 3.4e-3 -- inside the bar."""
     from neurst_amd.criterions import build_criterion
     from oracle.projections import sign_projections
     fx = np.load(os.path.join(GOLDEN, f"oracle_s_real_b{batch}.npz"))
@@ -385,7 +385,9 @@ def test_speech_transformer_s_bf16_step_against_the_oracle_fixture(batch):
     bad = [(n, float(h), float(e)) for n, h, e in zip(names, per_hip, per_emu) if h > 2.0 * e + 4e-3]
     assert not bad, f"{len(bad)} gradient tensors farther from the oracle than bf16 rounding explains: {bad[:6]}"
     assert rep["grad_norm_rel_err_worst"] <= 5e-2, rep
-    assert rep["grad_global_rel_l2"] <= (1.2e-2 if batch >= 128 else 2.2e-2), rep     # measured 1.03e-2 / 1.87e-2
+    # the north star's bf16 bar of 1e-2 at the benchmark batch: met since the residual stream is carried in float32
+    # (round 5: 8.8e-3 measured by projections, 1.05e-2 before; at 32 utterances 1.25e-2, 1.87e-2 before)
+    assert rep["grad_global_rel_l2"] <= (1.0e-2 if batch >= 128 else 1.6e-2), rep
 
 
 def _grad_errors(grads, grads_ref):
