@@ -297,6 +297,14 @@ int nst_layernorm_bwd_deferred(const void* dy, const void* x, const void* y, con
                                int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
                                void* stream);
 int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs_host, int njobs, void* stream);
+/* nst_layernorm_relu_bwd without the saved activation y (ABI 9): the ReLU gate is recomputed as LN(x) > 0 from x, the saved
+ * statistics, gamma and beta -- the expression the forward evaluated -- which takes a quarter off the traffic of the
+ * front end's 576 000-row backward (audio_modalities.py:102-104).  job_out == NULL: parameter gradients finished by this call.
+ * Needs d % 8 == 0, d <= 1024, 16-byte aligned rows and a workspace (NST_ERR_UNSUPPORTED otherwise). */
+int nst_layernorm_relu_bwd_regate(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
+                                  int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
+                                  void* stream);
 
 /* fp32 residual stream of the pre-norm path (ABI 9).  PrePostProcessingWrapper (neurst/layers/common_layers.py:73-85) computes
  * inputs + dropout(layer(LN(inputs))) in float32; a bf16 path that rounds that sum to bf16 after every sub-layer carries 24

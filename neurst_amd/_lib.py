@@ -103,6 +103,7 @@ SIGNATURES = {
     "nst_layernorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P],
     "nst_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_ln_finalize_multi": [_P, _I, _P],
+    "nst_layernorm_relu_bwd_regate": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_add_layernorm_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd_mixed": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],

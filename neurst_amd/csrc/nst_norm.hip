@@ -358,20 +358,28 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
                                                          const T* __restrict__ dres, T* __restrict__ dx, int64_t rows, int d,
                                                          float* __restrict__ partial, T* __restrict__ dz, uint32_t dz_thresh,
                                                          float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid,
-                                                         const uint64_t* __restrict__ seed_dev) {
+                                                         const uint64_t* __restrict__ seed_dev,
+                                                         const float* __restrict__ beta = nullptr) {
   if (dz) dz_seed = seed_with_offset(dz_seed, seed_dev);   // wave-uniform
+  // RELU with yout == NULL: the gate relu'(LN(x)) is recomputed from x, the saved statistics and beta -- the same expression the
+  // forward evaluated -- instead of read back from the saved activation (a quarter of this kernel's traffic)
+  const bool regate = RELU && yout == nullptr;
   constexpr int RPW = 64 / LPR;
   constexpr int W = LPR * S * 8;  // padded row width
   __shared__ float red[4][2][W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, li = lane % LPR;
   float gm[S][8], g_acc[S][8], b_acc[S][8];
+  float bt[RELU ? S : 1][8];
   bool cok[S];
 #pragma unroll
   for (int c = 0; c < S; ++c) {
     const int col = (li + c * LPR) * 8;
     cok[c] = col < d;
     if (cok[c]) load8<float>(gamma + col, gm[c]); else zero8(gm[c]);
+    if constexpr (RELU) {
+      if (cok[c] && regate) load8<float>(beta + col, bt[c]); else zero8(bt[c]);
+    }
     zero8(g_acc[c]); zero8(b_acc[c]);
   }
   const float inv_d = 1.0f / (float)d;
@@ -391,7 +399,7 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
         if (rok && cok[c]) {
           load8<TX>(x + off, xv[u][c]);
           load8<T>(dy + off, gv[u][c]);
-          if (RELU) load8<T>(yout + off, rv[u][c]);
+          if (RELU) { if (!regate) load8<T>(yout + off, rv[u][c]); else zero8(rv[u][c]); }
           else if (dres) load8<T>(dres + off, rv[u][c]);
           else zero8(rv[u][c]);
         } else {
@@ -408,8 +416,11 @@ __global__ void __launch_bounds__(256) ln_bwd_wide_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float g = gv[u][c][j];
-          if (RELU) g = rv[u][c][j] > 0.f ? g : 0.f;
           const float xhat = cok[c] ? (xv[u][c][j] - mu[u]) * rs[u] : 0.f;
+          if constexpr (RELU) {
+            const bool open_ = regate ? (xhat * gm[c][j] + bt[c][j]) > 0.f : rv[u][c][j] > 0.f;
+            g = open_ ? g : 0.f;
+          }
           const float dxh = g * gm[c][j];
           g_acc[c][j] += g * xhat;
           b_acc[c][j] += g;
@@ -560,8 +571,10 @@ int launch_add_fwd(const void* x, const void* delta, float* xout, const float* g
 template <typename T, bool RELU, typename TX = T>
 int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, float* partial, int* nblocks,
-               hipStream_t st, void* dz, uint32_t dz_thresh, float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid, bool* dz_done) {
-  if (partial && wide_ok<T>(d, x, dy, dx, RELU ? y : dres) && wide_ok<T>(d, gamma, nullptr, nullptr, nullptr)) {
+               hipStream_t st, void* dz, uint32_t dz_thresh, float dz_inv_keep, uint64_t dz_seed, uint64_t dz_sid, bool* dz_done,
+               const float* beta = nullptr) {
+  if (RELU && !y && !(partial && beta)) return -1;   // the recomputed gate exists on the wide path only
+  if (partial && wide_ok<T>(d, x, dy, dx, RELU ? y : dres) && wide_ok<T>(d, gamma, beta, nullptr, nullptr)) {
     const int lpr = d <= 128 ? 16 : (d <= 256 ? 32 : 64);
     // rows in flight per lane group.  d_model = 256: one row (fewer registers, 4 waves per SIMD) measured 0.05 ms per step
     // faster than two
@@ -570,7 +583,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     int64_t wb = (rows + 4 * (64 / lpr) * U_ - 1) / (4 * (64 / lpr) * U_);
     if (wb > 512) wb = 512;
     *nblocks = (int)wb;
-#define NST_LN_BWDW(L, S, UU) ln_bwd_wide_kernel<T, L, S, RELU, UU, TX><<<(int)wb, 256, 0, st>>>((const T*)dy, (const TX*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr())
+#define NST_LN_BWDW(L, S, UU) ln_bwd_wide_kernel<T, L, S, RELU, UU, TX><<<(int)wb, 256, 0, st>>>((const T*)dy, (const TX*)x, (const T*)y, gamma, mean, rstd, (const T*)dres, (T*)dx, rows, d, partial, (T*)dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, nst_seed_offset_devptr(), beta)
     *dz_done = true;
     if (lpr == 16) NST_LN_BWDW(16, 1, 2); else if (lpr == 32) NST_LN_BWDW(32, 1, 1);
     else if (d <= 512) NST_LN_BWDW(64, 1, 2); else NST_LN_BWDW(64, 2, 2);
@@ -578,6 +591,7 @@ int launch_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     return 0;
   }
   if constexpr (!std::is_same<T, TX>::value) return -1;   // mixed input types exist on the wide path only (caller reports it)
+  if (RELU && !y) return -1;
   int64_t blocks = (rows + 2 * LN_WAVES - 1) / (2 * LN_WAVES);
   const int64_t cap = partial ? 1024 : 512;  // atomics: one per column per block, keep the fan-in per address small
   if (blocks > cap) blocks = cap;
@@ -619,14 +633,15 @@ __global__ void __launch_bounds__(1024) ln_bwd_finalize_multi_kernel(LnJobs jobs
 int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int d, int dtype,
                   int accumulate, void* ws, int64_t ws_bytes, void* stream, bool relu, void* dz = nullptr, float dz_p = 0.f,
-                  uint64_t dz_seed = 0, uint64_t dz_sid = 0, NstLnFinalizeJob* job_out = nullptr, int x_dtype = -1) {
+                  uint64_t dz_seed = 0, uint64_t dz_sid = 0, NstLnFinalizeJob* job_out = nullptr, int x_dtype = -1,
+                  const float* beta = nullptr) {
   if (job_out) memset(job_out, 0, sizeof(*job_out));
   if (x_dtype < 0) x_dtype = dtype;
   const bool x32 = x_dtype == NST_F32 && dtype == NST_BF16;   // the saved input of the fp32 residual stream
   NST_CHECK_ARG(x_dtype == dtype || x32, "layernorm_bwd: x_dtype %d with dtype %d (only f32 x with bf16 gradients is mixed)", x_dtype, dtype);
   NST_CHECK_ARG(!(x32 && relu), "layernorm_bwd: the ReLU variant has no mixed-type form");
   NST_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
-  NST_CHECK_ARG(!relu || y, "layernorm_relu_bwd: y is required");
+  NST_CHECK_ARG(!relu || y || beta, "layernorm_relu_bwd: y (the saved activation) or beta (to recompute the gate) is required");
   NST_CHECK_ARG(d > 0 && d <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: d=%d unsupported", d);
   NST_CHECK_ARG(dtype == NST_F32 || dtype == NST_BF16, "layernorm_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
@@ -645,6 +660,14 @@ int ln_bwd_common(const void* dy, const void* x, const void* y, const float* gam
   if (x32) {
     if (!partial || launch_bwd<bf16_t, false, float>(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done) != 0) {
       nst_set_error("layernorm_bwd: f32 x with bf16 gradients needs d %% 8 == 0, d <= 1024, 16-byte aligned rows and a workspace");
+      return NST_ERR_UNSUPPORTED;
+    }
+  } else if (relu && !y) {
+    const int rc = dtype == NST_F32
+        ? launch_bwd<float, true>(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done, beta)
+        : launch_bwd<bf16_t, true>(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, partial, &nblocks, st, dz, dz_thresh, dz_inv_keep, dz_seed, dz_sid, &dz_done, beta);
+    if (rc != 0) {
+      nst_set_error("layernorm_relu_bwd without y: needs d %% 8 == 0, d <= 1024, 16-byte aligned rows and a workspace");
       return NST_ERR_UNSUPPORTED;
     }
   } else if (dtype == NST_F32) {
@@ -736,6 +759,16 @@ extern "C" int nst_layernorm_bwd_mixed(const void* dy, const void* x, int x_dtyp
                                        void* stream) {
   return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
                        workspace_bytes, stream, false, dz, dz ? dropout_p : 0.f, seed, stream_id, job_out, x_dtype);
+}
+// nst_layernorm_relu_bwd without the saved activation: the gate relu'(LN(x)) is recomputed from x, mean, rstd, gamma and beta
+// (job_out optional as in nst_layernorm_bwd_deferred)
+extern "C" int nst_layernorm_relu_bwd_regate(const void* dy, const void* x, const float* gamma, const float* beta,
+                                             const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                             int64_t rows, int d, int dtype, int accumulate, void* workspace,
+                                             int64_t workspace_bytes, NstLnFinalizeJob* job_out, void* stream) {
+  NST_CHECK_ARG(beta, "layernorm_relu_bwd_regate: null beta");
+  return ln_bwd_common(dy, x, nullptr, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, d, dtype, accumulate, workspace,
+                       workspace_bytes, stream, true, nullptr, 0.f, 0, 0, job_out, -1, beta);
 }
 extern "C" int nst_ln_finalize_multi(const NstLnFinalizeJob* jobs, int njobs, void* stream) {
   NST_CHECK_ARG(njobs >= 0 && njobs <= 16 && (njobs == 0 || jobs), "ln_finalize_multi: 0..16 jobs");

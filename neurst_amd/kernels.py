@@ -152,8 +152,10 @@ def add_layernorm_supported(d, dtype):
     return dtype == torch.bfloat16 and d % 8 == 0 and d <= 1024
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
-    """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x)).
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None,
+                  regate_beta=None):
+    """dx = LN'(dy) (+ dres).  With y given: backward of relu(LN(x)); with regate_beta (the LayerNorm's beta) instead of y the
+    ReLU gate is recomputed from x and the saved statistics (nst_layernorm_relu_bwd_regate: the saved activation is not read).
     emit_dropout=(p, seed, site): also returns dz = dropout_backward(dx) under that mask -> (dx, dz).
     batch (SplitkBatch): the dgamma / dbeta reduction is left to the batch's next flush (one launch for all pending
     LayerNorms, on the stream that flushes -- the weight-gradient stream), see nst_layernorm_bwd_deferred."""
@@ -162,6 +164,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
     rows = x.numel() // d
     dx = torch.empty_like(dy)
     slot = batch.ln_slot(d) if batch is not None else None
+    if regate_beta is not None:
+        assert y is None and dres is None and emit_dropout is None and x.dtype == dy.dtype
+        if slot is not None:
+            ws_ptr, ws_bytes, job = slot
+        else:
+            ws = _workspace(64 << 20, x.device)
+            ws_ptr, ws_bytes, job = ws.data_ptr(), ws.numel(), None
+        check(lib.nst_layernorm_relu_bwd_regate(_p(dy), _p(x), _p(gamma), _p(regate_beta), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                                _p(dbeta), rows, d, _dt(x), int(accumulate), ws_ptr, ws_bytes, job, _stream()),
+              "layernorm_relu_bwd_regate")
+        return dx
     if x.dtype != dy.dtype:       # saved input of the fp32 residual stream: f32 x, bf16 gradients
         assert x.dtype == torch.float32 and dy.dtype == torch.bfloat16 and y is None
         assert dres is None or (dres.is_contiguous() and dres.dtype == dy.dtype)

@@ -66,7 +66,9 @@ def add_layernorm_fwd(x, delta, gamma, beta, eps, want_sum=True):
     return y.to(delta.dtype).reshape(x.shape), (xs.reshape(x.shape) if want_sum else None), mean.float(), rstd.float()
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, y=None, emit_dropout=None, batch=None,
+                  regate_beta=None):
+    # (regate_beta: nst_layernorm_relu_bwd_regate -- the ReLU gate recomputed from x, the saved statistics, gamma and beta)
     # (x.dtype != dy.dtype: the f32 sum saved by add_layernorm_fwd under bf16 gradients, nst_layernorm_bwd_mixed)
     assert dy.is_contiguous() and x.is_contiguous() and (dy.dtype == x.dtype or (x.dtype == torch.float32 and y is None))
     assert dres is None or (dres.is_contiguous() and dres.dtype == dy.dtype and y is None)
@@ -75,6 +77,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dre
     if y is not None:  # backward of relu(LN(x)): gate by the saved output
         g = g * (y.reshape(-1, d) > 0).to(F64)
     xh = (x.reshape(-1, d).to(F64) - mean.to(F64)[:, None]) * rstd.to(F64)[:, None]
+    if regate_beta is not None:
+        assert y is None and dres is None and emit_dropout is None
+        g = g * ((xh * gamma.to(F64) + regate_beta.to(F64)) > 0).to(F64)
     dg, db = (g * xh).sum(0).float(), g.sum(0).float()
     if accumulate:
         dgamma.add_(dg)

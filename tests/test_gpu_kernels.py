@@ -180,6 +180,13 @@ def test_layernorm(K, dtype, rows, d, relu):
     if relu:
         dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, y=y)
         close(tag + ".dx", dx, xr.grad, dtype, scale=3.0)
+        if d % 8 == 0:   # the same with the gate recomputed from x and the statistics instead of read from y
+            dg_r, db_r = torch.full((d,), 7.0, device=DEV), torch.full((d,), 7.0, device=DEV)
+            dx_r = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dg_r, db_r, regate_beta=beta.to(DEV))
+            close(tag + ".dx_regate", dx_r, xr.grad, dtype, scale=3.0)
+            if dtype == torch.float32:   # fp32: y > 0 and the recomputed LN(x) > 0 agree except where LN(x) is within an ulp of 0
+                assert float((dx_r != dx).float().mean()) < 1e-3
+                close(tag + ".dgamma_regate", dg_r, gr.grad, dtype, scale=2.0)
     else:
         dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dgamma, dbeta, dres=dres.to(DEV))
         close(tag + ".dx", dx, xr.grad + dres.double(), dtype, scale=2.0)
