@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split over the ranks (default: per-GPU batch, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--main-stream-priority", type=int, default=int(os.environ.get("NST_MAIN_PRIORITY", "0")),
+    ap.add_argument("--main-stream-priority", type=int, default=0,
                     help="-1: run the step on a high-priority HIP stream (the weight-gradient stream keeps the default priority)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step from captured HIP graphs (training/train_step.py graph mode): the default -- on one rank "
@@ -381,7 +381,7 @@ def main():
                                            "lr_schedule.params": hp["lr_schedule.params"]})
     # NST_DIST_FORCE=1 (with one rank): run the exchange path -- buckets, communication stream, RCCL -- on a one-GPU box
     reducer = GradientReducer(model.store, force=os.environ.get("NST_DIST_FORCE", "0") == "1",
-                              overlap=os.environ.get("NST_DIST_OVERLAP", "1") != "0", wire_dtype=args.wire)
+                              wire_dtype=args.wire)
     reducer.broadcast_parameters(0)
     step_fn = TrainStep(model, crit, opt, reducer, use_graph=args.graph)
     ds = SyntheticSpeechDataset({"batch_per_gpu": B, "frames": T, "feature_dim": F, "trg_len": L, "vocab_size": V,

@@ -1299,7 +1299,7 @@ extern "C" int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void
   const int64_t tkp = ((int64_t)d->Tk + kblock - 1) / kblock * kblock, tqp = ((int64_t)d->Tq + TR - 1) / TR * TR;
   const int64_t ds_need = (int64_t)d->B * d->H * tkp * tqp * 2;
   const bool use_ds = d->dtype == NST_BF16 && vec && d->ds_workspace && d->ds_workspace_bytes >= ds_need &&
-                      nst_aligned16(d->ds_workspace) && env_int("NST_ATTN_DS", 1) != 0;
+                      nst_aligned16(d->ds_workspace);
   if (use_ds) {
     p.dst = (bf16_t*)d->ds_workspace; p.tqp = (int)tqp; p.tkp = (int)tkp; p.ds_kblock = kblock;
     dim3 gk((d->Tk + kblock - 1) / kblock, d->H, d->B), gq((d->Tq + TR - 1) / TR, d->H, d->B);

@@ -1263,11 +1263,7 @@ __global__ void __launch_bounds__(V2W_THREADS) conv_gemm_kernel_v2w(AL la, BL lb
 }
 
 
-bool conv_use_wide() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+bool conv_use_wide() { return true; }
 
 // dw2[i] (+)= sum_z slabs[z][i]  (dense [9C, C] output);  db2[j] (+)= sum_z cs_parts[z][j] when cs_parts != NULL
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
@@ -1309,11 +1305,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
 
 int conv_nst() { return 2; }   // stages of the v2 ring (three measured no faster in round 2 and are gone)
 
-bool conv_use_v2() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_V1"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+bool conv_use_v2() { return true; }
 
 template <typename KernelT>
 void conv_allow_big_lds(KernelT kernel, int bytes) {
@@ -1447,13 +1439,8 @@ __global__ void __launch_bounds__(G256_THREADS, 2) conv2_fwd256_kernel(Conv2Fwd2
   epilogue_v3<bf16_t, IdentityRowMap, EF>(acc[1], epi, a.y, (int64_t)C, a.M, C, m0 + wr * 128 + 64, wc * 64, ep, rowmap, lane);
 }
 
-// NST_CONV2_G256=0: the generic implicit-GEMM kernels (A/B switch; the LDS-resident patch kernels of rounds 2-3 -- 967 us forward,
-// 887 us data gradient on the benchmark shape against 788 / 787 here -- were removed in round 4)
-bool conv2_use_g256() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_CONV2_G256"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+// (the generic implicit-GEMM kernels below serve the shapes the 256 x 256 kernels do not take: C != 256, fp32, unaligned)
+bool conv2_use_g256() { return true; }
 
 // returns true when the 256 x 256 kernel handled the call
 bool conv2_fwd_g256(const void* x, const void* w2, const float* b2, void* y, int B, int T1, int F1, int C, int relu, hipStream_t st) {
@@ -1664,12 +1651,10 @@ __global__ void __launch_bounds__(G256_THREADS) conv2_dgrad256_kernel(Conv2Dgrad
   }
 }
 
-// returns true when the 256 x 256 kernel handled the call (NST_CONV2_DGRAD_G256=0: the per-class implicit GEMMs below)
+// returns true when the 256 x 256 kernel handled the call
 bool conv2_dgrad_g256(const void* dy, const void* w2, void* dx, int B, int T1, int F1, int C, hipStream_t st) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("NST_CONV2_DGRAD_G256"); enabled = (e && e[0] == '0') ? 0 : 1; }
   const int T2 = T1 / 2, F2 = F1 / 2;
-  if (!enabled || C != 256 || (T1 & 1) || (F1 & 1) || T1 < 2 || F1 < 2 || !nst_aligned16(dy) || !nst_aligned16(w2) || !nst_aligned16(dx))
+  if (C != 256 || (T1 & 1) || (F1 & 1) || T1 < 2 || F1 < 2 || !nst_aligned16(dy) || !nst_aligned16(w2) || !nst_aligned16(dx))
     return false;
   const int64_t M = (int64_t)B * T2 * F2;
   if (M >= (1ll << 30) || M < 256) return false;
@@ -1825,14 +1810,12 @@ __global__ void __launch_bounds__(G256_THREADS) conv2_wgrad256_kernel(Conv2Wgrad
   epilogue_v3<float, IdentityRowMap, 0>(acc[1], epi, Ct, (int64_t)C, 256, C, wr * 128 + 64, wc * 64, ep, rowmap, lane);
 }
 
-// returns true when the 256 x 256 kernel handled the call (slabs + reduce included); NST_CONV2_WGRAD_G256=0: the generic kernels
+// returns true when the 256 x 256 kernel handled the call (slabs + reduce included)
 bool conv2_wgrad_g256(const void* x, const void* dy, float* dw2, float* db2, int B, int T1, int F1, int C, int accumulate, void* ws,
                       int64_t ws_bytes, hipStream_t st, bool* db2_done) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("NST_CONV2_WGRAD_G256"); enabled = (e && e[0] == '0') ? 0 : 1; }
   const int T2 = (T1 + 1) / 2, F2 = (F1 + 1) / 2;
   const int64_t P = (int64_t)B * T2 * F2;
-  if (!enabled || C != 256 || !ws || !nst_aligned16(x) || !nst_aligned16(dy) || !nst_aligned16(dw2) || !nst_aligned16(ws) ||
+  if (C != 256 || !ws || !nst_aligned16(x) || !nst_aligned16(dy) || !nst_aligned16(dw2) || !nst_aligned16(ws) ||
       P >= (1ll << 30))
     return false;
   const int KT = (int)((P + 63) / 64);
@@ -1989,9 +1972,7 @@ extern "C" int nst_conv1_ln_relu_bwd(const float* src, const float* w1, const fl
   const int64_t nrows = (int64_t)B * T1;
   int blocks = (int)((nrows + 3) / 4 > 1024 ? 1024 : (nrows + 3) / 4);
   const bool vec = (C % 4 == 0) && ((((uintptr_t)dout) & 15) == 0);
-  static int use_mfma = -1;
-  if (use_mfma < 0) { const char* e = getenv("NST_CONV1_BWD_VALU"); use_mfma = (e && e[0] == '1') ? 0 : 1; }
-  if (use_mfma && dtype == NST_BF16 && (C == 64 || C == 128 || C == 256) && (int64_t)B * T1 * F1 < ((int64_t)1 << 31)) {
+  if (dtype == NST_BF16 && (C == 64 || C == 128 || C == 256) && (int64_t)B * T1 * F1 < ((int64_t)1 << 31)) {
     const int64_t npix = (int64_t)B * T1 * F1;
     FastDiv dF1, dT1;
     dF1.init((uint32_t)F1);

@@ -483,11 +483,7 @@ static int xent_consts(int V, float ls, float* conf, float* low, float* norm) {
   return 0;
 }
 
-static bool xent_vec() {   // NST_XENT_VEC=0: the scalar kernels (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_XENT_VEC"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+static bool xent_vec() { return true; }   // (the scalar kernels serve unaligned / odd vocabularies)
 
 extern "C" int nst_ls_xent_fwd(const void* logits, const int64_t* labels, const float* weights, float* xent, float* lse,
                                int64_t rows, int V, int64_t ldl, float label_smoothing, int dtype, void* stream) {

@@ -997,11 +997,9 @@ int launch_pair(const FfnArgs& a, hipStream_t st) {
 }
 
 // v2 (eight waves, two per SIMD): forward, full chip (>= 160 workgroups of 128 rows), F a multiple of 64 whose bias fits the
-// 16 KB behind the P tile.  NST_FFN_V2=0 keeps the one-wave-per-SIMD kernel (A/B switch).
+// 16 KB behind the P tile.
 bool use_v2_fwd(const FfnArgs& a) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_FFN_V2"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1 && a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
+  return a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
 }
 
 template <int DROP, bool FULL>
@@ -1020,10 +1018,8 @@ int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
   return NST_OK;
 }
 
-bool use_v2_bwd(const FfnArgs& a) {   // NST_FFN_V2_BWD=0: the one-wave-per-SIMD backward
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_FFN_V2_BWD"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1 && a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
+bool use_v2_bwd(const FfnArgs& a) {
+  return a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
 }
 
 int launch_pair_v2_bwd(const FfnArgs& a_in, hipStream_t st) {
@@ -1056,7 +1052,7 @@ int launch_pair_v2_bwd(const FfnArgs& a_in, hipStream_t st) {
 
 int launch_pair_v2_fwd(const FfnArgs& a_in, hipStream_t st) {
   FfnArgs a = a_in;
-  { static int m = -1; if (m < 0) { const char* e = getenv("NST_FFN_ROT"); m = e ? atoi(e) : 0; } a.rot_mode = m; }
+  a.rot_mode = 0;   // rotated chunk order per workgroup (per-XCD rotation measured no faster)
   const bool full = a.M % V2_ROWS == 0;
   const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
   if (full && drop == 3) return launch_v2_fwd<3, true>(a, st);
@@ -1172,9 +1168,7 @@ extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, 
 }
 
 extern "C" int64_t nst_ffn_gate_bits_bytes(const NstFfnDesc* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("NST_FFN_GATE_BITS"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || !d || !nst_ffn_supported(d->d_model, d->filter_size, d->dtype) || d->rows <= 0 || d->rows >= (1 << 30)) return 0;
+  if (!d || !nst_ffn_supported(d->d_model, d->filter_size, d->dtype) || d->rows <= 0 || d->rows >= (1 << 30)) return 0;
   FfnArgs a;
   memset(&a, 0, sizeof(a));
   a.M = (int)d->rows; a.F = d->filter_size;

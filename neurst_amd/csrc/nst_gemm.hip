@@ -102,11 +102,7 @@ void allow_big_lds(KernelT kernel, int bytes) {
   if (ndone < 64) done[ndone++] = (const void*)kernel;
 }
 
-bool use_v2() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NST_GEMM_V1"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+bool use_v2() { return true; }   // (the register-staged kernel serves operands the LDS-DMA path cannot take: unaligned, odd widths)
 
 // sum_z src[z * zs .. +4): 8 slabs per round, all 8 loads in flight before the first add (a runtime-bound loop of single
 // loads is one dependent memory round trip per slab: the 64 slabs of a 256x256 gradient took ~60 us that way).  The adds

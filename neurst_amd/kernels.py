@@ -561,7 +561,7 @@ def attention_fwd(q, k, v, H, dh, key_bias=None, causal=False, dropout_p=0.0, se
 
 def rowdot_supported(x, n):
     """gemm(rowdot=...) needs the bf16 stream kernel and whole 64-column heads."""
-    return x.is_cuda and x.dtype == torch.bfloat16 and n % 64 == 0 and os.environ.get("NST_GEMM_ROWDOT", "1") != "0"
+    return x.is_cuda and x.dtype == torch.bfloat16 and n % 64 == 0
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, H, dh, key_bias=None, causal=False, dropout_p=0.0, seed=0,

@@ -32,17 +32,18 @@ def glorot_uniform(shape, gen, fan_in=None, fan_out=None):
     return (torch.rand(*shape, generator=gen, dtype=torch.float64) * 2 - 1).mul_(lim).float()
 
 
-_WGRAD_UNITS = int(os.environ.get("NST_WGRAD_UNITS", "256"))
-_WGRAD_SPLIT8 = os.environ.get("NST_WGRAD_SPLIT8", "1") != "0"
-_WGRAD_UNITS_SMALL = int(os.environ.get("NST_WGRAD_UNITS_SMALL", "128"))   # gradients of fewer than 8 tiles (256 x 256 kernels)
+_WGRAD_UNITS = 256          # workgroups a split-K weight gradient is cut into
+_WGRAD_SPLIT8 = True        # split factors in multiples of 8: a K slice per XCD
+_WGRAD_UNITS_SMALL = 128    # gradients of fewer than 8 tiles (256 x 256 kernels)
 # the one-launch feed-forward wins when its 128-row workgroups fill the chip (encoder: 28 800 rows at the benchmark shape);
 # below that (decoder: 9 600 rows) the two persistent GEMMs are as fast or faster (scripts/ffn_bench.py)
 _WGRAD_GROUP_MAX_BYTES = 6 << 30    # activations a pending weight-gradient group may keep alive before it is launched early
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("NST_FFN_MIN_ROWS", "16384"))
-# the backward pair (NST_FFN_FUSED_BWD=0: two persistent GEMMs instead).  It holds all 160 KB of a CU's LDS, so no
+# the backward pair.  It holds all 160 KB of a CU's LDS, so no
 # weight-gradient workgroup shares its CUs, but at 97 us against 124 us for the two GEMMs it still wins in the step
 # (17.03 vs 17.31 ms, profiles/r02_ffn_*.json)
-_FFN_FUSED_BWD = os.environ.get("NST_FFN_FUSED_BWD", "1") != "0"
+_FFN_FUSED = True          # the one-launch feed-forward pair where it is supported (tests pin the two-GEMM path with False)
+_FFN_FUSED_BWD = True
 
 
 def _wgrad_split(rows, k_in, n_out, dtype, units=None):
@@ -93,8 +94,6 @@ class ResidualStream(object):
 
     @staticmethod
     def supported(rt, dim, pre_norm=True):
-        if os.environ.get("NST_STREAM32", "1") == "0":      # (A/B while the round is measured; removed with the other experiment switches)
-            return False
         return bool(pre_norm) and K.add_layernorm_supported(dim, rt.dtype)
 
 
@@ -162,7 +161,7 @@ class Dense(Layer):
         self.in_dim, self.out_dim = in_dim, out_dim
         self.kernel = rt.store.add(name + "/kernel", (in_dim, out_dim), glorot_uniform((in_dim, out_dim), gen))
         self.bias = rt.store.add(name + "/bias", (out_dim,), torch.zeros(out_dim)) if use_bias else None
-        self.wgrad_units = None   # workgroups the weight gradient is cut into (None: NST_WGRAD_UNITS)
+        self.wgrad_units = None   # workgroups the weight gradient is cut into (None: _WGRAD_UNITS)
         self.wgrad_grouped = True  # the weight gradient may wait for the stack's grouped launch (Runtime.wgrad_group)
 
     def forward(self, x, **epi):
@@ -224,7 +223,7 @@ class TransformerFFN(Layer):
         self.dense2 = Dense(rt, name + "/dense2", filter_size, hidden_size, gen)
         self.rate = dropout_rate
         self.site = self._site()
-        self.fused = os.environ.get("NST_FFN_FUSED", "1") != "0" and K.ffn_supported(hidden_size, filter_size, rt.dtype)
+        self.fused = _FFN_FUSED and K.ffn_supported(hidden_size, filter_size, rt.dtype)
         if self.fused:
             self._w1t = rt.store.add_transposed(self.dense1.kernel)
             self._w2t = rt.store.add_transposed(self.dense2.kernel)

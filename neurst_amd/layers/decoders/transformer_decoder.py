@@ -1,6 +1,5 @@
 """TransformerDecoder (neurst/layers/decoders/transformer_decoder.py:23-228): the training branch
 (cache["decoding_states"] is None) and incremental decoding with per-layer caches (wait-k lagging is not built)."""
-import os
 
 import torch
 
@@ -9,6 +8,9 @@ from neurst_amd.layers import layer_utils
 from neurst_amd.layers.common_layers import LayerNorm, ResidualStream, dropped_grad
 from neurst_amd.layers.decoders.decoder import Decoder, register_decoder
 from neurst_amd.layers.transformer_layers import TransformerDecoderLayer
+
+
+KV_GROUP = True     # one GEMM for the cross-attention k|v projections of all layers (see TransformerDecoder.build)
 
 
 @register_decoder
@@ -46,10 +48,10 @@ class TransformerDecoder(Decoder):
         # copy [d, n * 2d] (refreshed once per optimizer step), so the projection is ONE GEMM whose output the layers read as
         # column blocks, and d(memory) = [d(k|v) of all layers] . packed^T is ONE GEMM with K = n * 2d instead of n
         # accumulating ones.  The weight gradients stay per layer (the data-parallel reducer ships a layer's gradients as soon
-        # as that layer's backward is queued).  NST_DEC_KV_GROUP=0: per-layer projections.
+        # as that layer's backward is queued).  KV_GROUP = False: per-layer projections (tests).
         self._kv_group, self._kv_atts = None, []
         atts = [l._cross.att for l in self._stacking_layers if l._with_cross_attention]
-        if os.environ.get("NST_DEC_KV_GROUP", "1") != "0" and len(atts) >= 2 \
+        if KV_GROUP and len(atts) >= 2 \
                 and len({tuple(a.kv_transform.kernel.shape) for a in atts}) == 1:
             self._kv_group = rt.store.add_packed([a.kv_transform.kernel for a in atts], [a.kv_transform.bias for a in atts])
             self._kv_atts = atts

@@ -6,7 +6,6 @@
            GEMM epilogue
 Variables (TF names/layouts): conv{1,2}/{kernel(HWIO),bias}, ln{1,2}/{gamma,beta}, output_dense/{kernel,bias}.
 """
-import os
 
 import torch
 
@@ -39,7 +38,7 @@ class AudioConv2dSubsamplingLayer(Layer):
         # launch (1.05 -> 1.59 ms stand-alone, step 14.08 -> 14.36 ms: profiles/r04_history/c3_group_bench_0.json, c5_ab_step.log); its weight gradient keeps the split-K path on the weight-gradient stream
         self._dense_layer.wgrad_grouped = False   # (as a small group of their own on the weight-gradient stream: 13.0 -> 13.8 ms, c17_ab_side_group.log)
         # (its weight gradient runs at the very end of the backward next to the conv kernels; 512 units measured no better)
-        self._dense_layer.wgrad_units = int(os.environ.get("NST_FRONT_WGRAD_UNITS", "256"))
+        self._dense_layer.wgrad_units = 256
 
     @property
     def embedding_dim(self):

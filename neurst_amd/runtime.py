@@ -335,11 +335,11 @@ class Runtime(object):
         self._sites = 0
         self._posenc_cache = {}
         # Weight-gradient GEMMs do not feed the backward chain: they run on a second HIP stream so that their
-        # workgroups fill the ramp-up / tail gaps of the dgrad-path kernels (NST_WGRAD_STREAM=0 keeps one stream).
+        # workgroups fill the ramp-up / tail gaps of the dgrad-path kernels.
         self.wgrad_stream = None
         self.capture = None   # set by TrainStep while it captures a step (see run_wgrad)
-        if self.device.type == "cuda" and os.environ.get("NST_WGRAD_STREAM", "1") != "0":
-            self.wgrad_stream = make_stream(self.device, int(os.environ.get("NST_WGRAD_PRIORITY", "1")))
+        if self.device.type == "cuda":
+            self.wgrad_stream = make_stream(self.device, 1)      # low-priority class, see make_stream
 
     @contextlib.contextmanager
     def on_wgrad_stream(self, *tensors):
@@ -369,8 +369,8 @@ class Runtime(object):
 
     def wgrad_batch(self):
         """The split-K batch of the weight-gradient stream (kernels.SplitkBatch), created on first use; None on the CPU tier
-        or with NST_WGRAD_BATCH=0."""
-        if self.device.type != "cuda" or os.environ.get("NST_WGRAD_BATCH", "1") == "0":
+        ."""
+        if self.device.type != "cuda":
             return None
         if getattr(self, "_wgrad_batch", None) is None:
             from neurst_amd import kernels
@@ -378,10 +378,8 @@ class Runtime(object):
         return self._wgrad_batch
 
     def wgrad_group(self):
-        """The pending weight-gradient group (kernels.WgradGroup) or None: NST_WGRAD_GROUP=0, or a runtime without a device."""
+        """The pending weight-gradient group (kernels.WgradGroup) or None (a runtime without a device)."""
         if self.device.type != "cuda" and not getattr(self, "_wgrad_group_on_cpu", False):
-            return None
-        if os.environ.get("NST_WGRAD_GROUP", "1") == "0":
             return None
         if getattr(self, "_wgrad_group", None) is None:
             from neurst_amd import kernels

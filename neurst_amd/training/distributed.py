@@ -152,7 +152,7 @@ class GradientReducer(object):
             # has the least launch overhead -- 13.05-13.08 vs 13.10 ms with 32 MiB pieces, profiles/r04_history/c18_ab_exchange.log)
             bucket_bytes = int(float(os.environ.get("NST_DIST_BUCKET_MB", "256")) * (1 << 20))
         if min_bucket_bytes is None:
-            min_bucket_bytes = int(float(os.environ.get("NST_DIST_MIN_BUCKET_MB", "8")) * (1 << 20))
+            min_bucket_bytes = 8 << 20
         self.store, self.group = store, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # exchanges are issued when there is someone to exchange with -- or on request with an initialised one-rank group

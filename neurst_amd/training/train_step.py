@@ -48,8 +48,8 @@ class _StepCapture(object):
         self.segments, self.deferred, self.keep = [], [], []
         self.cur = None
         self._fresh = False      # nothing has been queued since the current segment was opened by a layer boundary
-        self.min_deferred = max(1, int(os.environ.get("NST_GRAPH_MIN_DEFERRED", "6")))
-        self.force_cuts = os.environ.get("NST_GRAPH_FORCE_CUTS", "1") != "0"   # A/B switch of Runtime.sublayer_boundary(force=True)
+        self.min_deferred = 6        # weight-gradient calls that make a layer boundary cut the capture (measured in DESIGN 5b)
+        self.force_cuts = True       # Runtime.sublayer_boundary(force=True) cuts whatever is pending
 
     def begin(self):
         self.cur = _Segment()
@@ -121,7 +121,7 @@ class _StepCapture(object):
         closed here (`_fresh`); a mid-layer boundary (sublayer_boundary) is followed by more compute-stream work of the
         same layer (LayerNorm backward, bias gradients), so a bucket reported after it must cut the capture again."""
         # a cut costs two graph launches (~10-20 us of idle compute stream each); waiting for a few weight-gradient calls
-        # trades that against a later start of the weight-gradient graph (NST_GRAPH_MIN_DEFERRED, measured in DESIGN 5b)
+        # trades that against a later start of the weight-gradient graph (min_deferred, measured in DESIGN 5b)
         self._fresh = False
         if len(self.deferred) >= self.min_deferred or (force and self.deferred and self.force_cuts):
             self._close()
@@ -188,16 +188,14 @@ class TrainStep(object):
         self._seen, self._captured = set(), {}
         self._lr_dev = self._cap_stream = self._side_stream = None
         self.replays = 0
-        # The step runs on a HIGH-priority stream of its own (NST_STEP_PRIORITY=0: on the caller's stream): the runtime then
+        # The step runs on a HIGH-priority stream of its own: the runtime then
         # keeps it on hardware queues apart from the weight-gradient stream (low class) and from the exchange (default class),
         # whatever streams other libraries created before -- see runtime.make_stream.  The caller's stream is ordered before
         # and after the step, so the step still behaves like work queued on the caller's stream.
         self._step_stream = None
         if model.rt.device.type == "cuda":
-            prio = int(os.environ.get("NST_STEP_PRIORITY", "-1"))
-            if prio != 0:
-                from neurst_amd.runtime import make_stream
-                self._step_stream = make_stream(model.rt.device, prio)
+            from neurst_amd.runtime import make_stream
+            self._step_stream = make_stream(model.rt.device, -1)
         if self.use_graph:
             model.rt.enable_device_step()
             self._lr_dev = torch.zeros(1, dtype=torch.float32, device=model.rt.device)
@@ -330,7 +328,7 @@ class TrainStep(object):
         from neurst_amd import kernels as K
         rt, red = self.model.rt, self.reducer
         if rt.wgrad_stream is None:
-            raise RuntimeError("graph mode needs the weight-gradient stream (NST_WGRAD_STREAM=1)")
+            raise RuntimeError("graph mode needs the weight-gradient stream (a Runtime on a ROCm device)")
         cap = _CapturedStep()
         cap.static_inputs = [{k: v.clone() for k, v in b.items() if torch.is_tensor(v)} for b in batches]
         full = [dict(b, **sb) for b, sb in zip(batches, cap.static_inputs)]

@@ -212,7 +212,7 @@ def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
     from neurst_amd.runtime import Runtime
     outs = []
     for fused in ("1", "0"):
-        monkeypatch.setenv("NST_FFN_FUSED", fused)
+        monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED", fused == "1")
         monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_MIN_ROWS", 1)
         monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_BWD", True)
         rt = Runtime(device=DEV, dtype="bfloat16", seed=3)

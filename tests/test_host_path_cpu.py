@@ -126,7 +126,7 @@ def test_speech_transformer_host_schedule_matches_oracle(cpu_kernels, case):
 
 
 def test_grouped_cross_attention_projection_equals_per_layer_and_leaves_nothing_behind(cpu_kernels, monkeypatch):
-    """TransformerDecoder's grouped k|v projection (one GEMM over the packed kv_transform kernels, NST_DEC_KV_GROUP) against the
+    """TransformerDecoder's grouped k|v projection (one GEMM over the packed kv_transform kernels, transformer_decoder.KV_GROUP) against the
     per-layer projections: same logits and gradients; and the per-layer hand-over attributes (_kv_pre / _dkv_out) never survive
     a call -- a training forward that dies inside the decoder must not feed its k|v to the next (teacher-forced, not grouped)
     evaluation forward of a DIFFERENT batch."""
@@ -134,7 +134,7 @@ def test_grouped_cross_attention_projection_equals_per_layer_and_leaves_nothing_
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     outs = []
     for grouped in ("1", "0"):
-        monkeypatch.setenv("NST_DEC_KV_GROUP", grouped)
+        monkeypatch.setattr("neurst_amd.layers.decoders.transformer_decoder.KV_GROUP", grouped == "1")
         model, cfg, shape = _speech_model("small")
         assert (model._decoder._kv_group is not None) == (grouped == "1")
         inputs = _speech_inputs(shape)
@@ -144,7 +144,7 @@ def test_grouped_cross_attention_projection_equals_per_layer_and_leaves_nothing_
         outs.append((logits.double(), model.store.grad.clone().double()))
         assert all(getattr(a, "_kv_pre", None) is None and getattr(a, "_dkv_out", None) is None for a in model._decoder._kv_atts)
     assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-5
-    monkeypatch.setenv("NST_DEC_KV_GROUP", "1")
+    monkeypatch.setattr("neurst_amd.layers.decoders.transformer_decoder.KV_GROUP", True)
     model, cfg, shape = _speech_model("small")
     inputs, other = _speech_inputs(shape), _speech_inputs(shape, seed=99)
     want = model(other, is_training=False).double()
@@ -1030,7 +1030,7 @@ def test_fused_feed_forward_host_wiring_matches_the_two_gemm_schedule(cpu_kernel
     for pre_norm in (True, False):
         outs = []
         for fused in ("1", "0"):
-            monkeypatch.setenv("NST_FFN_FUSED", fused)
+            monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED", fused == "1")
             monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_MIN_ROWS", 1)
             monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_BWD", True)
             rt = Runtime(device="cpu", dtype="bfloat16", seed=3)
