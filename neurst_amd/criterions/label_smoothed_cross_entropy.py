@@ -76,9 +76,19 @@ class LabelSmoothedCrossEntropy(Criterion):
         if loss_scale_dev is not None:
             inv = inv * loss_scale_dev.reshape(1)
         inv = inv.contiguous()
-        # the gradient keeps the logits' row stride (rows padded to whole 128-byte lines, text_modalities.py)
-        out = torch.empty_strided(l2.shape, l2.stride(), dtype=l2.dtype, device=l2.device)
-        return K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), out=out, gscale_dev=inv).view(B, L, V)
+        # the gradient keeps the logits' row stride (rows padded to whole 128-byte lines, text_modalities.py); its padding columns
+        # are allocated too and ZERO, so that the consumer may run its products over a vocabulary rounded up to 8 columns
+        stride = l2.stride(0)
+        if stride > V and l2.stride(1) == 1:
+            buf = torch.empty(l2.shape[0], stride, dtype=l2.dtype, device=l2.device)
+            buf[:, V:].zero_()
+            out = buf[:, :V]
+        else:
+            out = torch.empty_strided(l2.shape, l2.stride(), dtype=l2.dtype, device=l2.device)
+        g = K.ls_xent_bwd(l2, labels, weights, lse, self._label_smoothing, float(loss_scale), out=out, gscale_dev=inv).view(B, L, V)
+        if stride > V and l2.stride(1) == 1:
+            g._nst_zero_padded = stride      # columns [V, stride) of every row exist and are zero
+        return g
 
     def reduce_metrics(self, eval_res_list):
         nll_sum = nll_samples = nll_tokens = 0.

@@ -70,8 +70,12 @@ struct Dense256Args {
   int reserved0;
   Epilogue ep;
 };
+// Persistent: a workgroup walks tiles id = blockIdx.x, + gridDim.x, ... (grid = a multiple of 8, so it keeps its XCD and
+// xcd_remap hands every XCD a contiguous run of tiles -- neighbours share an A row panel in that L2); the loads a tile starts
+// with are issued in FRONT of the previous tile's store epilogue (gemm256_prologue / PRE, as in the conv2 data gradient: the
+// epilogue's scratch lives in buffer 1's A images, which the prologue does not touch).
 template <typename OutT, int BMODE, int EF>
-__global__ void __launch_bounds__(G256_THREADS, 2) dense_gemm256_kernel(Dense256Args<OutT> args) {
+__global__ void __launch_bounds__(G256_THREADS) dense_gemm256_kernel(Dense256Args<OutT> args) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   typedef Dense256Args<OutT> Args;
   const NST_AS4 Args* ka = (const NST_AS4 Args*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -79,29 +83,53 @@ __global__ void __launch_bounds__(G256_THREADS, 2) dense_gemm256_kernel(Dense256
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int ntiles = ka->ntiles, tiles_n = ka->tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);      // an XCD gets a contiguous run of tiles: neighbours share an A row panel
-  const int tm = tile / tiles_n;
-  const int m0 = tm * G256_TILE, n0 = (tile - tm * tiles_n) * G256_TILE;
-  floatx4_t acc[2][4][4], cs[4];
+  const int nk = (ka->K + 63) >> 6;
+  int id = blockIdx.x;
+  if (id >= ntiles) return;
+  auto origin = [&](int i, int& m0, int& n0) {
+    const int tile = xcd_remap(i, ntiles);
+    const int tm = tile / tiles_n;
+    m0 = tm * G256_TILE;
+    n0 = (tile - tm * tiles_n) * G256_TILE;
+  };
+  Dma256<MODE_RC> da;
+  Dma256<BMODE> db;
+  int m0, n0;
+  origin(id, m0, n0);
   {
     const DenseLoader<bf16_t> la = kload(&ka->la), lb = kload(&ka->lb);
-    Dma256<MODE_RC> da;
-    Dma256<BMODE> db;
     da.init(la, m0, 0, wave, lane);
     db.init(lb, n0, 0, wave, lane);
-    gemm256_mainloop<MODE_RC, BMODE, false>(smem_dyn, da, db, (ka->K + 63) >> 6, false, acc, cs);
   }
-  asm volatile("" ::: "memory");
-  const NST_AS4 Args* k2 = launder(ka);
-  Epilogue ep = kload(&k2->ep);
-  if ((EF & EF_DROP) != 0) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
-  float* epi = reinterpret_cast<float*>(smem_dyn + wave * V3_EPI_BYTES_PER_WAVE);
-  const IdentityRowMap rowmap;
-  OutT* C = k2->C;
-  const int64_t ldc = k2->ldc;
-  const int M = k2->M, N = k2->N;
-  epilogue_v3<OutT, IdentityRowMap, EF>(acc[0], epi, C, ldc, M, N, m0 + wr * 128, n0 + wc * 64, ep, rowmap, lane);
-  epilogue_v3<OutT, IdentityRowMap, EF>(acc[1], epi, C, ldc, M, N, m0 + wr * 128 + 64, n0 + wc * 64, ep, rowmap, lane);
+  gemm256_prologue(smem_dyn, da, db, nk);
+  float* epi = reinterpret_cast<float*>(smem_dyn + G256_KT_BYTES + wave * V3_EPI_BYTES_PER_WAVE);
+  floatx4_t acc[2][4][4], cs[4];
+#pragma unroll 1
+  while (true) {
+    gemm256_mainloop<MODE_RC, BMODE, false, 0, true>(smem_dyn, da, db, nk, false, acc, cs);
+    asm volatile("" ::: "memory");
+    const int cm0 = m0, cn0 = n0;
+    id += gridDim.x;
+    const bool more = id < ntiles;     // workgroup-uniform
+    if (more) {
+      origin(id, m0, n0);
+      const NST_AS4 Args* k1 = launder(ka);
+      const DenseLoader<bf16_t> la = kload(&k1->la), lb = kload(&k1->lb);
+      da.init(la, m0, 0, wave, lane);
+      db.init(lb, n0, 0, wave, lane);
+      gemm256_prologue(smem_dyn, da, db, nk);
+    }
+    const NST_AS4 Args* k2 = launder(ka);
+    Epilogue ep = kload(&k2->ep);
+    if ((EF & EF_DROP) != 0) ep.seed = seed_with_offset(ep.seed, ep.seed_dev);   // wave-uniform
+    const IdentityRowMap rowmap;
+    OutT* C = k2->C;
+    const int64_t ldc = k2->ldc;
+    const int M = k2->M, N = k2->N;
+    epilogue_v3<OutT, IdentityRowMap, EF>(acc[0], epi, C, ldc, M, N, cm0 + wr * 128, cn0 + wc * 64, ep, rowmap, lane);
+    epilogue_v3<OutT, IdentityRowMap, EF>(acc[1], epi, C, ldc, M, N, cm0 + wr * 128 + 64, cn0 + wc * 64, ep, rowmap, lane);
+    if (!more) break;
+  }
 }
 
 // copies a by-value chunk of the product table into device memory (tables of more than G256_MAX_PROBLEMS products)
@@ -278,11 +306,12 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
       Dense256Args<OutT> ga;
       ga.la = la; ga.lb = lb; ga.C = (OutT*)C; ga.ldc = d->ldc; ga.M = d->M; ga.N = d->N; ga.K = d->K;
       ga.tiles_n = (d->N + 255) / 256; ga.ntiles = t256; ga.reserved0 = 0; ga.ep = ep;
+      const int pgrid = cus & ~7;     // one persistent workgroup per CU (128 KB of LDS), a multiple of 8: it keeps its XCD
 #define NST_GEMM_256(BMO, EF_)                                                                       \
   do {                                                                                               \
     auto kfn = dense_gemm256_kernel<OutT, BMO, EF_>;                                                 \
     allow_big_lds(kfn, G256_LDS_BYTES);                                                              \
-    kfn<<<t256, G256_THREADS, G256_LDS_BYTES, st>>>(ga);                                             \
+    kfn<<<t256 < pgrid ? t256 : pgrid, G256_THREADS, G256_LDS_BYTES, st>>>(ga);                      \
     return 0;                                                                                        \
   } while (0)
       if (bmode == MODE_OC) {   // forward projections: x [M, K] . W [K, N]

@@ -17,11 +17,20 @@ class WordEmbeddingSharedWeights(Layer):
         self._share_softmax_weights = share_softmax_weights
         scope = "shared" if share_softmax_weights else "emb"
         init = torch.randn(vocab_size, embedding_dim, generator=gen, dtype=torch.float64) * embedding_dim ** -0.5
-        self._shared_weights = rt.store.add(f"{name}/{scope}/weights", (vocab_size, embedding_dim), init.float())
+        # A vocabulary that is not a multiple of 8 (32 003) makes the table an operand no 16-byte-granular kernel can take: the tied
+        # logits, their input gradient and the table's weight gradient then ran on the scalar fall-back kernels (19.6 of the 53 ms
+        # of GPU time of a transformer_big step).  The table and the bias therefore keep (Vp8 - V) zero rows behind them in the
+        # flat buffers (ParamStore.add tail_pad): the three products run over Vp8 rows / columns, the extra logits are x . 0 + 0,
+        # their gradients are kept exactly zero (the criterion zeroes the padding columns of d logits), so the padding never
+        # leaves zero and the variables keep their reference shapes [V, d] / [V].
+        self._vp8 = (vocab_size + 7) // 8 * 8
+        pad_rows = self._vp8 - vocab_size
+        self._shared_weights = rt.store.add(f"{name}/{scope}/weights", (vocab_size, embedding_dim), init.float(),
+                                            tail_pad=pad_rows * embedding_dim)
         self._bias = None
         if share_softmax_weights and use_bias:
             # created without an initializer in the reference => Keras default glorot_uniform on shape [V]
-            self._bias = rt.store.add(f"{name}/{scope}/bias", (vocab_size,), glorot_uniform((vocab_size,), gen))
+            self._bias = rt.store.add(f"{name}/{scope}/bias", (vocab_size,), glorot_uniform((vocab_size,), gen), tail_pad=pad_rows)
         self._stack = []
 
     embedding_dim = property(lambda self: self._embedding_dim)
@@ -60,8 +69,17 @@ class WordEmbeddingSharedWeights(Layer):
                 # padded to whole lines (the tensor handed out is the [rows, V] view of the [rows, Vp] buffer)
                 vp = ((V * esz + 127) // 128) * (128 // esz)
                 out = torch.empty(x2.shape[0], vp, dtype=x2.dtype, device=x2.device)[:, :V]
-            logits = K.gemm(x2, self._shared_weights.compute, x2.shape[0], V, d, trans_b=True,
-                            bias=None if self._bias is None else self._bias.data, out=out)
+            vp8 = self._vp8
+            if out is not None and vp8 != V and out.stride(0) >= vp8:
+                # over the zero-padded table: Vp8 columns into the padded rows, the [rows, V] view handed on (see __init__)
+                st = self.rt.store
+                wpad, _ = st.padded_views(self._shared_weights, vp8)
+                bpad = None if self._bias is None else st.master[self._bias.offset:self._bias.offset + vp8]
+                K.gemm(x2, wpad, x2.shape[0], vp8, d, trans_b=True, bias=bpad, out=out.as_strided((x2.shape[0], vp8), out.stride()))
+                logits = out
+            else:
+                logits = K.gemm(x2, self._shared_weights.compute, x2.shape[0], V, d, trans_b=True,
+                                bias=None if self._bias is None else self._bias.data, out=out)
             if is_training:
                 self._stack.append(("linear", x2))
             return logits.view(*inputs.shape[:-1], V)
@@ -78,6 +96,19 @@ class WordEmbeddingSharedWeights(Layer):
             rows = dl.shape[0]
             acc_w = st.acc_flag(W)
             acc_b = st.acc_flag(self._bias) if self._bias is not None else False
+
+            vp8 = self._vp8
+            padded = vp8 != V and dl.stride(0) >= vp8 and getattr(dy, "_nst_zero_padded", 0) >= vp8
+            if padded:     # d logits with zero padding columns (the criterion keeps them zero): every product over Vp8
+                dlp = dl.as_strided((rows, vp8), dl.stride())
+                wpad, gpad = st.padded_views(W, vp8)
+
+                def table_grads():
+                    K.gemm(dlp, x2, vp8, d, rows, trans_a=True, out=gpad, accumulate=acc_w, split_k=_wgrad_split(rows, vp8, d, dl.dtype))
+                    if self._bias is not None:
+                        K.colsum(dl, self._bias.grad, accumulate=acc_b)
+                self.rt.run_wgrad(table_grads, dl, x2)
+                return K.gemm(dlp, wpad, rows, d, vp8).view(*dy.shape[:-1], d)
 
             def table_grads():   # parameter gradients only: off the dgrad chain, on the weight-gradient stream
                 K.gemm(dl, x2, V, d, rows, trans_a=True, out=W.grad, accumulate=acc_w, split_k=_wgrad_split(rows, V, d, dl.dtype))

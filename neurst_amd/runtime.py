@@ -17,11 +17,12 @@ _ALIGN = 8  # elements: keeps every parameter 32-byte (fp32) / 16-byte (bf16) al
 
 
 class Param(object):
-    __slots__ = ("name", "shape", "offset", "numel", "data", "grad", "compute", "_init")
+    __slots__ = ("name", "shape", "offset", "numel", "data", "grad", "compute", "_init", "tail_pad")
 
-    def __init__(self, name, shape, init):
+    def __init__(self, name, shape, init, tail_pad=0):
         self.name, self.shape = name, tuple(shape)
         self.numel = int(math.prod(self.shape)) if len(self.shape) else 1
+        self.tail_pad = int(tail_pad)     # zero elements kept behind the parameter in every flat buffer (ParamStore.padded_views)
         self._init = init
         self.offset = -1
         self.data = self.grad = self.compute = None
@@ -56,16 +57,29 @@ class ParamStore(object):
         self._transposed = []     # (param, handle): bf16 copies stored transposed (the fused feed-forward's forward operands)
         self._packed = []         # PackedCopy handles: kernels of several layers side by side as one GEMM operand
 
-    def add(self, name, shape, init):
-        """init: CPU float tensor of `shape` (the reference's initializer already applied)."""
+    def add(self, name, shape, init, tail_pad=0):
+        """init: CPU float tensor of `shape` (the reference's initializer already applied).  tail_pad: elements that stay ZERO
+        behind the parameter in the master / shadow / gradient buffers, so that kernels may read (and write zero gradients to) a
+        few rows past its end -- an embedding table whose vocabulary is not a multiple of 8 is a GEMM operand of 8-row granularity
+        that way (padded_views)."""
         if self.finalized:
             raise RuntimeError("ParamStore already finalized")
         if name in self.params:
             raise ValueError(f"duplicate variable name: {name}")
         init = torch.as_tensor(init, dtype=torch.float32).reshape(shape)
-        p = Param(name, shape, init)
+        p = Param(name, shape, init, tail_pad)
         self.params[name] = p
         return p
+
+    def padded_views(self, p, rows):
+        """(compute, grad) views of parameter p with `rows` leading rows, the rows past p.shape[0] lying in its zero tail pad."""
+        inner = p.numel // p.shape[0]
+        n = rows * inner
+        assert p.shape[0] <= rows and n <= p.numel + p.tail_pad, (p.name, rows, p.tail_pad)
+        sl = slice(p.offset, p.offset + n)
+        src = self.shadow if self.shadow is not None else self.master
+        shape = (rows,) + tuple(p.shape[1:])
+        return src[sl].view(shape), self.grad[sl].view(shape)
 
     def add_transposed(self, param):
         """Registers a transposed bf16 copy of a 2-D parameter; after finalize() `handle.t` is the [cols, rows] view, kept
@@ -91,7 +105,7 @@ class ParamStore(object):
         off = 0
         for p in self.params.values():
             p.offset = off
-            off += (p.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+            off += (p.numel + p.tail_pad + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = off
         self.device, self.compute_dtype = torch.device(device), compute_dtype
         host = torch.zeros(off, dtype=torch.float32)

@@ -222,7 +222,7 @@ class GradientReducer(object):
             return None
         start = min(p.offset for p in ps)
         last = max(ps, key=lambda p: p.offset)
-        end = last.offset + (last.numel + 7) // 8 * 8
+        end = last.offset + (last.numel + getattr(last, "tail_pad", 0) + 7) // 8 * 8
         return start, min(end, self.store.total)
 
     def _uncovered(self, start, end):
