@@ -269,7 +269,7 @@ class ParamStore(object):
         return sum(p.numel for p in self.params.values())
 
 
-_HWQ_NOTE = [None]
+_HWQ_NOTE = [None, None]     # (the line logged by the first call, the value of the variable behind it)
 
 
 def configure_training_process():
@@ -290,6 +290,8 @@ def configure_training_process():
     import logging
     import torch
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if _HWQ_NOTE[0] is not None and _HWQ_NOTE[1] == cur:
+        return _HWQ_NOTE[0]          # a repeated call (bench.py asks again for its JSON line): what the FIRST call did
     if cur is not None:
         note = f"GPU_MAX_HW_QUEUES={cur} (taken from the environment)"
     elif torch.cuda.is_initialized():
@@ -297,9 +299,8 @@ def configure_training_process():
     else:
         os.environ["GPU_MAX_HW_QUEUES"] = "1"
         note = "GPU_MAX_HW_QUEUES=1 (training default: one hardware queue per stream-priority class)"
-    if _HWQ_NOTE[0] != note:
-        logging.getLogger("neurst_amd").info(note)
-        _HWQ_NOTE[0] = note
+    logging.getLogger("neurst_amd").info(note)
+    _HWQ_NOTE[0], _HWQ_NOTE[1] = note, os.environ.get("GPU_MAX_HW_QUEUES")
     return note
 
 
