@@ -377,3 +377,84 @@ def test_weight_gradient_split_survives_the_library_rounding_and_pins_to_xcds():
     assert _wgrad_split(28800, 256, 2048, torch.bfloat16) == 8          # FFN: 32 tiles x 8 slices = one slice per XCD
     assert _wgrad_split(28800, 256, 768, torch.bfloat16) == 24
     assert _wgrad_split(28800, 5120, 256, torch.bfloat16, units=512) == 6
+
+
+def test_bench_autotune_picks_by_the_two_percent_rule_and_survives_bad_candidates(monkeypatch, tmp_path):
+    """bench.autotune (the N > 1 self-diagnosis VERDICT r4 item 4 asks for), with the child jobs replaced by canned outputs:
+    a crashed candidate and one that prints no JSON are recorded and skipped, a candidate must beat the default by more than
+    2 % to replace it, factors the caller fixed in the environment are not varied, the other ranks read rank 0's choice."""
+    import argparse
+    import json
+    import subprocess as sp
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+
+    for k in ("GPU_MAX_HW_QUEUES", "NCCL_MAX_NCHANNELS", "NST_DIST_NATIVE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_PORT", "45991")
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    args = argparse.Namespace(autotune_budget=200.0, dtype="bf16", model="speech_transformer_s", batch=8, frames=96, vocab=64,
+                              wire="bf16", graph=None, ragged=False, strong=False)
+    outputs = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            assert kw.get("start_new_session") is True and "WORLD_SIZE" not in env and env["NST_BENCH_CHILD"] == "1"
+            label = next(lb for lb, c in bench.AUTOTUNE_CANDIDATES if all(env.get(k) == v for k, v in c.items()))
+            self.out, self.returncode, self.pid = outputs[label], 0, 1
+
+        def communicate(self, timeout=None):
+            if isinstance(self.out, Exception):
+                raise self.out
+            return self.out, "trace\nlast line of stderr"
+
+    monkeypatch.setattr(sp, "Popen", FakeProc)
+    line = lambda ms: "noise\n" + json.dumps({"ms_per_step": ms, "exchange": {"exposed_ms": 0.1}}) + "\n"
+
+    # 1.5 % faster is noise: the default stays; the crashed / silent candidates are in the report with their reason
+    outputs.update(hwq1_ch16_torch=line(10.0), hwq2_ch16_torch=line(9.85), hwq1_ch32_torch="no json here\n",
+                   hwq1_ch16_native=OSError("spawn failed"))
+    rep = bench.autotune(args, 0, 2)
+    assert rep["chosen"] == "hwq1_ch16_torch" and os.environ["GPU_MAX_HW_QUEUES"] == "1"
+    by = {c["label"]: c for c in rep["candidates"]}
+    assert "no JSON line" in by["hwq1_ch32_torch"]["error"] and "last line of stderr" in by["hwq1_ch32_torch"]["error"]
+    assert by["hwq1_ch16_native"]["error"].startswith("OSError") and by["hwq2_ch16_torch"]["ms_per_step"] == 9.85
+    # another rank of the same launch reads the published choice
+    for k in rep["chosen_env"]:
+        monkeypatch.delenv(k, raising=False)
+    rep1 = bench.autotune(args, 1, 2)
+    assert rep1["chosen"] == rep["chosen"] and os.environ["NCCL_MAX_NCHANNELS"] == "16"
+
+    # 5 % faster wins
+    for k in rep["chosen_env"]:
+        monkeypatch.delenv(k, raising=False)
+    outputs.update(hwq2_ch16_torch=line(9.5), hwq1_ch32_torch=line(9.9), hwq1_ch16_native=line(10.4))
+    rep = bench.autotune(args, 0, 2)
+    assert rep["chosen"] == "hwq2_ch16_torch" and os.environ["GPU_MAX_HW_QUEUES"] == "2"
+
+    # a factor the caller fixed is not a factor: the hw-queue candidate collapses onto the default and is not run
+    for k in rep["chosen_env"]:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    outputs.clear()
+    outputs.update(hwq1_ch16_torch=line(10.0), hwq1_ch32_torch=line(9.0), hwq1_ch16_native=line(9.9))
+
+    class FakeProcFixed(FakeProc):
+        def __init__(self, cmd, env=None, **kw):
+            assert env["GPU_MAX_HW_QUEUES"] == "4"
+            label = next(lb for lb, c in bench.AUTOTUNE_CANDIDATES if lb in outputs and
+                         all(env.get(k) == v for k, v in c.items() if k != "GPU_MAX_HW_QUEUES"))
+            self.out, self.returncode, self.pid = outputs[label], 0, 1
+
+    monkeypatch.setattr(sp, "Popen", FakeProcFixed)
+    rep = bench.autotune(args, 0, 2)
+    assert [c["label"] for c in rep["candidates"]] == ["hwq1_ch16_torch", "hwq1_ch32_torch", "hwq1_ch16_native"]
+    assert rep["chosen"] == "hwq1_ch32_torch" and rep["fixed_by_caller"] == {"GPU_MAX_HW_QUEUES": "4"}
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4" and os.environ["NCCL_MAX_NCHANNELS"] == "32"
+    # no usable candidate at all: the defaults stay and the report says so
+    outputs.update(hwq1_ch16_torch="", hwq1_ch32_torch="", hwq1_ch16_native="")
+    for k in ("NCCL_MAX_NCHANNELS", "NST_DIST_NATIVE"):
+        monkeypatch.delenv(k, raising=False)
+    rep = bench.autotune(args, 0, 2)
+    assert rep["chosen"] is None and rep["chosen_env"] == {} and "NCCL_MAX_NCHANNELS" not in os.environ
