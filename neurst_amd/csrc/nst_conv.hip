@@ -366,85 +366,9 @@ __device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lan
   v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
   return v;
 }
-// ---------------------------------------------------------------------------------------------
-// Layer 1 forward, bf16 output, C == 256: TWO output pixels per wavefront pass (round 4).  The one-pixel-per-wave kernel at the
-// top of this file spends ~75 vector instructions per pixel, 16 of them the two all-lane reductions with their v_readlane
-// tails (423-495 us on the benchmark shape).  Here a half wave owns a pixel --
-// lane l: pixel 2 j + (l >> 5), channels 8 (l & 31) .. + 7 -- so one instruction stream serves two pixels: the 9-tap
-// products are the same 36 packed FMAs, a LayerNorm reduction is 4 DPP steps + one v_permlane16_swap for BOTH pixels and
-// leaves the sum in every lane, and a lane stores its 8 channels as one 16-byte piece.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4) conv1_fwd_pair_kernel(const float* __restrict__ src, const float* __restrict__ w1,
-                                                            const float* __restrict__ b1, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, bf16_t* __restrict__ out,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
-                                                            int T_, int F, int T1, int F1, int layer_norm, float eps) {
-  typedef floatx2_hw_t f2;
-  constexpr int C = 256;
-  __shared__ float xs_all[4][3][C1_MAXF + 2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5, c0 = (lane & 31) * 8;
-  float(*xs)[C1_MAXF + 2] = xs_all[wave];
-  f2 w[4][9], bias[4], g[4], be[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = c0 + 2 * q;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) w[q][t] = f2{w1[t * C + c], w1[t * C + c + 1]};
-    bias[q] = f2{b1[c], b1[c + 1]};
-    g[q] = layer_norm ? f2{gamma[c], gamma[c + 1]} : f2{1.f, 1.f};
-    be[q] = layer_norm ? f2{beta[c], beta[c + 1]} : f2{0.f, 0.f};
-  }
-  const int nrows = B * T1;
-  const float inv_c = 1.f / (float)C;
-  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
-    const int b = row / T1, to = row - b * T1;
-    c1_stage_rows(xs, src, b, to, T_, F, lane);
-    __builtin_amdgcn_wave_barrier();
-    for (int fo2 = 0; fo2 < F1; fo2 += 2) {
-      const int fo = fo2 + half;
-      const bool valid = fo < F1;
-      const int foc = valid ? fo : F1 - 1;   // (an odd F1: the second half repeats the last pixel and does not store)
-      f2 z[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) z[q] = bias[q];
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float xv = xs[kh][2 * foc + kw];
-          const f2 x2 = f2{xv, xv};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] = __builtin_elementwise_fma(w[q][kh * 3 + kw], x2, z[q]);
-        }
-      const int64_t pix = (int64_t)row * F1 + foc;
-      if (layer_norm) {
-        const f2 s2 = (z[0] + z[1]) + (z[2] + z[3]);
-        const float mean = c1_swap16_add(c1_row16_sum(s2.x + s2.y)) * inv_c;
-        const f2 m2 = f2{mean, mean};
-        f2 sq = f2{0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          z[q] = z[q] - m2;
-          sq = __builtin_elementwise_fma(z[q], z[q], sq);
-        }
-        const float rstd = rsqrtf(c1_swap16_add(c1_row16_sum(sq.x + sq.y)) * inv_c + eps);
-        const f2 r2 = f2{rstd, rstd};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[q] = __builtin_elementwise_fma(z[q] * r2, g[q], be[q]);
-        if ((lane & 31) == 0 && valid) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
-      }
-      if (valid) {
-        uint4 raw;
-        raw.x = pack_bf16x2(fmaxf(z[0].x, 0.f), fmaxf(z[0].y, 0.f));
-        raw.y = pack_bf16x2(fmaxf(z[1].x, 0.f), fmaxf(z[1].y, 0.f));
-        raw.z = pack_bf16x2(fmaxf(z[2].x, 0.f), fmaxf(z[2].y, 0.f));
-        raw.w = pack_bf16x2(fmaxf(z[3].x, 0.f), fmaxf(z[3].y, 0.f));
-        *reinterpret_cast<uint4*>(out + pix * C + c0) = raw;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+__device__ __forceinline__ uint32_t c1_relu_bf16x2(uint32_t w) {   // v_pk_max_i16: -0 and every negative value -> +0
+  typedef short c1_short2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(c1_short2_t, w), c1_short2_t{0, 0}));
 }
 
 __device__ __forceinline__ void c1_split_bf16(float x, bf16_t& hi, bf16_t& lo) {
@@ -869,6 +793,208 @@ __global__ void __launch_bounds__(WV * 64, WV == 8 ? 2 : 1) conv1_bwd_mfma_kerne
         else if (q == 9) atomicAdd(db1 + c, t);
         else atomicAdd((q == 10 ? dgamma : dbeta) + c, t);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer 1 forward on the matrix cores (round 5; bf16 output, C == 256).  Its predecessor (two pixels per wavefront pass on the
+// vector ALU: 36 packed FMAs for the taps + the LayerNorm per pair) took 340 us on the benchmark shape, twice the write time of
+// its 1.18 GB output; this one 245.  Here the
+// conv is product (1) of the backward kernel with the operands swapped: Z^T[channel, pixel] = W^T . P^T, so that a lane of the
+// 16 x 16 accumulator holds 4 CHANNELS of ONE pixel -- the LayerNorm sums are in-lane adds plus two lane swaps, and with the
+// channel rows of a pair of MFMAs interleaved (row g*4 + r of MFMA j = channel pb*32 + g*8 + j*4 + r) a lane ends up with 8
+// consecutive channels: one 16-byte store.  Same K-slot layout as the backward (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi for the nine
+// taps, 1*b_hi + 1*b_lo): the pre-norm activation agrees with the fp32 kernels to ~2^-16 relative and is what the backward
+// recomputes.  A wave owns 16 consecutive pixels per pass; the 16 weight fragments are shared through LDS.
+// ---------------------------------------------------------------------------------------------
+template <bool LN>
+__global__ void __launch_bounds__(256, 2) conv1_fwd_mfma_kernel(const float* __restrict__ src, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, int T_,
+                                                                int F, int T1, int F1, int64_t npix, FastDiv dF1, FastDiv dT1,
+                                                                float eps) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int C = 256;
+  __shared__ __attribute__((aligned(16))) float gb_s[2][C];   // gamma, beta
+  __shared__ __attribute__((aligned(16))) float pt_s[4][2][4][16][12];   // per wave: 2 blocks x 4 groups x 16 pixels: the 9 taps
+  __shared__ uint4 wf_s[17][64];                                   // the 16 weight fragments (A operands) + the sum fragment
+  __shared__ __attribute__((aligned(16))) char tr_s[4 * 16 * 528];   // per wave: the 16 output rows of a pass
+  float(*wsum_s)[C] = reinterpret_cast<float(*)[C]>(tr_s);   // prologue only: w1 | b1 rows, then their channel sums in column 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, lc = lane & 15;
+  for (int c = tid; c < C; c += 256) {
+    gb_s[0][c] = LN ? gamma[c] : 1.f;
+    gb_s[1][c] = LN ? beta[c] : 0.f;
+  }
+  // weight fragments: A operand of MFMA (pb, j), lane (g, lc): row lc = channel pb*32 + (lc>>2)*8 + j*4 + (lc&3); K slots of g.
+  // Fragment 16 holds the channel SUMS of the weights in every row: its product is 256 x the LayerNorm mean of the pixel, in
+  // all four accumulator registers of all four lanes of the pixel (no adds, no lane swaps).
+  for (int i = tid; i < 10 * C; i += 256) wsum_s[i / C][i % C] = i < 9 * C ? w1[i] : b1[i - 9 * C];
+  __syncthreads();
+  if (tid < 10) {
+    float t = 0.f;
+    for (int c = 0; c < C; ++c) t += wsum_s[tid][c];
+    wsum_s[tid][0] = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < 17 * 64; i += 256) {
+    const int m = i >> 6, l = i & 63, gg = l >> 4, ll = l & 15;
+    const int c = (m >> 1) * 32 + (ll >> 2) * 8 + (m & 1) * 4 + (ll & 3);
+    bf16_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float x = 0.f;
+      bool want_lo = false;
+      if (gg < 3) { x = m < 16 ? w1[k * C + c] : wsum_s[k][0]; want_lo = (gg == 1); }
+      else if (k < 3) { x = m < 16 ? w1[8 * C + c] : wsum_s[8][0]; want_lo = (k == 1); }
+      else if (k < 5) { x = m < 16 ? b1[c] : wsum_s[9][0]; want_lo = (k == 4); }
+      bf16_t hi, lo;
+      c1_split_bf16(x, hi, lo);
+      v[k] = want_lo ? lo : hi;
+    }
+    wf_s[m][l] = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16),
+                            v[6] | ((uint32_t)v[7] << 16));
+  }
+  __syncthreads();
+
+  const int64_t ngroups = (npix + 15) >> 4;
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  const int64_t first = (int64_t)blockIdx.x * 4 + wave;
+  // The taps are fetched a BLOCK of four groups at a time (lane quarter q gathers pixel lc of the block's group q: every lane
+  // works) and one to two blocks ahead: vector memory operations retire in order, so a wave that waits for a load also waits
+  // for every store it issued before that load -- with a look-ahead of one or two groups it sat on its own stores every pass
+  // (ablation: 184 us of arithmetic, + 43 with the stores, + 43 with the gather, + 178 with both).
+  struct Taps { float x[9]; };
+  auto gather = [&](int64_t blk) {   // groups first + (4 blk + q) gstride, q = lane >> 4
+    Taps q;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) q.x[t] = 0.f;
+    const int64_t grp_l = first + (4 * blk + g) * gstride;
+    const int64_t p = grp_l * 16 + lc;
+    if (grp_l < ngroups && p < npix) {
+      uint32_t row, fo, b, to;
+      dF1.divmod((uint32_t)p, row, fo);
+      dT1.divmod(row, b, to);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ti = 2 * (int)to + kh - 1;
+        if (ti >= 0 && ti < T_) {
+          const float* sp = src + ((int64_t)b * T_ + ti) * F;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int fi = 2 * (int)fo + kw - 1;
+            if (fi >= 0 && fi < F) q.x[kh * 3 + kw] = sp[fi];
+          }
+        }
+      }
+    }
+    return q;
+  };
+  auto write_taps = [&](const Taps& q, int buf) {   // table [buf][q][lc]
+    float* row = &pt_s[wave][buf][g][lc][0];
+    *reinterpret_cast<float4*>(row) = make_float4(q.x[0], q.x[1], q.x[2], q.x[3]);
+    *reinterpret_cast<float4*>(row + 4) = make_float4(q.x[4], q.x[5], q.x[6], q.x[7]);
+    row[8] = q.x[8];
+  };
+  const float inv_c = 1.f / (float)C;
+  Taps pend;
+  write_taps(gather(0), 0);
+  pend = gather(1);
+  int64_t n = 0;
+  for (int64_t grp = first; grp < ngroups; grp += gstride, ++n) {
+    const int64_t p0 = grp * 16;
+    const int blk = (int)(n >> 2), q4 = (int)(n & 3);
+    if (q4 == 0) {   // block blk starts: its tables are in buffer blk & 1; the next block's taps go into the other one
+      write_taps(pend, (blk + 1) & 1);
+      pend = gather(blk + 2);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tables are written
+    __builtin_amdgcn_wave_barrier();
+    const float(*pt)[12] = pt_s[wave][blk & 1][q4];
+    // ---- B operand: pixel lc, K slots of g (x_hi, x_hi, x_lo for taps 0..7; g = 3: tap 8 three times, the two ones of the bias)
+    bf16x8_t bfrag;
+    {
+      const float4 xa = *reinterpret_cast<const float4*>(&pt[lc][0]);
+      const float4 xb = *reinterpret_cast<const float4*>(&pt[lc][4]);
+      const float x8 = pt[lc][8];
+      const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+      bf16_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bf16_t hi, lo;
+        c1_split_bf16(xs[k], hi, lo);
+        v[k] = g == 2 ? lo : hi;
+      }
+      if (g == 3) {
+        bf16_t hi, lo;
+        c1_split_bf16(x8, hi, lo);
+        v[0] = hi; v[1] = hi; v[2] = lo; v[3] = 0x3F80; v[4] = 0x3F80; v[5] = 0; v[6] = 0; v[7] = 0;
+      }
+      union { uint32_t w[4]; bf16x8_t f; } pk;
+      pk.w[0] = v[0] | ((uint32_t)v[1] << 16); pk.w[1] = v[2] | ((uint32_t)v[3] << 16);
+      pk.w[2] = v[4] | ((uint32_t)v[5] << 16); pk.w[3] = v[6] | ((uint32_t)v[7] << 16);
+      bfrag = pk.f;
+    }
+
+    floatx4_t z[8][2];
+#pragma unroll
+    for (int pb = 0; pb < 8; ++pb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        z[pb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf_s[pb * 2 + j][lane]), bfrag, floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const int64_t pix = p0 + lc;
+    const bool valid = pix < npix;
+    f2 rs2 = f2{1.f, 1.f};
+    if (LN) {
+      const floatx4_t zs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf_s[16][lane]), bfrag,
+                                                                    floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const float mean = zs[0] * inv_c;
+      const f2 m2 = f2{mean, mean};
+      f2 sq = f2{0.f, 0.f};
+#pragma unroll
+      for (int pb = 0; pb < 8; ++pb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f2 d0 = f2{z[pb][j][0], z[pb][j][1]} - m2, d1 = f2{z[pb][j][2], z[pb][j][3]} - m2;
+          sq = __builtin_elementwise_fma(d0, d0, sq);
+          sq = __builtin_elementwise_fma(d1, d1, sq);
+          z[pb][j][0] = d0.x; z[pb][j][1] = d0.y; z[pb][j][2] = d1.x; z[pb][j][3] = d1.y;
+        }
+      const float rstd = rsqrtf(c1_swap32_add(c1_swap16_add(sq.x + sq.y)) * inv_c + eps);
+      rs2 = f2{rstd, rstd};
+      if (g == 0 && valid) { mean_out[pix] = mean; rstd_out[pix] = rstd; }
+    }
+    // ---- normalise, ReLU (on the packed bf16 pair: a negative bf16 is a negative int16), rows through LDS: a lane holds 16-byte
+    // pieces of ONE pixel, stored directly every instruction would write 64-byte pieces of 16 rows; through the (528-byte pitch)
+    // row buffer an instruction writes two whole 512-byte rows (- 25 us)
+    char* trw = tr_s + wave * (16 * 528) + lc * 528 + g * 16;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pb = 0; pb < 8; ++pb) {
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f2 y0 = f2{z[pb][j][0], z[pb][j][1]}, y1 = f2{z[pb][j][2], z[pb][j][3]};
+        if (LN) {
+          const float4 gv = *reinterpret_cast<const float4*>(&gb_s[0][pb * 32 + g * 8 + j * 4]);
+          const float4 bv = *reinterpret_cast<const float4*>(&gb_s[1][pb * 32 + g * 8 + j * 4]);
+          y0 = __builtin_elementwise_fma(y0 * rs2, f2{gv.x, gv.y}, f2{bv.x, bv.y});
+          y1 = __builtin_elementwise_fma(y1 * rs2, f2{gv.z, gv.w}, f2{bv.z, bv.w});
+        }
+        w[2 * j] = c1_relu_bf16x2(pack_bf16x2(y0.x, y0.y));
+        w[2 * j + 1] = c1_relu_bf16x2(pack_bf16x2(y1.x, y1.y));
+      }
+      *reinterpret_cast<uint4*>(trw + pb * 64) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int prow = 2 * i + (lane >> 5);
+      const uint4 v = *reinterpret_cast<const uint4*>(tr_s + wave * (16 * 528) + prow * 528 + (lane & 31) * 16);
+      if (p0 + prow < npix) *reinterpret_cast<uint4*>(out + (p0 + prow) * C + (lane & 31) * 8) = v;
     }
   }
 }
@@ -1912,6 +2038,12 @@ int conv2_wgrad_t(const void* x, const void* dy, float* dw2, float* db2, int B, 
   return 0;
 }
 
+int device_cu_count() {
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return cus > 0 ? cus : 256;
+}
+
 int check_conv_dims(const char* name, int B, int T, int F, int C) {
   NST_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0, "%s: bad dims B=%d T=%d F=%d C=%d", name, B, T, F, C);
   NST_CHECK_ARG((int64_t)B * T * F < ((int64_t)1 << 30) && (int64_t)9 * C < ((int64_t)1 << 24), "%s: problem too large for 32-bit row indices", name);
@@ -1938,8 +2070,17 @@ extern "C" int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const fl
   if (out_dtype == NST_F32) {
     if (vec) { if (C <= 256) NST_C1F(float, 4, true); else NST_C1F(float, 8, true); }
     else { if (C <= 256) NST_C1F(float, 4, false); else NST_C1F(float, 8, false); }
-  } else if (vec && C == 256) {   // 495 -> 410 us on the benchmark shape (2.9 TB/s of stores: what LayerNorm's write side reaches too)
-    conv1_fwd_pair_kernel<<<blocks, 256, 0, st>>>(src, w1, b1, gamma, beta, (bf16_t*)out, mean, rstd, B, T, F, T1, F1, layer_norm, eps);
+  } else if (vec && C == 256 && (int64_t)B * T1 * F1 < ((int64_t)1 << 31)) {   // the conv on the matrix cores (see the kernel)
+    const int64_t npix = (int64_t)B * T1 * F1;
+    FastDiv dF1, dT1;
+    dF1.init((uint32_t)F1);
+    dT1.init((uint32_t)T1);
+    const int64_t wgs = (((npix + 15) >> 4) + 3) / 4;
+    const int mb = (int)(wgs > 2 * device_cu_count() ? 2 * device_cu_count() : wgs);   // two workgroups per CU (77 KB of LDS each)
+    if (layer_norm)
+      conv1_fwd_mfma_kernel<true><<<mb, 256, 0, st>>>(src, w1, b1, gamma, beta, (bf16_t*)out, mean, rstd, T, F, T1, F1, npix, dF1, dT1, eps);
+    else
+      conv1_fwd_mfma_kernel<false><<<mb, 256, 0, st>>>(src, w1, b1, gamma, beta, (bf16_t*)out, mean, rstd, T, F, T1, F1, npix, dF1, dT1, eps);
   } else {
     if (vec) { if (C <= 256) NST_C1F(bf16_t, 4, true); else NST_C1F(bf16_t, 8, true); }
     else { if (C <= 256) NST_C1F(bf16_t, 4, false); else NST_C1F(bf16_t, 8, false); }

@@ -714,7 +714,7 @@ def _conv1_ref(src, w1, b1, gamma, beta, ln):
                                         # C = 256 takes the second (eight-wave, packed-f32) backward: without LayerNorm, and
                                         # with more 32-pixel groups (2500) than waves (2048: a wave re-stages its one tile buffer)
                                         (2, 37, 24, 256, False), (20, 200, 80, 256, True),
-                                        # an odd output width: the two-pixel forward's second half wave idles on the last pixel
+                                        # an odd output width, 462 pixels: the bf16 forward's 16-pixel groups straddle rows, the last is ragged
                                         (2, 21, 42, 256, True)])
 def test_conv1(K, dtype, B, T, F, C, ln):
     if B == 20 and dtype == torch.float32:
@@ -733,6 +733,13 @@ def test_conv1(K, dtype, B, T, F, C, ln):
     out, mean, rstd = K.conv1_ln_relu_fwd(dv(src), dv(w1), dv(b1), dv(gamma), dv(beta), ln, 1e-6, dtype)
     tag = f"conv1[{dtype},B{B}T{T}F{F}C{C}{'ln' if ln else ''}]"
     close(tag + ".out", out, ref, dtype)
+    if ln:   # the saved statistics are fp32 whatever the output type (the bf16 C = 256 forward computes the taps as hi/lo bf16
+        # products on the matrix cores: ~2^-16 relative per product)
+        pre = torch.nn.functional.conv2d(src.double()[:, None], w1.double().permute(3, 2, 0, 1), b1.double(), stride=2,
+                                         padding=1).permute(0, 2, 3, 1)
+        m_ref, v_ref = pre.mean(-1), pre.var(-1, unbiased=False)
+        assert (mean.cpu().double().reshape(m_ref.shape) - m_ref).abs().max() < 2e-5, tag
+        assert ((rstd.cpu().double().reshape(m_ref.shape) * (v_ref + 1e-6).sqrt()) - 1).abs().max() < 1e-4, tag
     dw1, db1 = torch.full((3, 3, 1, C), 5.0, device=DEV), torch.full((C,), 5.0, device=DEV)
     dg, dbe = torch.full((C,), 5.0, device=DEV), torch.full((C,), 5.0, device=DEV)
     K.conv1_ln_relu_bwd(dv(src), dv(w1), dv(b1), dv(gamma), dv(beta), mean, rstd, dv(dout), dw1, db1, dg, dbe, ln, 1e-6)
