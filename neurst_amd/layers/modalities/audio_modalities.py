@@ -78,7 +78,10 @@ class AudioConv2dSubsamplingLayer(Layer):
             dz = K.scale_dropout_bwd(dz.contiguous(), float(d) ** 0.5, 0.0)
         a2_2d = a2.view(B * T2, F2 * C)
         self._dense_layer.backward_params(a2_2d, dz)
-        self.rt.sublayer_boundary(force=True)   # (K = 5120 weight gradient next to the dgrad and the LayerNorm backward below)
+        # (K = 5120 weight gradient next to the dgrad and the LayerNorm backward below; its split-K reduce goes into the same
+        # weight-gradient graph -- flushed at the end of the backward pass it started behind the last compute-stream kernel)
+        self.rt.flush_wgrads()
+        self.rt.sublayer_boundary(force=True)
         if ln:
             da2 = self._dense_layer.backward_input(dz)
             acc = st.acc_flag(self.g2)
