@@ -239,7 +239,9 @@ int nst_attention_bwd(const NstAttnDesc* d, const void* q, const void* k, const 
  * AudioConv2dSubsamplingLayer.call  neurst/layers/modalities/audio_modalities.py:84-109.
  * Layer 1 (C_in = 1): pad 1 -> Conv2D 3x3 s2 VALID + bias -> LayerNorm(C, eps) -> ReLU, fused in one pass.
  *   src [B,T,F] dtype f32 (the feature tensor is always f32), w1 [3,3,1,C] f32 (HWIO), out [B,T1,F1,C] dtype.
- *   mean/rstd [B*T1*F1] f32 saved for backward (ignored / may be NULL when layer_norm==0). */
+ *   mean/rstd [B*T1*F1] f32 saved for backward (ignored / may be NULL when layer_norm==0).
+ *   bf16 output with C == 256: the taps run on the matrix cores as hi/lo bf16 splits of the f32 operands (x_hi*w_hi + x_hi*w_lo +
+ *   x_lo*w_hi: ~2^-16 relative to the f32 product, the same arithmetic nst_conv1_ln_relu_bwd recomputes); every other case f32 FMAs. */
 int nst_conv1_ln_relu_fwd(const float* src, const float* w1, const float* b1, const float* gamma,
                           const float* beta, void* out, float* mean, float* rstd, int B, int T, int F, int C,
                           int layer_norm, float eps, int out_dtype, void* stream);
