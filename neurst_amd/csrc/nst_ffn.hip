@@ -1078,6 +1078,29 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const TransposeJob*
   const TransposeJob q = jobs[j];
   const int t = blockIdx.x - q.tile0, tr = t / q.tiles_c, tc = t - tr * q.tiles_c;
   const int r0 = tr * 64, c0 = tc * 64;
+  // 16-byte global accesses when both shapes allow it (every weight matrix of the models does): 8 elements of a source row
+  // in, 8 elements of a destination row (= 8 source rows of one column, gathered from the tile) out; element-wise otherwise
+  const bool vec = ((q.rows | q.cols) & 7) == 0 && ((((uintptr_t)q.src) | ((uintptr_t)q.dst)) & 15) == 0;
+  if (vec) {
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int r = e >> 3, c = (e & 7) * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r0 + r < q.rows && c0 + c < q.cols) v = *reinterpret_cast<const uint4*>(q.src + (int64_t)(r0 + r) * q.cols + c0 + c);
+      uint32_t* t32 = reinterpret_cast<uint32_t*>(&tile[r][c]);   // (row pitch 132 bytes: 4-byte aligned)
+      t32[0] = v.x; t32[1] = v.y; t32[2] = v.z; t32[3] = v.w;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int c = e >> 3, r = (e & 7) * 8;
+      if (r0 + r < q.rows && c0 + c < q.cols) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)tile[r + 2 * i][c] | ((uint32_t)tile[r + 2 * i + 1][c] << 16);
+        *reinterpret_cast<uint4*>(q.dst + (int64_t)(c0 + c) * q.rows + r0 + r) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int r = e >> 6, c = e & 63;
     tile[r][c] = (r0 + r < q.rows && c0 + c < q.cols) ? q.src[(int64_t)(r0 + r) * q.cols + c0 + c] : (bf16_t)0;

@@ -340,6 +340,16 @@ class TrainStep(object):
         sc = _StepCapture(rt, cap.pool, stream, self._side_stream)
         if red is not None:
             red.capture_cut = sc.cut_for_bucket
+        # No destructor of a device object may run while the step is being captured: garbage left by earlier work (an older
+        # TrainStep's graphs, events, streams in reference cycles) is collected NOW, on an idle device, and the cyclic collector
+        # stays off until the capture has ended -- what torch.cuda.graph() does on entry; a collection that freed a captured
+        # graph of an earlier model in the middle of this capture aborted the process (seen when tests/test_gpu_graph.py ran
+        # behind tests/test_gpu_model.py in one interpreter).
+        import gc
+        torch.cuda.synchronize(rt.device)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         rt.capture = sc
         try:
             with torch.cuda.stream(stream):
@@ -350,6 +360,8 @@ class TrainStep(object):
                 cap.loss = loss
                 sc.finish()
         finally:
+            if gc_was_on:
+                gc.enable()
             rt.capture = None
             if red is not None:
                 red.capture_cut = None

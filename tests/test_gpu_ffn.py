@@ -205,6 +205,29 @@ def test_transposed_weight_copies_follow_the_optimizer():
     check()
 
 
+def test_transpose_launch_vector_and_elementwise_paths():
+    """nst_transpose_bf16 on a table of matrices: shapes with both sides a multiple of 8 take the 16-byte path (incl. tiles cut by
+    the matrix edge), anything else the element-wise one; bit-exact."""
+    import numpy as np
+    from neurst_amd import kernels as K
+    shapes = [(256, 2048), (2048, 256), (72, 200), (8, 8), (64, 64), (65, 130), (7, 24), (136, 9)]
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(r, c, generator=g).to(torch.bfloat16).to(DEV) for r, c in shapes]
+    dsts = [torch.full((c, r), 7.0, dtype=torch.bfloat16, device=DEV) for r, c in shapes]
+    rows, tiles = [], 0
+    for (r, c), a, b in zip(shapes, srcs, dsts):
+        tiles_c = (c + 63) // 64
+        rows.append((a.data_ptr(), b.data_ptr(), r, c, tiles_c, tiles))
+        tiles += ((r + 63) // 64) * tiles_c
+    arr = np.array(rows, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("tiles_c", "<i4"),
+                                         ("tile0", "<i4")]))
+    table = torch.from_numpy(arr.view(np.uint8).copy()).to(DEV)
+    K.transpose_bf16(table, len(shapes), tiles)
+    torch.cuda.synchronize()
+    for (r, c), a, b in zip(shapes, srcs, dsts):
+        assert torch.equal(b, a.t()), (r, c)
+
+
 def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
     """TransformerFFN inside the pre-norm wrapper: fused launch vs the two-GEMM composition, forward and backward, same
     dropout masks (both dropouts on)."""

@@ -206,3 +206,29 @@ def test_graph_replay_at_the_benchmark_configuration():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
     d = (we - wg).abs() * _solid(ve, 1e-4)
     assert float((d > 1e-3).float().mean()) < 1e-3, float(d.max())
+
+
+def test_capture_survives_garbage_of_an_earlier_captured_step():
+    """A captured step that has become garbage (reference cycle) must not be collected in the middle of the next capture: its
+    graphs' destructors ran inside the new capture and aborted the process (TrainStep._capture collects before it starts and
+    keeps the cyclic collector off until the capture has ended).  The collector's thresholds are set so low here that an
+    unprotected capture collects within its first few allocations."""
+    import gc
+    batches = [_batch(300 + i) for i in range(3)]
+    model, step, _ = _setup("bfloat16", 0.1, True)
+    for b in batches:
+        step(b)
+    torch.cuda.synchronize()
+    assert step.replays >= 1
+    cycle = [model, step]
+    cycle.append(cycle)          # garbage only the cyclic collector can free, holding the first step's graphs
+    del model, step, cycle
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        model2, step2, _ = _setup("bfloat16", 0.1, True, seed=12)
+        losses = [float(step2(b)) for b in batches]
+        torch.cuda.synchronize()
+    finally:
+        gc.set_threshold(*old)
+    assert gc.isenabled() and step2.replays >= 1 and all(l == l for l in losses)
