@@ -11,3 +11,6 @@ timeout 300 python bench.py --model speech_transformer_m --no-cpu-baseline --roo
 timeout 300 python scripts/bench_text.py --model transformer_base --batch 256 > $O/${T}_bench_text_transformer_base_bf16.json 2>/dev/null; tail -1 $O/${T}_bench_text_transformer_base_bf16.json | cut -c1-300
 timeout 300 python scripts/bench_text.py --model transformer_big --batch 256 > $O/${T}_bench_text_transformer_big_bf16.json 2>/dev/null; tail -1 $O/${T}_bench_text_transformer_big_bf16.json | cut -c1-300
 timeout 300 python scripts/bench_decode.py --graphs > $O/${T}_bench_decode_bf16.json 2>/dev/null; tail -1 $O/${T}_bench_decode_bf16.json | cut -c1-300
+# the exchange path over RCCL with ONE forced rank (both carriers): the line carries the per-step exchange timings (HIP events)
+NST_DIST_FORCE=1 NST_DIST_NATIVE=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 0 2>/dev/null | grep '^{' | tail -1 > $O/${T}_bench_forced_exchange.json; cut -c1-200 $O/${T}_bench_forced_exchange.json
+NST_DIST_FORCE=1 NST_DIST_NATIVE=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 0 2>/dev/null | grep '^{' | tail -1 > $O/${T}_bench_forced_exchange_native.json; cut -c1-200 $O/${T}_bench_forced_exchange_native.json
