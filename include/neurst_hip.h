@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NST_ABI_VERSION 9
+#define NST_ABI_VERSION 10
 
 enum { NST_F32 = 0, NST_BF16 = 1 };
 
@@ -326,6 +326,46 @@ int nst_layernorm_bwd_mixed(const void* dy, const void* x, int x_dtype, const fl
                             const float* rstd, const void* dres, void* dx, void* dz, float dropout_p, uint64_t seed,
                             uint64_t stream_id, float* dgamma, float* dbeta, int64_t rows, int d, int dtype, int accumulate,
                             void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out, void* stream);
+
+/* ------------------------------------------------------------------ whole-row products of the pre-norm wrapper (ABI 10)
+ * PrePostProcessingWrapper.call, neurst/layers/common_layers.py:73-85: inputs + dropout(layer(LayerNorm(inputs))).  With
+ * d_model = 256 a workgroup owns complete output rows, so the wrapper's row-wise stages run in the epilogue of the product
+ * that makes the row (bf16 operands, f32 accumulation; nst_rowgemm_supported says whether a shape qualifies: n = 256,
+ * k a multiple of 64).
+ *   A [rows, k] (lda);  W: trans_b == 0: [k, 256] (ldb) -- a dense kernel as stored, forward;  trans_b == 1: [256, k] (ldb) --
+ *   the same kernel read as the input-gradient operand (dX = dZ . W^T). */
+typedef struct NstRowGemmDesc {
+  int64_t rows;
+  int n, k;                 /* n must be 256 */
+  int trans_b;
+  int dtype;                /* NST_BF16 */
+  int64_t lda, ldb;
+  float dropout_p;          /* fwd: the wrapper's dropout on the product; bwd: the mask of the dz copy */
+  float eps;                /* fwd: LayerNorm epsilon */
+  uint64_t seed, stream_id; /* Philox key of that mask (element index row * 256 + col, as nst_gemm) */
+} NstRowGemmDesc;
+int nst_rowgemm_supported(int n, int k, int dtype);
+/* The LAST product of a sub-layer (attention output_transform, multi_head_attention.py:219; feed-forward dense2,
+ * common_layers.py:159) with the wrapper's dropout, the residual add and the NEXT wrapper's LayerNorm (common_layers.py:77) in
+ * its epilogue:  delta = bf16(dropout(A . W + bias));  x_out = x + delta (f32, nullable);  y = LayerNorm(x + delta; gamma,
+ * beta, eps) (bf16);  mean / rstd [rows] of the sum.  Equals nst_gemm (bias, dropout) followed by nst_add_layernorm_fwd. */
+int nst_gemm_add_layernorm_fwd(const NstRowGemmDesc* desc, const void* A, const void* W, const float* bias, const float* x,
+                               float* x_out, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                               void* stream);
+/* The FIRST product of a sub-layer's backward chain (input gradient of qkv_transform / q_transform / dense1: g = A . W is the
+ * gradient w.r.t. the LayerNorm output) with the LayerNorm backward in its epilogue:  dx = LayerNorm'(bf16(g); x, mean, rstd,
+ * gamma) + dres (bf16; dres nullable);  dz (nullable) = dx under the dropout mask of the desc;  dgamma / dbeta as in
+ * nst_layernorm_bwd_deferred (workspace >= ceil(rows / 32) * 2 * 256 * 4 bytes holds the per-workgroup partial sums; job_out
+ * NULL: finished by this call).  Equals nst_gemm followed by nst_layernorm_bwd_mixed. */
+int nst_gemm_layernorm_bwd(const NstRowGemmDesc* desc, const void* A, const void* W, const float* x, const float* gamma,
+                           const float* mean, const float* rstd, const void* dres, void* dx, void* dz, float* dgamma,
+                           float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
+                           void* stream);
+/* C [rows, 256] = bf16(A . W) and, with src / dst, dst[(b * 4 + h) * rows_per_batch + t] = sum over head h's 64 columns of
+ * C[b * rows_per_batch + t, .] o src[same] (f32): the attention output projection's input gradient together with the
+ * delta = rowsum(dO o O) its attention backward needs (nst_gemm's rowdot epilogue on whole rows). */
+int nst_gemm_rowdot256(const NstRowGemmDesc* desc, const void* A, const void* W, void* C, const void* src, float* dst,
+                       int rows_per_batch, void* stream);
 
 /* ------------------------------------------------------------------ target embedding
  * WordEmbeddingSharedWeights._bottom + PositionEmbeddingWrapper.call

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
-NST_ABI_VERSION = 9
+NST_ABI_VERSION = 10
 NST_COMM_F16, NST_COMM_U8 = 2, 3
 NST_COMM_UNIQUE_ID_BYTES = 128
 
@@ -51,6 +51,12 @@ class NstSplitkJob(C.Structure):
 class NstLnFinalizeJob(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("nblocks", C.c_int), ("d", C.c_int),
                 ("accumulate", C.c_int), ("reserved", C.c_int)]
+
+
+class NstRowGemmDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("n", C.c_int), ("k", C.c_int), ("trans_b", C.c_int), ("dtype", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("dropout_p", C.c_float), ("eps", C.c_float),
+                ("seed", C.c_uint64), ("stream_id", C.c_uint64)]
 
 
 class NstAttnDesc(C.Structure):
@@ -106,6 +112,10 @@ SIGNATURES = {
     "nst_layernorm_relu_bwd_regate": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
     "nst_add_layernorm_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "nst_layernorm_bwd_mixed": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P],
+    "nst_rowgemm_supported": [_I, _I, _I],
+    "nst_gemm_add_layernorm_fwd": [C.POINTER(NstRowGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nst_gemm_layernorm_bwd": [C.POINTER(NstRowGemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P],
+    "nst_gemm_rowdot256": [C.POINTER(NstRowGemmDesc), _P, _P, _P, _P, _P, _I, _P],
     "nst_gemm": [C.POINTER(NstGemmDesc), _P, _P, _P, _P],
     "nst_gemm_wgrad_group": [_P, _P, _P, _P, _I, _P, _L, _P],
     "nst_splitk_reduce_multi": [_P, _I, _P],

@@ -1,0 +1,554 @@
+// Whole-row GEMMs for d_model = 256 (bf16): out[M, 256] = A[M, K] . Bop, every workgroup owns BM COMPLETE output rows, so the
+// stages of the reference's pre-norm wrapper that need a whole row run in the epilogue of the product that makes the row
+// (neurst/layers/common_layers.py:73-85: inputs + dropout(layer(LayerNorm(inputs)))):
+//
+//   forward  (nst_gemm_add_layernorm_fwd): the LAST product of a sub-layer (attention output projection
+//            multi_head_attention.py:219, feed-forward dense2 common_layers.py:159)
+//               x_new = x + dropout(A . W + b)         the float32 residual stream, written once
+//               y     = LayerNorm(x_new; gamma, beta)  the NEXT wrapper's normalised input (bf16), mean / rstd saved
+//            instead of GEMM -> delta (bf16) -> nst_add_layernorm_fwd: delta never travels (29 MB per encoder sub-layer at the
+//            benchmark shape) and one launch disappears;
+//   backward (nst_gemm_layernorm_bwd): the FIRST product of the sub-layer's backward chain (qkv / q projection, dense1:
+//            g = dZ . W^T is the gradient w.r.t. the LayerNorm output)
+//               dx = LayerNorm'(g; x, mean, rstd, gamma) + dres      (+ dz = dropout-backward copy for the next sub-layer)
+//               partial sums of dgamma / dbeta per workgroup for the deferred finalize (nst_ln_finalize_multi)
+//            instead of GEMM -> g (bf16) -> nst_layernorm_bwd_mixed;
+//   rowdot   (nst_gemm_rowdot256): the attention output projection's input gradient d(context) = dZ . Wo^T together with
+//            delta[b, h, t] = sum over the head's 64 columns of d(context) o context for the attention backward.
+//
+// Structure: 256 threads = 4 waves, wave w owns output columns [64 w, 64 w + 64) of all BM rows (BM = 64 or 32; 64 rows keep
+// two workgroups on a CU: 2 x 80 KB of LDS).  K is walked in steps of 64 through two LDS stages filled by LDS-DMA
+// (global_load_lds_dwordx4; the stage images are the swizzled, unpadded ones of nst_gemm_core.h, so its fragment readers are
+// used unchanged: A [BM][64 k], the weights as two images of 128 output columns each).  The MFMAs run "transposed" (weights as
+// the A operand), so a lane ends up with 4 consecutive columns of one row and the accumulators go to an LDS tile
+// [BM][256] f32 with 16-byte writes.  Behind one barrier the waves change roles: wave w owns rows [w BM/4, (w+1) BM/4), 32
+// lanes per row, 8 consecutive columns per lane -- the access pattern of the wide LayerNorm kernels (nst_norm.hip), whole
+// 1 KB / 512-byte row segments per half wave, row reductions inside the half wave by DPP + lane-row swaps.
+#include "nst_gemm_core.h"
+
+using namespace nstgemm;
+
+namespace {
+
+constexpr int RN = 256;              // output columns = d_model
+constexpr int R_THREADS = 256;
+constexpr int TILE_LD = 260;         // floats per row of the epilogue tile (1040 bytes: 16-lane groups hit distinct banks)
+enum { EPI_LN_FWD = 0, EPI_LN_BWD = 1, EPI_ROWDOT = 2, EPI_PLAIN = 3 };
+
+struct RowArgs {
+  const bf16_t* A;       // [M, K], row stride lda
+  const bf16_t* W;       // OC: [K, 256] (ldb)   RC: [256, K] (ldb)
+  int64_t lda, ldb;
+  int M, K;
+  // forward
+  const float* bias;     // [256] or null
+  uint32_t drop_thresh;
+  float drop_inv_keep;
+  uint64_t seed, stream_id;
+  const uint64_t* seed_dev;
+  const float* x;        // fwd: the residual stream [M, 256] f32; bwd: the saved LayerNorm input (f32)
+  float* x_out;          // fwd: x + delta (nullable)
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int reserved0;
+  bf16_t* y;             // fwd: LayerNorm output; bwd: dx; rowdot / plain: C [M, 256]
+  float* mean;           // fwd: out; bwd: in
+  float* rstd;
+  // backward
+  const bf16_t* dres;    // [M, 256] or null
+  bf16_t* dz;            // [M, 256] or null: dx under the dropout mask (drop_thresh, drop_inv_keep, seed, stream_id)
+  float* partial;        // [gridDim.x][2][256]
+  // rowdot
+  const bf16_t* rd_src;  // [M, 256]
+  float* rd_dst;         // [(b * 4 + h) * T + t]
+  int rd_T;
+  int reserved1;
+};
+
+template <int BM>
+struct RowCfg {
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int STAGE = A_BYTES + 2 * 16384;
+  static constexpr int A_IPW = BM / 32;                 // DMA instructions per wave and K step for the A image
+  static constexpr int MI = BM / 16;
+  static constexpr int TILE_BYTES = BM * TILE_LD * 4;
+  static constexpr int RED_BYTES = 4 * 2 * RN * 4;
+  static constexpr int LDS = (2 * STAGE > TILE_BYTES + RED_BYTES) ? 2 * STAGE : TILE_BYTES + RED_BYTES;
+  static constexpr int RPW = BM / 4;                    // rows a wave owns in the row phase
+  static constexpr int PASSES = RPW / 2;                // two rows (32 lanes each) per pass
+};
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) -> LDS [lds_addr_uniform + lane * 16]
+__device__ __forceinline__ void rg_glds(const void* sbase, uint32_t voff, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 4\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr_uniform)
+      : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) unsigned rg_uint2_t;
+__device__ __forceinline__ float rg_swap16_add(float v) {
+  const rg_uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rg_swap32_add(float v) {
+  const rg_uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 32 lanes of a half wave (every lane of the half ends up with it)
+__device__ __forceinline__ float half_sum(float v) {
+  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+  return rg_swap16_add(v);
+}
+__device__ __forceinline__ void rg_load8_bf16(const bf16_t* __restrict__ p, float (&v)[8]) {
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+  v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+  v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+__device__ __forceinline__ void rg_load8_f32(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void rg_store8_bf16(bf16_t* __restrict__ p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                            pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void rg_store8_f32(float* __restrict__ p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <int BM, int BMODE, int EPI>
+__global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
+  typedef RowCfg<BM> C;
+  typedef SwzFrag<bf16_t, MODE_RC> RA;
+  typedef SwzFrag<bf16_t, BMODE> RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = a.M;
+  const int m0 = blockIdx.x * BM;
+  const int nk = a.K >> 6;
+
+  // ---------------------------------------------------------------- DMA source offsets (per lane, constant over K)
+  uint32_t voffA[C::A_IPW], voffB[8];
+#pragma unroll
+  for (int s = 0; s < C::A_IPW; ++s) {
+    const int c = (wave * C::A_IPW + s) * 64 + lane;
+    const int row = c >> 3, slot = c & 7;
+    const int kch = slot ^ ((row >> 1) & 7);
+    int rg = m0 + row;
+    rg = rg < M ? rg : M - 1;                 // rows past the end read the last row (their results are never stored)
+    voffA[s] = (uint32_t)((int64_t)(rg - m0) * a.lda * 2 + kch * 16);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int t = wave * 8 + s;               // 0 .. 31: image t >> 4, 1 KB piece t & 15 of it
+    const int h = t >> 4, c = (t & 15) * 64 + lane;
+    if (BMODE == MODE_RC) {
+      const int row = c >> 3, slot = c & 7;
+      const int kch = slot ^ ((row >> 1) & 7);
+      voffB[s] = (uint32_t)((int64_t)(128 * h + row) * a.ldb * 2 + kch * 16);
+    } else {
+      const int r = c >> 4, c16 = c & 15;
+      const int g = (r & 3) | (((r >> 3) & 1) << 2);
+      voffB[s] = (uint32_t)((int64_t)r * a.ldb * 2 + (128 * h + (c16 ^ (g << 1)) * 8) * 2);
+    }
+  }
+  const char* baseA = reinterpret_cast<const char*>(a.A) + ((int64_t)m0 * a.lda) * 2;
+  const char* baseB = reinterpret_cast<const char*>(a.W);
+  const int64_t stepB = BMODE == MODE_RC ? 128 : (int64_t)64 * a.ldb * 2;
+  auto issue = [&](int kt, int stage) {
+    const uint32_t sa = smem_addr + (uint32_t)stage * C::STAGE;
+    const char* pa = baseA + (int64_t)kt * 128;
+    const char* pb = baseB + (int64_t)kt * stepB;
+#pragma unroll
+    for (int s = 0; s < C::A_IPW; ++s) rg_glds(pa, voffA[s], sa + (uint32_t)(wave * C::A_IPW + s) * 1024u);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rg_glds(pb, voffB[s], sa + C::A_BYTES + (uint32_t)(wave * 8 + s) * 1024u);
+  };
+  issue(0, 0);
+
+  floatx4_t acc[C::MI][4];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---------------------------------------------------------------- main loop: two stages, one K step in flight
+  const int bimg = (wave >> 1) * 16384, wnl = (wave & 1) * 64;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* As = smem + (kt & 1) * C::STAGE;
+    const char* Bs = As + C::A_BYTES + bimg;
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 32) {
+      typename RA::Frag af[C::MI];
+      typename RB::Frag bf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = RB::read(Bs, wnl + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) af[i] = RA::read(As, i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights are the A operand
+    }
+  }
+  __builtin_amdgcn_s_barrier();      // every wave is done reading the stages: the tile reuses their LDS
+  asm volatile("" ::: "memory");
+
+  // ---------------------------------------------------------------- accumulators -> LDS tile [BM][256] f32
+  float* tile = reinterpret_cast<float*>(smem);
+  {
+    const int ml = lane & 15, nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const floatx4_t v = acc[i][j];
+        *reinterpret_cast<float4*>(tile + (i * 16 + ml) * TILE_LD + wave * 64 + j * 16 + nq) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- row phase: wave w owns rows [w RPW, +RPW), 32 lanes per row
+  const int sub = lane >> 5, li = lane & 31, col = li * 8;
+  uint64_t seed = a.seed;
+  if ((EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) && a.drop_thresh) seed = seed_with_offset(a.seed, a.seed_dev);   // wave-uniform
+  const float inv_d = 1.0f / (float)RN;
+
+  if constexpr (EPI == EPI_LN_FWD) {
+    float gm[8], bt[8], bs[8];
+    rg_load8_f32(a.gamma + col, gm);
+    rg_load8_f32(a.beta + col, bt);
+    if (a.bias) rg_load8_f32(a.bias + col, bs);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bs[j] = 0.f;
+    }
+#pragma unroll
+    for (int p0 = 0; p0 < C::PASSES; p0 += 2) {
+      float v[2][8], xr[2][8];
+      int rowg[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rl = wave * C::RPW + (p0 + u) * 2 + sub;
+        rowg[u] = m0 + rl;
+        ok[u] = rowg[u] < M;
+        const int rc = ok[u] ? rowg[u] : M - 1;
+        rg_load8_f32(a.x + (int64_t)rc * RN + col, xr[u]);
+        const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
+        const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
+        v[u][0] = t0.x + bs[0]; v[u][1] = t0.y + bs[1]; v[u][2] = t0.z + bs[2]; v[u][3] = t0.w + bs[3];
+        v[u][4] = t1.x + bs[4]; v[u][5] = t1.y + bs[5]; v[u][6] = t1.z + bs[6]; v[u][7] = t1.w + bs[7];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (a.drop_thresh) {
+          float m[8];
+          dropout_keep8(seed, a.stream_id, (uint64_t)rowg[u] * (uint64_t)RN + (uint64_t)col, a.drop_thresh, a.drop_inv_keep, m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] *= m[j];
+        }
+        // the sub-layer's contribution is rounded to bf16 before it joins the stream, as the unfused pair does
+        // (GEMM epilogue -> bf16 delta -> nst_add_layernorm_fwd): both paths then produce the same sum bit for bit
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = bf16_to_f32(f32_to_bf16(v[u][j])) + xr[u][j];
+        if (a.x_out && ok[u]) rg_store8_f32(a.x_out + (int64_t)rowg[u] * RN + col, v[u]);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[u][j];
+        const float mean = half_sum(s) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[u][j] - mean; sq += t * t; }
+        const float rstd = rsqrtf(half_sum(sq) * inv_d + a.eps);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[u][j] - mean) * rstd * gm[j] + bt[j];
+        if (ok[u]) {
+          rg_store8_bf16(a.y + (int64_t)rowg[u] * RN + col, o);
+          if (li == 0) { a.mean[rowg[u]] = mean; a.rstd[rowg[u]] = rstd; }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_LN_BWD) {
+    float gm[8], g_acc[8], b_acc[8];
+    rg_load8_f32(a.gamma + col, gm);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g_acc[j] = 0.f; b_acc[j] = 0.f; }
+#pragma unroll
+    for (int p0 = 0; p0 < C::PASSES; p0 += 2) {
+      float g[2][8], xv[2][8], rv[2][8], mu[2], rs[2];
+      int rowg[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rl = wave * C::RPW + (p0 + u) * 2 + sub;
+        rowg[u] = m0 + rl;
+        ok[u] = rowg[u] < M;
+        const int rc = ok[u] ? rowg[u] : M - 1;
+        rg_load8_f32(a.x + (int64_t)rc * RN + col, xv[u]);
+        if (a.dres) rg_load8_bf16(a.dres + (int64_t)rc * RN + col, rv[u]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rv[u][j] = 0.f;
+        }
+        mu[u] = a.mean[rc];
+        rs[u] = a.rstd[rc];
+        const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
+        const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
+        const float keep = ok[u] ? 1.f : 0.f;   // rows past the end add nothing to the column sums
+        g[u][0] = t0.x * keep; g[u][1] = t0.y * keep; g[u][2] = t0.z * keep; g[u][3] = t0.w * keep;
+        g[u][4] = t1.x * keep; g[u][5] = t1.y * keep; g[u][6] = t1.z * keep; g[u][7] = t1.w * keep;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float s1 = 0.f, s2 = 0.f, xh[8], dxh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // the product's output is rounded to bf16 first, as the unfused pair hands it over (GEMM -> bf16 -> LayerNorm backward)
+          const float gj = bf16_to_f32(f32_to_bf16(g[u][j]));
+          xh[j] = (xv[u][j] - mu[u]) * rs[u];
+          dxh[j] = gj * gm[j];
+          g_acc[j] += gj * xh[j];
+          b_acc[j] += gj;
+          s1 += dxh[j];
+          s2 += dxh[j] * xh[j];
+        }
+        const float c1 = half_sum(s1) * inv_d, c2 = half_sum(s2) * inv_d;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs[u] * (dxh[j] - c1 - xh[j] * c2) + rv[u][j];
+        if (ok[u]) {
+          const int64_t off = (int64_t)rowg[u] * RN + col;
+          rg_store8_bf16(a.y + off, o);
+          if (a.dz) {
+            float m[8];
+            dropout_keep8(seed, a.stream_id, (uint64_t)off, a.drop_thresh, a.drop_inv_keep, m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= m[j];
+            rg_store8_bf16(a.dz + off, o);
+          }
+        }
+      }
+    }
+    // column sums: the two half waves hold different rows of the same columns; then the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g_acc[j] = rg_swap32_add(g_acc[j]); b_acc[j] = rg_swap32_add(b_acc[j]); }
+    float* red = reinterpret_cast<float*>(smem + C::TILE_BYTES);
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * 2 + 0) * RN + col + j] = g_acc[j];
+        red[(wave * 2 + 1) * RN + col + j] = b_acc[j];
+      }
+    }
+    __syncthreads();
+    {
+      const int e = tid;   // 256 threads = 256 columns
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+        a.partial[((int64_t)blockIdx.x * 2 + pass) * RN + e] =
+            (red[(0 * 2 + pass) * RN + e] + red[(1 * 2 + pass) * RN + e]) + (red[(2 * 2 + pass) * RN + e] + red[(3 * 2 + pass) * RN + e]);
+    }
+  } else {
+    // EPI_ROWDOT / EPI_PLAIN: C = acc (+ bias) as bf16; rowdot: per head (64 columns = 8 lanes) sum of C (as stored) o src
+    float bs[8];
+    if (EPI == EPI_PLAIN && a.bias) rg_load8_f32(a.bias + col, bs);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bs[j] = 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < C::PASSES; ++p) {
+      const int rl = wave * C::RPW + p * 2 + sub;
+      const int rowg = m0 + rl;
+      const bool ok = rowg < M;
+      const int rc = ok ? rowg : M - 1;
+      const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
+      const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
+      float v[8] = {t0.x + bs[0], t0.y + bs[1], t0.z + bs[2], t0.w + bs[3], t1.x + bs[4], t1.y + bs[5], t1.z + bs[6], t1.w + bs[7]};
+      if (ok) rg_store8_bf16(a.y + (int64_t)rowg * RN + col, v);
+      if constexpr (EPI == EPI_ROWDOT) {
+        float sv[8];
+        rg_load8_bf16(a.rd_src + (int64_t)rc * RN + col, sv);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot = fmaf(bf16_to_f32(f32_to_bf16(v[j])), sv[j], dot);
+        dot = dpp_add(dot, 0); dot = dpp_add(dot, 1); dot = dpp_add(dot, 2);   // the 8 lanes of a head
+        if (ok && (li & 7) == 0) {
+          const int b = rowg / a.rd_T, t = rowg - b * a.rd_T;
+          a.rd_dst[((int64_t)b * 4 + (li >> 3)) * a.rd_T + t] = dot;
+        }
+      }
+    }
+  }
+}
+
+template <typename KernelT>
+void rg_allow_lds(KernelT kernel) {
+  static thread_local const void* done[32];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kernel) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (ndone < 32) done[ndone++] = (const void*)kernel;
+}
+
+// rows per workgroup: 64 while that still gives every CU a workgroup, else 32
+int rg_pick_bm(int64_t M) { return M >= 64 * 224 ? 64 : 32; }
+
+template <int BMODE, int EPI>
+int rg_launch(const RowArgs& a, hipStream_t st, int* nblocks_out) {
+  const int bm = rg_pick_bm(a.M);
+  if (bm == 64) {
+    auto k = rowgemm_kernel<64, BMODE, EPI>;
+    rg_allow_lds(k);
+    const int nb = (a.M + 63) / 64;
+    k<<<nb, R_THREADS, RowCfg<64>::LDS, st>>>(a);
+    if (nblocks_out) *nblocks_out = nb;
+  } else {
+    auto k = rowgemm_kernel<32, BMODE, EPI>;
+    rg_allow_lds(k);
+    const int nb = (a.M + 31) / 32;
+    k<<<nb, R_THREADS, RowCfg<32>::LDS, st>>>(a);
+    if (nblocks_out) *nblocks_out = nb;
+  }
+  return NST_OK;
+}
+
+int rg_check_common(const NstRowGemmDesc* d, const void* A, const void* W, const char* what) {
+  NST_CHECK_ARG(d && A && W, "%s: null pointer", what);
+  NST_CHECK_ARG(d->rows > 0 && d->rows < (1 << 30), "%s: rows=%lld", what, (long long)d->rows);
+  NST_CHECK_ARG(nst_rowgemm_supported(d->n, d->k, d->dtype), "%s: unsupported shape n=%d k=%d dtype=%d (n = 256, k %% 64 == 0, bf16)",
+                what, d->n, d->k, d->dtype);
+  NST_CHECK_ARG(d->lda >= d->k && d->lda % 8 == 0 && nst_aligned16(A), "%s: A needs 16-byte aligned rows (lda=%lld)", what, (long long)d->lda);
+  const int64_t ldb_min = d->trans_b ? d->k : d->n;
+  NST_CHECK_ARG(d->ldb >= ldb_min && d->ldb % 8 == 0 && nst_aligned16(W), "%s: W needs 16-byte aligned rows (ldb=%lld)", what, (long long)d->ldb);
+  NST_CHECK_ARG(d->lda * 2 * 64 < (1ll << 31) && d->ldb * 2 * 256 < (1ll << 31), "%s: leading dimensions exceed the 32-bit DMA offsets", what);
+  return NST_OK;
+}
+
+void rg_fill(RowArgs& a, const NstRowGemmDesc* d, const void* A, const void* W) {
+  memset(&a, 0, sizeof(a));
+  a.A = (const bf16_t*)A; a.W = (const bf16_t*)W;
+  a.lda = d->lda; a.ldb = d->ldb;
+  a.M = (int)d->rows; a.K = d->k;
+}
+
+}  // namespace
+
+extern "C" int nst_rowgemm_supported(int n, int k, int dtype) {
+  return (dtype == NST_BF16 && n == RN && k >= 64 && k % 64 == 0 && k <= 16384) ? 1 : 0;
+}
+
+extern "C" int nst_gemm_add_layernorm_fwd(const NstRowGemmDesc* d, const void* A, const void* W, const float* bias, const float* x,
+                                          float* x_out, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                          void* stream) {
+  if (d && d->rows == 0) return NST_OK;
+  int rc = rg_check_common(d, A, W, "gemm_add_layernorm_fwd");
+  if (rc != NST_OK) return rc;
+  NST_CHECK_ARG(x && gamma && beta && y && mean && rstd, "gemm_add_layernorm_fwd: null pointer");
+  NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(y) && nst_aligned16(gamma) && nst_aligned16(beta) && (!x_out || nst_aligned16(x_out)) &&
+                    (!bias || nst_aligned16(bias)),
+                "gemm_add_layernorm_fwd: operands must be 16-byte aligned");
+  NST_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm_add_layernorm_fwd: dropout_p=%f", d->dropout_p);
+  RowArgs a;
+  rg_fill(a, d, A, W);
+  a.bias = bias; a.x = x; a.x_out = x_out; a.gamma = gamma; a.beta = beta; a.eps = d->eps;
+  a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd;
+  nst_dropout_params16(d->dropout_p, &a.drop_thresh, &a.drop_inv_keep);
+  a.seed = d->seed; a.stream_id = d->stream_id;
+  a.seed_dev = nst_seed_offset_devptr();
+  if (!a.seed_dev) return NST_ERR_LAUNCH;
+  if (d->trans_b) rg_launch<MODE_RC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
+  else rg_launch<MODE_OC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
+  NST_CHECK_LAUNCH("gemm_add_layernorm_fwd");
+  return NST_OK;
+}
+
+extern "C" int nst_gemm_layernorm_bwd(const NstRowGemmDesc* d, const void* A, const void* W, const float* x, const float* gamma,
+                                      const float* mean, const float* rstd, const void* dres, void* dx, void* dz, float* dgamma,
+                                      float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes,
+                                      NstLnFinalizeJob* job_out, void* stream) {
+  if (job_out) memset(job_out, 0, sizeof(*job_out));
+  if (d && d->rows == 0) return NST_OK;
+  int rc = rg_check_common(d, A, W, "gemm_layernorm_bwd");
+  if (rc != NST_OK) return rc;
+  NST_CHECK_ARG(x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "gemm_layernorm_bwd: null pointer");
+  NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(dx) && nst_aligned16(gamma) && (!dres || nst_aligned16(dres)) && (!dz || nst_aligned16(dz)) &&
+                    (((uintptr_t)workspace) & 15) == 0,
+                "gemm_layernorm_bwd: operands must be 16-byte aligned");
+  NST_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm_layernorm_bwd: dropout_p=%f", d->dropout_p);
+  const int bm = rg_pick_bm(d->rows);
+  const int64_t nb = (d->rows + bm - 1) / bm;
+  if (workspace_bytes < nb * 2 * RN * 4) {
+    nst_set_error("gemm_layernorm_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)(nb * 2 * RN * 4));
+    return NST_ERR_WORKSPACE;
+  }
+  RowArgs a;
+  rg_fill(a, d, A, W);
+  a.x = x; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+  a.dres = (const bf16_t*)dres; a.y = (bf16_t*)dx; a.dz = (bf16_t*)dz; a.partial = (float*)workspace;
+  if (dz) {
+    nst_dropout_params16(d->dropout_p, &a.drop_thresh, &a.drop_inv_keep);
+    a.seed = d->seed; a.stream_id = d->stream_id;
+  }
+  a.seed_dev = nst_seed_offset_devptr();
+  if (!a.seed_dev) return NST_ERR_LAUNCH;
+  int nblocks = 0;
+  if (d->trans_b) rg_launch<MODE_RC, EPI_LN_BWD>(a, (hipStream_t)stream, &nblocks);
+  else rg_launch<MODE_OC, EPI_LN_BWD>(a, (hipStream_t)stream, &nblocks);
+  NST_CHECK_LAUNCH("gemm_layernorm_bwd");
+  NstLnFinalizeJob job;
+  memset(&job, 0, sizeof(job));
+  job.partial = (const float*)workspace; job.dgamma = dgamma; job.dbeta = dbeta;
+  job.nblocks = nblocks; job.d = RN; job.accumulate = accumulate;
+  if (job_out) {
+    *job_out = job;
+    return NST_OK;
+  }
+  return nst_ln_finalize_multi(&job, 1, stream);
+}
+
+extern "C" int nst_gemm_rowdot256(const NstRowGemmDesc* d, const void* A, const void* W, void* C_, const void* src, float* dst,
+                                  int rows_per_batch, void* stream) {
+  if (d && d->rows == 0) return NST_OK;
+  int rc = rg_check_common(d, A, W, "gemm_rowdot256");
+  if (rc != NST_OK) return rc;
+  NST_CHECK_ARG(C_ && nst_aligned16(C_), "gemm_rowdot256: C must be 16-byte aligned");
+  NST_CHECK_ARG((src == nullptr) == (dst == nullptr), "gemm_rowdot256: src and dst come together");
+  NST_CHECK_ARG(!src || (nst_aligned16(src) && rows_per_batch > 0 && d->rows % rows_per_batch == 0),
+                "gemm_rowdot256: rows=%lld is not a multiple of rows_per_batch=%d", (long long)d->rows, rows_per_batch);
+  RowArgs a;
+  rg_fill(a, d, A, W);
+  a.y = (bf16_t*)C_;
+  a.rd_src = (const bf16_t*)src; a.rd_dst = dst; a.rd_T = rows_per_batch;
+  if (src) {
+    if (d->trans_b) rg_launch<MODE_RC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);
+    else rg_launch<MODE_OC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);
+  } else {
+    if (d->trans_b) rg_launch<MODE_RC, EPI_PLAIN>(a, (hipStream_t)stream, nullptr);
+    else rg_launch<MODE_OC, EPI_PLAIN>(a, (hipStream_t)stream, nullptr);
+  }
+  NST_CHECK_LAUNCH("gemm_rowdot256");
+  return NST_OK;
+}

@@ -9,8 +9,8 @@ import os
 
 import torch
 
-from neurst_amd._lib import (NST_BF16, NST_F32, NstAttnDesc, NstFfnDesc, NstGemmDesc, NstLnFinalizeJob, NstSplitkJob, check,
-                             lib)
+from neurst_amd._lib import (NST_BF16, NST_F32, NstAttnDesc, NstFfnDesc, NstGemmDesc, NstLnFinalizeJob, NstRowGemmDesc, NstSplitkJob,
+                             check, lib)
 
 FLOAT_MIN = -1.0e9  # neurst/utils/compat.py:24
 
@@ -427,6 +427,89 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, out=None, out_dtype=None, 
         nbytes = (M * K + K * N) * esz + M * N * osz * (2 if accumulate else 1)
         nbytes += M * N * osz * ((residual is not None) + (gate_src is not None))
         PROBE.end(ev, 2.0 * M * N * K, nbytes)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ whole-row products (d_model 256)
+def rowgemm_supported(A, n, k):
+    """Whether the whole-row products exist for A [rows, k] -> [rows, n] (nst_rowgemm_supported: bf16, n = 256, k % 64 == 0)."""
+    return (A.dtype == torch.bfloat16 and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) % 8 == 0 and A.data_ptr() % 16 == 0
+            and A.shape[0] > 0 and bool(lib.nst_rowgemm_supported(int(n), int(k), NST_BF16)))
+
+
+def _rowgemm_desc(A, W, trans_b, dropout_p=0.0, seed=0, stream_id=0, eps=0.0):
+    rows, k = A.shape
+    assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.bfloat16 and A.dtype == torch.bfloat16 and A.stride(1) == 1
+    n = W.shape[0] if trans_b else W.shape[1]
+    assert (W.shape[1] if trans_b else W.shape[0]) == k, f"rowgemm operand shapes {tuple(A.shape)} x {tuple(W.shape)} trans_b={trans_b}"
+    d = NstRowGemmDesc()
+    d.rows, d.n, d.k, d.trans_b, d.dtype = rows, n, k, int(bool(trans_b)), NST_BF16
+    d.lda, d.ldb = A.stride(0), W.stride(0)
+    d.dropout_p, d.eps, d.seed, d.stream_id = float(dropout_p), float(eps), int(seed), int(stream_id)
+    return d, rows, n, k
+
+
+def gemm_add_layernorm_fwd(A, W, x, gamma, beta, eps, bias=None, trans_b=False, dropout_p=0.0, seed=0, stream_id=0, want_sum=True):
+    """nst_gemm_add_layernorm_fwd: delta = bf16(dropout(A @ W + bias)); xs = x + delta (f32); y = LayerNorm(xs) (bf16).
+    A [rows, k] bf16, W [k, 256] (or [256, k] with trans_b), x [rows, 256] f32 -> (y, xs | None, mean, rstd): what
+    gemm(.., bias, dropout) followed by add_layernorm_fwd returns, in one launch."""
+    d, rows, n, k = _rowgemm_desc(A, W, trans_b, dropout_p, seed, stream_id, eps)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == rows * n
+    y = torch.empty(rows, n, dtype=torch.bfloat16, device=A.device)
+    xs = torch.empty(rows, n, dtype=torch.float32, device=A.device) if want_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=A.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=A.device)
+    ev = PROBE.begin("gemm_rows")
+    check(lib.nst_gemm_add_layernorm_fwd(C.byref(d), _p(A), _p(W), _p(bias), _p(x), _p(xs), _p(gamma), _p(beta), _p(y), _p(mean),
+                                         _p(rstd), _stream()), "gemm_add_layernorm_fwd")
+    if ev is not None:
+        PROBE.end(ev, 2.0 * rows * n * k, (rows * k + k * n) * 2 + rows * n * (4 + 2 + (4 if want_sum else 0)))
+    return y, xs, mean, rstd
+
+
+def gemm_layernorm_bwd(A, W, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, emit_dropout=None, batch=None,
+                       trans_b=True):
+    """nst_gemm_layernorm_bwd: g = bf16(A @ W^T) (trans_b: W is the dense kernel [256, k] as stored), then exactly
+    layernorm_bwd(g, x, ...) with the f32 saved input: dx (+ dres), optionally (dx, dz) with emit_dropout=(p, seed, site);
+    dgamma / dbeta finished here or by the batch's next flush."""
+    d, rows, n, k = _rowgemm_desc(A, W, trans_b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == rows * n
+    assert dres is None or (dres.is_contiguous() and dres.dtype == torch.bfloat16 and dres.numel() == rows * n)
+    dx = torch.empty(rows, n, dtype=torch.bfloat16, device=A.device)
+    dz = None
+    if emit_dropout is not None:
+        d.dropout_p, d.seed, d.stream_id = float(emit_dropout[0]), int(emit_dropout[1]), int(emit_dropout[2])
+        dz = torch.empty_like(dx)
+    slot = batch.ln_slot(n) if batch is not None else None
+    if slot is not None:
+        ws_ptr, ws_bytes, job = slot
+    else:
+        ws = _workspace(64 << 20, A.device)
+        ws_ptr, ws_bytes, job = ws.data_ptr(), ws.numel(), None
+    ev = PROBE.begin("gemm_rows")
+    check(lib.nst_gemm_layernorm_bwd(C.byref(d), _p(A), _p(W), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dz),
+                                     _p(dgamma), _p(dbeta), int(accumulate), ws_ptr, ws_bytes, job, _stream()),
+          "gemm_layernorm_bwd")
+    if ev is not None:
+        PROBE.end(ev, 2.0 * rows * n * k, (rows * k + k * n) * 2 + rows * n * (4 + 2 + 2 * (dres is not None) + 2 * (dz is not None)))
+    return (dx, dz) if emit_dropout is not None else dx
+
+
+def gemm_rowdot256(A, W, rowdot=None, trans_b=True):
+    """nst_gemm_rowdot256: C [rows, 256] = bf16(A @ W^T); rowdot=(src [rows, 256] bf16, dst f32 [rows/T, 4, T], T) also leaves
+    the per-head row sums of C o src (the attention backward's delta)."""
+    d, rows, n, k = _rowgemm_desc(A, W, trans_b)
+    out = torch.empty(rows, n, dtype=torch.bfloat16, device=A.device)
+    src = dst = None
+    T = 0
+    if rowdot is not None:
+        src, dst, T = rowdot
+        assert src.dtype == torch.bfloat16 and src.is_contiguous() and src.numel() == rows * n
+        assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == rows * (n // 64)
+    ev = PROBE.begin("gemm_rows")
+    check(lib.nst_gemm_rowdot256(C.byref(d), _p(A), _p(W), _p(out), _p(src), _p(dst), int(T), _stream()), "gemm_rowdot256")
+    if ev is not None:
+        PROBE.end(ev, 2.0 * rows * n * k, (rows * k + k * n) * 2 + rows * n * (2 + 2 * (src is not None)))
     return out
 
 

@@ -101,7 +101,7 @@ class MultiHeadAttention(Layer):
             return self.output_transform.backward_input(dz, rowdot=(ctx2, delta, Tq)), delta
         return self.output_transform.backward_input(dz), None
 
-    def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None):
+    def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None, ln_bwd=None):
         """Returns d(query) (+ residual, post-norm wrapper); d(memory) is written (or accumulated) into `dmemory`
         [B*Tk, d]."""
         query, memory, q, kv, ctx, (lse, dmask), bias, B, Tq, Tk, p, lag = self._saved
@@ -122,7 +122,7 @@ class MultiHeadAttention(Layer):
         self.kv_transform.backward_params(memory, dkv)
         if dmemory is not None and not grouped:
             self.kv_transform.backward_input(dkv, out=dmemory, accumulate=dmemory_accumulate)
-        return self.q_transform.backward_input(dq, **({} if residual is None else {"residual": residual}))
+        return self.q_transform.backward_input(dq, ln_bwd=ln_bwd, **({} if residual is None else {"residual": residual}))
 
 
 class MultiHeadSelfAttention(MultiHeadAttention):
@@ -164,7 +164,7 @@ class MultiHeadSelfAttention(MultiHeadAttention):
             self._saved = (x, qkv, ctx, (lse, dmask), bias, causal, B, T, p)
         return out
 
-    def backward(self, dz, residual=None):
+    def backward(self, dz, residual=None, ln_bwd=None):
         x, qkv, ctx, (lse, dmask), bias, causal, B, T, p = self._saved
         self._saved = None
         d, H, dh = self.num_units, self.num_heads, self.dh
@@ -176,4 +176,4 @@ class MultiHeadSelfAttention(MultiHeadAttention):
                         g3[..., d:2 * d], g3[..., 2 * d:], H, dh, key_bias=bias, causal=causal, dropout_p=p,
                         seed=self.rt.step_seed, stream_id=self.site, drop_mask=dmask, delta=delta)
         self.qkv_transform.backward_params(x, dqkv)
-        return self.qkv_transform.backward_input(dqkv, **({} if residual is None else {"residual": residual}))
+        return self.qkv_transform.backward_input(dqkv, ln_bwd=ln_bwd, **({} if residual is None else {"residual": residual}))

@@ -97,6 +97,64 @@ class ResidualStream(object):
         return bool(pre_norm) and K.add_layernorm_supported(dim, rt.dtype)
 
 
+_ROW_FUSION = True     # whole-row products carry the wrapper's LayerNorm stages in their epilogue (tests pin the unfused pairs with False)
+
+
+class DeferredDelta(object):
+    """The LAST product of a sub-layer (attention output projection, feed-forward dense2) that has not been launched: it waits
+    for the LayerNorm that consumes the residual stream next, because nst_gemm_add_layernorm_fwd runs the product, the wrapper's
+    dropout, the residual add and that LayerNorm in ONE launch (the bf16 `delta` then never travels).  Stands where
+    ResidualStream.delta stands; `plain()` launches the product on its own (the pair it replaces) where the fused kernel cannot
+    take the call (a bf16 stream in front of the first sub-layer of a stack)."""
+    __slots__ = ("A", "dense", "epi")
+
+    def __init__(self, A, dense, epi):
+        self.A, self.dense, self.epi = A, dense, epi
+
+    def plain(self):
+        return self.dense.forward(self.A, **self.epi)
+
+    def fused(self, x, gamma, beta, eps, want_sum):
+        d, e = self.dense, self.epi
+        return K.gemm_add_layernorm_fwd(self.A, d.kernel.compute, x, gamma, beta, eps, bias=None if d.bias is None else d.bias.data,
+                                        dropout_p=e.get("dropout_p", 0.0), seed=e.get("seed", 0), stream_id=e.get("stream_id", 0),
+                                        want_sum=want_sum)
+
+
+class LnBackward(object):
+    """The LayerNorm backward of a pre-norm wrapper, offered to the wrapped layer's backward: the layer's last input-gradient
+    product (N = d_model = 256: q / qkv projection, dense1) then runs it in its epilogue (nst_gemm_layernorm_bwd) and `done` tells
+    the wrapper that what came back is already d(inputs)."""
+    __slots__ = ("norm", "dres", "consumer", "done")
+
+    def __init__(self, norm, dres, consumer):
+        self.norm, self.dres, self.consumer, self.done = norm, dres, consumer, False
+
+    def eligible(self):
+        saved = getattr(self.norm, "_saved", None)
+        return saved is not None and saved[0].dtype == torch.float32 and saved[0].is_contiguous() \
+            and self.dres.dtype == torch.bfloat16 and self.dres.is_contiguous()
+
+    def run(self, dz, kernel):
+        """dz [rows, out] bf16, kernel [256, out] as stored: d(inputs) = LayerNorm'(dz . kernel^T) + dres."""
+        norm, rt = self.norm, self.norm.rt
+        x, mean, rstd = norm._saved
+        norm._saved = None
+        st = rt.store
+        acc = st.acc_flag(norm.gamma)
+        st.acc_flag(norm.beta)
+        p = self.consumer.drop_rate() if self.consumer is not None else 0.0
+        emit = (p, rt.step_seed, self.consumer.site) if p > 0 else None
+        out = K.gemm_layernorm_bwd(dz, kernel, x, norm.gamma.data, mean, rstd, norm.gamma.grad, norm.beta.grad, accumulate=acc,
+                                   dres=self.dres, emit_dropout=emit, batch=rt.wgrad_batch(), trans_b=True)
+        self.done = True
+        if emit is not None:
+            dx, dzz = out
+            dx._nst_dropped = (self.consumer.site, dzz)
+            return dx
+        return out
+
+
 class LayerNorm(Layer):
     """tf.keras.layers.LayerNormalization(epsilon, dtype=float32): variables <name>/gamma, <name>/beta."""
 
@@ -117,7 +175,17 @@ class LayerNorm(Layer):
         The backward normalises the saved sum again (nst_layernorm_bwd_mixed reads it as f32)."""
         if stream.delta is None:
             return self.forward(stream.x, save=save), None
-        y, xs, mean, rstd = K.add_layernorm_fwd(stream.x, stream.delta, self.gamma.data, self.beta.data, self.eps,
+        delta = stream.delta
+        if isinstance(delta, DeferredDelta):
+            if stream.x.dtype == torch.float32 and stream.x.is_contiguous():
+                y, xs, mean, rstd = delta.fused(stream.x, self.gamma.data, self.beta.data, self.eps, want_sum or save)
+                xs = None if xs is None else xs.view(stream.x.shape)
+                y = y.view(stream.x.shape)
+                if save:
+                    self._saved = (xs, mean, rstd)
+                return y, xs
+            delta = delta.plain()
+        y, xs, mean, rstd = K.add_layernorm_fwd(stream.x, delta, self.gamma.data, self.beta.data, self.eps,
                                                 want_sum=want_sum or save)
         if save:
             self._saved = (xs, mean, rstd)
@@ -164,7 +232,12 @@ class Dense(Layer):
         self.wgrad_units = None   # workgroups the weight gradient is cut into (None: _WGRAD_UNITS)
         self.wgrad_grouped = True  # the weight gradient may wait for the stack's grouped launch (Runtime.wgrad_group)
 
-    def forward(self, x, **epi):
+    def forward(self, x, defer_ln=False, **epi):
+        """defer_ln (the pre-norm wrapper's float32 residual stream): the product is handed back unlaunched (DeferredDelta) when
+        the whole-row kernel can run it together with the next LayerNorm."""
+        if defer_ln and _ROW_FUSION and x.dim() == 2 and not (set(epi) - {"dropout_p", "seed", "stream_id"}) \
+                and K.rowgemm_supported(x, self.out_dim, self.in_dim):
+            return DeferredDelta(x, self, epi)
         return K.gemm(x, self.kernel.compute, x.shape[0], self.out_dim, self.in_dim,
                       bias=None if self.bias is None else self.bias.data, **epi)
 
@@ -191,8 +264,11 @@ class Dense(Layer):
             split_k=_wgrad_split(rows, self.in_dim, self.out_dim, x.dtype, self.wgrad_units), batch=self.rt.wgrad_batch(),
             **bias_kw), x, dz)
 
-    def backward_input(self, dz, **epi):
-        """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy)."""
+    def backward_input(self, dz, ln_bwd=None, **epi):
+        """dx = dz @ kernel^T  (kernel [in,out] read as the [N,K] operand: no transpose copy).
+        ln_bwd (LnBackward): the wrapper's LayerNorm backward rides in the epilogue when the whole-row kernel takes the product."""
+        if ln_bwd is not None and _ROW_FUSION and not epi and K.rowgemm_supported(dz, self.in_dim, self.out_dim) and ln_bwd.eligible():
+            return ln_bwd.run(dz, self.kernel.compute)
         return K.gemm(dz, self.kernel.compute, dz.shape[0], self.in_dim, self.out_dim, trans_b=True, **epi)
 
 
@@ -230,7 +306,8 @@ class TransformerFFN(Layer):
 
     def forward(self, x, is_training, epilogue=None):
         p = self.rate if is_training else 0.0
-        epi = epilogue or {}
+        epi = dict(epilogue or {})
+        defer_ln = epi.pop("defer_ln", False)
         use_fused = self.fused and x.shape[0] >= _FFN_FUSED_MIN_ROWS and x.is_contiguous() \
             and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"})
         if use_fused:
@@ -241,13 +318,14 @@ class TransformerFFN(Layer):
         else:
             bits = None
             h = self.dense1.forward(x, relu=True, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
-            y = self.dense2.forward(h, **epi)
+            y = self.dense2.forward(h, defer_ln=defer_ln, **epi)
         if is_training:
             self._saved = (x, h, p, bits)
         return y
 
-    def backward(self, dz, residual=None):
-        """residual (post-norm wrapper): added to the returned input gradient in the last GEMM's epilogue."""
+    def backward(self, dz, residual=None, ln_bwd=None):
+        """residual (post-norm wrapper): added to the returned input gradient in the last GEMM's epilogue.
+        ln_bwd (pre-norm wrapper, LnBackward): its LayerNorm backward may ride on dense1's input gradient (two-GEMM path)."""
         x, h, p, bits = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
@@ -258,7 +336,7 @@ class TransformerFFN(Layer):
             return dx
         dh = self.dense2.backward_input(dz, gate_src=h, gate_scale=K.dropout_inv_keep(p))
         self.dense1.backward_params(x, dh)
-        return self.dense1.backward_input(dh, **({} if residual is None else {"residual": residual}))
+        return self.dense1.backward_input(dh, ln_bwd=ln_bwd, **({} if residual is None else {"residual": residual}))
 
 
 class PrePostProcessingWrapper(Layer):
@@ -284,7 +362,7 @@ class PrePostProcessingWrapper(Layer):
             assert self.pre_norm
             y, xs = self.norm.forward_stream(x, save=is_training)
             delta = self.layer.forward(y, is_training=is_training,
-                                       epilogue=dict(dropout_p=p, seed=self.rt.step_seed, stream_id=self.site), **kwargs)
+                                       epilogue=dict(dropout_p=p, seed=self.rt.step_seed, stream_id=self.site, defer_ln=True), **kwargs)
             return ResidualStream(x.x if xs is None else xs, delta)
         epi = dict(residual=x, dropout_p=p, seed=self.rt.step_seed, stream_id=self.site)
         if not self.pre_norm:
@@ -306,8 +384,11 @@ class PrePostProcessingWrapper(Layer):
             self.rt.sublayer_boundary()
             return out
         dz = dropped_grad(self.rt, dy, self._p, self.site)
-        dn = self.layer.backward(dz)
+        ln = LnBackward(self.norm, dy, consumer) if _ROW_FUSION else None
+        dn = self.layer.backward(dz, ln_bwd=ln) if ln is not None and ln.eligible() else self.layer.backward(dz)
         self.rt.sublayer_boundary()
+        if ln is not None and ln.done:      # the layer's last input-gradient product carried the LayerNorm backward
+            return dn
         return self.norm.backward(dn, dres=dy, consumer=consumer)
 
 

@@ -50,8 +50,9 @@ class _CrossAttentionAdapter(object):
         return self.att.forward(y, memory, B, Tq, Tk, memory_bias=memory_bias, is_training=is_training,
                                 epilogue=epilogue, cache=cache, lagging=lagging)
 
-    def backward(self, dz, residual=None):
-        return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate, residual=residual)
+    def backward(self, dz, residual=None, ln_bwd=None):
+        return self.att.backward(dz, dmemory=self.dmemory, dmemory_accumulate=self.dmemory_accumulate, residual=residual,
+                                 ln_bwd=ln_bwd)
 
 
 class TransformerDecoderLayer(Layer):

@@ -155,6 +155,43 @@ _SEED_OFFSET = [0]      # the scalar in use: a one-element list, rebound by drop
 _SEED_OWN = _SEED_OFFSET
 
 
+# ---------------------------------------------------------------------------------------------------- whole-row products
+def rowgemm_supported(A, n, k):
+    return A.dtype == torch.bfloat16 and A.dim() == 2 and A.stride(1) == 1 and A.shape[0] > 0 and n == 256 and k % 64 == 0 and k >= 64
+
+
+def gemm_add_layernorm_fwd(A, W, x, gamma, beta, eps, bias=None, trans_b=False, dropout_p=0.0, seed=0, stream_id=0, want_sum=True):
+    """nst_gemm_add_layernorm_fwd = nst_gemm (bias, dropout, bf16 output) followed by nst_add_layernorm_fwd."""
+    rows, k = A.shape
+    n = W.shape[0] if trans_b else W.shape[1]
+    assert rowgemm_supported(A, n, k) and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == rows * n
+    delta = gemm(A, W, rows, n, k, trans_b=trans_b, bias=bias, dropout_p=dropout_p, seed=seed, stream_id=stream_id)
+    return add_layernorm_fwd(x.reshape(rows, n), delta, gamma, beta, eps, want_sum=want_sum)
+
+
+def gemm_layernorm_bwd(A, W, x, gamma, mean, rstd, dgamma, dbeta, accumulate=False, dres=None, emit_dropout=None, batch=None,
+                       trans_b=True):
+    """nst_gemm_layernorm_bwd = nst_gemm (bf16 output) followed by nst_layernorm_bwd_mixed."""
+    rows, k = A.shape
+    n = W.shape[0] if trans_b else W.shape[1]
+    assert rowgemm_supported(A, n, k) and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == rows * n
+    g = gemm(A, W, rows, n, k, trans_b=trans_b)
+    return layernorm_bwd(g, x.reshape(rows, n), gamma, mean, rstd, dgamma, dbeta, accumulate=accumulate,
+                         dres=None if dres is None else dres.reshape(rows, n), emit_dropout=emit_dropout, batch=batch)
+
+
+def gemm_rowdot256(A, W, rowdot=None, trans_b=True):
+    rows, k = A.shape
+    n = W.shape[0] if trans_b else W.shape[1]
+    assert rowgemm_supported(A, n, k)
+    out = gemm(A, W, rows, n, k, trans_b=trans_b)
+    if rowdot is not None:
+        src, dst, T = rowdot
+        prod = (out.to(F64) * src.reshape(rows, n).to(F64)).reshape(rows // T, T, n // 64, 64).sum(-1)   # [B, T, H]
+        dst.copy_(prod.permute(0, 2, 1).reshape(dst.shape).float())
+    return out
+
+
 def dropout_seed_offset_bind(scalar):
     """On the CPU tier the bound scalar is the runtime's 1-element int64 tensor (or None for the library's own)."""
     global _SEED_OFFSET
@@ -521,7 +558,8 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "add_layernorm_fwd", "add_layernorm_
           "embedding_bwd", "scale_posenc_dropout_fwd", "scale_dropout_bwd", "ls_xent_fwd", "ls_xent_bwd", "adam_update",
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
           "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi",
-          "gemm_wgrad_group", "seq_mask", "xent_reduce"]
+          "gemm_wgrad_group", "seq_mask", "xent_reduce", "rowgemm_supported", "gemm_add_layernorm_fwd", "gemm_layernorm_bwd",
+          "gemm_rowdot256"]
 
 
 def seq_mask(lengths, max_len, on_token, on_padding, halvings=0, stride=2):

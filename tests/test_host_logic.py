@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, s), f"{s} declared in include/neurst_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 9
+    assert _lib.lib.nst_abi_version() == _lib.NST_ABI_VERSION == 10
     out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (nst_[a-z0-9_]+)", out))
     assert exported == set(syms)

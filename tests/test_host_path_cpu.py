@@ -54,6 +54,7 @@ def _speech_model(case, dropout=0.0, **extra):
     cases = {  # d, H, enc, dec, ffn, C, B, T, F, L, V, ragged
         "toy": (8, 2, 2, 2, 10, 5, 2, 11, 80, 3, 5, False),
         "small": (32, 2, 2, 2, 64, 8, 3, 38, 16, 9, 50, True),
+        "row": (256, 4, 2, 2, 128, 8, 2, 22, 16, 5, 40, True),      # d_model 256: the whole-row products take their calls
     }
     d, H, ne, nd, ffn, C, B, T, F, L, V, ragged = cases[case]
     from neurst_amd.models import build_model
@@ -1050,6 +1051,42 @@ def test_fused_feed_forward_host_wiring_matches_the_two_gemm_schedule(cpu_kernel
         assert float((y1 - y0).abs().max()) <= 2e-2 * float(y0.abs().max())
         assert float((dx1 - dx0).abs().max()) <= 2e-2 * float(dx0.abs().max())
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-2
+
+
+def test_whole_row_products_host_wiring_matches_the_unfused_pairs(cpu_kernels, monkeypatch):
+    """bf16, d_model 256: the last product of a sub-layer waits for the next LayerNorm (DeferredDelta ->
+    nst_gemm_add_layernorm_fwd) and the first input-gradient product of a sub-layer's backward carries that LayerNorm's backward
+    (LnBackward -> nst_gemm_layernorm_bwd).  Over the emulated kernels -- where a fused entry IS the composition of the pair it
+    replaces -- logits, loss and the flat gradient buffer must equal the unfused schedule's bit for bit, with every dropout on;
+    and the fused entries must have taken every call they can take (all but the first sub-layer of each stack, whose stream is
+    still the bf16 embedding output)."""
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    outs, calls = [], {}
+    for fused in (True, False):
+        monkeypatch.setattr("neurst_amd.layers.common_layers._ROW_FUSION", fused)
+        n = {"fwd": 0, "bwd": 0}
+        real_f, real_b = K.gemm_add_layernorm_fwd, K.gemm_layernorm_bwd
+        monkeypatch.setattr(K, "gemm_add_layernorm_fwd", lambda *a, _r=real_f, _n=n, **k: (_n.__setitem__("fwd", _n["fwd"] + 1), _r(*a, **k))[1])
+        monkeypatch.setattr(K, "gemm_layernorm_bwd", lambda *a, _r=real_b, _n=n, **k: (_n.__setitem__("bwd", _n["bwd"] + 1), _r(*a, **k))[1])
+        model, cfg, shape = _speech_model("row", dropout=0.1, dtype="bfloat16")
+        inputs = _speech_inputs(shape)
+        logits = model(inputs, is_training=True)
+        loss = crit.reduce_loss(inputs, logits)
+        model.backward(crit.backward())
+        outs.append((logits.double().clone(), float(loss), model.store.grad.clone()))
+        calls[fused] = dict(n)
+        monkeypatch.setattr(K, "gemm_add_layernorm_fwd", real_f)
+        monkeypatch.setattr(K, "gemm_layernorm_bwd", real_b)
+        # evaluation forward (no dropout, nothing saved) goes the same way
+        ev = model(inputs, is_training=False)
+        outs[-1] += (ev.double().clone(),)
+    # 2 encoder layers x 2 sub-layers + 2 decoder layers x 3 sub-layers, minus the first sub-layer of each stack
+    assert calls[True] == {"fwd": 8, "bwd": 8} and calls[False] == {"fwd": 0, "bwd": 0}, calls
+    (l1, s1, g1, e1), (l0, s0, g0, e0) = outs
+    assert torch.equal(l1, l0) and s1 == s0 and torch.equal(e1, e0)
+    assert torch.equal(g1, g0)
 
 
 def test_dynamic_loss_scale_skips_overflow_steps_and_follows_the_reference_schedule(cpu_kernels):
