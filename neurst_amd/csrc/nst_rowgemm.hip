@@ -26,6 +26,10 @@
 // 1 KB / 512-byte row segments per half wave, row reductions inside the half wave by DPP + lane-row swaps.
 #include "nst_gemm_core.h"
 
+#include <stdlib.h>
+
+#include <utility>
+
 using namespace nstgemm;
 
 namespace {
@@ -66,15 +70,17 @@ struct RowArgs {
   int reserved1;
 };
 
-template <int BM>
+template <int BM, int NST>
 struct RowCfg {
   static constexpr int A_BYTES = BM * 128;
   static constexpr int STAGE = A_BYTES + 2 * 16384;
   static constexpr int A_IPW = BM / 32;                 // DMA instructions per wave and K step for the A image
+  static constexpr int IPW = A_IPW + 8;                 // ... for the whole stage
   static constexpr int MI = BM / 16;
   static constexpr int TILE_BYTES = BM * TILE_LD * 4;
   static constexpr int RED_BYTES = 4 * 2 * RN * 4;
-  static constexpr int LDS = (2 * STAGE > TILE_BYTES + RED_BYTES) ? 2 * STAGE : TILE_BYTES + RED_BYTES;
+  static constexpr int LDS = (NST * STAGE > TILE_BYTES + RED_BYTES) ? NST * STAGE : TILE_BYTES + RED_BYTES;
+  static_assert(NST >= 2 && NST <= 4 && (NST - 2) * IPW < 64, "stage ring depth");
   static constexpr int RPW = BM / 4;                    // rows a wave owns in the row phase
   static constexpr int PASSES = RPW / 2;                // two rows (32 lanes each) per pass
 };
@@ -85,7 +91,7 @@ __device__ __forceinline__ void rg_glds(const void* sbase, uint32_t voff, uint32
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %3\n\t"
-      "s_nop 4\n\t"
+      "s_nop 1\n\t"
       "global_load_lds_dwordx4 %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
@@ -127,9 +133,9 @@ __device__ __forceinline__ void rg_store8_f32(float* __restrict__ p, const float
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-template <int BM, int BMODE, int EPI>
+template <int BM, int NST, int BMODE, int EPI>
 __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
-  typedef RowCfg<BM> C;
+  typedef RowCfg<BM, NST> C;
   typedef SwzFrag<bf16_t, MODE_RC> RA;
   typedef SwzFrag<bf16_t, BMODE> RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,7 +184,22 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) rg_glds(pb, voffB[s], sa + C::A_BYTES + (uint32_t)(wave * 8 + s) * 1024u);
   };
-  issue(0, 0);
+  // The f32 rows the row phase adds (forward) / normalises again (backward) are requested FIRST, in the row phase's own lane
+  // layout: their HBM latency and transfer then run under the whole K loop instead of behind it (vmcnt retires in issue order,
+  // so the first K step waits for them once -- every later wait finds them landed).
+  const int sub = lane >> 5, li = lane & 31, col = li * 8;
+  float xpre[(EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) ? C::PASSES : 1][8];
+  if constexpr (EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) {
+#pragma unroll
+    for (int p = 0; p < C::PASSES; ++p) {
+      int rowg = m0 + wave * C::RPW + p * 2 + sub;
+      rowg = rowg < M ? rowg : M - 1;
+      rg_load8_f32(a.x + (int64_t)rowg * RN + col, xpre[p]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s, s);
 
   floatx4_t acc[C::MI][4];
 #pragma unroll
@@ -186,29 +207,63 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-  // ---------------------------------------------------------------- main loop: two stages, one K step in flight
+  // ---------------------------------------------------------------- main loop: ring of NST stages, NST - 1 K steps in flight
+  // One K step = a stream of 8 MI MFMA positions (two halves of 32 k: column block j outer, row block i inner).  The IPW DMA
+  // instructions that refill the ring are spread over the positions, ONE behind an MFMA at a time: issued back to back in
+  // front of the step they keep the wave out of the matrix core for their whole issue time (call 3 of round 6: the K = 768 /
+  // 2048 products ran at 36 - 49 GB/s of DMA per CU where the same ring without MFMAs moves 70 - 117).
   const int bimg = (wave >> 1) * 16384, wnl = (wave & 1) * 64;
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+  int stage = 0, stage_in = NST - 1;     // stage being multiplied / stage the next issue fills
+  constexpr int NPOS = 8 * C::MI;
+  auto kstep = [&](auto has_next_tag, int kt) {
+    constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+    // K step kt has landed; the (up to NST - 2) younger steps stay in flight: a COUNTED wait, never a drain
+    const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+    if (NST == 2 || ahead <= 0) wait_vmcnt<0>();
+    else if (NST == 3 || ahead == 1) wait_vmcnt<C::IPW>();
+    else wait_vmcnt<(NST > 3 ? 2 : 1) * C::IPW>();
+    __builtin_amdgcn_s_barrier();      // ... for every wave, and every wave is done reading the stage the next issue fills
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const char* As = smem + (kt & 1) * C::STAGE;
+    const uint32_t sa = smem_addr + (uint32_t)stage_in * C::STAGE;
+    const char* pa = baseA + (int64_t)(kt + NST - 1) * 128;
+    const char* pb = baseB + (int64_t)(kt + NST - 1) * stepB;
+    stage_in = stage_in + 1 == NST ? 0 : stage_in + 1;
+    const char* As = smem + stage * C::STAGE;
+    stage = stage + 1 == NST ? 0 : stage + 1;
     const char* Bs = As + C::A_BYTES + bimg;
+    typename RA::Frag af[2][C::MI];
+    typename RB::Frag bf[2][4];
 #pragma unroll
-    for (int kk = 0; kk < 64; kk += 32) {
-      typename RA::Frag af[C::MI];
-      typename RB::Frag bf[4];
+    for (int j = 0; j < 4; ++j) bf[0][j] = RB::read(Bs, wnl + j * 16, 0, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = RB::read(Bs, wnl + j * 16, kk, lane);
+    for (int i = 0; i < C::MI; ++i) af[0][i] = RA::read(As, i * 16, 0, lane);
+    [&]<int... PP>(std::integer_sequence<int, PP...>) {
+      ([&] {
+        constexpr int P = PP;
+        if constexpr (P == 1) {   // the second half's fragments: requested behind the first MFMA, they land under the first half
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) af[i] = RA::read(As, i * 16, kk, lane);
+          for (int j = 0; j < 4; ++j) bf[1][j] = RB::read(Bs, wnl + j * 16, 32, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < C::MI; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights are the A operand
-    }
+          for (int i = 0; i < C::MI; ++i) af[1][i] = RA::read(As, i * 16, 32, lane);
+        }
+        constexpr int half = P / (4 * C::MI), j = (P % (4 * C::MI)) / C::MI, i = P % C::MI;
+        constexpr int d = (P * C::IPW) / NPOS;
+        constexpr bool DMA_HERE = HAS_NEXT && (P == 0 || d != ((P - 1) * C::IPW) / NPOS);
+        // (the DMA is inline asm: the scheduler would otherwise sink all of them behind the step's MFMAs -- seen in the ISA)
+        if constexpr (DMA_HERE) __builtin_amdgcn_sched_barrier(0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[half][j], af[half][i], acc[i][j], 0, 0, 0);   // D[n][m]: weights are the A operand
+        if constexpr (DMA_HERE) {
+          if constexpr (d < C::A_IPW) rg_glds(pa, voffA[d], sa + (uint32_t)(wave * C::A_IPW + d) * 1024u);
+          else rg_glds(pb, voffB[d - C::A_IPW], sa + C::A_BYTES + (uint32_t)(wave * 8 + (d - C::A_IPW)) * 1024u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, NPOS>());
+  };
+  {
+    int kt = 0;
+    for (; kt + NST - 1 < nk; ++kt) kstep(std::true_type(), kt);
+    for (; kt < nk; ++kt) kstep(std::false_type(), kt);
   }
   __builtin_amdgcn_s_barrier();      // every wave is done reading the stages: the tile reuses their LDS
   asm volatile("" ::: "memory");
@@ -228,7 +283,6 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
   __syncthreads();
 
   // ---------------------------------------------------------------- row phase: wave w owns rows [w RPW, +RPW), 32 lanes per row
-  const int sub = lane >> 5, li = lane & 31, col = li * 8;
   uint64_t seed = a.seed;
   if ((EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) && a.drop_thresh) seed = seed_with_offset(a.seed, a.seed_dev);   // wave-uniform
   const float inv_d = 1.0f / (float)RN;
@@ -252,8 +306,8 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
         const int rl = wave * C::RPW + (p0 + u) * 2 + sub;
         rowg[u] = m0 + rl;
         ok[u] = rowg[u] < M;
-        const int rc = ok[u] ? rowg[u] : M - 1;
-        rg_load8_f32(a.x + (int64_t)rc * RN + col, xr[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[u][j] = xpre[p0 + u][j];
         const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
         const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
         v[u][0] = t0.x + bs[0]; v[u][1] = t0.y + bs[1]; v[u][2] = t0.z + bs[2]; v[u][3] = t0.w + bs[3];
@@ -305,7 +359,8 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
         rowg[u] = m0 + rl;
         ok[u] = rowg[u] < M;
         const int rc = ok[u] ? rowg[u] : M - 1;
-        rg_load8_f32(a.x + (int64_t)rc * RN + col, xv[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[u][j] = xpre[p0 + u][j];
         if (a.dres) rg_load8_bf16(a.dres + (int64_t)rc * RN + col, rv[u]);
         else {
 #pragma unroll
@@ -413,24 +468,45 @@ void rg_allow_lds(KernelT kernel) {
   if (ndone < 32) done[ndone++] = (const void*)kernel;
 }
 
-// rows per workgroup: 64 while that still gives every CU a workgroup, else 32
-int rg_pick_bm(int64_t M) { return M >= 64 * 224 ? 64 : 32; }
+// (rows per workgroup, stages): 64 rows while that still gives every CU a workgroup, else 32; two stages (two workgroups per CU)
+// for the short reductions, a deeper ring (one workgroup per CU, more bytes in flight) for the long ones.
+// NST_ROWGEMM_CFG="<rows>,<stages>" overrides (benchmarks).
+struct RgCfg { int bm, nst; };
+RgCfg rg_pick(int64_t M, int K) {
+  static int forced_bm = -1, forced_nst = 0;
+  if (forced_bm < 0) {
+    forced_bm = 0;
+    const char* e = getenv("NST_ROWGEMM_CFG");
+    if (e) sscanf(e, "%d,%d", &forced_bm, &forced_nst);
+  }
+  RgCfg c;
+  c.bm = M >= 64 * 224 ? 64 : 32;
+  c.nst = 2;      // (deeper rings at one workgroup per CU lost to two stages at two workgroups per CU for every shape: call 3 of round 6)
+  if (forced_bm == 64 || forced_bm == 32) c.bm = forced_bm;
+  if (forced_nst >= 2 && forced_nst <= 4) c.nst = forced_nst;
+  if (c.bm == 64 && c.nst == 4) c.nst = 3;   // (64 rows x 4 stages would not fit the LDS)
+  return c;
+}
+
+template <int BM, int NST, int BMODE, int EPI>
+void rg_launch_one(const RowArgs& a, hipStream_t st, int* nblocks_out) {
+  auto k = rowgemm_kernel<BM, NST, BMODE, EPI>;
+  rg_allow_lds(k);
+  const int nb = (a.M + BM - 1) / BM;
+  k<<<nb, R_THREADS, RowCfg<BM, NST>::LDS, st>>>(a);
+  if (nblocks_out) *nblocks_out = nb;
+}
 
 template <int BMODE, int EPI>
 int rg_launch(const RowArgs& a, hipStream_t st, int* nblocks_out) {
-  const int bm = rg_pick_bm(a.M);
-  if (bm == 64) {
-    auto k = rowgemm_kernel<64, BMODE, EPI>;
-    rg_allow_lds(k);
-    const int nb = (a.M + 63) / 64;
-    k<<<nb, R_THREADS, RowCfg<64>::LDS, st>>>(a);
-    if (nblocks_out) *nblocks_out = nb;
+  const RgCfg c = rg_pick(a.M, a.K);
+  if (c.bm == 64) {
+    if (c.nst == 2) rg_launch_one<64, 2, BMODE, EPI>(a, st, nblocks_out);
+    else rg_launch_one<64, 3, BMODE, EPI>(a, st, nblocks_out);
   } else {
-    auto k = rowgemm_kernel<32, BMODE, EPI>;
-    rg_allow_lds(k);
-    const int nb = (a.M + 31) / 32;
-    k<<<nb, R_THREADS, RowCfg<32>::LDS, st>>>(a);
-    if (nblocks_out) *nblocks_out = nb;
+    if (c.nst == 2) rg_launch_one<32, 2, BMODE, EPI>(a, st, nblocks_out);
+    else if (c.nst == 3) rg_launch_one<32, 3, BMODE, EPI>(a, st, nblocks_out);
+    else rg_launch_one<32, 4, BMODE, EPI>(a, st, nblocks_out);
   }
   return NST_OK;
 }
@@ -498,7 +574,7 @@ extern "C" int nst_gemm_layernorm_bwd(const NstRowGemmDesc* d, const void* A, co
                     (((uintptr_t)workspace) & 15) == 0,
                 "gemm_layernorm_bwd: operands must be 16-byte aligned");
   NST_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm_layernorm_bwd: dropout_p=%f", d->dropout_p);
-  const int bm = rg_pick_bm(d->rows);
+  const int bm = rg_pick(d->rows, d->k).bm;
   const int64_t nb = (d->rows + bm - 1) / bm;
   if (workspace_bytes < nb * 2 * RN * 4) {
     nst_set_error("gemm_layernorm_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)(nb * 2 * RN * 4));

@@ -97,7 +97,8 @@ class ResidualStream(object):
         return bool(pre_norm) and K.add_layernorm_supported(dim, rt.dtype)
 
 
-_ROW_FUSION = True     # whole-row products carry the wrapper's LayerNorm stages in their epilogue (tests pin the unfused pairs with False)
+# whole-row products carry the wrapper's LayerNorm stages in their epilogue (tests and A/B runs pin the unfused pairs: NST_ROW_FUSION=0)
+_ROW_FUSION = os.environ.get("NST_ROW_FUSION", "1") != "0"
 
 
 class DeferredDelta(object):

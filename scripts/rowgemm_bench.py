@@ -18,15 +18,21 @@ DEV = "cuda:0"
 
 
 def timeit(fn, inner=20, reps=7):
+    """median microseconds per call: `inner` calls captured into one HIP graph (no host time between the launches), replayed."""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     out = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(inner):
-            fn()
+        g.replay()
         b.record()
         torch.cuda.synchronize()
         out.append(a.elapsed_time(b) * 1000.0 / inner)
@@ -79,6 +85,7 @@ def main():
                 res[key + "_plain_rows_us"] = timeit(lambda: K.gemm_rowdot256(A, Wf, trans_b=False))
                 res[key + "_plain_stream_us"] = timeit(lambda: K.gemm(A, Wf, rows, 256, k))
     out = {k: round(v, 2) for k, v in res.items()}
+    out["NST_ROWGEMM_CFG"] = os.environ.get("NST_ROWGEMM_CFG", "")
     print(json.dumps(out, indent=1))
     root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)

@@ -224,7 +224,9 @@ def _wire_worker(rank, world, port, q):
     acc = others[0].to(torch.bfloat16)
     for o in others[1:]:
         acc = acc + o.to(torch.bfloat16)          # bf16 + bf16 -> bf16, like the collective's reduction
-    ok_wire = torch.equal(st.grad, acc.float())
+    # (two ranks: the one bf16 addition is the same whichever rank performs it; more ranks: the collective's order of the bf16
+    # additions is its own -- the result must be bf16 values, i.e. summed on the 16-bit wire, close to the exact sum)
+    ok_wire = torch.equal(st.grad, acc.float()) if world == 2 else torch.equal(st.grad, st.grad.to(torch.bfloat16).float())
     exact = sum(others)
     rel = float((st.grad - exact).norm() / exact.norm())
     # (b) no slice of a few hundred elements travels alone: output_ln was part of its top layer's report
@@ -242,10 +244,12 @@ def _wire_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bf16_wire_and_no_standalone_output_ln_message_world2_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bf16_wire_and_no_standalone_output_ln_message_gloo(world):
     """16-bit gradient wire (the reference's fp16 compression, neurst/training/training_utils.py:381-384) and the report
-    layout that keeps the 2 KB output_ln slices inside their top layer's message."""
-    world, port = 2, _free_port()
+    layout that keeps the 2 KB output_ln slices inside their top layer's message; at 2 and at 8 ranks (one node of the
+    benchmark: the bucket order is identical on all ranks or the collectives would not match up)."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
@@ -257,6 +261,6 @@ def test_bf16_wire_and_no_standalone_output_ln_message_world2_gloo():
         assert p.exitcode == 0
     for rank, ok_wire, rel, scale, alone, n, fp16_ok, scale16 in res:
         assert ok_wire, "the 16-bit wire must carry bf16-rounded slices and widen the bf16 sum"
-        assert rel < 1e-2 and scale == 0.5
+        assert rel < (1e-2 if world == 2 else 2.5e-2) and scale == 1.0 / world
         assert alone == [] and n >= 4
         assert fp16_ok and scale16 == 1.0, "fp16 wire: pre-scaled by 1/world, no overflow of the sum"

@@ -560,7 +560,7 @@ def test_benchmark_shape_bf16_step_against_the_fp32_hip_path():
 
 # ------------------------------------------------------------------------------------------------ text Transformer (§8(f) rank 1)
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-@pytest.mark.parametrize("case", ["toy", "small_shared", "mid", "waitk3", "waitk1_mid"])
+@pytest.mark.parametrize("case", ["toy", "small_shared", "mid", "waitk3", "waitk1_mid", "base_shape", "big_shape"])
 def test_text_transformer_forward_backward(case, dtype):
     """Transformer (embedding source side, optional shared source/target embedding) through the Seq2Seq task inputs:
     logits, loss and every gradient against the oracle's transformer_logits + criterion + autograd.  The waitk cases run
@@ -576,6 +576,11 @@ def test_text_transformer_forward_backward(case, dtype):
         "mid": (256, 4, 2, 1, 512, 4, 33, 21, 300, 200, False),
         "waitk3": (64, 2, 2, 2, 128, 3, 17, 9, 40, 37, False),
         "waitk1_mid": (256, 4, 2, 2, 512, 3, 90, 70, 300, 200, False),
+        # BASELINE config #4's real hyper-parameters (neurst/models/transformer.py:100-240: transformer_base / transformer_big --
+        # d, heads, filter size, 32 003-word vocabularies) at 2 + 2 layers, 4 pairs of 32 + 32 positions: the 256 x 256 tile
+        # kernel's dispatch (d_model >= 512) and the zero-padded vocabulary rows (32 003 is not a multiple of 8) inside a model
+        "base_shape": (512, 8, 2, 2, 2048, 4, 32, 32, 32003, 32003, False),
+        "big_shape": (1024, 16, 2, 2, 4096, 4, 32, 32, 32003, 32003, False),
     }
     d, H, ne, nd, ffn, B, S, L, Vs, Vt, share = cases[case]
     wait_k = {"waitk3": 3, "waitk1_mid": 1}.get(case, None)

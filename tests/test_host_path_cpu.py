@@ -536,7 +536,7 @@ def _dp_inputs(shape, step, rank, world):
     return inp
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_data_parallel_train_step_gloo_matches_oracle_average(world):
     """N ranks, different batches (N = 4: unequal token counts per rank, _dp_inputs): after two steps every rank holds the
     weights the oracle gets from the MEAN of the per-rank gradients (hvd.Average, hvd_utils.py:46-62) under Keras Adam; the
@@ -548,7 +548,7 @@ def test_data_parallel_train_step_gloo_matches_oracle_average(world):
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    res = sorted((q.get(timeout=360) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
