@@ -150,6 +150,10 @@ SIGNATURES = {
     "nst_ffn_gate_bits_bytes": [C.POINTER(NstFfnDesc)],
     "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "nst_ffn_ln_supported": [C.POINTER(NstFfnDesc)],
+    "nst_ffn_add_layernorm_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P],
+    "nst_ffn_layernorm_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _I, _P,
+                              _L, _P, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
     "nst_pack2d": [_P, _I, _I, _P],
     "nst_stream_create": [_I, C.POINTER(C.c_void_p)],

@@ -38,6 +38,7 @@
 //     reads the same 8 contiguous units of its row);
 //   * the same permutation on the output rows of the second product gives every lane 16 consecutive output columns.
 #include "nst_common.h"
+#include "nst_rowphase.h"
 
 #include <stdlib.h>
 
@@ -72,6 +73,10 @@ struct FfnArgs {
   // v2: the gate of the backward as one bit per hidden element (opaque layout, see ffn_pair8_kernel): written by the forward
   // when non-null, read by the backward INSTEAD of the saved activation when non-null
   uint16_t* gate_bits;
+  // LN variants of the eight-wave kernel (nst_ffn_add_layernorm_fwd / nst_ffn_layernorm_bwd): the output tile goes through LDS to
+  // the row phase of nst_rowphase.h instead of to `out` directly
+  rowphase::RowEpi rp;
+  uint64_t rp_seed;
 };
 
 __device__ __forceinline__ int pi32(int r) { return (((r >> 2) & 1) << 4) + ((r >> 3) << 2) + (r & 3); }
@@ -569,7 +574,7 @@ constexpr int V2_ROWS = 128;
 // values it stores) and writes them as gate_bits[(2 chunk + hh) * M + row][h] (uint16): one 128-byte store per wave and chunk.
 // The backward then fetches 4 bytes per row and half chunk (one LDS-DMA instruction per wave and chunk) instead of 64:
 // 7.4 MB instead of 118 MB at the benchmark shape, and the weight-gradient stream running beside it keeps that bandwidth.
-template <int MODE, int DROP, bool FULL, int DBG = 0, bool BITS = false>
+template <int MODE, int DROP, bool FULL, int DBG = 0, bool BITS = false, bool LN = false>
 __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   static_assert(MODE == MODE_FWD || DROP == 0, "the backward has no dropout of its own (the gate carries the forward's mask)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -904,7 +909,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   uint4 rres[4][2];
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob) rres[ob][0] = rres[ob][1] = make_uint4(0u, 0u, 0u, 0u);
-  if (a.residual) {
+  if (!LN && a.residual) {
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
       const uint4* rp = reinterpret_cast<const uint4*>(a.residual + (int64_t)row_c * D + 128 * hh + 32 * ob + 16 * h);
@@ -915,6 +920,31 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   span(std::false_type(), nch - 1, smem + V2_W1, smem + V2_W2 + ((nch - 1) & 1) * 32768);
 
   if constexpr (MODE == MODE_BWD) wait_vm<0>();   // (the clamped gate copy of "chunk nch")
+  if constexpr (LN) {
+    // ---------------------------------------------------------------- LN variants: the raw output tile [128][256] f32 goes through
+    // LDS (every weight / P buffer is free now) to the row phase shared with the whole-row products: forward bias + dropout + the
+    // float32 residual stream + the NEXT LayerNorm; backward the LayerNorm backward of the wrapper around this feed-forward pair
+    wait_vm<0>();
+    barrier();                          // every wave is done with the last span's fragments
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      float* tp = tile + (32 * rg + i_l) * rowphase::TILE_LD + 128 * hh + 32 * ob + 16 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(tp + 4 * q) = make_float4(accY[ob][4 * q], accY[ob][4 * q + 1], accY[ob][4 * q + 2], accY[ob][4 * q + 3]);
+    }
+    __syncthreads();
+    const float nopre[1][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    if constexpr (MODE == MODE_FWD) {
+      rowphase::ln_fwd<16, false>(tile, a.rp, a.seed2 + seed_off, m0, M, wave, lane, nopre);
+    } else {
+      uint64_t sd = a.rp_seed;
+      if (a.rp.dz) sd = seed_with_offset(a.rp_seed, a.seed_dev);   // wave-uniform
+      rowphase::ln_bwd<8, 16, false>(tile, tile + 128 * rowphase::TILE_LD, a.rp, sd, m0, M, tid, wave, lane, nopre);
+    }
+    return;
+  }
   // ---------------------------------------------------------------- final epilogue: 16 consecutive output columns per lane and block
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob) {
@@ -1016,6 +1046,22 @@ int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
   allow_lds(k, lds);
   k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
   return NST_OK;
+}
+
+// LN variants: training shapes of the eight-wave kernel with gate bits
+template <int DROP, bool FULL>
+void launch_v2_fwd_ln(const FfnArgs& a, hipStream_t st) {
+  const int lds = V2_BIAS + a.F * 4;
+  auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true, true>;
+  allow_lds(k, lds);
+  k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+}
+template <bool FULL>
+void launch_v2_bwd_ln(const FfnArgs& a, hipStream_t st) {
+  const int lds = V2_BIAS + 16384;
+  auto k = ffn_pair8_kernel<MODE_BWD, 0, FULL, 0, true, true>;
+  allow_lds(k, lds);
+  k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
 }
 
 bool use_v2_bwd(const FfnArgs& a) {
@@ -1232,6 +1278,108 @@ extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidd
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_bwd");
   return NST_OK;
+}
+
+extern "C" int nst_ffn_ln_supported(const NstFfnDesc* d) {
+  if (!d || !nst_ffn_supported(d->d_model, d->filter_size, d->dtype) || d->rows <= 0 || d->rows >= (1 << 30)) return 0;
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = (int)d->rows; a.F = d->filter_size;
+  return (use_v2_fwd(a) && use_v2_bwd(a) && (int64_t)d->rows * d->filter_size * 2 < (1ll << 32)) ? 1 : 0;
+}
+
+extern "C" int nst_ffn_add_layernorm_fwd(const NstFfnDesc* d, const void* x, const void* w1t, const float* b1, const void* w2t,
+                                         const float* b2, const float* x_res, float* x_out, const float* gamma, const float* beta,
+                                         float eps, void* hidden, void* y, float* mean, float* rstd, void* stream) {
+  NST_CHECK_ARG(d && x && w1t && w2t && hidden && y && x_res && gamma && beta && mean && rstd, "ffn_add_layernorm_fwd: null pointer");
+  NST_CHECK_ARG(nst_ffn_ln_supported(d) && d->gate_bits, "ffn_add_layernorm_fwd: needs the eight-wave kernel's shapes (rows >= %d) and gate bits",
+                128 * 160);
+  NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(w1t) && nst_aligned16(w2t) && nst_aligned16(hidden) && nst_aligned16(y) &&
+                    nst_aligned16(x_res) && (!x_out || nst_aligned16(x_out)) && nst_aligned16(gamma) && nst_aligned16(beta) &&
+                    (!b2 || nst_aligned16(b2)),
+                "ffn_add_layernorm_fwd: operands must be 16-byte aligned");
+  NST_CHECK_ARG(d->hidden_dropout_p >= 0.f && d->hidden_dropout_p < 1.f && d->output_dropout_p >= 0.f && d->output_dropout_p < 1.f,
+                "ffn_add_layernorm_fwd: dropout rate");
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xin = (const bf16_t*)x; a.wa = (const bf16_t*)w1t; a.wb = (const bf16_t*)w2t;
+  a.bias_a = b1; a.bias_b = nullptr;
+  a.mid_out = (bf16_t*)hidden; a.out = (bf16_t*)y;
+  a.seed_dev = d->seed_offset ? d->seed_offset : nst_seed_offset_devptr();
+  if (!a.seed_dev) return NST_ERR_LAUNCH;
+  a.M = (int)d->rows; a.F = d->filter_size;
+  nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
+  nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);
+  a.seed1 = d->hidden_seed; a.stream1 = d->hidden_stream_id; a.seed2 = d->output_seed; a.stream2 = d->output_stream_id;
+  const int64_t need = nst_ffn_gate_bits_bytes(d);
+  NST_CHECK_ARG(need > 0 && d->gate_bits_bytes >= need && ((uintptr_t)d->gate_bits & 3) == 0, "ffn_add_layernorm_fwd: gate_bits holds %lld bytes, %lld needed",
+                (long long)d->gate_bits_bytes, (long long)need);
+  a.gate_bits = (uint16_t*)d->gate_bits;
+  a.rp.bias = b2; a.rp.drop_thresh = a.drop2_thresh; a.rp.drop_inv_keep = a.drop2_inv_keep; a.rp.stream_id = a.stream2;
+  a.rp.x = x_res; a.rp.x_out = x_out; a.rp.gamma = gamma; a.rp.beta = beta; a.rp.eps = eps;
+  a.rp.y = (bf16_t*)y; a.rp.mean = mean; a.rp.rstd = rstd;
+  a.rot_mode = 0;
+  const bool full = a.M % V2_ROWS == 0;
+  const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
+  if (full && drop == 3) launch_v2_fwd_ln<3, true>(a, (hipStream_t)stream);
+  else if (full && drop == 0) launch_v2_fwd_ln<0, true>(a, (hipStream_t)stream);
+  else launch_v2_fwd_ln<3, false>(a, (hipStream_t)stream);
+  NST_CHECK_LAUNCH("ffn_add_layernorm_fwd");
+  return NST_OK;
+}
+
+extern "C" int nst_ffn_layernorm_bwd(const NstFfnDesc* d, const void* dy, const void* hidden, const void* w2, const void* w1,
+                                     const float* x_ln, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                     void* dhidden, void* dx, void* dz, float dz_p, uint64_t dz_seed, uint64_t dz_stream_id,
+                                     float* dgamma, float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes,
+                                     NstLnFinalizeJob* job_out, void* stream) {
+  if (job_out) memset(job_out, 0, sizeof(*job_out));
+  NST_CHECK_ARG(d && dy && hidden && w2 && w1 && dhidden && dx && x_ln && gamma && mean && rstd && dgamma && dbeta && workspace,
+                "ffn_layernorm_bwd: null pointer");
+  NST_CHECK_ARG(nst_ffn_ln_supported(d) && d->gate_bits, "ffn_layernorm_bwd: needs the eight-wave kernel's shapes and gate bits");
+  NST_CHECK_ARG(nst_aligned16(dy) && nst_aligned16(hidden) && nst_aligned16(w1) && nst_aligned16(w2) && nst_aligned16(dhidden) &&
+                    nst_aligned16(dx) && nst_aligned16(x_ln) && nst_aligned16(gamma) && (!dres || nst_aligned16(dres)) &&
+                    (!dz || nst_aligned16(dz)) && (((uintptr_t)workspace) & 15) == 0,
+                "ffn_layernorm_bwd: operands must be 16-byte aligned");
+  NST_CHECK_ARG(dz_p >= 0.f && dz_p < 1.f, "ffn_layernorm_bwd: dropout_p=%f", dz_p);
+  FfnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xin = (const bf16_t*)dy; a.wa = (const bf16_t*)w2; a.wb = (const bf16_t*)w1;
+  a.gate = (const bf16_t*)hidden;
+  a.mid_out = (bf16_t*)dhidden; a.out = (bf16_t*)dx;
+  a.M = (int)d->rows; a.F = d->filter_size;
+  uint32_t th; float inv;
+  nst_dropout_params16(d->hidden_dropout_p, &th, &inv);
+  a.gate_scale = th ? inv : 1.0f;
+  NST_CHECK_ARG(d->gate_bits_bytes >= (int64_t)a.M * (a.F / 32) * 4 && ((uintptr_t)d->gate_bits & 3) == 0,
+                "ffn_layernorm_bwd: gate_bits holds %lld bytes", (long long)d->gate_bits_bytes);
+  a.gate_bits = (uint16_t*)d->gate_bits;
+  const int nb = (a.M + V2_ROWS - 1) / V2_ROWS;
+  if (workspace_bytes < (int64_t)nb * 2 * D * 4) {
+    nst_set_error("ffn_layernorm_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)nb * 2 * D * 4);
+    return NST_ERR_WORKSPACE;
+  }
+  a.seed_dev = nst_seed_offset_devptr();
+  if (!a.seed_dev) return NST_ERR_LAUNCH;
+  a.rp.x = x_ln; a.rp.gamma = gamma; a.rp.mean = const_cast<float*>(mean); a.rp.rstd = const_cast<float*>(rstd);
+  a.rp.dres = (const bf16_t*)dres; a.rp.y = (bf16_t*)dx; a.rp.dz = (bf16_t*)dz; a.rp.partial = (float*)workspace;
+  if (dz) {
+    nst_dropout_params16(dz_p, &a.rp.drop_thresh, &a.rp.drop_inv_keep);
+    a.rp_seed = dz_seed; a.rp.stream_id = dz_stream_id;
+  }
+  a.rot_mode = 0;
+  if (a.M % V2_ROWS == 0) launch_v2_bwd_ln<true>(a, (hipStream_t)stream);
+  else launch_v2_bwd_ln<false>(a, (hipStream_t)stream);
+  NST_CHECK_LAUNCH("ffn_layernorm_bwd");
+  NstLnFinalizeJob job;
+  memset(&job, 0, sizeof(job));
+  job.partial = (const float*)workspace; job.dgamma = dgamma; job.dbeta = dbeta;
+  job.nblocks = nb; job.d = D; job.accumulate = accumulate;
+  if (job_out) {
+    *job_out = job;
+    return NST_OK;
+  }
+  return nst_ln_finalize_multi(&job, 1, stream);
 }
 
 extern "C" int nst_transpose_bf16(const NstTransposeJob* jobs_dev, int njobs, int total_tiles, void* stream) {

@@ -25,18 +25,17 @@
 // lanes per row, 8 consecutive columns per lane -- the access pattern of the wide LayerNorm kernels (nst_norm.hip), whole
 // 1 KB / 512-byte row segments per half wave, row reductions inside the half wave by DPP + lane-row swaps.
 #include "nst_gemm_core.h"
+#include "nst_rowphase.h"
 
 #include <stdlib.h>
 
 #include <utility>
 
 using namespace nstgemm;
+using namespace rowphase;
 
 namespace {
 
-constexpr int RN = 256;              // output columns = d_model
-constexpr int R_THREADS = 256;
-constexpr int TILE_LD = 260;         // floats per row of the epilogue tile (1040 bytes: 16-lane groups hit distinct banks)
 enum { EPI_LN_FWD = 0, EPI_LN_BWD = 1, EPI_ROWDOT = 2, EPI_PLAIN = 3 };
 
 struct RowArgs {
@@ -44,25 +43,9 @@ struct RowArgs {
   const bf16_t* W;       // OC: [K, 256] (ldb)   RC: [256, K] (ldb)
   int64_t lda, ldb;
   int M, K;
-  // forward
-  const float* bias;     // [256] or null
-  uint32_t drop_thresh;
-  float drop_inv_keep;
-  uint64_t seed, stream_id;
+  uint64_t seed;
   const uint64_t* seed_dev;
-  const float* x;        // fwd: the residual stream [M, 256] f32; bwd: the saved LayerNorm input (f32)
-  float* x_out;          // fwd: x + delta (nullable)
-  const float* gamma;
-  const float* beta;
-  float eps;
-  int reserved0;
-  bf16_t* y;             // fwd: LayerNorm output; bwd: dx; rowdot / plain: C [M, 256]
-  float* mean;           // fwd: out; bwd: in
-  float* rstd;
-  // backward
-  const bf16_t* dres;    // [M, 256] or null
-  bf16_t* dz;            // [M, 256] or null: dx under the dropout mask (drop_thresh, drop_inv_keep, seed, stream_id)
-  float* partial;        // [gridDim.x][2][256]
+  RowEpi e;              // the row phase's operands (nst_rowphase.h); e.y is C for the rowdot / plain forms
   // rowdot
   const bf16_t* rd_src;  // [M, 256]
   float* rd_dst;         // [(b * 4 + h) * T + t]
@@ -70,18 +53,24 @@ struct RowArgs {
   int reserved1;
 };
 
-template <int BM, int NST>
+template <int BM, int NST, int NW = 4>
 struct RowCfg {
-  static constexpr int A_BYTES = BM * 128;
+  static constexpr int RG = NW / 4;                     // row groups of waves (4 waves side by side cover the 256 columns)
+  static constexpr int GROWS = BM / RG;                 // rows a wave multiplies
+  static constexpr int IMG_ROWS = (BM + 31) / 32 * 32;  // rows of the A image (BM = 48: 64, the last 16 repeat row BM - 1)
+  static constexpr int A_BYTES = IMG_ROWS * 128;
   static constexpr int STAGE = A_BYTES + 2 * 16384;
-  static constexpr int A_IPW = BM / 32;                 // DMA instructions per wave and K step for the A image
-  static constexpr int IPW = A_IPW + 8;                 // ... for the whole stage
-  static constexpr int MI = BM / 16;
+  static constexpr int A_IPW = IMG_ROWS / 8 / NW;       // DMA instructions per wave and K step for the A image
+  static constexpr int B_IPW = 32 / NW;                 // ... for the two weight images
+  static constexpr int IPW = A_IPW + B_IPW;             // ... for the whole stage
+  static constexpr int MI = GROWS / 16;
   static constexpr int TILE_BYTES = BM * TILE_LD * 4;
-  static constexpr int RED_BYTES = 4 * 2 * RN * 4;
+  static constexpr int RED_BYTES = NW * 2 * RN * 4;
   static constexpr int LDS = (NST * STAGE > TILE_BYTES + RED_BYTES) ? NST * STAGE : TILE_BYTES + RED_BYTES;
-  static_assert(NST >= 2 && NST <= 4 && (NST - 2) * IPW < 64, "stage ring depth");
-  static constexpr int RPW = BM / 4;                    // rows a wave owns in the row phase
+  static_assert(NST >= 2 && NST <= 4 && (NST - 2) * IPW < 64 && GROWS % 16 == 0 && (BM / NW) % 2 == 0 && (NW == 4 || NW == 8) &&
+                    (IMG_ROWS / 8) % NW == 0, "stage ring depth / tile height");
+  static_assert(LDS <= 160 * 1024, "LDS of a CU");
+  static constexpr int RPW = BM / NW;                   // rows a wave owns in the row phase
   static constexpr int PASSES = RPW / 2;                // two rows (32 lanes each) per pass
 };
 
@@ -99,43 +88,9 @@ __device__ __forceinline__ void rg_glds(const void* sbase, uint32_t voff, uint32
       : "memory");
 }
 
-typedef __attribute__((ext_vector_type(2))) unsigned rg_uint2_t;
-__device__ __forceinline__ float rg_swap16_add(float v) {
-  const rg_uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float rg_swap32_add(float v) {
-  const rg_uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// sum over the 32 lanes of a half wave (every lane of the half ends up with it)
-__device__ __forceinline__ float half_sum(float v) {
-  v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
-  return rg_swap16_add(v);
-}
-__device__ __forceinline__ void rg_load8_bf16(const bf16_t* __restrict__ p, float (&v)[8]) {
-  const uint4 raw = *reinterpret_cast<const uint4*>(p);
-  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
-  v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
-  v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
-}
-__device__ __forceinline__ void rg_load8_f32(const float* __restrict__ p, float (&v)[8]) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ void rg_store8_bf16(bf16_t* __restrict__ p, const float (&v)[8]) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                            pack_bf16x2(v[6], v[7]));
-}
-__device__ __forceinline__ void rg_store8_f32(float* __restrict__ p, const float (&v)[8]) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-
-template <int BM, int NST, int BMODE, int EPI>
-__global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
-  typedef RowCfg<BM, NST> C;
+template <int BM, int NST, int NW, int BMODE, int EPI>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) rowgemm_kernel(RowArgs a) {
+  typedef RowCfg<BM, NST, NW> C;
   typedef SwzFrag<bf16_t, MODE_RC> RA;
   typedef SwzFrag<bf16_t, BMODE> RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,24 +98,25 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, wrow = (wave >> 2) * C::GROWS;   // this wave multiplies rows [wrow, +GROWS) x columns [64 wc, +64)
   const int M = a.M;
   const int m0 = blockIdx.x * BM;
   const int nk = a.K >> 6;
 
   // ---------------------------------------------------------------- DMA source offsets (per lane, constant over K)
-  uint32_t voffA[C::A_IPW], voffB[8];
+  uint32_t voffA[C::A_IPW], voffB[C::B_IPW];
 #pragma unroll
   for (int s = 0; s < C::A_IPW; ++s) {
     const int c = (wave * C::A_IPW + s) * 64 + lane;
     const int row = c >> 3, slot = c & 7;
     const int kch = slot ^ ((row >> 1) & 7);
-    int rg = m0 + row;
+    int rg = m0 + (row < BM ? row : BM - 1);  // (image rows past the tile: any valid row, never multiplied)
     rg = rg < M ? rg : M - 1;                 // rows past the end read the last row (their results are never stored)
     voffA[s] = (uint32_t)((int64_t)(rg - m0) * a.lda * 2 + kch * 16);
   }
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int t = wave * 8 + s;               // 0 .. 31: image t >> 4, 1 KB piece t & 15 of it
+  for (int s = 0; s < C::B_IPW; ++s) {
+    const int t = wave * C::B_IPW + s;        // 0 .. 31: image t >> 4, 1 KB piece t & 15 of it
     const int h = t >> 4, c = (t & 15) * 64 + lane;
     if (BMODE == MODE_RC) {
       const int row = c >> 3, slot = c & 7;
@@ -182,7 +138,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
     for (int s = 0; s < C::A_IPW; ++s) rg_glds(pa, voffA[s], sa + (uint32_t)(wave * C::A_IPW + s) * 1024u);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) rg_glds(pb, voffB[s], sa + C::A_BYTES + (uint32_t)(wave * 8 + s) * 1024u);
+    for (int s = 0; s < C::B_IPW; ++s) rg_glds(pb, voffB[s], sa + C::A_BYTES + (uint32_t)(wave * C::B_IPW + s) * 1024u);
   };
   // The f32 rows the row phase adds (forward) / normalises again (backward) are requested FIRST, in the row phase's own lane
   // layout: their HBM latency and transfer then run under the whole K loop instead of behind it (vmcnt retires in issue order,
@@ -194,7 +150,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
     for (int p = 0; p < C::PASSES; ++p) {
       int rowg = m0 + wave * C::RPW + p * 2 + sub;
       rowg = rowg < M ? rowg : M - 1;
-      rg_load8_f32(a.x + (int64_t)rowg * RN + col, xpre[p]);
+      rg_load8_f32(a.e.x + (int64_t)rowg * RN + col, xpre[p]);
     }
   }
 #pragma unroll
@@ -212,7 +168,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
   // instructions that refill the ring are spread over the positions, ONE behind an MFMA at a time: issued back to back in
   // front of the step they keep the wave out of the matrix core for their whole issue time (call 3 of round 6: the K = 768 /
   // 2048 products ran at 36 - 49 GB/s of DMA per CU where the same ring without MFMAs moves 70 - 117).
-  const int bimg = (wave >> 1) * 16384, wnl = (wave & 1) * 64;
+  const int bimg = (wc >> 1) * 16384, wnl = (wc & 1) * 64;
   int stage = 0, stage_in = NST - 1;     // stage being multiplied / stage the next issue fills
   constexpr int NPOS = 8 * C::MI;
   auto kstep = [&](auto has_next_tag, int kt) {
@@ -236,7 +192,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[0][j] = RB::read(Bs, wnl + j * 16, 0, lane);
 #pragma unroll
-    for (int i = 0; i < C::MI; ++i) af[0][i] = RA::read(As, i * 16, 0, lane);
+    for (int i = 0; i < C::MI; ++i) af[0][i] = RA::read(As, wrow + i * 16, 0, lane);
     [&]<int... PP>(std::integer_sequence<int, PP...>) {
       ([&] {
         constexpr int P = PP;
@@ -244,7 +200,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) bf[1][j] = RB::read(Bs, wnl + j * 16, 32, lane);
 #pragma unroll
-          for (int i = 0; i < C::MI; ++i) af[1][i] = RA::read(As, i * 16, 32, lane);
+          for (int i = 0; i < C::MI; ++i) af[1][i] = RA::read(As, wrow + i * 16, 32, lane);
         }
         constexpr int half = P / (4 * C::MI), j = (P % (4 * C::MI)) / C::MI, i = P % C::MI;
         constexpr int d = (P * C::IPW) / NPOS;
@@ -254,7 +210,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[half][j], af[half][i], acc[i][j], 0, 0, 0);   // D[n][m]: weights are the A operand
         if constexpr (DMA_HERE) {
           if constexpr (d < C::A_IPW) rg_glds(pa, voffA[d], sa + (uint32_t)(wave * C::A_IPW + d) * 1024u);
-          else rg_glds(pb, voffB[d - C::A_IPW], sa + C::A_BYTES + (uint32_t)(wave * 8 + (d - C::A_IPW)) * 1024u);
+          else rg_glds(pb, voffB[d - C::A_IPW], sa + C::A_BYTES + (uint32_t)(wave * C::B_IPW + (d - C::A_IPW)) * 1024u);
           __builtin_amdgcn_sched_barrier(0);
         }
       }(), ...);
@@ -277,157 +233,23 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const floatx4_t v = acc[i][j];
-        *reinterpret_cast<float4*>(tile + (i * 16 + ml) * TILE_LD + wave * 64 + j * 16 + nq) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(tile + (wrow + i * 16 + ml) * TILE_LD + wc * 64 + j * 16 + nq) = make_float4(v[0], v[1], v[2], v[3]);
       }
   }
   __syncthreads();
 
   // ---------------------------------------------------------------- row phase: wave w owns rows [w RPW, +RPW), 32 lanes per row
   uint64_t seed = a.seed;
-  if ((EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) && a.drop_thresh) seed = seed_with_offset(a.seed, a.seed_dev);   // wave-uniform
-  const float inv_d = 1.0f / (float)RN;
+  if ((EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) && a.e.drop_thresh) seed = seed_with_offset(a.seed, a.seed_dev);   // wave-uniform
 
   if constexpr (EPI == EPI_LN_FWD) {
-    float gm[8], bt[8], bs[8];
-    rg_load8_f32(a.gamma + col, gm);
-    rg_load8_f32(a.beta + col, bt);
-    if (a.bias) rg_load8_f32(a.bias + col, bs);
-    else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bs[j] = 0.f;
-    }
-#pragma unroll
-    for (int p0 = 0; p0 < C::PASSES; p0 += 2) {
-      float v[2][8], xr[2][8];
-      int rowg[2];
-      bool ok[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rl = wave * C::RPW + (p0 + u) * 2 + sub;
-        rowg[u] = m0 + rl;
-        ok[u] = rowg[u] < M;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xr[u][j] = xpre[p0 + u][j];
-        const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
-        const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
-        v[u][0] = t0.x + bs[0]; v[u][1] = t0.y + bs[1]; v[u][2] = t0.z + bs[2]; v[u][3] = t0.w + bs[3];
-        v[u][4] = t1.x + bs[4]; v[u][5] = t1.y + bs[5]; v[u][6] = t1.z + bs[6]; v[u][7] = t1.w + bs[7];
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (a.drop_thresh) {
-          float m[8];
-          dropout_keep8(seed, a.stream_id, (uint64_t)rowg[u] * (uint64_t)RN + (uint64_t)col, a.drop_thresh, a.drop_inv_keep, m);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[u][j] *= m[j];
-        }
-        // the sub-layer's contribution is rounded to bf16 before it joins the stream, as the unfused pair does
-        // (GEMM epilogue -> bf16 delta -> nst_add_layernorm_fwd): both paths then produce the same sum bit for bit
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[u][j] = bf16_to_f32(f32_to_bf16(v[u][j])) + xr[u][j];
-        if (a.x_out && ok[u]) rg_store8_f32(a.x_out + (int64_t)rowg[u] * RN + col, v[u]);
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[u][j];
-        const float mean = half_sum(s) * inv_d;
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = v[u][j] - mean; sq += t * t; }
-        const float rstd = rsqrtf(half_sum(sq) * inv_d + a.eps);
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (v[u][j] - mean) * rstd * gm[j] + bt[j];
-        if (ok[u]) {
-          rg_store8_bf16(a.y + (int64_t)rowg[u] * RN + col, o);
-          if (li == 0) { a.mean[rowg[u]] = mean; a.rstd[rowg[u]] = rstd; }
-        }
-      }
-    }
+    ln_fwd<C::RPW, true>(tile, a.e, seed, m0, M, wave, lane, xpre);
   } else if constexpr (EPI == EPI_LN_BWD) {
-    float gm[8], g_acc[8], b_acc[8];
-    rg_load8_f32(a.gamma + col, gm);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { g_acc[j] = 0.f; b_acc[j] = 0.f; }
-#pragma unroll
-    for (int p0 = 0; p0 < C::PASSES; p0 += 2) {
-      float g[2][8], xv[2][8], rv[2][8], mu[2], rs[2];
-      int rowg[2];
-      bool ok[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rl = wave * C::RPW + (p0 + u) * 2 + sub;
-        rowg[u] = m0 + rl;
-        ok[u] = rowg[u] < M;
-        const int rc = ok[u] ? rowg[u] : M - 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xv[u][j] = xpre[p0 + u][j];
-        if (a.dres) rg_load8_bf16(a.dres + (int64_t)rc * RN + col, rv[u]);
-        else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) rv[u][j] = 0.f;
-        }
-        mu[u] = a.mean[rc];
-        rs[u] = a.rstd[rc];
-        const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
-        const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
-        const float keep = ok[u] ? 1.f : 0.f;   // rows past the end add nothing to the column sums
-        g[u][0] = t0.x * keep; g[u][1] = t0.y * keep; g[u][2] = t0.z * keep; g[u][3] = t0.w * keep;
-        g[u][4] = t1.x * keep; g[u][5] = t1.y * keep; g[u][6] = t1.z * keep; g[u][7] = t1.w * keep;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float s1 = 0.f, s2 = 0.f, xh[8], dxh[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          // the product's output is rounded to bf16 first, as the unfused pair hands it over (GEMM -> bf16 -> LayerNorm backward)
-          const float gj = bf16_to_f32(f32_to_bf16(g[u][j]));
-          xh[j] = (xv[u][j] - mu[u]) * rs[u];
-          dxh[j] = gj * gm[j];
-          g_acc[j] += gj * xh[j];
-          b_acc[j] += gj;
-          s1 += dxh[j];
-          s2 += dxh[j] * xh[j];
-        }
-        const float c1 = half_sum(s1) * inv_d, c2 = half_sum(s2) * inv_d;
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rs[u] * (dxh[j] - c1 - xh[j] * c2) + rv[u][j];
-        if (ok[u]) {
-          const int64_t off = (int64_t)rowg[u] * RN + col;
-          rg_store8_bf16(a.y + off, o);
-          if (a.dz) {
-            float m[8];
-            dropout_keep8(seed, a.stream_id, (uint64_t)off, a.drop_thresh, a.drop_inv_keep, m);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= m[j];
-            rg_store8_bf16(a.dz + off, o);
-          }
-        }
-      }
-    }
-    // column sums: the two half waves hold different rows of the same columns; then the four waves through LDS
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { g_acc[j] = rg_swap32_add(g_acc[j]); b_acc[j] = rg_swap32_add(b_acc[j]); }
-    float* red = reinterpret_cast<float*>(smem + C::TILE_BYTES);
-    if (sub == 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[(wave * 2 + 0) * RN + col + j] = g_acc[j];
-        red[(wave * 2 + 1) * RN + col + j] = b_acc[j];
-      }
-    }
-    __syncthreads();
-    {
-      const int e = tid;   // 256 threads = 256 columns
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass)
-        a.partial[((int64_t)blockIdx.x * 2 + pass) * RN + e] =
-            (red[(0 * 2 + pass) * RN + e] + red[(1 * 2 + pass) * RN + e]) + (red[(2 * 2 + pass) * RN + e] + red[(3 * 2 + pass) * RN + e]);
-    }
+    ln_bwd<NW, C::RPW, true>(tile, reinterpret_cast<float*>(smem + C::TILE_BYTES), a.e, seed, m0, M, tid, wave, lane, xpre);
   } else {
     // EPI_ROWDOT / EPI_PLAIN: C = acc (+ bias) as bf16; rowdot: per head (64 columns = 8 lanes) sum of C (as stored) o src
     float bs[8];
-    if (EPI == EPI_PLAIN && a.bias) rg_load8_f32(a.bias + col, bs);
+    if (EPI == EPI_PLAIN && a.e.bias) rg_load8_f32(a.e.bias + col, bs);
     else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) bs[j] = 0.f;
@@ -441,7 +263,7 @@ __global__ void __launch_bounds__(R_THREADS, 2) rowgemm_kernel(RowArgs a) {
       const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
       const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
       float v[8] = {t0.x + bs[0], t0.y + bs[1], t0.z + bs[2], t0.w + bs[3], t1.x + bs[4], t1.y + bs[5], t1.z + bs[6], t1.w + bs[7]};
-      if (ok) rg_store8_bf16(a.y + (int64_t)rowg * RN + col, v);
+      if (ok) rg_store8_bf16(a.e.y + (int64_t)rowg * RN + col, v);
       if constexpr (EPI == EPI_ROWDOT) {
         float sv[8];
         rg_load8_bf16(a.rd_src + (int64_t)rc * RN + col, sv);
@@ -479,34 +301,44 @@ RgCfg rg_pick(int64_t M, int K) {
     const char* e = getenv("NST_ROWGEMM_CFG");
     if (e) sscanf(e, "%d,%d", &forced_bm, &forced_nst);
   }
+  (void)K;
   RgCfg c;
-  c.bm = M >= 64 * 224 ? 64 : 32;
-  c.nst = 2;      // (deeper rings at one workgroup per CU lost to two stages at two workgroups per CU for every shape: call 3 of round 6)
-  if (forced_bm == 64 || forced_bm == 32) c.bm = forced_bm;
-  if (forced_nst >= 2 && forced_nst <= 4) c.nst = forced_nst;
-  if (c.bm == 64 && c.nst == 4) c.nst = 3;   // (64 rows x 4 stages would not fit the LDS)
+  // every CU gets a workgroup of 64 rows: two workgroups per CU, two stages each (deeper rings at one workgroup per CU lost
+  // for every shape: call 3 of round 6).  Fewer rows than that (the decoder's 9 600): the launch is a chain of L2 round trips
+  // per workgroup, so ONE workgroup per CU with the whole LDS as a four-stage ring (three K steps in flight) and 48 rows, if
+  // that is a single round of workgroups; 32 rows x two stages otherwise.
+  if (M >= 64 * 224) { c.bm = 64; c.nst = 2; }
+  else if ((M + 47) / 48 <= 256 && M > 32 * 64) { c.bm = 48; c.nst = 4; }
+  else { c.bm = 32; c.nst = 2; }
+  if (forced_bm == 64 && (forced_nst == 2 || forced_nst == 3)) { c.bm = 64; c.nst = forced_nst; }
+  if (forced_bm == 32 && forced_nst == 2) { c.bm = 32; c.nst = 2; }
+  if (forced_bm == 48 && forced_nst == 4) { c.bm = 48; c.nst = 4; }
+  // eight waves: two row groups of 64 rows, one workgroup per CU ("128,3": every call of >= 128 rows; "128,2": the calls that fill the chip)
+  if (forced_bm == 128 && M >= (forced_nst == 3 ? 128 : 64 * 224)) { c.bm = 128; c.nst = 3; }
   return c;
 }
 
-template <int BM, int NST, int BMODE, int EPI>
+template <int BM, int NST, int NW, int BMODE, int EPI>
 void rg_launch_one(const RowArgs& a, hipStream_t st, int* nblocks_out) {
-  auto k = rowgemm_kernel<BM, NST, BMODE, EPI>;
+  auto k = rowgemm_kernel<BM, NST, NW, BMODE, EPI>;
   rg_allow_lds(k);
   const int nb = (a.M + BM - 1) / BM;
-  k<<<nb, R_THREADS, RowCfg<BM, NST>::LDS, st>>>(a);
+  k<<<nb, 64 * NW, RowCfg<BM, NST, NW>::LDS, st>>>(a);
   if (nblocks_out) *nblocks_out = nb;
 }
 
 template <int BMODE, int EPI>
 int rg_launch(const RowArgs& a, hipStream_t st, int* nblocks_out) {
   const RgCfg c = rg_pick(a.M, a.K);
-  if (c.bm == 64) {
-    if (c.nst == 2) rg_launch_one<64, 2, BMODE, EPI>(a, st, nblocks_out);
-    else rg_launch_one<64, 3, BMODE, EPI>(a, st, nblocks_out);
+  if (c.bm == 128) {
+    rg_launch_one<128, 3, 8, BMODE, EPI>(a, st, nblocks_out);
+  } else if (c.bm == 64) {
+    if (c.nst == 2) rg_launch_one<64, 2, 4, BMODE, EPI>(a, st, nblocks_out);
+    else rg_launch_one<64, 3, 4, BMODE, EPI>(a, st, nblocks_out);
+  } else if (c.bm == 48) {
+    rg_launch_one<48, 4, 4, BMODE, EPI>(a, st, nblocks_out);
   } else {
-    if (c.nst == 2) rg_launch_one<32, 2, BMODE, EPI>(a, st, nblocks_out);
-    else if (c.nst == 3) rg_launch_one<32, 3, BMODE, EPI>(a, st, nblocks_out);
-    else rg_launch_one<32, 4, BMODE, EPI>(a, st, nblocks_out);
+    rg_launch_one<32, 2, 4, BMODE, EPI>(a, st, nblocks_out);
   }
   return NST_OK;
 }
@@ -549,10 +381,10 @@ extern "C" int nst_gemm_add_layernorm_fwd(const NstRowGemmDesc* d, const void* A
   NST_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm_add_layernorm_fwd: dropout_p=%f", d->dropout_p);
   RowArgs a;
   rg_fill(a, d, A, W);
-  a.bias = bias; a.x = x; a.x_out = x_out; a.gamma = gamma; a.beta = beta; a.eps = d->eps;
-  a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd;
-  nst_dropout_params16(d->dropout_p, &a.drop_thresh, &a.drop_inv_keep);
-  a.seed = d->seed; a.stream_id = d->stream_id;
+  a.e.bias = bias; a.e.x = x; a.e.x_out = x_out; a.e.gamma = gamma; a.e.beta = beta; a.e.eps = d->eps;
+  a.e.y = (bf16_t*)y; a.e.mean = mean; a.e.rstd = rstd;
+  nst_dropout_params16(d->dropout_p, &a.e.drop_thresh, &a.e.drop_inv_keep);
+  a.seed = d->seed; a.e.stream_id = d->stream_id;
   a.seed_dev = nst_seed_offset_devptr();
   if (!a.seed_dev) return NST_ERR_LAUNCH;
   if (d->trans_b) rg_launch<MODE_RC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
@@ -582,11 +414,11 @@ extern "C" int nst_gemm_layernorm_bwd(const NstRowGemmDesc* d, const void* A, co
   }
   RowArgs a;
   rg_fill(a, d, A, W);
-  a.x = x; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
-  a.dres = (const bf16_t*)dres; a.y = (bf16_t*)dx; a.dz = (bf16_t*)dz; a.partial = (float*)workspace;
+  a.e.x = x; a.e.gamma = gamma; a.e.mean = const_cast<float*>(mean); a.e.rstd = const_cast<float*>(rstd);
+  a.e.dres = (const bf16_t*)dres; a.e.y = (bf16_t*)dx; a.e.dz = (bf16_t*)dz; a.e.partial = (float*)workspace;
   if (dz) {
-    nst_dropout_params16(d->dropout_p, &a.drop_thresh, &a.drop_inv_keep);
-    a.seed = d->seed; a.stream_id = d->stream_id;
+    nst_dropout_params16(d->dropout_p, &a.e.drop_thresh, &a.e.drop_inv_keep);
+    a.seed = d->seed; a.e.stream_id = d->stream_id;
   }
   a.seed_dev = nst_seed_offset_devptr();
   if (!a.seed_dev) return NST_ERR_LAUNCH;
@@ -616,7 +448,7 @@ extern "C" int nst_gemm_rowdot256(const NstRowGemmDesc* d, const void* A, const 
                 "gemm_rowdot256: rows=%lld is not a multiple of rows_per_batch=%d", (long long)d->rows, rows_per_batch);
   RowArgs a;
   rg_fill(a, d, A, W);
-  a.y = (bf16_t*)C_;
+  a.e.y = (bf16_t*)C_;
   a.rd_src = (const bf16_t*)src; a.rd_dst = dst; a.rd_T = rows_per_batch;
   if (src) {
     if (d->trans_b) rg_launch<MODE_RC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);

@@ -575,6 +575,67 @@ def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None, gate_bits=None):
     return dx, dhidden
 
 
+def ffn_ln_supported(rows, d, f):
+    """Whether the feed-forward pair carries the wrapper's row stages for this call (nst_ffn_ln_supported: the eight-wave kernel's
+    shapes -- >= 20 480 rows, d_model 256 -- with gate bits)."""
+    desc = _ffn_desc(int(rows), int(d), int(f), 0.0, 0, 0)
+    return bool(lib.nst_ffn_ln_supported(C.byref(desc)))
+
+
+def ffn_add_layernorm_fwd(x, w1t, b1, w2t, b2, x_res, gamma, beta, eps, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0,
+                          out_seed=0, out_site=0, want_sum=True):
+    """nst_ffn_add_layernorm_fwd: ffn_fwd (no residual, gate bits saved) and add_layernorm_fwd on the float32 stream x_res in one
+    launch -> (y bf16 = LayerNorm(x_res + delta), xs f32 | None, mean, rstd, hidden, gate_bits)."""
+    rows, d = x.shape
+    f = w1t.shape[0]
+    assert x.is_contiguous() and w1t.is_contiguous() and w2t.is_contiguous() and w1t.shape == (f, d) and w2t.shape == (d, f)
+    assert x_res.dtype == torch.float32 and x_res.is_contiguous() and x_res.numel() == rows * d and rows * f * 2 < (1 << 32)
+    hidden = torch.empty(rows, f, dtype=x.dtype, device=x.device)
+    y = torch.empty_like(x)
+    xs = torch.empty(rows, d, dtype=torch.float32, device=x.device) if want_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    desc = _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p, out_seed, out_site)
+    nbytes = int(lib.nst_ffn_gate_bits_bytes(C.byref(desc)))
+    bits = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
+    desc.gate_bits, desc.gate_bits_bytes = bits.data_ptr(), nbytes
+    ev = PROBE.begin("ffn_fwd")
+    check(lib.nst_ffn_add_layernorm_fwd(C.byref(desc), _p(x), _p(w1t), _p(b1), _p(w2t), _p(b2), _p(x_res), _p(xs), _p(gamma), _p(beta),
+                                        float(eps), _p(hidden), _p(y), _p(mean), _p(rstd), _stream()), "ffn_add_layernorm_fwd")
+    PROBE.end(ev, 4.0 * rows * d * f)
+    return y, xs, mean, rstd, hidden, bits
+
+
+def ffn_layernorm_bwd(dy, hidden, w2, w1, x_ln, gamma, mean, rstd, dgamma, dbeta, hidden_p=0.0, gate_bits=None, accumulate=False,
+                      dres=None, emit_dropout=None, batch=None):
+    """nst_ffn_layernorm_bwd: ffn_bwd followed by layernorm_bwd (f32 saved input x_ln) in one launch
+    -> (dx, dz | None, dhidden)."""
+    rows, d = dy.shape
+    f = w2.shape[0]
+    assert dy.is_contiguous() and hidden.is_contiguous() and w1.is_contiguous() and w2.is_contiguous() and gate_bits is not None
+    assert w2.shape == (f, d) and w1.shape == (d, f) and hidden.shape == (rows, f)
+    assert x_ln.dtype == torch.float32 and x_ln.is_contiguous() and x_ln.numel() == rows * d
+    assert dres is None or (dres.is_contiguous() and dres.dtype == dy.dtype and dres.numel() == rows * d)
+    dhidden = torch.empty_like(hidden)
+    dx = torch.empty_like(dy)
+    p, seed, site = emit_dropout if emit_dropout is not None else (0.0, 0, 0)
+    dz = torch.empty_like(dy) if emit_dropout is not None else None
+    desc = _ffn_desc(rows, d, f, hidden_p, 0, 0)
+    desc.gate_bits, desc.gate_bits_bytes = gate_bits.data_ptr(), gate_bits.numel()
+    slot = batch.ln_slot(d) if batch is not None else None
+    if slot is not None:
+        ws_ptr, ws_bytes, job = slot
+    else:
+        ws = _workspace(64 << 20, dy.device)
+        ws_ptr, ws_bytes, job = ws.data_ptr(), ws.numel(), None
+    ev = PROBE.begin("ffn_bwd")
+    check(lib.nst_ffn_layernorm_bwd(C.byref(desc), _p(dy), _p(hidden), _p(w2), _p(w1), _p(x_ln), _p(gamma), _p(mean), _p(rstd),
+                                    _p(dres), _p(dhidden), _p(dx), _p(dz), float(p), int(seed), int(site), _p(dgamma), _p(dbeta),
+                                    int(accumulate), ws_ptr, ws_bytes, job, _stream()), "ffn_layernorm_bwd")
+    PROBE.end(ev, 4.0 * rows * d * f)
+    return dx, dz, dhidden
+
+
 def transpose_bf16(table, njobs, total_tiles):
     """Runs a device-resident table of NstTransposeJob (see ParamStore.finalize): dst[cols, rows] = src[rows, cols]^T."""
     check(lib.nst_transpose_bf16(_p(table), njobs, total_tiles, _stream()), "transpose_bf16")

@@ -19,6 +19,9 @@ from neurst_amd import kernels as K
 from neurst_amd.layers.common_layers import Layer, MultiHeadDenseLayer
 
 
+_ROWDOT_ROWS = os.environ.get("NST_ROW_FUSION", "1") != "0"    # nst_gemm_rowdot256 where it wins (see _output_backward_input)
+
+
 class MultiHeadAttention(Layer):
     """Cross attention: q from `query`, k|v from `memory` (variables q_transform, kv_transform, output_transform)."""
 
@@ -98,7 +101,13 @@ class MultiHeadAttention(Layer):
         delta = rowsum(d(context) o context) per head for the attention backward (no separate pass over both tensors)."""
         if self.dh == 64 and K.rowdot_supported(dz, self.num_units):
             delta = torch.empty_like(lse)
-            return self.output_transform.backward_input(dz, rowdot=(ctx2, delta, Tq)), delta
+            ot = self.output_transform
+            # the decoder's row count (fewer rows than fill the chip with 128 x 128 tiles): the whole-row kernel's 48-row
+            # workgroups take the product (7.3 against 8.7 us at 9 600 rows; at the encoder's 28 800 the stream kernel wins)
+            if _ROWDOT_ROWS and self.num_units == 256 and ctx2.is_contiguous() and dz.shape[0] < 64 * 224 \
+                    and K.rowgemm_supported(dz, ot.in_dim, ot.out_dim):
+                return K.gemm_rowdot256(dz, ot.kernel.compute, rowdot=(ctx2, delta, Tq), trans_b=True), delta
+            return ot.backward_input(dz, rowdot=(ctx2, delta, Tq)), delta
         return self.output_transform.backward_input(dz), None
 
     def backward(self, dz, dmemory=None, dmemory_accumulate=False, residual=None, ln_bwd=None):

@@ -122,6 +122,34 @@ class DeferredDelta(object):
                                         want_sum=want_sum)
 
 
+class DeferredFfn(DeferredDelta):
+    """The whole feed-forward pair, not launched yet: nst_ffn_add_layernorm_fwd runs both products, both dropouts, the residual add
+    and the next LayerNorm in one launch (the eight-wave kernel's shapes, training).  Either way the launch leaves the layer's
+    saved state (input, hidden activation, gate bits) behind."""
+    __slots__ = ("ffn", "p")
+
+    def __init__(self, ffn, x, p, epi):
+        super().__init__(x, None, epi)
+        self.ffn, self.p = ffn, p
+
+    def plain(self):
+        f, e = self.ffn, self.epi
+        y, h, bits = K.ffn_fwd(self.A, f._w1t.t, f.dense1.bias.data, f._w2t.t, f.dense2.bias.data, residual=None, hidden_p=self.p,
+                               hidden_seed=f.rt.step_seed, hidden_site=f.site, out_p=e.get("dropout_p", 0.0), out_seed=e.get("seed", 0),
+                               out_site=e.get("stream_id", 0), save_gate_bits=True)
+        f._saved = (self.A, h, self.p, bits)
+        return y
+
+    def fused(self, x, gamma, beta, eps, want_sum):
+        f, e = self.ffn, self.epi
+        y, xs, mean, rstd, h, bits = K.ffn_add_layernorm_fwd(
+            self.A, f._w1t.t, f.dense1.bias.data, f._w2t.t, f.dense2.bias.data, x, gamma, beta, eps, hidden_p=self.p,
+            hidden_seed=f.rt.step_seed, hidden_site=f.site, out_p=e.get("dropout_p", 0.0), out_seed=e.get("seed", 0),
+            out_site=e.get("stream_id", 0), want_sum=want_sum)
+        f._saved = (self.A, h, self.p, bits)
+        return y, xs, mean, rstd
+
+
 class LnBackward(object):
     """The LayerNorm backward of a pre-norm wrapper, offered to the wrapped layer's backward: the layer's last input-gradient
     product (N = d_model = 256: q / qkv projection, dense1) then runs it in its epilogue (nst_gemm_layernorm_bwd) and `done` tells
@@ -136,8 +164,7 @@ class LnBackward(object):
         return saved is not None and saved[0].dtype == torch.float32 and saved[0].is_contiguous() \
             and self.dres.dtype == torch.bfloat16 and self.dres.is_contiguous()
 
-    def run(self, dz, kernel):
-        """dz [rows, out] bf16, kernel [256, out] as stored: d(inputs) = LayerNorm'(dz . kernel^T) + dres."""
+    def _begin(self):
         norm, rt = self.norm, self.norm.rt
         x, mean, rstd = norm._saved
         norm._saved = None
@@ -146,14 +173,31 @@ class LnBackward(object):
         st.acc_flag(norm.beta)
         p = self.consumer.drop_rate() if self.consumer is not None else 0.0
         emit = (p, rt.step_seed, self.consumer.site) if p > 0 else None
+        return x, mean, rstd, acc, emit
+
+    def _end(self, dx, dzz):
+        self.done = True
+        if dzz is not None:
+            dx._nst_dropped = (self.consumer.site, dzz)
+        return dx
+
+    def run(self, dz, kernel):
+        """dz [rows, out] bf16, kernel [256, out] as stored: d(inputs) = LayerNorm'(dz . kernel^T) + dres."""
+        norm, rt = self.norm, self.norm.rt
+        x, mean, rstd, acc, emit = self._begin()
         out = K.gemm_layernorm_bwd(dz, kernel, x, norm.gamma.data, mean, rstd, norm.gamma.grad, norm.beta.grad, accumulate=acc,
                                    dres=self.dres, emit_dropout=emit, batch=rt.wgrad_batch(), trans_b=True)
-        self.done = True
-        if emit is not None:
-            dx, dzz = out
-            dx._nst_dropped = (self.consumer.site, dzz)
-            return dx
-        return out
+        return self._end(*(out if emit is not None else (out, None)))
+
+    def run_ffn(self, dz, hidden, w2, w1, hidden_p, bits):
+        """The feed-forward pair's input gradient with this LayerNorm backward behind it (nst_ffn_layernorm_bwd)
+        -> (d(inputs), d(hidden))."""
+        norm, rt = self.norm, self.norm.rt
+        x, mean, rstd, acc, emit = self._begin()
+        dx, dzz, dh = K.ffn_layernorm_bwd(dz, hidden, w2, w1, x, norm.gamma.data, mean, rstd, norm.gamma.grad, norm.beta.grad,
+                                          hidden_p=hidden_p, gate_bits=bits, accumulate=acc, dres=self.dres, emit_dropout=emit,
+                                          batch=rt.wgrad_batch())
+        return self._end(dx, dzz), dh
 
 
 class LayerNorm(Layer):
@@ -311,6 +355,9 @@ class TransformerFFN(Layer):
         defer_ln = epi.pop("defer_ln", False)
         use_fused = self.fused and x.shape[0] >= _FFN_FUSED_MIN_ROWS and x.is_contiguous() \
             and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"})
+        if use_fused and defer_ln and _ROW_FUSION and is_training and not (set(epi) - {"dropout_p", "seed", "stream_id"}) \
+                and K.ffn_ln_supported(x.shape[0], x.shape[1], self.dense1.out_dim):
+            return DeferredFfn(self, x, p, epi)       # launched by the next LayerNorm (or on its own: DeferredFfn.plain)
         if use_fused:
             y, h, bits = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
                                    residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed,
@@ -331,6 +378,11 @@ class TransformerFFN(Layer):
         self._saved = None
         self.dense2.backward_params(h, dz)
         if self.fused and _FFN_FUSED_BWD and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
+            if ln_bwd is not None and _ROW_FUSION and bits is not None and residual is None and ln_bwd.eligible() \
+                    and K.ffn_ln_supported(dz.shape[0], dz.shape[1], self.dense1.out_dim):
+                dx, dh = ln_bwd.run_ffn(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, p, bits)
+                self.dense1.backward_params(x, dh)
+                return dx
             dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual,
                                gate_bits=bits)
             self.dense1.backward_params(x, dh)

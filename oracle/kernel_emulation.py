@@ -248,6 +248,30 @@ def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None, gate_bits=None):
     return dx.to(dy.dtype), dh
 
 
+def ffn_ln_supported(rows, d, f):
+    return d == 256 and f % 128 == 0 and rows >= 128 * 160
+
+
+def ffn_add_layernorm_fwd(x, w1t, b1, w2t, b2, x_res, gamma, beta, eps, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0,
+                          out_seed=0, out_site=0, want_sum=True):
+    """nst_ffn_add_layernorm_fwd = nst_ffn_fwd (no residual, gate bits) followed by nst_add_layernorm_fwd."""
+    delta, hidden, bits = ffn_fwd(x, w1t, b1, w2t, b2, residual=None, hidden_p=hidden_p, hidden_seed=hidden_seed,
+                                  hidden_site=hidden_site, out_p=out_p, out_seed=out_seed, out_site=out_site, save_gate_bits=True)
+    y, xs, mean, rstd = add_layernorm_fwd(x_res.reshape(x.shape), delta, gamma, beta, eps, want_sum=want_sum)
+    return y, xs, mean, rstd, hidden, torch.zeros(4, dtype=torch.uint8)     # (a stand-in for the device's opaque gate bits)
+
+
+def ffn_layernorm_bwd(dy, hidden, w2, w1, x_ln, gamma, mean, rstd, dgamma, dbeta, hidden_p=0.0, gate_bits=None, accumulate=False,
+                      dres=None, emit_dropout=None, batch=None):
+    """nst_ffn_layernorm_bwd = nst_ffn_bwd followed by nst_layernorm_bwd_mixed."""
+    assert gate_bits is not None
+    g, dhidden = ffn_bwd(dy, hidden, w2, w1, hidden_p=hidden_p, residual=None, gate_bits=None)   # (the activation is the gate here)
+    out = layernorm_bwd(g, x_ln.reshape(dy.shape), gamma, mean, rstd, dgamma, dbeta, accumulate=accumulate,
+                        dres=None if dres is None else dres.reshape(dy.shape), emit_dropout=emit_dropout, batch=batch)
+    dx, dz = out if emit_dropout is not None else (out, None)
+    return dx, dz, dhidden
+
+
 def transpose_bf16(table, njobs, total_tiles):
     """`table` on the CPU tier is the Python list of (src, dst) tensor pairs ParamStore keeps next to the device table."""
     for src, dst in table:
@@ -559,7 +583,7 @@ _NAMES = ["layernorm_fwd", "layernorm_bwd", "add_layernorm_fwd", "add_layernorm_
           "cast_f32_to_bf16", "ffn_supported", "ffn_fwd", "ffn_bwd", "transpose_bf16", "pack2d",
           "dropout_seed_offset_bind", "dropout_seed_offset_set", "dropout_seed_offset_add", "loss_scale_update", "splitk_reduce_multi",
           "gemm_wgrad_group", "seq_mask", "xent_reduce", "rowgemm_supported", "gemm_add_layernorm_fwd", "gemm_layernorm_bwd",
-          "gemm_rowdot256"]
+          "gemm_rowdot256", "ffn_ln_supported", "ffn_add_layernorm_fwd", "ffn_layernorm_bwd"]
 
 
 def seq_mask(lengths, max_len, on_token, on_padding, halvings=0, stride=2):

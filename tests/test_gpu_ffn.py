@@ -253,3 +253,70 @@ def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
     (y1, dx1, g1), (y0, dx0, g0) = outs
     assert rel(y1, y0) <= 1e-2 and rel(dx1, dx0) <= 2e-2
     assert float((g1 - g0).norm() / g0.norm()) <= 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ the pair with the wrapper's row stages
+@pytest.mark.parametrize("M,F,p1,p2", [(28800, 2048, 0.1, 0.1), (28800, 2048, 0.0, 0.0), (20480 + 40, 256, 0.25, 0.1), (25600, 128, 0.1, 0.0)])
+def test_ffn_add_layernorm_fwd_equals_the_pair_of_launches(M, F, p1, p2):
+    """nst_ffn_add_layernorm_fwd against nst_ffn_fwd (no residual, the same masks, gate bits) + nst_add_layernorm_fwd on the
+    float32 stream: the same hidden activation and gate bits bit for bit (one main loop), the same sum / LayerNorm output /
+    statistics up to the f32 accumulation order of the row reductions."""
+    from neurst_amd import kernels as K
+    assert K.ffn_ln_supported(M, 256, F) and not K.ffn_ln_supported(9600, 256, 2048)
+    x, _, w1, w2, b1, b2 = _operands(M, F, seed=3 * M + F)
+    g = torch.Generator().manual_seed(M + 5)
+    xres = (torch.randn(M, 256, generator=g) * 2.0).to(DEV)
+    gamma, beta = (1.0 + 0.2 * torch.randn(256, generator=g)).to(DEV), (0.1 * torch.randn(256, generator=g)).to(DEV)
+    d = lambda t: t.to(DEV)
+    w1t, w2t = d(w1.t().contiguous()), d(w2.t().contiguous())
+    kw = dict(hidden_p=p1, hidden_seed=77, hidden_site=3, out_p=p2, out_seed=77, out_site=4)
+    y, xs, mean, rstd, h, bits = K.ffn_add_layernorm_fwd(d(x), w1t, d(b1), w2t, d(b2), xres, gamma, beta, 1e-6, **kw)
+    delta, h2, bits2 = K.ffn_fwd(d(x), w1t, d(b1), w2t, d(b2), save_gate_bits=True, **kw)
+    y2, xs2, mean2, rstd2 = K.add_layernorm_fwd(xres, delta, gamma, beta, 1e-6)
+    assert torch.equal(h, h2) and torch.equal(bits, bits2), "hidden activation / gate bits differ from the plain pair kernel"
+    assert torch.equal(xs, xs2), "the float32 stream differs (same product, same rounding of delta)"
+    assert rel(y, y2.float().cpu()) <= 1e-2 and float((y.float() - y2.float()).norm() / y2.float().norm()) <= 2e-3
+    assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(rstd, rstd2, rtol=1e-5, atol=0)
+    y3, none, _, _, _, _ = K.ffn_add_layernorm_fwd(d(x), w1t, d(b1), w2t, d(b2), xres, gamma, beta, 1e-6, want_sum=False, **kw)
+    assert none is None and torch.equal(y3, y)
+
+
+@pytest.mark.parametrize("M,F,p1,drop", [(28800, 2048, 0.1, True), (28800, 2048, 0.0, False), (20480 + 40, 256, 0.25, True), (25600, 128, 0.1, False)])
+def test_ffn_layernorm_bwd_equals_the_pair_of_launches(M, F, p1, drop):
+    """nst_ffn_layernorm_bwd against nst_ffn_bwd + nst_layernorm_bwd_mixed: d(hidden) bit for bit, dx / dz / dgamma / dbeta up to
+    the accumulation order; also through the deferred finalize of the batch."""
+    from neurst_amd import kernels as K
+    x, _, w1, w2, b1, b2 = _operands(M, F, seed=5 * M + F)
+    g = torch.Generator().manual_seed(M + 9)
+    d = lambda t: t.to(DEV)
+    w1t, w2t = d(w1.t().contiguous()), d(w2.t().contiguous())
+    _, h, bits = K.ffn_fwd(d(x), w1t, d(b1), w2t, d(b2), hidden_p=p1, hidden_seed=5, hidden_site=2, save_gate_bits=True)
+    dy = d(rnd(M, 256, seed=M + 2))
+    dres = d(rnd(M, 256, seed=M + 3))
+    xln = (torch.randn(M, 256, generator=g) * 2.0 + 0.3).to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(256, generator=g)).to(DEV)
+    mean = xln.mean(1)
+    rstd = ((xln - mean[:, None]).pow(2).mean(1) + 1e-6).rsqrt()
+    emit = (0.2, 31337, 6) if drop else None
+    dg, db = torch.full((256,), 7.0, device=DEV), torch.full((256,), 7.0, device=DEV)
+    dx, dz, dh = K.ffn_layernorm_bwd(dy, h, d(w2), d(w1), xln, gamma, mean, rstd, dg, db, hidden_p=p1, gate_bits=bits, dres=dres,
+                                     emit_dropout=emit)
+    gmid, dh2 = K.ffn_bwd(dy, h, d(w2), d(w1), hidden_p=p1, gate_bits=bits)
+    dg2, db2 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    out2 = K.layernorm_bwd(gmid, xln, gamma, mean, rstd, dg2, db2, dres=dres, emit_dropout=emit)
+    dx2, dz2 = out2 if drop else (out2, None)
+    assert torch.equal(dh, dh2), "d(hidden) differs from the plain pair kernel"
+    assert rel(dx, dx2.float().cpu()) <= 1e-2 and float((dx.float() - dx2.float()).norm() / dx2.float().norm()) <= 2e-3
+    assert rel(dg, dg2.cpu()) <= 1e-3 and rel(db, db2.cpu()) <= 1e-3
+    if drop:
+        assert rel(dz, dz2.float().cpu()) <= 1e-2 and float(((dz == 0) != (dz2 == 0)).float().mean()) < 1e-3
+    else:
+        assert dz is None
+    batch = K.SplitkBatch(DEV)
+    dg3, db3 = torch.full((256,), 3.0, device=DEV), torch.full((256,), -2.0, device=DEV)
+    dx3, dz3, dh3 = K.ffn_layernorm_bwd(dy, h, d(w2), d(w1), xln, gamma, mean, rstd, dg3, db3, hidden_p=p1, gate_bits=bits, dres=dres,
+                                        emit_dropout=emit, accumulate=True, batch=batch)
+    assert batch.ln_n == 1 and torch.equal(dx3, dx) and torch.equal(dh3, dh)
+    batch.flush()
+    torch.cuda.synchronize()
+    assert torch.allclose(dg3, dg + 3.0, rtol=1e-5, atol=1e-4) and torch.allclose(db3, db - 2.0, rtol=1e-5, atol=1e-4)

@@ -47,7 +47,8 @@ def _weights(k, trans_b, seed):
 
 
 # rows: below one tile, ragged tails of both tile heights, the decoder (9 600) and encoder (28 800) row counts of the benchmark
-SHAPES = [(5, 64), (37, 256), (64 * 3 + 5, 256), (1000, 768), (9600, 256), (9600, 2048), (14400, 128), (28800, 256), (28800 + 17, 256)]
+SHAPES = [(5, 64), (37, 256), (64 * 3 + 5, 256), (1000, 768), (4000, 768), (9600, 256), (9600 + 13, 256), (9600, 2048), (14400, 128),
+          (28800, 256), (28800 + 17, 256)]
 
 
 @pytest.mark.parametrize("trans_b", [False, True])

@@ -1089,6 +1089,47 @@ def test_whole_row_products_host_wiring_matches_the_unfused_pairs(cpu_kernels, m
     assert torch.equal(g1, g0)
 
 
+def test_feed_forward_pair_with_row_stages_host_wiring(cpu_kernels, monkeypatch):
+    """The one-launch feed-forward pair carrying the wrapper's row stages (DeferredFfn -> nst_ffn_add_layernorm_fwd,
+    LnBackward.run_ffn -> nst_ffn_layernorm_bwd) against the unfused schedule over the emulated kernels: the next LayerNorm's
+    output, the float32 stream, the gradient handed upstream (and its dropped copy) and the flat gradient buffer are identical;
+    the fused entries were taken exactly once each."""
+    from neurst_amd import kernels as K
+    from neurst_amd.layers.common_layers import LayerNorm, PrePostProcessingWrapper, ResidualStream, TransformerFFN
+    from neurst_amd.runtime import Runtime
+    monkeypatch.setattr("neurst_amd.layers.common_layers._FFN_FUSED_MIN_ROWS", 1)
+    monkeypatch.setattr(K, "ffn_ln_supported", lambda rows, d, f: True)
+    outs, calls = [], {}
+    for fused in (True, False):
+        monkeypatch.setattr("neurst_amd.layers.common_layers._ROW_FUSION", fused)
+        n = {"fwd": 0, "bwd": 0}
+        real_f, real_b = K.ffn_add_layernorm_fwd, K.ffn_layernorm_bwd
+        monkeypatch.setattr(K, "ffn_add_layernorm_fwd", lambda *a, _r=real_f, _n=n, **k: (_n.__setitem__("fwd", _n["fwd"] + 1), _r(*a, **k))[1])
+        monkeypatch.setattr(K, "ffn_layernorm_bwd", lambda *a, _r=real_b, _n=n, **k: (_n.__setitem__("bwd", _n["bwd"] + 1), _r(*a, **k))[1])
+        rt = Runtime(device="cpu", dtype="bfloat16", seed=3)
+        prev = PrePostProcessingWrapper(rt, "p", TransformerFFN(rt, "p/ffn", 256, 128, 0.0, torch.Generator().manual_seed(2)), 256, 0.1, 1e-6)
+        w = PrePostProcessingWrapper(rt, "w", TransformerFFN(rt, "w/ffn", 256, 384, 0.2, torch.Generator().manual_seed(0)), 256, 0.1, 1e-6)
+        nxt = LayerNorm(rt, "n", 256, 1e-6)
+        rt.store.finalize(rt.device, rt.dtype)
+        prev._p = 0.1                                           # (the upstream wrapper only lends its dropout site to the backward)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(70, 256, generator=g)                   # the float32 stream in front of the wrapper
+        delta0 = torch.randn(70, 256, generator=g).to(torch.bfloat16)
+        stream = w.forward(ResidualStream(x, delta0), True)     # the wrapper's own LayerNorm adds delta0 (add_layernorm_fwd)
+        y, xs = nxt.forward_stream(stream, save=True)
+        rt.store.begin_backward()
+        dy = torch.randn(70, 256, generator=g).to(torch.bfloat16)
+        d_mid = nxt.backward(dy, consumer=w)
+        d_in = w.backward(d_mid, consumer=prev)
+        outs.append((y.double(), xs.double(), d_in.double(), d_in._nst_dropped[1].double(), rt.store.grad.clone()))
+        calls[fused] = dict(n)
+        monkeypatch.setattr(K, "ffn_add_layernorm_fwd", real_f)
+        monkeypatch.setattr(K, "ffn_layernorm_bwd", real_b)
+    assert calls[True] == {"fwd": 1, "bwd": 1} and calls[False] == {"fwd": 0, "bwd": 0}, calls
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_dynamic_loss_scale_skips_overflow_steps_and_follows_the_reference_schedule(cpu_kernels):
     """RevisedDynamicLossScale (neurst/training/revised_dynamic_loss_scale.py:48-107) around the train step: gradients carry the
     scale, a finite step applies them unscaled (same weights as the unscaled step), every `growth_steps` good steps the scale
