@@ -219,6 +219,37 @@ def _free_port():
         return sock.getsockname()[1]
 
 
+def autotune_path():
+    """The hand-off file of one run: keyed by the launcher's rendezvous port, its pid AND its start time (field 22 of
+    /proc/<pid>/stat, identical for every rank of the run), so a file left by an earlier run with the same port and pid is never
+    this run's file.  Deleted by rank 0 once every rank has confirmed the choice (confirm_autotune)."""
+    import tempfile
+    ppid = os.getppid()
+    try:
+        start = open(f"/proc/{ppid}/stat").read().rsplit(")", 1)[1].split()[19]
+    except Exception:
+        start = "0"
+    return os.path.join(tempfile.gettempdir(), f"nst_autotune_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{start}.json")
+
+
+def confirm_autotune(tune, rank):
+    """Behind init_process_group: every rank must hold the same chosen environment (a rank that timed out waiting for rank 0's
+    file would otherwise run the timed steps with another carrier / channel count and hang the first collective); then the
+    hand-off file goes away."""
+    import torch.distributed as dist
+    mine = sorted((tune or {}).get("chosen_env", {}).items())
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, mine)
+    if any(e != every[0] for e in every):
+        raise SystemExit(f"bench.py: ranks disagree on the autotuned environment: {every}")
+    dist.barrier()
+    if rank == 0:
+        try:
+            os.remove(autotune_path())
+        except OSError:
+            pass
+
+
 def autotune(args, rank, world):
     """N > 1, BEFORE this process touches HIP: rank 0 times each candidate as a short child job of its own (same N ranks on the
     same GPUs -- the parent ranks hold nothing on them yet), picks the fastest and tells the other ranks through a file next
@@ -228,7 +259,7 @@ def autotune(args, rank, world):
     with no usable candidate the defaults stay.  Returns the report that goes into the JSON line."""
     import subprocess
     import tempfile
-    path = os.path.join(tempfile.gettempdir(), f"nst_autotune_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.json")
+    path = autotune_path()
     fixed = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NCCL_MAX_NCHANNELS", "NST_DIST_NATIVE") if k in os.environ}
     if rank != 0:
         t_end = time.time() + args.autotune_budget + 90.0
@@ -348,6 +379,8 @@ def main():
     # per CU).  RCCL's default for large messages takes several times as many.  Override with NCCL_MAX_NCHANNELS.
     os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
     rank, local_rank, world = init_distributed()
+    if tune is not None and world > 1:
+        confirm_autotune(tune, rank)
     if args.graph is None:
         # graph replay is the default for ANY number of ranks since round 4: host issue time is ~1 ms instead of ~11 ms per
         # step, and the exchange is replayed eagerly between the captured segments (TrainStep); soak log of the forced
@@ -526,6 +559,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    reducer.close()
     print(json.dumps(out), flush=True)
 
 

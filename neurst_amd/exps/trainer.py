@@ -166,4 +166,5 @@ class Trainer(BaseExperiment):
                 if stop["stop"] > 0:
                     logging.info("early stop at step %d", step)
                     break
+        reducer.close()      # (explicit: the library's communicator is not left to the garbage collector)
         return last_loss

@@ -272,6 +272,24 @@ class ParamStore(object):
 _HWQ_NOTE = [None, None]     # (the line logged by the first call, the value of the variable behind it)
 
 
+# every NST_* variable something in this tree reads (the library, the host side, bench.py, the tests' kernel-selection switches)
+KNOWN_SWITCHES = frozenset((
+    "NST_TRAIN_GRAPH", "NST_DIST_BACKEND", "NST_DIST_FORCE", "NST_DIST_WIRE", "NST_DIST_NATIVE", "NST_DIST_TIMEOUT_MIN",
+    "NST_DIST_BUCKET_MB", "NST_DIST_DEBUG", "NST_RCCL_PATH", "NST_COMM_DEBUG", "NST_BENCH_CHILD", "NST_BENCH_HANG_DUMP_S",
+    "NST_BENCH_VERBOSE", "NST_FFN_MIN_ROWS", "NST_FFN_NW", "NST_ATTN_FUSED_BWD", "NST_ATTN_MI_FWD", "NST_ATTN_MI_DKDV", "NST_ATTN_MI_DQ",
+    "NST_ROW_FUSION", "NST_ROWGEMM_CFG", "NST_TEST_L2_F32", "NST_TEST_L2_BF16"))
+
+
+def warn_unknown_switches():
+    """A dead experiment switch must not silently mislabel a measurement (round 5: a profile script still set NST_WGRAD_STREAM=0
+    after the variable had been removed): every NST_* variable of the environment that nothing reads any more is reported."""
+    unknown = sorted(k for k in os.environ if k.startswith("NST_") and k not in KNOWN_SWITCHES)
+    if unknown:
+        import warnings
+        warnings.warn("environment variables that neurst_amd does not read (removed switches?): " + ", ".join(unknown))
+    return unknown
+
+
 def configure_training_process():
     """Process-wide HIP setting of the TRAINING entry points (init_distributed, bench.py, neurst-run); returns the line it logs.
     Must run before the first HIP call of the process (the runtime reads the variable once, when it initialises).
@@ -290,6 +308,8 @@ def configure_training_process():
     import logging
     import torch
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if _HWQ_NOTE[0] is None:
+        warn_unknown_switches()
     if _HWQ_NOTE[0] is not None and _HWQ_NOTE[1] == cur:
         return _HWQ_NOTE[0]          # a repeated call (bench.py asks again for its JSON line): what the FIRST call did
     if cur is not None:

@@ -202,8 +202,10 @@ class GradientReducer(object):
             self._wire_buf = torch.empty(store.total, dtype=self.wire_dtype, device=store.grad.device)
 
     def close(self):
-        """Releases the library's communicator (ncclCommDestroy, its stream and events); idempotent."""
-        comm, self._comm = self._comm, None
+        """Releases the library's communicator (ncclCommDestroy, its stream and events); idempotent.  Call it explicitly where
+        the reducer's life ends (Trainer.run, bench.py): the destructor below is only the last resort."""
+        comm = getattr(self, "_comm", None)     # (a constructor that raised early never assigned it)
+        self._comm = None
         if comm is not None:
             try:
                 comm.destroy()
@@ -211,6 +213,14 @@ class GradientReducer(object):
                 pass
 
     def __del__(self):
+        # a reference-count drop can land anywhere -- also in the middle of another step's graph capture, where destroying a
+        # communicator (stream + event destruction, a device synchronisation inside RCCL) would abort the capture: leave the
+        # communicator to process exit in that case
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
+        except Exception:
+            pass
         self.close()
 
     # ---- parameter ranges -------------------------------------------------------------------------------------

@@ -387,6 +387,11 @@ def test_speech_transformer_s_bf16_step_against_the_oracle_fixture(batch):
     # the model, 2.9e-2 against 1.1e-2 -- and 1.9 at 128; median 0.7 - 0.8)
     bad = [(n, float(h), float(e)) for n, h, e in zip(names, per_hip, per_emu) if h > 3.0 * e + 4e-3]
     assert not bad, f"{len(bad)} gradient tensors farther from the oracle than bf16 rounding explains: {bad[:6]}"
+    # ... and the wide band is for the SMALL tensors only: a tensor that carries more than 1 % of the gradient's norm stays
+    # within 2 x the emulation (a real regression in a tensor that matters cannot hide behind the q_transform's noise)
+    share = fx["grad_norm_ref"] / max(float(np.linalg.norm(fx["grad_norm_ref"])), 1e-30)
+    bad2 = [(n, float(h), float(e), float(w)) for n, h, e, w in zip(names, per_hip, per_emu, share) if w > 1e-2 and h > 2.0 * e + 2e-3]
+    assert not bad2, f"{len(bad2)} large gradient tensors beyond 2 x the emulation's distance: {bad2[:6]}"
     assert rep["grad_norm_rel_err_worst"] <= 5e-2, rep
     # the north star's bf16 bar of 1e-2 at the benchmark batch: met since the residual stream is carried in float32
     # (round 5: 8.8e-3 measured by projections, 1.05e-2 before; at 32 utterances 1.25e-2, 1.87e-2 before)

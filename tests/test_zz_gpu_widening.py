@@ -303,3 +303,84 @@ def test_criterion_kernels_match_the_reference_code(ls, variant):
     loss = crit.reduce_loss(inp, logits)
     assert abs(float(loss) - float(r[key + ":loss"])) < 1e-5
     assert float((crit.backward().cpu() - torch.from_numpy(r[key + ":dlogits"])).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ zero-padded vocabulary rows
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_vocabulary_padding_rows_stay_zero_through_training_and_a_checkpoint_round_trip(dtype, tmp_path):
+    """A vocabulary that is not a multiple of 8 keeps (Vp8 - V) zero rows behind the shared table and its bias in the flat
+    buffers (text_modalities.py: the tied logits, their input gradient and the table's weight gradient then run over Vp8
+    rows).  The invariant nothing else enforces: those rows of master, shadow, gradient and both Adam moments are EXACTLY zero
+    after optimizer steps with gradient accumulation and clipping and after a checkpoint save / restore -- one non-finite value
+    there would poison every later input gradient -- and the padded products are the ones that ran."""
+    from neurst_amd import kernels as K
+    from neurst_amd.criterions import build_criterion
+    from neurst_amd.models.transformer import Transformer
+    from neurst_amd.optimizers.adam import Adam
+    from neurst_amd.tasks import build_task
+    from neurst_amd.training.train_step import TrainStep
+    from neurst_amd.utils import compat
+    d, H, ffn, B, S, L, Vs, Vt = 64, 2, 128, 4, 9, 7, 29, 37
+    p = dict(Transformer.build_model_args_by_name("transformer_toy")["model.params"])
+    p.update({"modality.dim": d, "encoder.num_layers": 1, "decoder.num_layers": 1, "encoder.hidden_size": d, "decoder.hidden_size": d,
+              "encoder.num_attention_heads": H, "decoder.num_attention_heads": H, "encoder.filter_size": ffn, "decoder.filter_size": ffn})
+    task = build_task({"task.class": "translation", "task.params": {"src_vocab_size": Vs, "trg_vocab_size": Vt}})
+
+    def build():
+        return task.build_model({"model.class": "Transformer", "model.params": p}, device=DEV, dtype=dtype, init_seed=5)
+    model = build()
+    crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
+    opt = Adam(model.store, learning_rate=1e-2, beta_1=0.9, beta_2=0.98, epsilon=1e-9)
+    step = TrainStep(model, crit, opt, update_cycle=2, clip_norm=1.0, use_graph=False)
+    g = torch.Generator().manual_seed(3)
+
+    def batch():
+        def side(Lx, V):
+            ids = torch.randint(0, V - 3, (B, Lx), generator=g)
+            ids[:, -1] = V - 1
+            return ids
+        inp = task.example_to_input({"feature": side(S, Vs), "label": side(L, Vt)}, compat.ModeKeys.TRAIN)
+        return {k: v.to(DEV) for k, v in inp.items()}
+
+    padded_calls = []
+    real = K.gemm
+
+    def spy(A, Bm, M, N, Kd, *a, **k):
+        if 40 in (M, N, Kd):     # Vp8 of the 37-word target vocabulary
+            padded_calls.append((M, N, Kd))
+        return real(A, Bm, M, N, Kd, *a, **k)
+    K.gemm = spy
+    try:
+        for _ in range(3):
+            step([batch(), batch()])
+    finally:
+        K.gemm = real
+    assert len(padded_calls) >= 3 * 2 * 3, padded_calls      # logits, their input gradient and the table gradient of every micro batch
+
+    def tails(m):
+        st = m.store
+        out = []
+        for prm in st.params.values():
+            if getattr(prm, "tail_pad", 0):
+                sl = slice(prm.offset + prm.numel, prm.offset + prm.numel + prm.tail_pad)
+                bufs = [("master", st.master), ("grad", st.grad)] + ([("shadow", st.shadow)] if st.shadow is not None else [])
+                out += [(prm.name, nm, buf[sl]) for nm, buf in bufs]
+        return out
+    found = tails(model)
+    assert len(found) >= 4                                   # target table + bias (the 29-word source table pads too)
+    for name, nm, t in found:
+        assert t.numel() > 0 and float(t.float().abs().max()) == 0.0, f"{name}: {nm} padding left zero"
+    for name, buf in (("m", opt.m), ("v", opt.v)):
+        for prm in model.store.params.values():
+            if getattr(prm, "tail_pad", 0):
+                t = buf[prm.offset + prm.numel:prm.offset + prm.numel + prm.tail_pad]
+                assert float(t.abs().max()) == 0.0, f"{prm.name}: Adam {name} padding left zero"
+    # checkpoint round trip into a fresh model: variables travel in their reference shapes, the padding is rebuilt as zeros
+    sd = model.store.state_dict()
+    assert tuple(sd["target_symbol_modality/shared/weights"].shape) == (Vt, d)
+    fresh = build()
+    fresh.store.load_state_dict(sd)
+    for name, nm, t in tails(fresh):
+        assert float(t.float().abs().max()) == 0.0, f"restored {name}: {nm} padding"
+    b = batch()
+    assert torch.equal(model(b, is_training=False), fresh(b, is_training=False))
