@@ -528,21 +528,28 @@ int nst_ffn_fwd(const NstFfnDesc* desc, const void* x, const void* w1t, const fl
 int nst_ffn_bwd(const NstFfnDesc* desc, const void* dy, const void* hidden, const void* w2, const void* w1,
                 const void* residual, void* dhidden, void* dx, void* stream);
 /* The feed-forward pair (nst_ffn_fwd / nst_ffn_bwd above) with the same row stages behind its second product (ABI 10; the
- * eight-wave kernel's shapes with gate bits: nst_ffn_ln_supported):
+ * eight-wave kernel's shapes with gate bits):
  *   nst_ffn_add_layernorm_fwd = nst_ffn_fwd (residual NULL, output dropout of the desc) followed by nst_add_layernorm_fwd on the
  *     float32 stream x_res: x_out = x_res + delta, y = LayerNorm(x_out; gamma, beta, eps), mean / rstd;
  *   nst_ffn_layernorm_bwd = nst_ffn_bwd (residual NULL) followed by nst_layernorm_bwd_mixed of the wrapper's LayerNorm (saved
  *     input x_ln f32, mean, rstd, gamma; dres added; dz = dropped copy of dx under (dz_p, dz_seed, dz_stream_id), nullable;
- *     dgamma / dbeta through workspace >= ceil(rows / 128) * 2 * 256 * 4 bytes, job_out as in nst_layernorm_bwd_deferred). */
+ *     dgamma / dbeta through workspace >= ceil(rows / 32) * 2 * 256 * 4 bytes, job_out as in nst_layernorm_bwd_deferred).
+ * nst_ffn_ln_supported: 0 = no; 1 = one launch (>= 20 480 rows: every CU gets a 128-row tile); 2 = two launches (1 024 ..
+ * 20 479 rows, e.g. the decoder's 9 600: too few row tiles for the chip, so the hidden dimension is split over S workgroups per
+ * tile that leave f32 partial sums in `slabs` (nst_ffn_ln_slab_bytes(desc) bytes, 16-byte aligned, caller-owned scratch) and a
+ * second launch adds them and runs the row stages).  Gate bits are required in both modes: rows * (filter_size / 32) * 4 bytes
+ * (what nst_ffn_gate_bits_bytes returns where nst_ffn_fwd supports them); bits written by mode 2 are read by
+ * nst_ffn_layernorm_bwd only. */
 int nst_ffn_ln_supported(const NstFfnDesc* desc);
+int64_t nst_ffn_ln_slab_bytes(const NstFfnDesc* desc);
 int nst_ffn_add_layernorm_fwd(const NstFfnDesc* desc, const void* x, const void* w1t, const float* b1, const void* w2t,
                               const float* b2, const float* x_res, float* x_out, const float* gamma, const float* beta, float eps,
-                              void* hidden, void* y, float* mean, float* rstd, void* stream);
+                              void* hidden, void* y, float* mean, float* rstd, void* slabs, int64_t slabs_bytes, void* stream);
 int nst_ffn_layernorm_bwd(const NstFfnDesc* desc, const void* dy, const void* hidden, const void* w2, const void* w1,
                           const float* x_ln, const float* gamma, const float* mean, const float* rstd, const void* dres,
                           void* dhidden, void* dx, void* dz, float dz_p, uint64_t dz_seed, uint64_t dz_stream_id, float* dgamma,
                           float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
-                          void* stream);
+                          void* slabs, int64_t slabs_bytes, void* stream);
 
 /* Batched bf16 transposes dst[cols, rows] = src[rows, cols]^T, one launch for a table of matrices (device memory):
  * tile0 = number of 64x64 tiles of all earlier jobs, tiles_c = ceil(cols / 64); total_tiles = sum over jobs. */

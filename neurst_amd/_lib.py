@@ -151,9 +151,10 @@ SIGNATURES = {
     "nst_ffn_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "nst_ffn_ln_supported": [C.POINTER(NstFfnDesc)],
-    "nst_ffn_add_layernorm_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P],
+    "nst_ffn_ln_slab_bytes": [C.POINTER(NstFfnDesc)],
+    "nst_ffn_add_layernorm_fwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _L, _P],
     "nst_ffn_layernorm_bwd": [C.POINTER(NstFfnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U64, _P, _P, _I, _P,
-                              _L, _P, _P],
+                              _L, _P, _P, _L, _P],
     "nst_transpose_bf16": [_P, _I, _I, _P],
     "nst_pack2d": [_P, _I, _I, _P],
     "nst_stream_create": [_I, C.POINTER(C.c_void_p)],
@@ -178,7 +179,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "nst_last_error_string"
-                      else C.c_int64 if name in ("nst_attention_dropout_mask_bytes", "nst_ffn_gate_bits_bytes")
+                      else C.c_int64 if name in ("nst_attention_dropout_mask_bytes", "nst_ffn_gate_bits_bytes", "nst_ffn_ln_slab_bytes")
                       else C.c_uint32 if name == "nst_crc32c" else C.c_int)
     ver = lib.nst_abi_version()
     if ver != NST_ABI_VERSION:

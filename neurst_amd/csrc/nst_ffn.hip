@@ -77,6 +77,9 @@ struct FfnArgs {
   // the row phase of nst_rowphase.h instead of to `out` directly
   rowphase::RowEpi rp;
   uint64_t rp_seed;
+  // OUTM == 2 (hidden dimension split over gridDim.y workgroups per row tile): the raw f32 partial sums of the second product,
+  // [gridDim.y][M][256]; ffn_slab_rows_kernel adds the slabs and runs the row phase
+  float* slab;
 };
 
 __device__ __forceinline__ int pi32(int r) { return (((r >> 2) & 1) << 4) + ((r >> 3) << 2) + (r & 3); }
@@ -574,8 +577,12 @@ constexpr int V2_ROWS = 128;
 // values it stores) and writes them as gate_bits[(2 chunk + hh) * M + row][h] (uint16): one 128-byte store per wave and chunk.
 // The backward then fetches 4 bytes per row and half chunk (one LDS-DMA instruction per wave and chunk) instead of 64:
 // 7.4 MB instead of 118 MB at the benchmark shape, and the weight-gradient stream running beside it keeps that bandwidth.
-template <int MODE, int DROP, bool FULL, int DBG = 0, bool BITS = false, bool LN = false>
+// OUTM: 0 = the output tile leaves through the final epilogue below; 1 = through LDS to the row phase (LayerNorm stages of the
+// wrapper, nst_rowphase.h); 2 = the workgroup walks only ITS share of the hidden chunks (blockIdx.y of gridDim.y) and stores raw
+// f32 partial sums to a slab -- fewer row tiles than CUs (the decoder's 9 600 rows = 75 tiles) then still fill the chip
+template <int MODE, int DROP, bool FULL, int DBG = 0, bool BITS = false, int OUTM = 0>
 __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
+  constexpr bool LN = OUTM == 1;
   static_assert(MODE == MODE_FWD || DROP == 0, "the backward has no dropout of its own (the gate carries the forward's mask)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
@@ -585,12 +592,14 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   const int rg = wave & 3, hh = wave >> 2;
   const int i_l = lane & 31, h = lane >> 5;
   const int F = a.F, M = a.M;
-  const int nch = F / CH2;
+  const int nch_all = F / CH2;
+  const int c_base = OUTM == 2 ? (int)((blockIdx.y * nch_all) / gridDim.y) : 0;
+  const int nch = OUTM == 2 ? (int)(((blockIdx.y + 1) * nch_all) / gridDim.y) - c_base : nch_all;   // >= 2 (host)
   const int m0 = blockIdx.x * V2_ROWS;
   // rotated chunk order: the chip writes all columns of the hidden tensor at once (mode 0: per workgroup; mode 1: per XCD --
   // the 28 workgroups of an XCD then stream the SAME weight chunk through their shared L2 at about the same time)
   const int rot = a.rot_mode == 0 ? (int)(blockIdx.x % nch) : (a.rot_mode == 1 ? (int)(blockIdx.x & 7) * (nch >> 3) % nch : 0);
-  auto phys = [&](int c) { const int q = c + rot; return q >= nch ? q - nch : q; };
+  auto phys = [&](int c) { const int q = c + rot; return c_base + (q >= nch ? q - nch : q); };
   const int row = m0 + rg * 32 + i_l;   // this lane's row of Xin / outputs
   const bool row_ok = FULL || row < M;
   const int row_c = row_ok ? row : M - 1;
@@ -909,7 +918,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   uint4 rres[4][2];
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob) rres[ob][0] = rres[ob][1] = make_uint4(0u, 0u, 0u, 0u);
-  if (!LN && a.residual) {
+  if (OUTM == 0 && a.residual) {
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
       const uint4* rp = reinterpret_cast<const uint4*>(a.residual + (int64_t)row_c * D + 128 * hh + 32 * ob + 16 * h);
@@ -942,6 +951,17 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
       uint64_t sd = a.rp_seed;
       if (a.rp.dz) sd = seed_with_offset(a.rp_seed, a.seed_dev);   // wave-uniform
       rowphase::ln_bwd<8, 16, false>(tile, tile + 128 * rowphase::TILE_LD, a.rp, sd, m0, M, tid, wave, lane, nopre);
+    }
+    return;
+  }
+  if constexpr (OUTM == 2) {
+    if (row_ok) {
+      float* sp = a.slab + ((int64_t)blockIdx.y * M + row) * D + 128 * hh + 16 * h;
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(sp + 32 * ob + 4 * q) = make_float4(accY[ob][4 * q], accY[ob][4 * q + 1], accY[ob][4 * q + 2], accY[ob][4 * q + 3]);
     }
     return;
   }
@@ -1052,16 +1072,103 @@ int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
 template <int DROP, bool FULL>
 void launch_v2_fwd_ln(const FfnArgs& a, hipStream_t st) {
   const int lds = V2_BIAS + a.F * 4;
-  auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true, true>;
+  auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true, 1>;
   allow_lds(k, lds);
   k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
 }
 template <bool FULL>
 void launch_v2_bwd_ln(const FfnArgs& a, hipStream_t st) {
   const int lds = V2_BIAS + 16384;
-  auto k = ffn_pair8_kernel<MODE_BWD, 0, FULL, 0, true, true>;
+  auto k = ffn_pair8_kernel<MODE_BWD, 0, FULL, 0, true, 1>;
   allow_lds(k, lds);
   k<<<(a.M + V2_ROWS - 1) / V2_ROWS, 512, lds, st>>>(a);
+}
+
+// ---- hidden dimension split over workgroups (fewer than 160 row tiles of 128 rows): S slices fill the chip with S x tiles
+// workgroups, ffn_slab_rows_kernel adds their slabs and runs the row phase on 32-row tiles
+int ffn_split(int64_t M, int F) {
+  if (M >= 128 * 160 || M < 1024 || F % CH2 != 0 || F < 4 * CH2 || F > 4096) return 0;
+  const int tiles = (int)((M + V2_ROWS - 1) / V2_ROWS);
+  int S = 240 / tiles;
+  if (S > 4) S = 4;
+  while (S > 1 && (F / CH2) / S < 2) --S;
+  return S >= 2 ? S : 0;
+}
+
+struct SlabArgs {
+  const float* slab;
+  int S, M;
+  rowphase::RowEpi rp;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+};
+
+template <int EPI>   // 0: forward row phase, 1: backward
+__global__ void __launch_bounds__(256, 2) ffn_slab_rows_kernel(SlabArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * rowphase::TILE_LD + (EPI == 1 ? 4 * 2 * rowphase::RN : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, M = a.M;
+  // the f32 rows of the row phase first (its lane layout), then every slab piece of this thread: all loads of the workgroup are
+  // in flight before the first add
+  float xpre[4][8];
+  {
+    const int sub = lane >> 5, col = (lane & 31) * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int rowg = m0 + wave * 8 + p * 2 + sub;
+      rowg = rowg < M ? rowg : M - 1;
+      const float4 u0 = *reinterpret_cast<const float4*>(a.rp.x + (int64_t)rowg * D + col);
+      const float4 u1 = *reinterpret_cast<const float4*>(a.rp.x + (int64_t)rowg * D + col + 4);
+      xpre[p][0] = u0.x; xpre[p][1] = u0.y; xpre[p][2] = u0.z; xpre[p][3] = u0.w;
+      xpre[p][4] = u1.x; xpre[p][5] = u1.y; xpre[p][6] = u1.z; xpre[p][7] = u1.w;
+    }
+  }
+  float4 v[4][8];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    if (sl < a.S) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + tid, r = idx >> 6, c4 = (idx & 63) * 4;
+        int rowg = m0 + r;
+        rowg = rowg < M ? rowg : M - 1;
+        v[sl][i] = *reinterpret_cast<const float4*>(a.slab + ((int64_t)sl * M + rowg) * D + c4);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[sl][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = i * 256 + tid, r = idx >> 6, c4 = (idx & 63) * 4;
+    float4 t;   // slices in order 0, 1, 2, 3: a fixed summation order
+    t.x = ((v[0][i].x + v[1][i].x) + v[2][i].x) + v[3][i].x;
+    t.y = ((v[0][i].y + v[1][i].y) + v[2][i].y) + v[3][i].y;
+    t.z = ((v[0][i].z + v[1][i].z) + v[2][i].z) + v[3][i].z;
+    t.w = ((v[0][i].w + v[1][i].w) + v[2][i].w) + v[3][i].w;
+    *reinterpret_cast<float4*>(tile + r * rowphase::TILE_LD + c4) = t;
+  }
+  __syncthreads();
+  uint64_t sd = a.seed;
+  if (a.rp.drop_thresh) sd = seed_with_offset(a.seed, a.seed_dev);
+  if constexpr (EPI == 0) rowphase::ln_fwd<8, true>(tile, a.rp, sd, m0, M, wave, lane, xpre);
+  else rowphase::ln_bwd<4, 8, true>(tile, tile + 32 * rowphase::TILE_LD, a.rp, sd, m0, M, tid, wave, lane, xpre);
+}
+
+template <int DROP, bool FULL>
+void launch_v2_fwd_split(const FfnArgs& a, int S, hipStream_t st) {
+  const int lds = V2_BIAS + a.F * 4;
+  auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true, 2>;
+  allow_lds(k, lds);
+  k<<<dim3((a.M + V2_ROWS - 1) / V2_ROWS, S), 512, lds, st>>>(a);
+}
+template <bool FULL>
+void launch_v2_bwd_split(const FfnArgs& a, int S, hipStream_t st) {
+  const int lds = V2_BIAS + 16384;
+  auto k = ffn_pair8_kernel<MODE_BWD, 0, FULL, 0, true, 2>;
+  allow_lds(k, lds);
+  k<<<dim3((a.M + V2_ROWS - 1) / V2_ROWS, S), 512, lds, st>>>(a);
 }
 
 bool use_v2_bwd(const FfnArgs& a) {
@@ -1241,7 +1348,7 @@ extern "C" int64_t nst_ffn_gate_bits_bytes(const NstFfnDesc* d) {
   FfnArgs a;
   memset(&a, 0, sizeof(a));
   a.M = (int)d->rows; a.F = d->filter_size;
-  return (use_v2_fwd(a) && use_v2_bwd(a)) ? (int64_t)a.M * (a.F / 32) * 4 : 0;
+  return (use_v2_fwd(a) && use_v2_bwd(a)) ? (int64_t)a.M * (a.F / 32) * 4 : 0;   // (what nst_ffn_fwd / nst_ffn_bwd can use)
 }
 
 extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidden, const void* w2, const void* w1,
@@ -1285,15 +1392,25 @@ extern "C" int nst_ffn_ln_supported(const NstFfnDesc* d) {
   FfnArgs a;
   memset(&a, 0, sizeof(a));
   a.M = (int)d->rows; a.F = d->filter_size;
-  return (use_v2_fwd(a) && use_v2_bwd(a) && (int64_t)d->rows * d->filter_size * 2 < (1ll << 32)) ? 1 : 0;
+  if ((int64_t)d->rows * d->filter_size * 2 >= (1ll << 32)) return 0;
+  if (use_v2_fwd(a) && use_v2_bwd(a)) return 1;
+  return ffn_split(a.M, a.F) > 0 ? 2 : 0;
+}
+
+extern "C" int64_t nst_ffn_ln_slab_bytes(const NstFfnDesc* d) {
+  if (nst_ffn_ln_supported(d) != 2) return 0;
+  return (int64_t)ffn_split(d->rows, d->filter_size) * d->rows * D * 4;
 }
 
 extern "C" int nst_ffn_add_layernorm_fwd(const NstFfnDesc* d, const void* x, const void* w1t, const float* b1, const void* w2t,
                                          const float* b2, const float* x_res, float* x_out, const float* gamma, const float* beta,
-                                         float eps, void* hidden, void* y, float* mean, float* rstd, void* stream) {
+                                         float eps, void* hidden, void* y, float* mean, float* rstd, void* slabs, int64_t slabs_bytes,
+                                         void* stream) {
   NST_CHECK_ARG(d && x && w1t && w2t && hidden && y && x_res && gamma && beta && mean && rstd, "ffn_add_layernorm_fwd: null pointer");
-  NST_CHECK_ARG(nst_ffn_ln_supported(d) && d->gate_bits, "ffn_add_layernorm_fwd: needs the eight-wave kernel's shapes (rows >= %d) and gate bits",
-                128 * 160);
+  const int ln_mode = nst_ffn_ln_supported(d);
+  NST_CHECK_ARG(ln_mode && d->gate_bits, "ffn_add_layernorm_fwd: needs the eight-wave kernel's shapes (rows >= 1024) and gate bits");
+  NST_CHECK_ARG(ln_mode == 1 || (slabs && (((uintptr_t)slabs) & 15) == 0 && slabs_bytes >= nst_ffn_ln_slab_bytes(d)),
+                "ffn_add_layernorm_fwd: %lld bytes of slabs needed (nst_ffn_ln_slab_bytes)", (long long)nst_ffn_ln_slab_bytes(d));
   NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(w1t) && nst_aligned16(w2t) && nst_aligned16(hidden) && nst_aligned16(y) &&
                     nst_aligned16(x_res) && (!x_out || nst_aligned16(x_out)) && nst_aligned16(gamma) && nst_aligned16(beta) &&
                     (!b2 || nst_aligned16(b2)),
@@ -1311,7 +1428,7 @@ extern "C" int nst_ffn_add_layernorm_fwd(const NstFfnDesc* d, const void* x, con
   nst_dropout_params16(d->hidden_dropout_p, &a.drop1_thresh, &a.drop1_inv_keep);
   nst_dropout_params16(d->output_dropout_p, &a.drop2_thresh, &a.drop2_inv_keep);
   a.seed1 = d->hidden_seed; a.stream1 = d->hidden_stream_id; a.seed2 = d->output_seed; a.stream2 = d->output_stream_id;
-  const int64_t need = nst_ffn_gate_bits_bytes(d);
+  const int64_t need = (int64_t)a.M * (a.F / 32) * 4;     // (both forms of this entry write them, also where nst_ffn_fwd cannot)
   NST_CHECK_ARG(need > 0 && d->gate_bits_bytes >= need && ((uintptr_t)d->gate_bits & 3) == 0, "ffn_add_layernorm_fwd: gate_bits holds %lld bytes, %lld needed",
                 (long long)d->gate_bits_bytes, (long long)need);
   a.gate_bits = (uint16_t*)d->gate_bits;
@@ -1321,6 +1438,22 @@ extern "C" int nst_ffn_add_layernorm_fwd(const NstFfnDesc* d, const void* x, con
   a.rot_mode = 0;
   const bool full = a.M % V2_ROWS == 0;
   const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
+  if (ln_mode == 2) {
+    // fewer row tiles than CUs: the hidden dimension is split over S workgroups per tile (f32 slabs), a second launch adds the
+    // slabs and runs the row phase
+    const int S = ffn_split(a.M, a.F);
+    a.slab = (float*)slabs;
+    if (full && drop == 3) launch_v2_fwd_split<3, true>(a, S, (hipStream_t)stream);
+    else if (full && drop == 0) launch_v2_fwd_split<0, true>(a, S, (hipStream_t)stream);
+    else launch_v2_fwd_split<3, false>(a, S, (hipStream_t)stream);
+    NST_CHECK_LAUNCH("ffn_add_layernorm_fwd(split)");
+    SlabArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.slab = a.slab; sa.S = S; sa.M = a.M; sa.rp = a.rp; sa.seed = a.seed2; sa.seed_dev = a.seed_dev;
+    ffn_slab_rows_kernel<0><<<(a.M + 31) / 32, 256, 0, (hipStream_t)stream>>>(sa);
+    NST_CHECK_LAUNCH("ffn_add_layernorm_fwd(rows)");
+    return NST_OK;
+  }
   if (full && drop == 3) launch_v2_fwd_ln<3, true>(a, (hipStream_t)stream);
   else if (full && drop == 0) launch_v2_fwd_ln<0, true>(a, (hipStream_t)stream);
   else launch_v2_fwd_ln<3, false>(a, (hipStream_t)stream);
@@ -1332,11 +1465,14 @@ extern "C" int nst_ffn_layernorm_bwd(const NstFfnDesc* d, const void* dy, const 
                                      const float* x_ln, const float* gamma, const float* mean, const float* rstd, const void* dres,
                                      void* dhidden, void* dx, void* dz, float dz_p, uint64_t dz_seed, uint64_t dz_stream_id,
                                      float* dgamma, float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes,
-                                     NstLnFinalizeJob* job_out, void* stream) {
+                                     NstLnFinalizeJob* job_out, void* slabs, int64_t slabs_bytes, void* stream) {
   if (job_out) memset(job_out, 0, sizeof(*job_out));
   NST_CHECK_ARG(d && dy && hidden && w2 && w1 && dhidden && dx && x_ln && gamma && mean && rstd && dgamma && dbeta && workspace,
                 "ffn_layernorm_bwd: null pointer");
-  NST_CHECK_ARG(nst_ffn_ln_supported(d) && d->gate_bits, "ffn_layernorm_bwd: needs the eight-wave kernel's shapes and gate bits");
+  const int ln_mode = nst_ffn_ln_supported(d);
+  NST_CHECK_ARG(ln_mode && d->gate_bits, "ffn_layernorm_bwd: needs the eight-wave kernel's shapes and gate bits");
+  NST_CHECK_ARG(ln_mode == 1 || (slabs && (((uintptr_t)slabs) & 15) == 0 && slabs_bytes >= nst_ffn_ln_slab_bytes(d)),
+                "ffn_layernorm_bwd: %lld bytes of slabs needed (nst_ffn_ln_slab_bytes)", (long long)nst_ffn_ln_slab_bytes(d));
   NST_CHECK_ARG(nst_aligned16(dy) && nst_aligned16(hidden) && nst_aligned16(w1) && nst_aligned16(w2) && nst_aligned16(dhidden) &&
                     nst_aligned16(dx) && nst_aligned16(x_ln) && nst_aligned16(gamma) && (!dres || nst_aligned16(dres)) &&
                     (!dz || nst_aligned16(dz)) && (((uintptr_t)workspace) & 15) == 0,
@@ -1354,7 +1490,7 @@ extern "C" int nst_ffn_layernorm_bwd(const NstFfnDesc* d, const void* dy, const 
   NST_CHECK_ARG(d->gate_bits_bytes >= (int64_t)a.M * (a.F / 32) * 4 && ((uintptr_t)d->gate_bits & 3) == 0,
                 "ffn_layernorm_bwd: gate_bits holds %lld bytes", (long long)d->gate_bits_bytes);
   a.gate_bits = (uint16_t*)d->gate_bits;
-  const int nb = (a.M + V2_ROWS - 1) / V2_ROWS;
+  const int nb = ln_mode == 2 ? (a.M + 31) / 32 : (a.M + V2_ROWS - 1) / V2_ROWS;
   if (workspace_bytes < (int64_t)nb * 2 * D * 4) {
     nst_set_error("ffn_layernorm_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)nb * 2 * D * 4);
     return NST_ERR_WORKSPACE;
@@ -1368,7 +1504,18 @@ extern "C" int nst_ffn_layernorm_bwd(const NstFfnDesc* d, const void* dy, const 
     a.rp_seed = dz_seed; a.rp.stream_id = dz_stream_id;
   }
   a.rot_mode = 0;
-  if (a.M % V2_ROWS == 0) launch_v2_bwd_ln<true>(a, (hipStream_t)stream);
+  if (ln_mode == 2) {
+    const int S = ffn_split(a.M, a.F);
+    a.slab = (float*)slabs;
+    if (a.M % V2_ROWS == 0) launch_v2_bwd_split<true>(a, S, (hipStream_t)stream);
+    else launch_v2_bwd_split<false>(a, S, (hipStream_t)stream);
+    NST_CHECK_LAUNCH("ffn_layernorm_bwd(split)");
+    SlabArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.slab = a.slab; sa.S = S; sa.M = a.M; sa.rp = a.rp; sa.seed = a.rp_seed; sa.seed_dev = a.seed_dev;
+    if (!a.rp.dz) sa.rp.drop_thresh = 0;
+    ffn_slab_rows_kernel<1><<<nb, 256, 0, (hipStream_t)stream>>>(sa);
+  } else if (a.M % V2_ROWS == 0) launch_v2_bwd_ln<true>(a, (hipStream_t)stream);
   else launch_v2_bwd_ln<false>(a, (hipStream_t)stream);
   NST_CHECK_LAUNCH("ffn_layernorm_bwd");
   NstLnFinalizeJob job;

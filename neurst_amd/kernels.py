@@ -579,7 +579,13 @@ def ffn_ln_supported(rows, d, f):
     """Whether the feed-forward pair carries the wrapper's row stages for this call (nst_ffn_ln_supported: the eight-wave kernel's
     shapes -- >= 20 480 rows, d_model 256 -- with gate bits)."""
     desc = _ffn_desc(int(rows), int(d), int(f), 0.0, 0, 0)
-    return bool(lib.nst_ffn_ln_supported(C.byref(desc)))
+    return int(lib.nst_ffn_ln_supported(C.byref(desc)))      # 0 | 1 (one launch) | 2 (hidden dimension split + a row launch)
+
+
+def _ffn_slabs(desc, device):
+    """Scratch for the split form's f32 partial sums (None when the call is a single launch)."""
+    nbytes = int(lib.nst_ffn_ln_slab_bytes(C.byref(desc)))
+    return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes) if nbytes > 0 else (None, 0)
 
 
 def ffn_add_layernorm_fwd(x, w1t, b1, w2t, b2, x_res, gamma, beta, eps, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0,
@@ -596,12 +602,14 @@ def ffn_add_layernorm_fwd(x, w1t, b1, w2t, b2, x_res, gamma, beta, eps, hidden_p
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     desc = _ffn_desc(rows, d, f, hidden_p, hidden_seed, hidden_site, out_p, out_seed, out_site)
-    nbytes = int(lib.nst_ffn_gate_bits_bytes(C.byref(desc)))
-    bits = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
+    nbytes = rows * (f // 32) * 4       # (both forms of this entry write the bits; ffn_layernorm_bwd reads them)
+    bits = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     desc.gate_bits, desc.gate_bits_bytes = bits.data_ptr(), nbytes
+    slabs, slab_bytes = _ffn_slabs(desc, x.device)
     ev = PROBE.begin("ffn_fwd")
     check(lib.nst_ffn_add_layernorm_fwd(C.byref(desc), _p(x), _p(w1t), _p(b1), _p(w2t), _p(b2), _p(x_res), _p(xs), _p(gamma), _p(beta),
-                                        float(eps), _p(hidden), _p(y), _p(mean), _p(rstd), _stream()), "ffn_add_layernorm_fwd")
+                                        float(eps), _p(hidden), _p(y), _p(mean), _p(rstd), _p(slabs), slab_bytes, _stream()),
+          "ffn_add_layernorm_fwd")
     PROBE.end(ev, 4.0 * rows * d * f)
     return y, xs, mean, rstd, hidden, bits
 
@@ -628,10 +636,11 @@ def ffn_layernorm_bwd(dy, hidden, w2, w1, x_ln, gamma, mean, rstd, dgamma, dbeta
     else:
         ws = _workspace(64 << 20, dy.device)
         ws_ptr, ws_bytes, job = ws.data_ptr(), ws.numel(), None
+    slabs, slab_bytes = _ffn_slabs(desc, dy.device)
     ev = PROBE.begin("ffn_bwd")
     check(lib.nst_ffn_layernorm_bwd(C.byref(desc), _p(dy), _p(hidden), _p(w2), _p(w1), _p(x_ln), _p(gamma), _p(mean), _p(rstd),
                                     _p(dres), _p(dhidden), _p(dx), _p(dz), float(p), int(seed), int(site), _p(dgamma), _p(dbeta),
-                                    int(accumulate), ws_ptr, ws_bytes, job, _stream()), "ffn_layernorm_bwd")
+                                    int(accumulate), ws_ptr, ws_bytes, job, _p(slabs), slab_bytes, _stream()), "ffn_layernorm_bwd")
     PROBE.end(ev, 4.0 * rows * d * f)
     return dx, dz, dhidden
 

@@ -137,7 +137,7 @@ class DeferredFfn(DeferredDelta):
         y, h, bits = K.ffn_fwd(self.A, f._w1t.t, f.dense1.bias.data, f._w2t.t, f.dense2.bias.data, residual=None, hidden_p=self.p,
                                hidden_seed=f.rt.step_seed, hidden_site=f.site, out_p=e.get("dropout_p", 0.0), out_seed=e.get("seed", 0),
                                out_site=e.get("stream_id", 0), save_gate_bits=True)
-        f._saved = (self.A, h, self.p, bits)
+        f._saved = (self.A, h, self.p, bits)      # (bits None where nst_ffn_fwd has no bit path: the backward then gates by h)
         return y
 
     def fused(self, x, gamma, beta, eps, want_sum):
@@ -355,9 +355,11 @@ class TransformerFFN(Layer):
         defer_ln = epi.pop("defer_ln", False)
         use_fused = self.fused and x.shape[0] >= _FFN_FUSED_MIN_ROWS and x.is_contiguous() \
             and not (set(epi) - {"residual", "dropout_p", "seed", "stream_id"})
-        if use_fused and defer_ln and _ROW_FUSION and is_training and not (set(epi) - {"dropout_p", "seed", "stream_id"}) \
-                and K.ffn_ln_supported(x.shape[0], x.shape[1], self.dense1.out_dim):
-            return DeferredFfn(self, x, p, epi)       # launched by the next LayerNorm (or on its own: DeferredFfn.plain)
+        if self.fused and defer_ln and _ROW_FUSION and is_training and x.is_contiguous() \
+                and not (set(epi) - {"dropout_p", "seed", "stream_id"}) and K.ffn_ln_supported(x.shape[0], x.shape[1], self.dense1.out_dim):
+            # launched by the next LayerNorm (or on its own: DeferredFfn.plain).  Also below _FFN_FUSED_MIN_ROWS: the decoder's
+            # 9 600 rows take the pair kernel with the hidden dimension split over workgroups (nst_ffn_ln_supported == 2)
+            return DeferredFfn(self, x, p, epi)
         if use_fused:
             y, h, bits = K.ffn_fwd(x, self._w1t.t, self.dense1.bias.data, self._w2t.t, self.dense2.bias.data,
                                    residual=epi.get("residual"), hidden_p=p, hidden_seed=self.rt.step_seed,
@@ -377,12 +379,12 @@ class TransformerFFN(Layer):
         x, h, p, bits = self._saved
         self._saved = None
         self.dense2.backward_params(h, dz)
+        if self.fused and _FFN_FUSED_BWD and ln_bwd is not None and _ROW_FUSION and bits is not None and residual is None \
+                and dz.is_contiguous() and ln_bwd.eligible() and K.ffn_ln_supported(dz.shape[0], dz.shape[1], self.dense1.out_dim):
+            dx, dh = ln_bwd.run_ffn(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, p, bits)
+            self.dense1.backward_params(x, dh)
+            return dx
         if self.fused and _FFN_FUSED_BWD and dz.shape[0] >= _FFN_FUSED_MIN_ROWS and dz.is_contiguous():
-            if ln_bwd is not None and _ROW_FUSION and bits is not None and residual is None and ln_bwd.eligible() \
-                    and K.ffn_ln_supported(dz.shape[0], dz.shape[1], self.dense1.out_dim):
-                dx, dh = ln_bwd.run_ffn(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, p, bits)
-                self.dense1.backward_params(x, dh)
-                return dx
             dx, dh = K.ffn_bwd(dz, h, self.dense2.kernel.compute, self.dense1.kernel.compute, hidden_p=p, residual=residual,
                                gate_bits=bits)
             self.dense1.backward_params(x, dh)

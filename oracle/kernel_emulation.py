@@ -249,7 +249,7 @@ def ffn_bwd(dy, hidden, w2, w1, hidden_p=0.0, residual=None, gate_bits=None):
 
 
 def ffn_ln_supported(rows, d, f):
-    return d == 256 and f % 128 == 0 and rows >= 128 * 160
+    return (1 if rows >= 128 * 160 else 2 if rows >= 1024 else 0) if (d == 256 and f % 128 == 0) else 0
 
 
 def ffn_add_layernorm_fwd(x, w1t, b1, w2t, b2, x_res, gamma, beta, eps, hidden_p=0.0, hidden_seed=0, hidden_site=0, out_p=0.0,

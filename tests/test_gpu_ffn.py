@@ -256,13 +256,15 @@ def test_ffn_layer_fused_equals_two_gemm_path(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ the pair with the wrapper's row stages
-@pytest.mark.parametrize("M,F,p1,p2", [(28800, 2048, 0.1, 0.1), (28800, 2048, 0.0, 0.0), (20480 + 40, 256, 0.25, 0.1), (25600, 128, 0.1, 0.0)])
+@pytest.mark.parametrize("M,F,p1,p2", [(28800, 2048, 0.1, 0.1), (28800, 2048, 0.0, 0.0), (20480 + 40, 256, 0.25, 0.1), (25600, 128, 0.1, 0.0),
+                                       (9600, 2048, 0.1, 0.1), (9600, 2048, 0.0, 0.0), (4000 + 19, 512, 0.2, 0.1), (1024, 256, 0.1, 0.1)])
 def test_ffn_add_layernorm_fwd_equals_the_pair_of_launches(M, F, p1, p2):
     """nst_ffn_add_layernorm_fwd against nst_ffn_fwd (no residual, the same masks, gate bits) + nst_add_layernorm_fwd on the
     float32 stream: the same hidden activation and gate bits bit for bit (one main loop), the same sum / LayerNorm output /
     statistics up to the f32 accumulation order of the row reductions."""
     from neurst_amd import kernels as K
-    assert K.ffn_ln_supported(M, 256, F) and not K.ffn_ln_supported(9600, 256, 2048)
+    # >= 20 480 rows: one launch; 1 024 .. 20 479: the hidden dimension split over workgroups + a row launch (the decoder's 9 600)
+    assert K.ffn_ln_supported(M, 256, F) == (1 if M >= 20480 else 2) and not K.ffn_ln_supported(512, 256, 2048)
     x, _, w1, w2, b1, b2 = _operands(M, F, seed=3 * M + F)
     g = torch.Generator().manual_seed(M + 5)
     xres = (torch.randn(M, 256, generator=g) * 2.0).to(DEV)
@@ -273,15 +275,24 @@ def test_ffn_add_layernorm_fwd_equals_the_pair_of_launches(M, F, p1, p2):
     y, xs, mean, rstd, h, bits = K.ffn_add_layernorm_fwd(d(x), w1t, d(b1), w2t, d(b2), xres, gamma, beta, 1e-6, **kw)
     delta, h2, bits2 = K.ffn_fwd(d(x), w1t, d(b1), w2t, d(b2), save_gate_bits=True, **kw)
     y2, xs2, mean2, rstd2 = K.add_layernorm_fwd(xres, delta, gamma, beta, 1e-6)
-    assert torch.equal(h, h2) and torch.equal(bits, bits2), "hidden activation / gate bits differ from the plain pair kernel"
-    assert torch.equal(xs, xs2), "the float32 stream differs (same product, same rounding of delta)"
+    assert torch.equal(h, h2), "hidden activation differs from the plain pair kernel"
+    if M >= 20480:
+        assert torch.equal(bits, bits2), "gate bits differ from the plain pair kernel"
+        assert torch.equal(xs, xs2), "the float32 stream differs (same product, same rounding of delta)"
+    else:   # split form: the partial sums of the slices are added in another order (and nst_ffn_fwd has no bit path here)
+        assert bits2 is None and float((xs - xs2).abs().max()) <= 4e-3 * float(xs2.abs().max())
+        assert float((xs - xs2).norm() / xs2.norm()) <= 3e-4
     assert rel(y, y2.float().cpu()) <= 1e-2 and float((y.float() - y2.float()).norm() / y2.float().norm()) <= 2e-3
-    assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(rstd, rstd2, rtol=1e-5, atol=0)
+    if M >= 20480:
+        assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-6) and torch.allclose(rstd, rstd2, rtol=1e-5, atol=0)
+    else:   # (another summation order of the product: a delta entry may land one bf16 step away)
+        assert torch.allclose(mean, mean2, rtol=1e-3, atol=2e-4) and torch.allclose(rstd, rstd2, rtol=2e-3, atol=0)
     y3, none, _, _, _, _ = K.ffn_add_layernorm_fwd(d(x), w1t, d(b1), w2t, d(b2), xres, gamma, beta, 1e-6, want_sum=False, **kw)
     assert none is None and torch.equal(y3, y)
 
 
-@pytest.mark.parametrize("M,F,p1,drop", [(28800, 2048, 0.1, True), (28800, 2048, 0.0, False), (20480 + 40, 256, 0.25, True), (25600, 128, 0.1, False)])
+@pytest.mark.parametrize("M,F,p1,drop", [(28800, 2048, 0.1, True), (28800, 2048, 0.0, False), (20480 + 40, 256, 0.25, True), (25600, 128, 0.1, False),
+                                         (9600, 2048, 0.1, True), (9600, 2048, 0.0, False), (4000 + 19, 512, 0.2, True), (1024, 256, 0.1, False)])
 def test_ffn_layernorm_bwd_equals_the_pair_of_launches(M, F, p1, drop):
     """nst_ffn_layernorm_bwd against nst_ffn_bwd + nst_layernorm_bwd_mixed: d(hidden) bit for bit, dx / dz / dgamma / dbeta up to
     the accumulation order; also through the deferred finalize of the batch."""
@@ -290,7 +301,11 @@ def test_ffn_layernorm_bwd_equals_the_pair_of_launches(M, F, p1, drop):
     g = torch.Generator().manual_seed(M + 9)
     d = lambda t: t.to(DEV)
     w1t, w2t = d(w1.t().contiguous()), d(w2.t().contiguous())
-    _, h, bits = K.ffn_fwd(d(x), w1t, d(b1), w2t, d(b2), hidden_p=p1, hidden_seed=5, hidden_site=2, save_gate_bits=True)
+    # (the gate bits of the split form come from the LN forward entry only: nst_ffn_fwd has no bit path below 20 480 rows)
+    xr0 = torch.zeros(M, 256, device=DEV)
+    one, zero = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+    _, _, _, _, h, bits = K.ffn_add_layernorm_fwd(d(x), w1t, d(b1), w2t, d(b2), xr0, one, zero, 1e-6, hidden_p=p1, hidden_seed=5,
+                                                  hidden_site=2, want_sum=False)
     dy = d(rnd(M, 256, seed=M + 2))
     dres = d(rnd(M, 256, seed=M + 3))
     xln = (torch.randn(M, 256, generator=g) * 2.0 + 0.3).to(DEV)
@@ -301,7 +316,7 @@ def test_ffn_layernorm_bwd_equals_the_pair_of_launches(M, F, p1, drop):
     dg, db = torch.full((256,), 7.0, device=DEV), torch.full((256,), 7.0, device=DEV)
     dx, dz, dh = K.ffn_layernorm_bwd(dy, h, d(w2), d(w1), xln, gamma, mean, rstd, dg, db, hidden_p=p1, gate_bits=bits, dres=dres,
                                      emit_dropout=emit)
-    gmid, dh2 = K.ffn_bwd(dy, h, d(w2), d(w1), hidden_p=p1, gate_bits=bits)
+    gmid, dh2 = K.ffn_bwd(dy, h, d(w2), d(w1), hidden_p=p1, gate_bits=bits if M >= 20480 else None)
     dg2, db2 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
     out2 = K.layernorm_bwd(gmid, xln, gamma, mean, rstd, dg2, db2, dres=dres, emit_dropout=emit)
     dx2, dz2 = out2 if drop else (out2, None)
