@@ -26,10 +26,14 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROBED = ("gemm", "gemm_wgrad_group", "ffn_fwd", "ffn_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "attention_fwd", "attention_bwd")
+PROBED = ("gemm", "gemm_rows", "gemm_wgrad_group", "ffn_fwd", "ffn_bwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "attention_fwd", "attention_bwd")
 FAMILY_KERNELS = {
     "gemm": "dense_gemm_kernel_v3 family (every nst_gemm launch of a step: projections, logits, front dense, their input "
             "and weight gradients incl. split-K reduce; work = sum 2MNK)",
+    "gemm_rows": "rowgemm_kernel (whole-row products of round 6: nst_gemm_add_layernorm_fwd / nst_gemm_layernorm_bwd / "
+                 "nst_gemm_rowdot256 -- a product of the nst_gemm family TOGETHER with the wrapper's dropout + residual + "
+                 "LayerNorm forward, or the LayerNorm backward, of its rows; work = 2MNK only, bytes = operands + the row "
+                 "stages' f32 / bf16 rows: the HBM bound is the relevant one)",
     "gemm_wgrad_group": "gemm256_group_kernel (nst_gemm_wgrad_group: the weight gradients of a layer stack as ONE launch of "
                         "256 x 256 phase-staggered tiles, no split-K; work = sum 2MNK)",
     "ffn_fwd": "ffn_pair8_kernel<fwd> (dense1 + ReLU + dropout + dense2 in one launch; work = 4*M*d*ffn)",

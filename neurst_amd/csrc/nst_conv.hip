@@ -1525,8 +1525,52 @@ struct Im2colDma256 {
       const void* src = ok ? (const void*)(base[H][s] + off) : (const void*)g_nst_zero16;
       glds16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)s * 8192u));
     }
-    c0[H] += 64;
-    if (c0[H] == C) { c0[H] = 0; ++tap[H]; }
+    // K-step order: the nine TAPS of one 64-channel slice on consecutive K steps, then the next slice (round 6; it was the four
+    // slices of one tap): neighbouring output pixels share input columns between taps (kw = 2 of pixel f is kw = 0 of pixel
+    // f + 1), so the re-reads now come two K steps apart -- inside what the XCD's L2 holds -- instead of eight
+    if (++tap[H] == 9) { tap[H] = 0; c0[H] += 64; }
+  }
+};
+
+// The weight operand of the forward in the same K-step order: K step (slice, tap) reads rows [tap * C + c0, + 64) of w2 [9 C, C]
+// (reduction-major = OC images, the chunk mapping of Dma256<MODE_OC>).
+struct W2FwdDma256 {
+  const char* p[2][2];      // [half][piece]: &w2[r][col] of the chunk at (tap 0, slice 0)
+  int C;
+  int tap[2], c0[2];
+  __device__ __forceinline__ void init(const bf16_t* w2, int C_, int wave, int lane) {
+    C = C_;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = (s * 8 + wave) * 64 + lane;
+      const int r = c >> 4, c16 = c & 15;
+      const int g = (r & 3) | (((r >> 3) & 1) << 2);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) p[h][s] = reinterpret_cast<const char*>(w2 + (int64_t)r * C + h * 128 + (c16 ^ (g << 1)) * 8);
+    }
+    tap[0] = tap[1] = 0;
+    c0[0] = c0[1] = 0;
+  }
+  template <int H>
+  __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
+    const uint32_t dst = img + (uint32_t)wave * 1024u;
+    const int64_t off = ((int64_t)(tap[H] * C + c0[H]) * C) * 2;   // wave-uniform
+    const char* s0 = p[H][0] + off;
+    const char* s1 = p[H][1] + off;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(s0), "v"(s1), "s"(dst)
+        : "memory", "scc");
+    if (++tap[H] == 9) { tap[H] = 0; c0[H] += 64; }
   }
 };
 
@@ -1549,10 +1593,8 @@ __global__ void __launch_bounds__(G256_THREADS, 2) conv2_fwd256_kernel(Conv2Fwd2
   {
     Im2colDma256 da;
     da.init(a.la, m0, wave, lane);
-    DenseLoader<bf16_t> lb;   // Bop[j = co][r] = w2[r * C + co]  (reduction-major: outer = r, contig = co)
-    lb.base = a.w2; lb.ld = C; lb.outer_limit = 9 * C; lb.contig_limit = C; lb.vec = 1;
-    Dma256<MODE_OC> db;
-    db.init(lb, 0, 0, wave, lane);
+    W2FwdDma256 db;           // Bop[j = co][r] = w2[r * C + co]  (reduction-major), K steps in the order of Im2colDma256
+    db.init(a.w2, C, wave, lane);
     gemm256_mainloop<MODE_RC, MODE_OC, false, 0>(smem_dyn, da, db, (9 * C) >> 6, false, acc, cs);
   }
   asm volatile("" ::: "memory");
@@ -1674,7 +1716,8 @@ struct DyTapDma256 {
       mask[s] = m;
     }
   }
-  __device__ __forceinline__ void begin(int /*pt*/, int pf_) { pf = pf_; tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
+  int ntap;
+  __device__ __forceinline__ void begin(int pt_, int pf_) { pf = pf_; ntap = 1 << (pt_ + pf_); tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
   template <int H>
   __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
     const uint32_t dst = img + (uint32_t)wave * 1024u;
@@ -1687,8 +1730,11 @@ struct DyTapDma256 {
       const void* src = ok ? (const void*)(base + (off + (int64_t)s * 64 * C * 2)) : (const void*)g_nst_zero16;
       glds16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)s * 8192u));
     }
-    c0[H] += 64;
-    if (c0[H] == C) { c0[H] = 0; ++tp[H]; }
+    // K-step order inside a class: the TAPS of one 64-channel slice follow each other, then the next slice (round 6; it was the
+    // four slices of one tap).  The shifted windows of the taps are the same dy rows but for one pixel row / column, so
+    // consecutive K steps of a workgroup re-read what is still in its XCD's L2 -- with the slices inner the re-use distance
+    // was 4 K steps x 32 workgroups x 64 KB = twice the L2 and the counters showed dy crossing the HBM interface 7.7 times
+    if (++tp[H] == ntap) { tp[H] = 0; c0[H] += 64; }
   }
 };
 
@@ -1702,7 +1748,8 @@ struct W2TapDma256 {
     const int kchunk = slot ^ ((row >> 1) & 7);
     base = reinterpret_cast<const char*>(w2 + (int64_t)row * C + kchunk * 8);
   }
-  __device__ __forceinline__ void begin(int pt_, int pf_) { pt = pt_; pf = pf_; tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
+  int ntap;
+  __device__ __forceinline__ void begin(int pt_, int pf_) { pt = pt_; pf = pf_; ntap = 1 << (pt_ + pf_); tp[0] = tp[1] = 0; c0[0] = c0[1] = 0; }
   template <int H>
   __device__ __forceinline__ void issue(int /*t*/, uint32_t img, int wave) {
     const uint32_t dst = img + (uint32_t)wave * 1024u;
@@ -1725,8 +1772,7 @@ struct W2TapDma256 {
         : "=&s"(keep)
         : "v"(s0), "v"(s1), "s"(dst)
         : "memory", "scc");
-    c0[H] += 64;
-    if (c0[H] == C) { c0[H] = 0; ++tp[H]; }
+    if (++tp[H] == ntap) { tp[H] = 0; c0[H] += 64; }    // (the order of DyTapDma256: taps inner, slices outer)
   }
 };
 

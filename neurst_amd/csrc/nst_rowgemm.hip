@@ -50,7 +50,7 @@ struct RowArgs {
   const bf16_t* rd_src;  // [M, 256]
   float* rd_dst;         // [(b * 4 + h) * T + t]
   int rd_T;
-  int dbg;               // NST_ROWGEMM_DBG (ablation builds of the measurement only): 1 = no K loop, 2 = no row phase, 4 = no x prefetch
+  int reserved1;
 };
 
 template <int BM, int NST, int NW = 4>
@@ -111,7 +111,6 @@ __device__ __forceinline__ void rg_finish(char* smem, floatx4_t (&acc)[MI][4], c
       }
   }
   __syncthreads();
-  if (a.dbg & 2) return;
 
   // ---------------------------------------------------------------- row phase: wave w owns rows [w RPW, +RPW), 32 lanes per row
   uint64_t seed = a.seed;
@@ -168,7 +167,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) rowgemm_kernel(RowAr
   const int wc = wave & 3, wrow = (wave >> 2) * C::GROWS;   // this wave multiplies rows [wrow, +GROWS) x columns [64 wc, +64)
   const int M = a.M;
   const int m0 = blockIdx.x * BM;
-  const int nk = (a.dbg & 1) ? 0 : (a.K >> 6);
+  const int nk = a.K >> 6;
 
   // ---------------------------------------------------------------- DMA source offsets (per lane, constant over K)
   uint32_t voffA[C::A_IPW], voffB[C::B_IPW];
@@ -217,12 +216,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) rowgemm_kernel(RowAr
     for (int p = 0; p < C::PASSES; ++p) {
       int rowg = m0 + wave * C::RPW + p * 2 + sub;
       rowg = rowg < M ? rowg : M - 1;
-      if (a.dbg & 4) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xpre[p][j] = 0.f;
-      } else {
-        rg_load8_f32(a.e.x + (int64_t)rowg * RN + col, xpre[p]);
-      }
+      rg_load8_f32(a.e.x + (int64_t)rowg * RN + col, xpre[p]);
     }
   }
 #pragma unroll
@@ -296,173 +290,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) rowgemm_kernel(RowAr
   rg_finish<BM, NW, C::MI, EPI>(smem, acc, a, xpre, m0, M, tid, lane, wave, wrow, wc);
 }
 
-// =====================================================================================================================
-// Second form (round 6, late): the activation rows A come from HBM, the weights from L2 -- two streams with different latencies
-// behind ONE in-order vmcnt per wave.  In the kernel above every wave issues pieces of both, one K step ahead: the ablation with
-// cold caches (profiles/r06_history/c10_*: K loop alone 25 us for 44 MB of A at K = 768) shows the A stream is latency bound --
-// 16 KB of A in flight per CU.  Here the two streams live in SEPARATE rings of 32-deep K steps and in separate waves: waves 0, 1
-// issue only A pieces (ring of NA stages of BM x 64 bytes), waves 2, 3 only weight pieces (ring of NB stages of 16 KB), each wave
-// waits on its own stream with a counted vmcnt and the step's barrier publishes both.  Same LDS per workgroup (80 KB at 64 rows:
-// NA = 8, NB = 3), but 7 steps of A in flight instead of 1.
-//   A stage  [IMG_ROWS][32 k]  64-byte rows, 16-byte slot ^= (row >> 2) & 3 (applied to the DMA source and the fragment read)
-//   W stage  RC: [256 n][32 k] the same 64-byte rows;  OC: two images [32 k][128 n] of nst_gemm_core.h (SwzFrag OC reads rows 0..31)
-// =====================================================================================================================
-template <int BM, int NA, int NB>
-struct Row2Cfg {
-  static constexpr int IMG_ROWS = (BM + 31) / 32 * 32;
-  static constexpr int A_STAGE = IMG_ROWS * 64;
-  static constexpr int B_STAGE = 16384;
-  static constexpr int A_IPW = IMG_ROWS / 16 / 2;       // A pieces (1 KB = 16 rows) per A wave and step
-  static constexpr int B_IPW = 8;                       // weight pieces per W wave and step
-  static constexpr int MI = BM / 16;
-  static constexpr int RING = NA * A_STAGE + NB * B_STAGE;
-  static constexpr int TILE_BYTES = BM * TILE_LD * 4;
-  static constexpr int LDS = (RING > TILE_BYTES + 4 * 2 * RN * 4) ? RING : TILE_BYTES + 4 * 2 * RN * 4;
-  static constexpr int RPW = BM / 4, PASSES = RPW / 2;
-  static_assert(NA >= 2 && NB >= 2 && (NA - 2) * A_IPW < 64 && (NB - 2) * B_IPW < 64 && LDS <= 160 * 1024 && BM % 16 == 0 && RPW % 4 == 0, "rings");
-};
-
-// fragment of a 64-byte-row image: lane l holds row (row0 + (l & 15)), k elements 8 (l >> 4) .. + 7 of the 32-deep step
-__device__ __forceinline__ bf16x8_t rg2_frag(const char* img, int row0, int lane) {
-  const int r = row0 + (lane & 15);
-  return *reinterpret_cast<const bf16x8_t*>(img + r * 64 + (((lane >> 4) ^ ((r >> 2) & 3)) << 4));
-}
-
-template <int N>
-__device__ __forceinline__ void rg2_wait_younger(int younger_steps) {   // vmcnt <= N * younger_steps, younger_steps in 0 .. 6
-  switch (younger_steps) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<N>(); break;
-    case 2: wait_vmcnt<2 * N>(); break;
-    case 3: wait_vmcnt<3 * N>(); break;
-    case 4: wait_vmcnt<4 * N>(); break;
-    case 5: wait_vmcnt<5 * N>(); break;
-    default: wait_vmcnt<6 * N>(); break;
-  }
-}
-
-template <int BM, int NA, int NB, int BMODE, int EPI>
-__global__ void __launch_bounds__(256, 2) rowgemm2_kernel(RowArgs a) {
-  typedef Row2Cfg<BM, NA, NB> C;
-  typedef SwzFrag<bf16_t, MODE_OC> ROC;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool a_wave = wave < 2;          // waves 0, 1 own the A stream, waves 2, 3 the weight stream
-  const int M = a.M;
-  const int m0 = blockIdx.x * BM;
-  const int nk = (a.dbg & 1) ? 0 : (a.K >> 5);
-  constexpr int A_RING = 0, B_RING = NA * C::A_STAGE;
-
-  // ---------------------------------------------------------------- DMA source offsets of this wave's stream (constant over K)
-  uint32_t voff[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) voff[s] = 0;
-  if (a_wave) {
-#pragma unroll
-    for (int s = 0; s < C::A_IPW; ++s) {
-      const int c = (wave * C::A_IPW + s) * 64 + lane;     // 16-byte chunk of the stage: row c >> 2, slot c & 3
-      const int row = c >> 2, slot = c & 3;
-      const int kch = slot ^ ((row >> 2) & 3);
-      int rg = m0 + (row < BM ? row : BM - 1);
-      rg = rg < M ? rg : M - 1;
-      voff[s] = (uint32_t)((int64_t)(rg - m0) * a.lda * 2 + kch * 16);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int t = (wave - 2) * 8 + s, c = t * 64 + lane;  // piece t of 16
-      if (BMODE == MODE_RC) {
-        const int row = c >> 2, slot = c & 3;               // weight row n = row, 64-byte rows
-        const int kch = slot ^ ((row >> 2) & 3);
-        voff[s] = (uint32_t)((int64_t)row * a.ldb * 2 + kch * 16);
-      } else {
-        const int h = c >> 9, ci = c & 511;                 // image h (128 columns), chunk ci of [32 k][16 chunks]
-        const int r = ci >> 4, c16 = ci & 15;
-        const int g = (r & 3) | (((r >> 3) & 1) << 2);
-        voff[s] = (uint32_t)((int64_t)r * a.ldb * 2 + (128 * h + (c16 ^ (g << 1)) * 8) * 2);
-      }
-    }
-  }
-  const char* base = a_wave ? reinterpret_cast<const char*>(a.A) + ((int64_t)m0 * a.lda) * 2 : reinterpret_cast<const char*>(a.W);
-  const int64_t step_bytes = a_wave ? 64 : (BMODE == MODE_RC ? 64 : (int64_t)32 * a.ldb * 2);
-  // issue this wave's pieces of K step kt into ring slot `slot`
-  auto issue = [&](int kt, int slot) {
-    const char* p = base + (int64_t)kt * step_bytes;
-    if (a_wave) {
-      const uint32_t dst = smem_addr + A_RING + (uint32_t)slot * C::A_STAGE + (uint32_t)(wave * C::A_IPW) * 1024u;
-#pragma unroll
-      for (int s = 0; s < C::A_IPW; ++s) rg_glds(p, voff[s], dst + (uint32_t)s * 1024u);
-    } else {
-      const uint32_t dst = smem_addr + B_RING + (uint32_t)slot * C::B_STAGE + (uint32_t)((wave - 2) * 8) * 1024u;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) rg_glds(p, voff[s], dst + (uint32_t)s * 1024u);
-    }
-  };
-  const int depth = a_wave ? NA : NB;     // this wave's ring
-
-  const int sub = lane >> 5, li = lane & 31, col = li * 8;
-  (void)li;
-  float xpre[(EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) ? C::PASSES : 1][8];
-  if constexpr (EPI == EPI_LN_FWD || EPI == EPI_LN_BWD) {
-#pragma unroll
-    for (int p = 0; p < C::PASSES; ++p) {
-      int rowg = m0 + wave * C::RPW + p * 2 + sub;
-      rowg = rowg < M ? rowg : M - 1;
-      if (a.dbg & 4) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xpre[p][j] = 0.f;
-      } else {
-        rg_load8_f32(a.e.x + (int64_t)rowg * RN + col, xpre[p]);
-      }
-    }
-  }
-  for (int s = 0; s < depth - 1; ++s)
-    if (s < nk) issue(s, s);
-
-  floatx4_t acc[C::MI][4];
-#pragma unroll
-  for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int wc = wave, wnl = (wc & 1) * 64;
-  int slot_a = 0, slot_b = 0;              // ring slots of the step being multiplied
-  int slot_in = depth - 1;                 // slot this wave's next issue fills
-  const int ipw = a_wave ? C::A_IPW : C::B_IPW;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's stream: step kt has landed, the (up to depth - 2) younger steps stay in flight
-    const int younger = (nk - 1 - kt) < (depth - 2) ? (nk - 1 - kt) : (depth - 2);
-    if (a_wave) rg2_wait_younger<C::A_IPW>(younger); else rg2_wait_younger<C::B_IPW>(younger);
-    (void)ipw;
-    __builtin_amdgcn_s_barrier();          // both streams of step kt are visible; every wave is done with step kt - 1's slots
-    asm volatile("" ::: "memory");
-    if (kt + depth - 1 < nk) issue(kt + depth - 1, slot_in);
-    slot_in = slot_in + 1 == depth ? 0 : slot_in + 1;
-    const char* As = smem + A_RING + slot_a * C::A_STAGE;
-    const char* Bs = smem + B_RING + slot_b * C::B_STAGE;
-    slot_a = slot_a + 1 == NA ? 0 : slot_a + 1;
-    slot_b = slot_b + 1 == NB ? 0 : slot_b + 1;
-    bf16x8_t af[C::MI], bf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (BMODE == MODE_RC) bf[j] = rg2_frag(Bs, wc * 64 + j * 16, lane);
-      else bf[j] = ROC::read(Bs + (wc >> 1) * 8192, wnl + j * 16, 0, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) af[i] = rg2_frag(As, i * 16, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < C::MI; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights are the A operand
-  }
-  wait_vmcnt<0>();
-  rg_finish<BM, 4, C::MI, EPI>(smem, acc, a, xpre, m0, M, tid, lane, wave, 0, wc);
-}
-
 template <typename KernelT>
 void rg_allow_lds(KernelT kernel) {
   static thread_local const void* done[32];
@@ -493,11 +320,9 @@ RgCfg rg_pick(int64_t M, int K) {
   if (M >= 64 * 224) { c.bm = 64; c.nst = 2; }
   else if ((M + 47) / 48 <= 256 && M > 32 * 64) { c.bm = 48; c.nst = 4; }
   else { c.bm = 32; c.nst = 2; }
-  if (forced_bm == 64 && (forced_nst == 2 || forced_nst == 3)) { c.bm = 64; c.nst = forced_nst; }
+  if (forced_bm == 64 && forced_nst == 2) { c.bm = 64; c.nst = 2; }
   if (forced_bm == 32 && forced_nst == 2) { c.bm = 32; c.nst = 2; }
   if (forced_bm == 48 && forced_nst == 4) { c.bm = 48; c.nst = 4; }
-  // eight waves: two row groups of 64 rows, one workgroup per CU ("128,3": every call of >= 128 rows; "128,2": the calls that fill the chip)
-  if (forced_bm == 128 && M >= (forced_nst == 3 ? 128 : 64 * 224)) { c.bm = 128; c.nst = 3; }
   return c;
 }
 
@@ -510,36 +335,11 @@ void rg_launch_one(const RowArgs& a, hipStream_t st, int* nblocks_out) {
   if (nblocks_out) *nblocks_out = nb;
 }
 
-template <int BM, int NA, int NB, int BMODE, int EPI>
-void rg2_launch_one(const RowArgs& a, hipStream_t st, int* nblocks_out) {
-  auto k = rowgemm2_kernel<BM, NA, NB, BMODE, EPI>;
-  rg_allow_lds(k);
-  const int nb = (a.M + BM - 1) / BM;
-  k<<<nb, 256, Row2Cfg<BM, NA, NB>::LDS, st>>>(a);
-  if (nblocks_out) *nblocks_out = nb;
-}
-
-// NST_ROWGEMM_V2: 1 = the two-ring form for every call, 0 = never (default: see rg_launch)
-int rg_v2_mode() {
-  static int mode = -2;
-  if (mode == -2) { const char* e = getenv("NST_ROWGEMM_V2"); mode = e ? atoi(e) : -1; }
-  return mode;
-}
-
 template <int BMODE, int EPI>
 int rg_launch(const RowArgs& a, hipStream_t st, int* nblocks_out) {
   const RgCfg c = rg_pick(a.M, a.K);
-  if (rg_v2_mode() == 1 && c.bm != 128) {
-    if (c.bm == 64) rg2_launch_one<64, 8, 3, BMODE, EPI>(a, st, nblocks_out);
-    else if (c.bm == 48) rg2_launch_one<48, 8, 8, BMODE, EPI>(a, st, nblocks_out);
-    else rg2_launch_one<32, 8, 3, BMODE, EPI>(a, st, nblocks_out);
-    return NST_OK;
-  }
-  if (c.bm == 128) {
-    rg_launch_one<128, 3, 8, BMODE, EPI>(a, st, nblocks_out);
-  } else if (c.bm == 64) {
-    if (c.nst == 2) rg_launch_one<64, 2, 4, BMODE, EPI>(a, st, nblocks_out);
-    else rg_launch_one<64, 3, 4, BMODE, EPI>(a, st, nblocks_out);
+  if (c.bm == 64) {
+    rg_launch_one<64, 2, 4, BMODE, EPI>(a, st, nblocks_out);
   } else if (c.bm == 48) {
     rg_launch_one<48, 4, 4, BMODE, EPI>(a, st, nblocks_out);
   } else {
@@ -565,9 +365,6 @@ void rg_fill(RowArgs& a, const NstRowGemmDesc* d, const void* A, const void* W) 
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W;
   a.lda = d->lda; a.ldb = d->ldb;
   a.M = (int)d->rows; a.K = d->k;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("NST_ROWGEMM_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
 }
 
 }  // namespace

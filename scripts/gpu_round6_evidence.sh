@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 evidence run (one gpurun call): rocprofv3 stats + timeline of bench.py (graph replay and eager), PMC passes for the
+# Round-6 evidence run (one gpurun call): rocprofv3 stats + timeline of bench.py (graph replay and eager), PMC passes for the
 # feed-forward kernels (MFMA busy), the dense GEMM family (HBM bytes) and the whole step, micro-benchmarks, the bench lines.
-#   gpurun --timeout 2700 -- 'bash scripts/gpu_round5_evidence.sh [tag]'
+#   gpurun --timeout 2700 -- 'bash scripts/gpu_round6_evidence.sh [tag]'
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-T=${1:-r05}
+T=${1:-r06}
 O=gpurun_out
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q --tb=short > $O/${T}_gpu_tests_final.log 2>&1
@@ -23,6 +23,10 @@ PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUS
   scripts/pmc_kernel.sh $O/${T}_pmc_conv2.json conv2_ scripts/conv_bench.py --iters 3 > $O/${T}_pmc_conv2.log 2>&1
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU" \
   scripts/pmc_kernel.sh $O/${T}_pmc_ln.json ln_ bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 > $O/${T}_pmc_ln.log 2>&1
+PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" \
+  scripts/pmc_kernel.sh $O/${T}_pmc_rowgemm.json rowgemm_kernel bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 > $O/${T}_pmc_rowgemm.log 2>&1
+timeout 300 python scripts/rowgemm_bench.py ${T}_warm > /dev/null 2>&1; cp $O/${T}_warm_rowgemm_bench.json $O/${T}_rowgemm_bench_warm.json
+timeout 300 python scripts/rowgemm_bench.py ${T}_cold --cold > /dev/null 2>&1; cp $O/${T}_cold_rowgemm_bench.json $O/${T}_rowgemm_bench_cold.json
 timeout 120 python scripts/hbm_probe.py --out $O/${T}_hbm_probe.json > $O/${T}_hbm_probe.log 2>&1; tail -1 $O/${T}_hbm_probe.log | cut -c1-400
 timeout 300 python scripts/ffn_bench.py --rows 28800,9600 --out $O/${T}_ffn_bench.json > $O/${T}_ffn_bench.log 2>&1
 timeout 300 python scripts/conv_bench.py --out $O/${T}_conv_bench.json > $O/${T}_conv_bench.log 2>&1
