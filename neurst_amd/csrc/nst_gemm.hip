@@ -34,16 +34,6 @@ dense_gemm_kernel_v3(GemmArgs<OutT, DenseLoader<T>, DenseLoader<T>, IdentityRowM
   gemm_stream_v3<T, OutT, AMODE, BMODE, DenseLoader<T>, DenseLoader<T>, IdentityRowMap, CS, EF>(smem_dyn);
 }
 
-// eight-wave form of the stream kernel (two wave groups split every K step; nst_gemm_core.h: gemm_stream_v3_ks)
-template <typename OutT, int AMODE, int BMODE, bool CS, int EF>
-__global__ void __launch_bounds__(512, 2)
-dense_gemm_kernel_v3ks(GemmArgs<OutT, DenseLoader<bf16_t>, DenseLoader<bf16_t>, IdentityRowMap> args) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  (void)args;
-  gemm_stream_v3_ks<OutT, AMODE, BMODE, IdentityRowMap, CS, EF>(smem_dyn);
-}
-
-
 // 256 x 256 tiles, eight waves in two phase-staggered groups (nst_gemm256.h): nst_gemm_wgrad_group.  A SINGLE weight gradient
 // stays on the 128 x 128 stream kernel: alone it needs 32 K slices to fill the chip with 256 x 256 tiles, and their slabs cost
 // more than the tile saves (ffn1: 68 us against 53; profiles/r04_history/c1_g256_new.json / c1_g256_old.json).
@@ -353,9 +343,11 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
 #define NST_GEMM_LAUNCH3(AM, BMO, CS_) NST_GEMM_LAUNCH3E(AM, BMO, CS_, EF_GENERIC)
     // Specialised instantiations: the epilogue configurations a training step of the Transformer models actually issues
     // (enumerated by tracing a step; everything else takes the generic kernel below).
-    const int em = sizeof(T) == 2 ? epilogue_mask(ep) : -1;
+    // (round 6: the fp32 path -- BASELINE config #2 -- takes them too; its products ran on the generic-epilogue kernels, which
+    // keep ~100 scalars of the argument block alive around the epilogue: 205 - 224 SGPR spills each)
+    const int em = epilogue_mask(ep);
     if (em >= 0) {
-      if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+      if constexpr (sizeof(T) == sizeof(OutT)) {
         if (amode == MODE_RC && bmode == MODE_OC && !ep.colsum_dst) {   // forward projections: x [M,K] . W [K,N]
           switch (em) {
             case 0: NST_GEMM_LAUNCH3E(MODE_RC, MODE_OC, false, 0); return 0;
@@ -374,14 +366,14 @@ int launch(const NstGemmDesc* d, const void* A, const void* B, void* C, const Ep
             case 0: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, 0); return 0;
             case EF_BIAS: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_BIAS); return 0;
             case EF_GATE: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_GATE); return 0;
-            case EF_ROWDOT: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_ROWDOT); return 0;
+            case EF_ROWDOT: if constexpr (sizeof(T) == 2) { NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_ROWDOT); return 0; } break;
             case EF_ACCUM: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_ACCUM); return 0;
             case EF_RESID: NST_GEMM_LAUNCH3E(MODE_RC, MODE_RC, false, EF_RESID); return 0;
             default: break;
           }
         }
       }
-      if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
+      if constexpr (sizeof(OutT) == 4) {
         if (amode == MODE_OC && bmode == MODE_OC) {                     // weight gradients: x^T . dz, slabs or in place
           if (ep.colsum_dst) {
             if (em == 0) { NST_GEMM_LAUNCH3E(MODE_OC, MODE_OC, true, 0); return 0; }

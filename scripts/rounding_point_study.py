@@ -12,7 +12,9 @@ wrappers, one CLASS of kernel outputs at a time:
   ctx       attention context
   ffn_h     the saved feed-forward hidden activation (ReLU output)
   logits    the logits
-  conv      conv1 / conv2 outputs of the front end
+  conv1     conv1 + LayerNorm + ReLU output (one kernel: the largest activation of the model)          } round 5 lumped these
+  conv2     conv2 output (before its LayerNorm)                                                       } three into "conv" /
+  ln_relu   the LayerNorm + ReLU output behind conv2 = the input of the front end's output_dense       } "ln_y"; split in round 6
   dlogits   d(loss)/d(logits)
   ln_dx     LayerNorm backward output = the BACKWARD residual stream (dx + d(residual))
   dgrad     outputs of input-gradient GEMMs (d context, d(LN output), d memory, d decoder output)
@@ -23,7 +25,7 @@ wrappers, one CLASS of kernel outputs at a time:
             fp32 stream: what a fused residual-add + LayerNorm kernel reading a bf16 GEMM output computes
 
 `all` = every class rounded (must reproduce the bf16 emulation of tests/golden/make_oracle_b32.py); `all-X` = class X kept
-in fp32.  Output: profiles/r05_rounding_point_study.json (global rel-L2 of the 280 gradient tensors against the oracle run on
+in fp32.  Output: profiles/r06_rounding_point_study_b<batch>.json (global rel-L2 of the 280 gradient tensors against the oracle run on
 the same bf16-rounded weights, worst tensor, logits error).
 
     python scripts/rounding_point_study.py [batch=32] [config ...]
@@ -44,7 +46,7 @@ from oracle import kernel_emulation as E  # noqa: E402
 from oracle import neurst_oracle as O  # noqa: E402
 
 EXTRA = ["delta"]   # not a class of the bf16 path: only meaningful with `resid` lifted (see gemm below)
-CLASSES = ["resid", "ln_y", "proj", "ctx", "ffn_h", "logits", "conv", "dlogits", "ln_dx", "dgrad", "dqkv", "ffn_dh", "conv_dx"]
+CLASSES = ["resid", "ln_y", "proj", "ctx", "ffn_h", "logits", "conv1", "conv2", "ln_relu", "dlogits", "ln_dx", "dgrad", "dqkv", "ffn_dh", "conv_dx"]
 ROUND = set(CLASSES)
 PHASE = ["fwd"]
 VOCAB_MIN = 8000
@@ -61,7 +63,8 @@ def _wrap():
 
     def layernorm_fwd(x, *a, **k):
         y, m, r = o["layernorm_fwd"](x, *a, **k)
-        return _r(y, "ln_y"), m, r
+        relu = k.get("relu", a[3] if len(a) > 3 else False)
+        return _r(y, "ln_relu" if relu else "ln_y"), m, r
 
     def layernorm_bwd(*a, **k):
         assert k.get("emit_dropout") is None
@@ -101,10 +104,10 @@ def _wrap():
 
     def conv1_ln_relu_fwd(*a, **k):
         y, m, r = o["conv1_ln_relu_fwd"](*a, **k)
-        return _r(y, "conv"), m, r
+        return _r(y, "conv1"), m, r
 
     def conv2_fwd(*a, **k):
-        return _r(o["conv2_fwd"](*a, **k), "conv")
+        return _r(o["conv2_fwd"](*a, **k), "conv2")
 
     def conv2_dgrad(*a, **k):
         return _r(o["conv2_dgrad"](*a, **k), "conv_dx")
@@ -186,7 +189,7 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     configs = sys.argv[2:] or (["all"] + [f"all-{c}" for c in CLASSES] + ["all-resid-ln_dx", "none"])
     torch.set_num_threads(os.cpu_count() or 8)
-    out_path = os.path.join(ROOT, "profiles", f"r05_rounding_point_study_b{batch}.json")
+    out_path = os.path.join(ROOT, "profiles", f"r06_rounding_point_study_b{batch}.json")
     results = json.load(open(out_path))["results"] if os.path.exists(out_path) else {}
     ref = None
     for c in configs:
