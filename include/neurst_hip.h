@@ -333,7 +333,8 @@ int nst_layernorm_bwd_mixed(const void* dy, const void* x, int x_dtype, const fl
  * that makes the row (bf16 operands, f32 accumulation; nst_rowgemm_supported says whether a shape qualifies: n = 256,
  * k a multiple of 64).
  *   A [rows, k] (lda);  W: trans_b == 0: [k, 256] (ldb) -- a dense kernel as stored, forward;  trans_b == 1: [256, k] (ldb) --
- *   the same kernel read as the input-gradient operand (dX = dZ . W^T). */
+ *   the same kernel read as the input-gradient operand (dX = dZ . W^T).  Built orientations (NST_ERR_UNSUPPORTED otherwise):
+ *   nst_gemm_add_layernorm_fwd trans_b == 0; nst_gemm_layernorm_bwd and nst_gemm_rowdot256 trans_b == 1. */
 typedef struct NstRowGemmDesc {
   int64_t rows;
   int n, k;                 /* n must be 256 */
@@ -361,7 +362,7 @@ int nst_gemm_layernorm_bwd(const NstRowGemmDesc* desc, const void* A, const void
                            const float* mean, const float* rstd, const void* dres, void* dx, void* dz, float* dgamma,
                            float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, NstLnFinalizeJob* job_out,
                            void* stream);
-/* C [rows, 256] = bf16(A . W) and, with src / dst, dst[(b * 4 + h) * rows_per_batch + t] = sum over head h's 64 columns of
+/* C [rows, 256] = bf16(A . W^T) and dst[(b * 4 + h) * rows_per_batch + t] = sum over head h's 64 columns of
  * C[b * rows_per_batch + t, .] o src[same] (f32): the attention output projection's input gradient together with the
  * delta = rowsum(dO o O) its attention backward needs (nst_gemm's rowdot epilogue on whole rows). */
 int nst_gemm_rowdot256(const NstRowGemmDesc* desc, const void* A, const void* W, void* C, const void* src, float* dst,

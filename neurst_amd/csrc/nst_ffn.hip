@@ -15,28 +15,20 @@
 //
 // Why one kernel: with d_model = 256 the two GEMMs of an FFN are HBM / launch bound on the [M, F] hidden tensor
 // (118 MB per encoder layer at the benchmark shape): separate kernels write it, read it, and each has only 4 K steps
-// (dense1) or a 256-wide output (dense2).  Here a workgroup owns 32*NW rows, walks the hidden dimension in chunks of 128
-// columns, and the hidden tile goes from the first product's accumulators straight into the second product's B operand
-// (registers; the reduction index of the second product is laid out on the accumulator rows of the first).
+// (dense1) or a 256-wide output (dense2).  Here a workgroup owns 128 rows, walks the hidden dimension in chunks of 64
+// units, and the hidden tile stays on chip between the products (ffn_pair8_kernel below: eight waves, two per SIMD; the
+// four-wave kernel of round 2 that this header used to describe is scripts/r06_experiments/ffn_pair_four_wave_kernel.hip.txt).
+// Common to both: v_mfma_f32_32x32x16_bf16 with "transposed" accumulators (MFMA A operand = weights, B operand =
+// activations), so a lane owns ONE row m = lane & 31 of its 32-row group and 16 CONSECUTIVE columns per 32-column block; the
+// A-operand row r of a 32-row block holds hidden unit pi(r) = 16*((r >> 2) & 1) + 4*(r >> 3) + (r & 3), which makes the MFMA
+// result rows 8q + 4h + i of lane half h the 16 consecutive hidden units 16h + 4q + i -- bias, ReLU, one Philox call per 8
+// units, and the packed bf16 pairs ARE the B operand of the second product; weights arrive by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging) with the XOR swizzle applied to the DMA source address and to the fragment read.
 //
-// Structure (one wave per SIMD, 32 rows per wave, v_mfma_f32_32x32x16_bf16, accumulators "transposed": MFMA A operand =
-// weights, B operand = activations, so a lane owns ONE row m = lane & 31 of the tile and 16 CONSECUTIVE columns per
-// 32-column block):
-//   * Xin fragments of the wave's 32 rows live in registers for the whole kernel (64 VGPRs);
-//   * the weights stream through an LDS ring of 16 KB pieces filled by LDS-DMA (global_load_lds_dwordx4, no VGPR
-//     staging), DEPTH pieces ahead; one phase = one piece = 16 MFMAs per wave; a phase opens with a COUNTED
-//     s_waitcnt vmcnt + s_barrier (never a drain);
-//        A piece [128 hidden rows][64 k]   (128-byte rows, 16-byte slot ^= (row >> 1) & 7)
-//        B piece [256 out rows][32 hidden] ( 64-byte rows, 16-byte slot ^= (row >> 2) & 3)
-//        G piece [64 rows][128 hidden]     (backward only: the saved activation, the gate; slot ^= row & 15)
-//     the XOR is applied to the DMA source address and to the fragment read (same involution), all fragment reads are
-//     ds_read_b128 and conflict free for the 16-lane groups of that instruction;
-//   * the A-operand row r of a 32-row block holds hidden unit pi(r) = 16*((r >> 2) & 1) + 4*(r >> 3) + (r & 3): the MFMA
-//     result rows 8q + 4h + i of lane half h then are the 16 consecutive hidden units 16h + 4q + i -- bias, ReLU, one
-//     Philox call per 8 units, two 16-byte stores per 32-column block, and the packed bf16 pairs ARE the B operand of
-//     the second product (k slots of half h in k-block (nb, t) = hidden units 32nb + 16h + 8t + 0..7; the WB fragment
-//     reads the same 8 contiguous units of its row);
-//   * the same permutation on the output rows of the second product gives every lane 16 consecutive output columns.
+// Round 6: three exits for the 128 x 256 output tile (template parameter OUTM): the final epilogue (bias, dropout, residual,
+// bf16 store), the row phase of nst_rowphase.h behind an LDS tile (the wrapper's LayerNorm stages: nst_ffn_add_layernorm_fwd /
+// nst_ffn_layernorm_bwd), or raw f32 partial sums of a SLICE of the hidden dimension (gridDim.y slices per row tile, for row
+// counts that give fewer tiles than CUs; ffn_slab_rows_kernel adds the slabs and runs the row phase).
 #include "nst_common.h"
 #include "nst_rowphase.h"
 
@@ -194,354 +186,6 @@ __device__ __forceinline__ void glds_one_dword(const void* sbase, uint32_t voff,
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_addr_uniform)
       : "memory");
-}
-
-template <int MODE, int NW>
-struct Cfg {
-  static constexpr int NG = MODE == MODE_FWD ? 0 : (NW == 4 ? 2 : 1);   // 64-row gate pieces per chunk (backward)
-  static constexpr int PPC = 8 + NG;                      // pieces per chunk = ring slots (slot index is static)
-  static constexpr int DEPTH = PPC - 1;                   // pieces issued ahead of the one being consumed
-  static constexpr int IPW = 16 / NW;                     // DMA instructions per wave per piece
-  static constexpr int RING = PPC * PIECE;
-  // a phase opens once the piece it consumes AND the next one have landed (fragment reads run half a phase ahead of the
-  // MFMAs, so they reach into the next piece): DEPTH-2 younger pieces stay in flight
-  static constexpr int WAITN = IPW * (DEPTH - 2);
-  // ... plus the hidden-tile stores issued since (vmcnt retires loads and stores in issue order, so a store younger than
-  // the piece a phase needs must be COUNTED, or the wait also demands pieces that are not needed yet).  Two 16-byte stores
-  // per 32-column block: blocks 0 and 1 in the first phase of the second product, 2 and 3 in the next two; the window of
-  // younger operations at the opening of phase J spans every phase except J and J+1.
-  static constexpr int stores_in_phase(int j) { return j == 4 + NG ? 4 : ((j == 5 + NG || j == 6 + NG) ? 2 : 0); }
-  static constexpr int waitn_exact(int j) { return WAITN + 8 - stores_in_phase(j) - stores_in_phase((j + 1) % PPC); }
-  static_assert(WAITN + 8 <= 63, "vmcnt is a 6-bit counter");
-};
-
-// DROP: bit 0 = hidden dropout on, bit 1 = output dropout on (forward); FULL: M is a multiple of the workgroup's rows.
-// Both are template parameters so that a phase is ONE basic block: the scheduler can then place the mid epilogue's
-// VALU work between the MFMAs of the second product.
-// DBG: always 0.  It selected the ablation builds of rounds 2-3 (no hidden-tile store / no DMA / no MFMAs / no fragment reads;
-// their timings: DESIGN 5c); the branches are gone, the parameter stays so that kernel names match the earlier profiles.
-template <int MODE, int NW, int DROP, bool FULL, int DBG = 0>
-__global__ void __launch_bounds__(64 * NW, 1) ffn_pair_kernel(FfnArgs a) {
-  typedef Cfg<MODE, NW> C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) char* lds_char_ptr;
-  const uint32_t smem_addr = (uint32_t)(uintptr_t)((lds_char_ptr)smem);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m_l = lane & 31, h = lane >> 5;
-  const int F = a.F, M = a.M;
-  const int nch = F / CH;
-  const int m0 = blockIdx.x * (32 * NW);
-  // Workgroups walk the hidden chunks in ROTATED order (the sum over chunks does not care): at any moment the chip then
-  // writes all column positions of the [M, F] hidden tensor instead of one 256-byte column of every 2F-byte row -- with
-  // every workgroup on the same chunk, all hidden-tile stores of the chip hit the few memory channels that column maps to
-  // (measured: the stores cost 25-30 % of the kernel).
-  const int rot = blockIdx.x % nch;
-  auto phys = [&](int c) { const int q = c + rot; return q >= nch ? q - nch : q; };
-  const int row = m0 + wave * 32 + m_l;           // this lane's row of Xin / outputs
-  const bool row_ok = FULL || row < M;
-  const int row_c = row_ok ? row : M - 1;
-
-  uint64_t seed_off = 0;
-  if (MODE == MODE_FWD && DROP != 0) seed_off = seed_with_offset(0, a.seed_dev);
-
-  // ---------------------------------------------------------------- DMA source offsets (per lane, constant)
-  // A piece (chunk c, pa): rows 128c + r, bytes [128 pa, +128) of the 512-byte WA rows
-  // B piece (chunk c, pb): rows r (0..255), bytes [(128c + 32pb)*2, +64) of the 2F-byte WB rows
-  // G piece (chunk c, gi): rows min(m0 + 64gi + r, M-1), bytes [256c, +256) of the 2F-byte gate rows
-  uint32_t voff_a[C::IPW], voff_b[C::IPW], voff_g[C::NG > 0 ? C::NG : 1][C::IPW];
-#pragma unroll
-  for (int s = 0; s < C::IPW; ++s) {
-    const int t = wave * C::IPW + s;
-    {
-      const int r = 8 * t + (lane >> 3), sl = lane & 7;
-      voff_a[s] = (uint32_t)(r * (D * 2) + ((sl ^ ((r >> 1) & 7)) << 4));
-    }
-    {
-      const int r = 16 * t + (lane >> 2), sl = lane & 3;
-      voff_b[s] = (uint32_t)r * (uint32_t)(F * 2) + (uint32_t)((sl ^ ((r >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int gi = 0; gi < C::NG; ++gi) {
-      const int r = 4 * t + (lane >> 4), sl = lane & 15;
-      int rg = m0 + 64 * gi + r;
-      rg = rg < M ? rg : M - 1;
-      voff_g[gi][s] = (uint32_t)rg * (uint32_t)(F * 2) + (uint32_t)((sl ^ (r & 15)) << 4);
-    }
-  }
-  // issue the piece with static in-chunk index J of chunk c into ring slot J
-  auto issue_piece = [&](int c_logical, auto jtag) {
-    constexpr int J = decltype(jtag)::value;
-    const int c = phys(c_logical);
-    const uint32_t dst = smem_addr + (uint32_t)J * PIECE + (uint32_t)(wave * C::IPW) * 1024u;
-    if constexpr (J < 4) {
-      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wa) + ((int64_t)c * CH * D + J * 64) * 2, voff_a, dst);
-    } else if constexpr (J < 4 + C::NG) {
-      glds_piece<C::IPW, true>(reinterpret_cast<const char*>(a.gate) + (int64_t)c * CH * 2, voff_g[J - 4], dst);
-    } else {
-      glds_piece<C::IPW>(reinterpret_cast<const char*>(a.wb) + ((int64_t)c * CH + (J - 4 - C::NG) * 32) * 2, voff_b, dst);
-    }
-  };
-  // prologue: pieces 0 .. DEPTH-1 of chunk 0 (DEPTH < PPC)
-  [&]<int... Js>(std::integer_sequence<int, Js...>) {
-    (issue_piece(0, std::integral_constant<int, Js>()), ...);
-  }(std::make_integer_sequence<int, C::DEPTH>());
-
-  // ---------------------------------------------------------------- Xin fragments (B operand of the first product)
-  bf16x8_t xf[16];
-  {
-    const bf16_t* xr = a.xin + (int64_t)row_c * D + h * 8;
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb) xf[kb] = *reinterpret_cast<const bf16x8_t*>(xr + kb * 16);
-  }
-  // bias of the first product: staged once into LDS behind the ring (forward only)
-  float* bias_lds = reinterpret_cast<float*>(smem + C::RING);
-  if (MODE == MODE_FWD) {
-    const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;   // relu(z) * inv_keep == relu(z * inv_keep)
-    for (int i = tid; i < F; i += 64 * NW) bias_lds[i] = a.bias_a ? a.bias_a[i] * sc : 0.f;
-  }
-
-  // ---------------------------------------------------------------- fragment read offsets (per lane, constant)
-  const int pr = pi32(m_l);
-  uint32_t offA[4];   // A piece: row (nb*32 + pr), slot (2*kbl + h) ^ ((row >> 1) & 7)   [(row>>1)&7 == (pr>>1)&7]
-#pragma unroll
-  for (int kbl = 0; kbl < 4; ++kbl) offA[kbl] = (uint32_t)(pr * 128 + (((2 * kbl + h) ^ ((pr >> 1) & 7)) << 4));
-  uint32_t offB[2];   // B piece: row (db*32 + pr), slot (2h + t) ^ ((row >> 2) & 3)
-#pragma unroll
-  for (int t = 0; t < 2; ++t) offB[t] = (uint32_t)(pr * 64 + (((2 * h + t) ^ ((pr >> 2) & 3)) << 4));
-
-  floatx16_t accH[4], accY[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) accY[i][v] = 0.f;
-
-  uint32_t P[4][8];  // the chunk's hidden tile of this lane as packed bf16 pairs: P[nb][2q + (i >> 1)]
-  uint4 gq[MODE == MODE_BWD ? 4 : 1][2];   // backward: the saved activation of the lane's 4 x 16 hidden units (the gate)
-  constexpr int B0 = 4 + C::NG;            // ring slot of the first B piece
-
-  // opens the phase that consumes piece J of chunk c: pieces J and J+1 have landed for every wave (counted wait: the
-  // DEPTH-2 younger pieces -- and any stores issued since -- stay in flight), and every wave is done reading the slot
-  // the piece DEPTH ahead goes to (= piece J-1: its fragment reads ended half a phase ago)
-  auto open_phase = [&](int c, auto jtag) {
-    constexpr int J = decltype(jtag)::value;
-    if (c == nch - 1 && J > C::PPC - C::DEPTH) wait_vm<0>();   // fewer than DEPTH-1 younger pieces exist: drain
-    else if (c == 0 || !FULL) wait_vm<C::WAITN>();   // no (or predicated) stores behind the pieces: conservative
-    else wait_vm<C::waitn_exact(J)>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    constexpr int JN = (J + C::DEPTH) % C::PPC;
-    const int cn = c + (J + C::DEPTH) / C::PPC;
-    if (cn < nch) issue_piece(cn, std::integral_constant<int, JN>());
-  };
-
-  // The MFMAs of a chunk form a stream of 128 positions: s < 64: first product, phase pa = s >> 4, k-block kbl = (s >> 2) & 3,
-  // column block nb = s & 3; s >= 64: second product, phase pb = (s - 64) >> 4, k-block t = (s >> 3) & 1, row block db = s & 7.
-  // The weight fragment of position s is read PD positions early into a ring of PD registers quads.
-  // Ring of PD register quads, filled LOOK = PD - 2 positions ahead: the quad a read overwrites was last used by the MFMA
-  // issued TWO positions earlier.  (Refilling the quad of the MFMA that has just been issued makes the read wait until
-  // that MFMA has fetched its operands, and the in-order wave then issues MFMA and read strictly one after the other:
-  // measured, the fragment reads and the MFMAs did not overlap at all.)
-  constexpr int PD = 16, LOOK = PD - 2;
-  bf16x8_t wq[PD];
-  auto read_frag = [&](auto stag) {
-    constexpr int S = decltype(stag)::value & 127;
-    if constexpr (S < 64) {
-      constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
-      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + pa * PIECE + nb * (32 * 128) + offA[kbl]);
-    } else {
-      constexpr int pb = (S - 64) >> 4, t = (S >> 3) & 1, db = S & 7;
-      wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(smem + (B0 + pb) * PIECE + db * (32 * 64) + offB[t]);
-    }
-  };
-  // keeps the fragments of positions S and S-1 allocated across the read issued at position S, so that the register
-  // allocator cannot hand that read the quad of an MFMA still fetching its operands
-  auto pin_recent = [&](auto stag) {
-    constexpr int S = decltype(stag)::value;
-    const bf16x8_t f0 = wq[S % PD], f1 = wq[(S + PD - 1) % PD];
-    asm volatile("" ::"v"(f0), "v"(f1));
-  };
-  auto mfma_at = [&](auto stag) {
-    constexpr int S = decltype(stag)::value;
-    if constexpr (S < 64) {
-      constexpr int pa = S >> 4, kbl = (S >> 2) & 3, nb = S & 3;
-      if constexpr (pa == 0 && kbl == 0) {
-        const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        accH[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], xf[0], zero, 0, 0, 0);
-      } else {
-        accH[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], xf[pa * 4 + kbl], accH[nb], 0, 0, 0);
-      }
-    } else {
-      constexpr int pb = (S - 64) >> 4, t = (S >> 3) & 1, db = S & 7;
-      union { uint32_t u[4]; bf16x8_t f; } pf;
-      pf.u[0] = P[pb][4 * t + 0]; pf.u[1] = P[pb][4 * t + 1]; pf.u[2] = P[pb][4 * t + 2]; pf.u[3] = P[pb][4 * t + 3];
-      accY[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[S % PD], pf.f, accY[db], 0, 0, 0);
-    }
-  };
-
-  // mid epilogue of one 32-column block nb of chunk c: accumulators -> P[nb] (+ store)
-  // `stage`: 2 KB of wave-private LDS inside the ring slot of the CURRENT phase (its fragments were read a phase ago and
-  // its refill is only issued when the next phase opens): the 32 x 32 block goes through it so that a store instruction
-  // writes 16 rows x 64 contiguous bytes instead of 64 scattered 16-byte pieces (those cost ~20 % of the kernel: 64
-  // write requests per instruction on the path the LDS-DMA reads share)
-  const int st_row = lane >> 2, st_slot = lane & 3;
-  const bool st_ok0 = FULL || (m0 + wave * 32 + st_row) < M, st_ok1 = FULL || (m0 + wave * 32 + st_row + 16) < M;
-  auto mid_epilogue = [&](int c_logical, int nb, char* stage) {
-    const int c = phys(c_logical);
-    const int col0 = c * CH + nb * 32 + 16 * h;   // this lane's 16 consecutive hidden units
-    float v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = accH[nb][e];
-    if (MODE == MODE_FWD) {
-      const float4* bp = reinterpret_cast<const float4*>(bias_lds + col0);
-      const float sc = (DROP & 1) ? a.drop1_inv_keep : 1.0f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b = bp[q];
-        v[4 * q + 0] = fmaxf(fmaf(v[4 * q + 0], sc, b.x), 0.f);
-        v[4 * q + 1] = fmaxf(fmaf(v[4 * q + 1], sc, b.y), 0.f);
-        v[4 * q + 2] = fmaxf(fmaf(v[4 * q + 2], sc, b.z), 0.f);
-        v[4 * q + 3] = fmaxf(fmaf(v[4 * q + 3], sc, b.w), 0.f);
-      }
-      if constexpr ((DROP & 1) != 0) {
-        const uint64_t idx = (uint64_t)row * (uint64_t)F + (uint64_t)col0;   // multiple of 8
-        const Philox4 r0 = philox4x32_10(a.seed1 + seed_off, a.stream1, idx >> 3);
-        const Philox4 r1 = philox4x32_10(a.seed1 + seed_off, a.stream1, (idx >> 3) + 1);
-        const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {   // 16-bit field e of the two calls: keep iff field >= threshold (drop_field)
-          const uint32_t f = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-          v[e] = f >= a.drop1_thresh ? v[e] : 0.f;
-        }
-      }
-    } else {
-      union { uint4 u[2]; short s[16]; } g;
-      g.u[0] = gq[nb][0];
-      g.u[1] = gq[nb][1];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = g.s[e] > 0 ? v[e] * a.gate_scale : 0.f;   // bf16 > 0 <=> its bits as int16 > 0
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) P[nb][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-    {
-      uint4* w = reinterpret_cast<uint4*>(stage + m_l * 64 + h * 32);
-      w[0] = make_uint4(P[nb][0], P[nb][1], P[nb][2], P[nb][3]);
-      w[1] = make_uint4(P[nb][4], P[nb][5], P[nb][6], P[nb][7]);
-      // same wave, LDS operations complete in issue order: the reads below see the block
-      const uint4 r0 = *reinterpret_cast<const uint4*>(stage + st_row * 64 + st_slot * 16);
-      const uint4 r1 = *reinterpret_cast<const uint4*>(stage + (st_row + 16) * 64 + st_slot * 16);
-      bf16_t* o = a.mid_out + (int64_t)(m0 + wave * 32 + st_row) * F + (c * CH + nb * 32 + st_slot * 8);
-      // non-temporal: the hidden tensor streams out (118 MB per launch at the benchmark shape) and must not push the 2 MB of
-      // weights every CU re-reads out of the XCD's L2 (measured: -12 % kernel time against plain stores)
-      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-      if (st_ok0) __builtin_nontemporal_store(u32x4_t{r0.x, r0.y, r0.z, r0.w}, reinterpret_cast<u32x4_t*>(o));
-      if (st_ok1) __builtin_nontemporal_store(u32x4_t{r1.x, r1.y, r1.z, r1.w}, reinterpret_cast<u32x4_t*>(o + (int64_t)16 * F));
-    }
-  };
-
-  // pieces 0 and 1 of chunk 0 have landed: the first PD fragments
-  wait_vm<C::WAITN>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, I>()), ...); }(std::make_integer_sequence<int, LOOK>());
-
-#pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
-    // ---- first product: 4 phases of 4 k-blocks x 4 column blocks
-    [&]<int... SS>(std::integer_sequence<int, SS...>) {
-      ([&] {
-        constexpr int S = SS;
-        if constexpr ((S & 15) == 0) open_phase(c, std::integral_constant<int, (S >> 4)>());
-        mfma_at(std::integral_constant<int, S>());
-        // the fragment LOOK positions ahead; in the backward the first fragments of the second product wait for the gate phases
-        if constexpr (S + LOOK < 64 || MODE == MODE_FWD) read_frag(std::integral_constant<int, S + LOOK>());
-        pin_recent(std::integral_constant<int, S>());
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }(), ...);
-    }(std::make_integer_sequence<int, 64>());
-    if constexpr (MODE == MODE_BWD) {
-      // the gate pieces (no MFMA work): the lane's 4 x 32 bytes go to registers -- their slots are refilled while the
-      // second product still runs
-      // slot 4 (rows 0..63 of the workgroup) is refilled when phase 5 opens, slot 5 when phase 6 opens: each half of
-      // the workgroup reads its gate rows right after the phase that made them visible
-      const int rr = (NW == 4 ? (wave & 1) : wave) * 32 + m_l;
-      auto read_gate = [&](int slot_index) {
-        const char* gslot = smem + slot_index * PIECE + rr * 256;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            gq[nb][s2] = *reinterpret_cast<const uint4*>(gslot + (((nb * 4 + 2 * h + s2) ^ (rr & 15)) << 4));
-      };
-      open_phase(c, std::integral_constant<int, 4>());
-      if (NW != 4 || (wave >> 1) == 0) read_gate(4);
-      if constexpr (C::NG == 2) {
-        open_phase(c, std::integral_constant<int, 5>());
-        if ((wave >> 1) == 1) read_gate(5);
-      }
-      [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(std::integral_constant<int, 64 + I>()), ...); }(std::make_integer_sequence<int, LOOK>());
-    }
-    // ---- second product: 4 phases (one per 32-unit block) of 2 k-blocks x 8 output row blocks; the mid epilogue of the
-    //      NEXT block sits in the same scheduling region as this block's MFMAs
-    [&]<int... SS>(std::integer_sequence<int, SS...>) {
-      ([&] {
-        constexpr int S = 64 + SS;
-        if constexpr ((S & 15) == 0) {
-          constexpr int J = B0 + ((S - 64) >> 4);
-          open_phase(c, std::integral_constant<int, J>());
-          char* stage = smem + J * PIECE + wave * 2048;
-          if constexpr (S == 64) mid_epilogue(c, 0, stage);
-          if constexpr (S < 112) mid_epilogue(c, ((S - 64) >> 4) + 1, stage);
-        }
-        mfma_at(std::integral_constant<int, S>());
-        read_frag(std::integral_constant<int, S + LOOK>());   // positions >= 128: the next chunk's first fragments (slot 0)
-        pin_recent(std::integral_constant<int, S>());
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }(), ...);
-    }(std::make_integer_sequence<int, 64>());
-  }
-
-  // ---------------------------------------------------------------- final epilogue: 16 consecutive output columns per lane and block
-#pragma unroll
-  for (int db = 0; db < 8; ++db) {
-    const int col0 = db * 32 + 16 * h;
-    float v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = accY[db][e];
-    if (MODE == MODE_FWD) {
-      if (a.bias_b) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b = *reinterpret_cast<const float4*>(a.bias_b + col0 + 4 * q);
-          v[4 * q + 0] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
-        }
-      }
-      if constexpr ((DROP & 2) != 0) {
-        const uint64_t idx = (uint64_t)row * (uint64_t)D + (uint64_t)col0;
-        float k0[8], k1[8];
-        dropout_keep8(a.seed2 + seed_off, a.stream2, idx, a.drop2_thresh, a.drop2_inv_keep, k0);
-        dropout_keep8(a.seed2 + seed_off, a.stream2, idx + 8, a.drop2_thresh, a.drop2_inv_keep, k1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] *= k0[e]; v[8 + e] *= k1[e]; }
-      }
-    }
-    if (a.residual) {
-      union { uint4 u[2]; bf16_t s[16]; } r;
-      const uint4* rp = reinterpret_cast<const uint4*>(a.residual + (int64_t)row_c * D + col0);
-      r.u[0] = rp[0];
-      r.u[1] = rp[1];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += bf16_to_f32(r.s[e]);
-    }
-    if (row_ok) {
-      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-      u32x4_t* o = reinterpret_cast<u32x4_t*>(a.out + (int64_t)row * D + col0);
-      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, o);
-      __builtin_nontemporal_store(u32x4_t{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])}, o + 1);
-    }
-  }
 }
 
 // =====================================================================================================================
@@ -1016,36 +660,6 @@ void allow_lds(KernelT kernel, int /*bytes*/) {
   if (ndone < 16) done[ndone++] = (const void*)kernel;
 }
 
-template <int MODE, int NW, int DROP, bool FULL, int DBG = 0>
-int launch_one(const FfnArgs& a, hipStream_t st) {
-  typedef Cfg<MODE, NW> C;
-  const int lds = C::RING + (MODE == MODE_FWD ? a.F * 4 : 0);
-  if (lds > 160 * 1024) {
-    nst_set_error("ffn: filter size %d needs %d bytes of LDS", a.F, lds);
-    return NST_ERR_UNSUPPORTED;
-  }
-  auto k = ffn_pair_kernel<MODE, NW, DROP, FULL, DBG>;
-  allow_lds(k, lds);
-  const int rows = 32 * NW;
-  k<<<(a.M + rows - 1) / rows, 64 * NW, lds, st>>>(a);
-  return NST_OK;
-}
-
-// Instantiated variants: the training configuration (both dropouts on / off) at full tiles, and one generic variant
-// (both dropout branches compiled in -- a rate of 0 has threshold 0, i.e. keeps everything -- and row predicates).
-template <int MODE, int NW>
-int launch_pair(const FfnArgs& a, hipStream_t st) {
-  const bool full = a.M % (32 * NW) == 0;
-  if constexpr (MODE == MODE_BWD) {
-    return full ? launch_one<MODE, NW, 0, true>(a, st) : launch_one<MODE, NW, 0, false>(a, st);
-  } else {
-    const int drop = (a.drop1_thresh ? 1 : 0) | (a.drop2_thresh ? 2 : 0);
-    if (full && drop == 3) return launch_one<MODE, NW, 3, true>(a, st);
-    if (full && drop == 0) return launch_one<MODE, NW, 0, true>(a, st);
-    return launch_one<MODE, NW, 3, false>(a, st);
-  }
-}
-
 // v2 (eight waves, two per SIMD): forward, full chip (>= 160 workgroups of 128 rows), F a multiple of 64 whose bias fits the
 // 16 KB behind the P tile.
 bool use_v2_fwd(const FfnArgs& a) {
@@ -1213,14 +827,6 @@ int launch_pair_v2_fwd(const FfnArgs& a_in, hipStream_t st) {
   return launch_v2_fwd<3, false>(a, st);
 }
 
-// rows per workgroup: 128 when that still gives every CU a workgroup, else 64 (NST_FFN_NW overrides: 4 | 2)
-int pick_nw(int M) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("NST_FFN_NW"); forced = e ? atoi(e) : 0; }
-  if (forced == 2 || forced == 4) return forced;
-  return M >= 128 * 160 ? 4 : 2;
-}
-
 // [R, C] bf16 -> [C, R] bf16, 64x64 tiles through LDS, a table of matrices per launch
 struct TransposeJob { const bf16_t* src; bf16_t* dst; int rows, cols, tiles_c, tile0; };
 
@@ -1303,7 +909,7 @@ extern "C" int nst_pack2d(const NstPack2dJob* jobs_dev, int njobs, int total_blo
 }
 
 extern "C" int nst_ffn_supported(int d_model, int filter_size, int dtype) {
-  return dtype == NST_BF16 && d_model == D && filter_size >= CH && filter_size % CH == 0 && filter_size <= 8192 ? 1 : 0;
+  return dtype == NST_BF16 && d_model == D && filter_size >= CH && filter_size % CH == 0 && filter_size <= 4096 ? 1 : 0;
 }
 
 extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, const float* b1, const void* w2t, const float* b2,
@@ -1336,8 +942,7 @@ extern "C" int nst_ffn_fwd(const NstFfnDesc* d, const void* x, const void* w1t, 
                   (long long)need);
     a.gate_bits = (uint16_t*)d->gate_bits;
   }
-  const int rc = use_v2_fwd(a) ? launch_pair_v2_fwd(a, (hipStream_t)stream)
-                 : pick_nw(a.M) == 4 ? launch_pair<MODE_FWD, 4>(a, (hipStream_t)stream) : launch_pair<MODE_FWD, 2>(a, (hipStream_t)stream);
+  const int rc = launch_pair_v2_fwd(a, (hipStream_t)stream);   // (any row count: the four-wave kernel of round 2 is gone)
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_fwd");
   return NST_OK;
@@ -1378,10 +983,7 @@ extern "C" int nst_ffn_bwd(const NstFfnDesc* d, const void* dy, const void* hidd
                   "ffn_bwd: gate_bits holds %lld bytes", (long long)d->gate_bits_bytes);
     a.gate_bits = (uint16_t*)d->gate_bits;
   }
-  // the gate pieces are 64 rows: a workgroup of 128 rows needs M >= 64 (row clamp), 64-row workgroups one piece
-  const int rc = use_v2_bwd(a) ? launch_pair_v2_bwd(a, (hipStream_t)stream)
-                 : (pick_nw(a.M) == 4 && a.M >= 64) ? launch_pair<MODE_BWD, 4>(a, (hipStream_t)stream)
-                                                    : launch_pair<MODE_BWD, 2>(a, (hipStream_t)stream);
+  const int rc = launch_pair_v2_bwd(a, (hipStream_t)stream);
   if (rc != NST_OK) return rc;
   NST_CHECK_LAUNCH("ffn_bwd");
   return NST_OK;

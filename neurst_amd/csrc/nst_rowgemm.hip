@@ -36,7 +36,7 @@ using namespace rowphase;
 
 namespace {
 
-enum { EPI_LN_FWD = 0, EPI_LN_BWD = 1, EPI_ROWDOT = 2, EPI_PLAIN = 3 };
+enum { EPI_LN_FWD = 0, EPI_LN_BWD = 1, EPI_ROWDOT = 2 };
 
 struct RowArgs {
   const bf16_t* A;       // [M, K], row stride lda
@@ -94,7 +94,6 @@ __device__ __forceinline__ void rg_finish(char* smem, floatx4_t (&acc)[MI][4], c
                                           int M, int tid, int lane, int wave, int wrow, int wc) {
   constexpr int RPW = BM / NW, PASSES = RPW / 2, TILE_BYTES = BM * TILE_LD * 4;
   const int sub = lane >> 5, li = lane & 31, col = li * 8;
-  (void)sub; (void)li;
   __builtin_amdgcn_s_barrier();      // every wave is done reading the stages: the tile reuses their LDS
   asm volatile("" ::: "memory");
 
@@ -121,13 +120,7 @@ __device__ __forceinline__ void rg_finish(char* smem, floatx4_t (&acc)[MI][4], c
   } else if constexpr (EPI == EPI_LN_BWD) {
     ln_bwd<NW, RPW, true>(tile, reinterpret_cast<float*>(smem + TILE_BYTES), a.e, seed, m0, M, tid, wave, lane, xpre);
   } else {
-    // EPI_ROWDOT / EPI_PLAIN: C = acc (+ bias) as bf16; rowdot: per head (64 columns = 8 lanes) sum of C (as stored) o src
-    float bs[8];
-    if (EPI == EPI_PLAIN && a.e.bias) rg_load8_f32(a.e.bias + col, bs);
-    else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bs[j] = 0.f;
-    }
+    // EPI_ROWDOT: C = acc as bf16; per head (64 columns = 8 lanes) the sum of C (as stored) o src
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int rl = wave * RPW + p * 2 + sub;
@@ -136,19 +129,17 @@ __device__ __forceinline__ void rg_finish(char* smem, floatx4_t (&acc)[MI][4], c
       const int rc = ok ? rowg : M - 1;
       const float4 t0 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col);
       const float4 t1 = *reinterpret_cast<const float4*>(tile + rl * TILE_LD + col + 4);
-      float v[8] = {t0.x + bs[0], t0.y + bs[1], t0.z + bs[2], t0.w + bs[3], t1.x + bs[4], t1.y + bs[5], t1.z + bs[6], t1.w + bs[7]};
+      float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
       if (ok) rg_store8_bf16(a.e.y + (int64_t)rowg * RN + col, v);
-      if constexpr (EPI == EPI_ROWDOT) {
-        float sv[8];
-        rg_load8_bf16(a.rd_src + (int64_t)rc * RN + col, sv);
-        float dot = 0.f;
+      float sv[8];
+      rg_load8_bf16(a.rd_src + (int64_t)rc * RN + col, sv);
+      float dot = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dot = fmaf(bf16_to_f32(f32_to_bf16(v[j])), sv[j], dot);
-        dot = dpp_add(dot, 0); dot = dpp_add(dot, 1); dot = dpp_add(dot, 2);   // the 8 lanes of a head
-        if (ok && (li & 7) == 0) {
-          const int b = rowg / a.rd_T, t = rowg - b * a.rd_T;
-          a.rd_dst[((int64_t)b * 4 + (li >> 3)) * a.rd_T + t] = dot;
-        }
+      for (int j = 0; j < 8; ++j) dot = fmaf(bf16_to_f32(f32_to_bf16(v[j])), sv[j], dot);
+      dot = dpp_add(dot, 0); dot = dpp_add(dot, 1); dot = dpp_add(dot, 2);   // the 8 lanes of a head
+      if (ok && (li & 7) == 0) {
+        const int b = rowg / a.rd_T, t = rowg - b * a.rd_T;
+        a.rd_dst[((int64_t)b * 4 + (li >> 3)) * a.rd_T + t] = dot;
       }
     }
   }
@@ -380,6 +371,10 @@ extern "C" int nst_gemm_add_layernorm_fwd(const NstRowGemmDesc* d, const void* A
   int rc = rg_check_common(d, A, W, "gemm_add_layernorm_fwd");
   if (rc != NST_OK) return rc;
   NST_CHECK_ARG(x && gamma && beta && y && mean && rstd, "gemm_add_layernorm_fwd: null pointer");
+  if (d->trans_b) {   // (only the orientations a training step issues are instantiated: forward products read the kernel as stored)
+    nst_set_error("gemm_add_layernorm_fwd: trans_b = 1 is not built (a forward product reads W [k, 256])");
+    return NST_ERR_UNSUPPORTED;
+  }
   NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(y) && nst_aligned16(gamma) && nst_aligned16(beta) && (!x_out || nst_aligned16(x_out)) &&
                     (!bias || nst_aligned16(bias)),
                 "gemm_add_layernorm_fwd: operands must be 16-byte aligned");
@@ -392,8 +387,7 @@ extern "C" int nst_gemm_add_layernorm_fwd(const NstRowGemmDesc* d, const void* A
   a.seed = d->seed; a.e.stream_id = d->stream_id;
   a.seed_dev = nst_seed_offset_devptr();
   if (!a.seed_dev) return NST_ERR_LAUNCH;
-  if (d->trans_b) rg_launch<MODE_RC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
-  else rg_launch<MODE_OC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
+  rg_launch<MODE_OC, EPI_LN_FWD>(a, (hipStream_t)stream, nullptr);
   NST_CHECK_LAUNCH("gemm_add_layernorm_fwd");
   return NST_OK;
 }
@@ -407,6 +401,10 @@ extern "C" int nst_gemm_layernorm_bwd(const NstRowGemmDesc* d, const void* A, co
   int rc = rg_check_common(d, A, W, "gemm_layernorm_bwd");
   if (rc != NST_OK) return rc;
   NST_CHECK_ARG(x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "gemm_layernorm_bwd: null pointer");
+  if (!d->trans_b) {
+    nst_set_error("gemm_layernorm_bwd: trans_b = 0 is not built (an input-gradient product reads the kernel [256, k] as stored)");
+    return NST_ERR_UNSUPPORTED;
+  }
   NST_CHECK_ARG(nst_aligned16(x) && nst_aligned16(dx) && nst_aligned16(gamma) && (!dres || nst_aligned16(dres)) && (!dz || nst_aligned16(dz)) &&
                     (((uintptr_t)workspace) & 15) == 0,
                 "gemm_layernorm_bwd: operands must be 16-byte aligned");
@@ -428,8 +426,7 @@ extern "C" int nst_gemm_layernorm_bwd(const NstRowGemmDesc* d, const void* A, co
   a.seed_dev = nst_seed_offset_devptr();
   if (!a.seed_dev) return NST_ERR_LAUNCH;
   int nblocks = 0;
-  if (d->trans_b) rg_launch<MODE_RC, EPI_LN_BWD>(a, (hipStream_t)stream, &nblocks);
-  else rg_launch<MODE_OC, EPI_LN_BWD>(a, (hipStream_t)stream, &nblocks);
+  rg_launch<MODE_RC, EPI_LN_BWD>(a, (hipStream_t)stream, &nblocks);
   NST_CHECK_LAUNCH("gemm_layernorm_bwd");
   NstLnFinalizeJob job;
   memset(&job, 0, sizeof(job));
@@ -448,20 +445,18 @@ extern "C" int nst_gemm_rowdot256(const NstRowGemmDesc* d, const void* A, const 
   int rc = rg_check_common(d, A, W, "gemm_rowdot256");
   if (rc != NST_OK) return rc;
   NST_CHECK_ARG(C_ && nst_aligned16(C_), "gemm_rowdot256: C must be 16-byte aligned");
-  NST_CHECK_ARG((src == nullptr) == (dst == nullptr), "gemm_rowdot256: src and dst come together");
+  NST_CHECK_ARG(src && dst, "gemm_rowdot256: src and dst are required");
+  if (!d->trans_b) {
+    nst_set_error("gemm_rowdot256: trans_b = 0 is not built (the output projection's input gradient reads the kernel as stored)");
+    return NST_ERR_UNSUPPORTED;
+  }
   NST_CHECK_ARG(!src || (nst_aligned16(src) && rows_per_batch > 0 && d->rows % rows_per_batch == 0),
                 "gemm_rowdot256: rows=%lld is not a multiple of rows_per_batch=%d", (long long)d->rows, rows_per_batch);
   RowArgs a;
   rg_fill(a, d, A, W);
   a.e.y = (bf16_t*)C_;
   a.rd_src = (const bf16_t*)src; a.rd_dst = dst; a.rd_T = rows_per_batch;
-  if (src) {
-    if (d->trans_b) rg_launch<MODE_RC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);
-    else rg_launch<MODE_OC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);
-  } else {
-    if (d->trans_b) rg_launch<MODE_RC, EPI_PLAIN>(a, (hipStream_t)stream, nullptr);
-    else rg_launch<MODE_OC, EPI_PLAIN>(a, (hipStream_t)stream, nullptr);
-  }
+  rg_launch<MODE_RC, EPI_ROWDOT>(a, (hipStream_t)stream, nullptr);
   NST_CHECK_LAUNCH("gemm_rowdot256");
   return NST_OK;
 }

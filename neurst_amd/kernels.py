@@ -495,9 +495,9 @@ def gemm_layernorm_bwd(A, W, x, gamma, mean, rstd, dgamma, dbeta, accumulate=Fal
     return (dx, dz) if emit_dropout is not None else dx
 
 
-def gemm_rowdot256(A, W, rowdot=None, trans_b=True):
-    """nst_gemm_rowdot256: C [rows, 256] = bf16(A @ W^T); rowdot=(src [rows, 256] bf16, dst f32 [rows/T, 4, T], T) also leaves
-    the per-head row sums of C o src (the attention backward's delta)."""
+def gemm_rowdot256(A, W, rowdot, trans_b=True):
+    """nst_gemm_rowdot256: C [rows, 256] = bf16(A @ W^T); rowdot=(src [rows, 256] bf16, dst f32 [rows/T, 4, T], T) leaves the
+    per-head row sums of C o src (the attention backward's delta)."""
     d, rows, n, k = _rowgemm_desc(A, W, trans_b)
     out = torch.empty(rows, n, dtype=torch.bfloat16, device=A.device)
     src = dst = None

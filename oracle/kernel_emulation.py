@@ -180,7 +180,7 @@ def gemm_layernorm_bwd(A, W, x, gamma, mean, rstd, dgamma, dbeta, accumulate=Fal
                          dres=None if dres is None else dres.reshape(rows, n), emit_dropout=emit_dropout, batch=batch)
 
 
-def gemm_rowdot256(A, W, rowdot=None, trans_b=True):
+def gemm_rowdot256(A, W, rowdot, trans_b=True):
     rows, k = A.shape
     n = W.shape[0] if trans_b else W.shape[1]
     assert rowgemm_supported(A, n, k)

@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     from neurst_amd import kernels as K
     dev, d, F = "cuda:0", 256, args.ffn
-    res = {"nw_env": os.environ.get("NST_FFN_NW", "auto")}
+    res = {}
     for M in [int(r) for r in args.rows.split(",")]:
         g = torch.Generator().manual_seed(0)
         bf = torch.bfloat16

@@ -18,6 +18,8 @@ def fam(n):
     if "gemm256_group" in n or "g256_table" in n: return "weight-gradient GEMMs (grouped, 256 x 256 tiles)"
     if "dense_gemm_kernel_v3<unsigned short, float, 1, 1" in n: return "weight-gradient GEMMs"
     if "dense_gemm" in n: return "forward / input-gradient GEMMs"
+    if "rowgemm" in n: return "whole-row products (product + the wrapper's LayerNorm stages)"
+    if "ffn_slab_rows" in n: return "feed-forward pair"
     if "splitk" in n: return "split-K reduces"
     if "conv2" in n or "conv_splitk" in n: return "conv2"
     if "conv1" in n: return "conv1"

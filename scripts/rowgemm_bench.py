@@ -104,8 +104,6 @@ def main():
             if k == 256:
                 res[key + "_rowdot_rows_us"] = timeit(lambda: K.gemm_rowdot256(A, Wb, rowdot=(src, dst, T)))
                 res[key + "_rowdot_stream_us"] = timeit(lambda: K.gemm(A, Wb, rows, 256, k, trans_b=True, rowdot=(src, dst, T)))
-                res[key + "_plain_rows_us"] = timeit(lambda: K.gemm_rowdot256(A, Wf, trans_b=False))
-                res[key + "_plain_stream_us"] = timeit(lambda: K.gemm(A, Wf, rows, 256, k))
     out = {k: round(v, 2) for k, v in res.items()}
     out["NST_ROWGEMM_CFG"] = os.environ.get("NST_ROWGEMM_CFG", "")
     out["cold"] = timeit is timeit_cold

@@ -35,8 +35,7 @@ def _operands(M, F, seed):
     return x, res, w1, w2, b1, b2
 
 
-# M: full 128-row tiles (4 waves), 64-row tiles (2 waves), ragged tails of both kinds, one row, and a size past the
-# 128-row / 64-row switch
+# M: full 128-row tiles, ragged tails, fewer rows than one tile, one row, and sizes on both sides of the "fills the chip" mark
 @pytest.mark.parametrize("M,F", [(256, 256), (192, 128), (200, 512), (1, 128), (77, 2048), (9600, 2048), (20480 + 40, 256)])
 def test_ffn_forward_without_dropout(M, F):
     from neurst_amd import kernels as K
@@ -101,7 +100,7 @@ def test_ffn_backward(M, F, with_residual):
 
 def test_ffn_pair_at_the_benchmark_shape():
     """The shape and the kernel variants bench.py times: 28 800 rows x 2048 hidden units, 128-row workgroups on full tiles
-    (ffn_pair_kernel<fwd, 4, dropout on both sites, full> and <bwd, 4, full>).  Forward without dropout and the backward
+    (ffn_pair8_kernel<fwd, dropout on both sites, full> and <bwd, full>).  Forward without dropout and the backward
     against float64; with dropout the masks must equal the stream-GEMM path's masks for the same (seed, site) -- that path
     is pinned on the Philox restatement at the smaller sizes above -- and the values its outputs."""
     from neurst_amd import kernels as K

@@ -435,7 +435,7 @@ def s_real_bf16_noise_report(tag):
     ffn0 = model._encoder._stacking_layers[0]._ffn_layer.layer
     rows0 = ffn0._saved[1].shape[0]
     fused = {"rows": rows0, "one_launch_pair": bool(ffn0.fused and rows0 >= CL._FFN_FUSED_MIN_ROWS and CL._FFN_FUSED_BWD),
-             "NST_FFN_NW": os.environ.get("NST_FFN_NW", "")}
+             }
     model.backward(crit.backward())
     torch.cuda.synchronize()
     logits_hip = logits.float().cpu()
@@ -505,7 +505,7 @@ def test_speech_transformer_s_parity_with_the_benchmark_kernel_selection():
     read once per process, so the case runs in a child interpreter."""
     import subprocess
     import sys
-    env = dict(os.environ, NST_FFN_MIN_ROWS="1", NST_FFN_NW="4")
+    env = dict(os.environ, NST_FFN_MIN_ROWS="1")
     code = ("import json, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import test_gpu_model as T\n"
             "rep, e_hip, e_emu = T.s_real_bf16_noise_report('child')\n"
@@ -518,7 +518,7 @@ def test_speech_transformer_s_parity_with_the_benchmark_kernel_selection():
     rep, e_hip, e_emu = got["rep"], got["e_hip"], got["e_emu"]
     for k, v in rep.items():
         REPORT[f"st[s_real,bfloat16].bench_selection.{k}"] = v
-    assert rep["first_encoder_ffn"] == {"rows": 675, "one_launch_pair": True, "NST_FFN_NW": "4"}, rep["first_encoder_ffn"]
+    assert rep["first_encoder_ffn"] == {"rows": 675, "one_launch_pair": True}, rep["first_encoder_ffn"]
     _assert_bf16_noise_level(rep, e_hip, e_emu)
 
 

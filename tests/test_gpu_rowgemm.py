@@ -51,7 +51,7 @@ SHAPES = [(5, 64), (37, 256), (64 * 3 + 5, 256), (1000, 768), (4000, 768), (9600
           (28800, 256), (28800 + 17, 256)]
 
 
-@pytest.mark.parametrize("trans_b", [False, True])
+@pytest.mark.parametrize("trans_b", [False])      # (the orientation a forward product has: W [k, 256] as stored)
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("rows,k", SHAPES)
 def test_gemm_add_layernorm_fwd(K, rows, k, p, trans_b):
@@ -90,7 +90,7 @@ def test_gemm_add_layernorm_fwd(K, rows, k, p, trans_b):
     assert none is None and torch.equal(y3, y)
 
 
-@pytest.mark.parametrize("trans_b", [True, False])
+@pytest.mark.parametrize("trans_b", [True])       # (an input-gradient product reads the kernel [256, k] as stored)
 @pytest.mark.parametrize("drop", [False, True])
 @pytest.mark.parametrize("rows,k", SHAPES)
 def test_gemm_layernorm_bwd(K, rows, k, drop, trans_b):
@@ -162,10 +162,6 @@ def test_gemm_rowdot256(K, B, T, k):
     c2 = K.gemm(d(A), d(W), rows, 256, k, trans_b=True, rowdot=(d(src), dst2, T))
     check(tag + ".C vs stream kernel", c, c2.double(), 1e-2, 2e-3)
     check(tag + ".delta vs stream kernel", dst, dst2.double(), 5e-3)
-    # plain product (no row dots), forward weight layout
-    Wf = _weights(k, False, 24)
-    c3 = K.gemm_rowdot256(d(A), d(Wf), trans_b=False)
-    check(tag + ".plain", c3, E.gemm(A, Wf, rows, 256, k), 1e-2, 4e-3)
 
 
 def test_rowgemm_refuses_what_it_cannot_do(K):
@@ -176,3 +172,7 @@ def test_rowgemm_refuses_what_it_cannot_do(K):
     x = rnd(40, 256).to(DEV)
     with pytest.raises(RuntimeError):
         K.gemm_add_layernorm_fwd(A, W, x, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), 1e-6)
+    # orientations that no training step issues are not built
+    A2, W2 = rnd(40, 128, dtype=torch.bfloat16).to(DEV), rnd(256, 128, dtype=torch.bfloat16).to(DEV)
+    with pytest.raises(RuntimeError, match="not built"):
+        K.gemm_add_layernorm_fwd(A2, W2, x, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), 1e-6, trans_b=True)
