@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneurst_hip.so")
+# NST_LIBRARY: another build of the SAME library (measurement twins such as lib/libneurst_hip_ablation.so); still a HIP shared
+# object with the full ABI -- there is no other kind of back end to select
+LIB_PATH = os.environ.get("NST_LIBRARY") or os.path.join(_HERE, "lib", "libneurst_hip.so")
 
 NST_F32, NST_BF16 = 0, 1
 NST_ABI_VERSION = 10

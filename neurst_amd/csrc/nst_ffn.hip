@@ -339,6 +339,12 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) accY[i][v] = 0.f;
   uint32_t packed[8];
+  if constexpr (DBG != 0) {   // ablation builds (NST_FFN_ABLATION): stages may be missing, their registers still hold something defined
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accH[v] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed[e] = 0u;
+  }
 
   // ---- first product of chunk c (logical): 16 dependent MFMAs (same accumulator: the matrix core forwards it)
   auto a_phase = [&](int c_logical) {
@@ -362,6 +368,12 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     float v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = accH[e];
+    if constexpr ((DBG & 32) != 0) {   // ablation: the conversion only
+#pragma unroll
+      for (int e = 0; e < 8; ++e) packed[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      if constexpr (MODE == MODE_BWD) { if constexpr (decltype(first_tag)::value || !FULL) wait_vm<0>(); issue_g(c_logical + 1); }
+      return;
+    }
     if constexpr (MODE == MODE_BWD) {
       // this lane's 16 gate values: row i_l of the wave's region (64-byte rows), bytes [32 h, +32)
       if constexpr (decltype(first_tag)::value || !FULL) wait_vm<0>(); else wait_vm<10>();   // (2 stores + 8 weight DMAs are younger than the gate copy)
@@ -425,15 +437,20 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
         acc = (acc << 1) | nz;
       }
       const uint32_t m16 = (acc & 0xffu) | ((acc >> 8) & 0xff00u);
-      if (row_ok) a.gate_bits[((int64_t)(2 * c + hh) * M + row) * 2 + h] = (uint16_t)m16;
+      if constexpr ((DBG & 1) == 0)
+        if (row_ok) a.gate_bits[((int64_t)(2 * c + hh) * M + row) * 2 + h] = (uint16_t)m16;
     }
   };
   auto write_p = [&]() {   // this lane's 16 units = slots 4 hh + 2 h, + 1 of its row
+    if constexpr ((DBG & 64) != 0) return;
     char* prow = smem + V2_P + offP;
     *reinterpret_cast<uint4*>(prow + ((((uint32_t)(4 * hh + 2 * h)) ^ pz) << 4)) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     *reinterpret_cast<uint4*>(prow + ((((uint32_t)(4 * hh + 2 * h + 1)) ^ pz) << 4)) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
   };
   // ---- the saved activation of chunk c, stored from the P tile in whole row pieces
+  // (round 6: reading the two row pieces at the top of the span and storing them four MFMAs later -- no lgkmcnt(0) in front of
+  // the stores -- measured no faster forward and 5 % slower backward on the same box: the 7 us that the stage ablation assigns
+  // to these stores is the stores, not the wait in front of them)
   auto store_hidden = [&](int c_logical) {
     const int c = phys(c_logical);
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -442,7 +459,8 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
       const int r = st_r0 + 8 * q;
       const uint4 d = *reinterpret_cast<const uint4*>(smem + V2_P + r * 128 + ((st_slot ^ ((r >> 1) & 7)) << 4));
       bf16_t* o = a.mid_out + (int64_t)(m0 + r) * F + (c * CH2 + st_slot * 8);
-      if (q == 0 ? st_ok0 : st_ok1) __builtin_nontemporal_store(u32x4_t{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4_t*>(o));
+      if constexpr ((DBG & 1) == 0)
+        if (q == 0 ? st_ok0 : st_ok1) __builtin_nontemporal_store(u32x4_t{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4_t*>(o));
     }
   };
   auto barrier = [&]() {
@@ -457,9 +475,17 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   // latency (not its bandwidth) paced the MFMAs: "no fragment reads" took 16 of 85 us (gpurun_out/r03_ffn_v2_ablation.log).
   constexpr int PD = 8, LOOK = 6;
   bf16x8_t wq[PD], pf[4];
+  if constexpr (DBG != 0) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) wq[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
   auto read_frag = [&](auto stag, const char* w1, const char* w2) {
     constexpr int S = decltype(stag)::value;
-    if constexpr (S < 16) {
+    if constexpr ((DBG & 4) != 0) {
+      return;
+    } else if constexpr (S < 16) {
       const uint32_t o = (offA ^ (uint32_t)(((2 * S) & 15) << 4)) + (uint32_t)((S >> 3) * 256);
       wq[S % PD] = *reinterpret_cast<const bf16x8_t*>(w1 + o);
     } else {
@@ -469,7 +495,9 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
   };
   auto mfma_at = [&](auto stag) {
     constexpr int S = decltype(stag)::value;
-    if constexpr (S == 0) {
+    if constexpr ((DBG & 8) != 0) {
+      return;
+    } else if constexpr (S == 0) {
       const floatx16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xf[0], zero, 0, 0, 0);
     } else if constexpr (S < 16) {
@@ -480,6 +508,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     }
   };
   auto read_p_frags = [&]() {
+    if constexpr ((DBG & 64) != 0) return;
     const char* prow = smem + V2_P + offP;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -513,7 +542,7 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
       ([&] {
         constexpr int S = S0 + SS;
         mfma_at(std::integral_constant<int, S>());
-        if constexpr (HAS_A && S >= 1 && S <= 8) {
+        if constexpr (HAS_A && S >= 1 && S <= 8 && (DBG & 2) == 0) {
           if constexpr (S <= 4) glds_one(src1, voff1[S - 1], dst1 + (uint32_t)(S - 1) * 1024u);
           else glds_one(src2, voff2[S - 5], dst2 + (uint32_t)(S - 5) * 1024u);
         }
@@ -550,12 +579,12 @@ __global__ void __launch_bounds__(512, 2) ffn_pair8_kernel(FfnArgs a) {
     // the weight DMAs issued early in this span have landed (the two hidden-tile stores are older still); the backward's two
     // gate DMAs of the next chunk are the youngest and stay in flight
     if (MODE == MODE_BWD && FULL) { if constexpr (BITS) wait_vm<1>(); else wait_vm<2>(); } else wait_vm<0>();
-    barrier();                          // X: P(c), W2 buffer c & 1 and W1 buffer (c+1) & 1 are free; the next span's weights are visible
+    if constexpr ((DBG & 16) == 0) barrier();   // X: P(c), W2 buffer c & 1 and W1 buffer (c+1) & 1 are free; the next span's weights are visible
     if (c + 2 < nch) burst(std::integral_constant<int, 0>(), smem + V2_W1 + (c & 1) * 32768, smem + V2_W2 + ((c + 1) & 1) * 32768);
     else burst(std::integral_constant<int, 16>(), smem + V2_W1, smem + V2_W2 + ((c + 1) & 1) * 32768);
     write_p();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    barrier();                          // Y: P(c+1) visible
+    if constexpr ((DBG & 16) == 0) barrier();   // Y: P(c+1) visible
   }
   // the residual rows of the final epilogue: requested HERE, so that their HBM latency runs under the last span (no LDS-DMA is
   // outstanding any more; in the loop an ordinary load would make the compiler's vmcnt wait drain the weight prefetch)
@@ -666,10 +695,42 @@ bool use_v2_fwd(const FfnArgs& a) {
   return a.F % CH2 == 0 && a.F >= 2 * CH2 && a.F <= 4096 && a.M >= 128 * 160;
 }
 
+// Ablation build (make -C neurst_amd/csrc ablation -> lib/libneurst_hip_ablation.so, -DNST_FFN_ABLATION; never the product
+// library): NST_FFN_DBG=<bits> launches the forward (dropout, full tiles, gate bits) / backward (full tiles, gate bits) kernel with
+// stages removed -- 1 hidden-tile and gate-bit stores, 2 weight DMA of the loop, 4 weight fragment reads, 8 MFMAs, 16 the loop's
+// barriers, 32 the mid epilogue's arithmetic, 64 the P tile's writes and reads.  Results are wrong by construction; only the
+// durations mean something (scripts/ffn_ablation.py, profiles/r06_ffn_ablation.json).
+#ifdef NST_FFN_ABLATION
+#define NST_FFN_DBG_LIST(X) X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(3) X(71) X(76) X(103) X(119) X(127)
+int ffn_dbg_bits() {
+  const char* e = getenv("NST_FFN_DBG");
+  return e ? atoi(e) : 0;
+}
+template <int MODE, int DROP>
+bool launch_ablation(const FfnArgs& a, int lds, hipStream_t st) {
+  const int dbg = ffn_dbg_bits();
+  if (dbg == 0 || a.M % V2_ROWS != 0 || !a.gate_bits) return false;
+#define NST_FFN_DBG_CASE(B)                                      \
+  if (dbg == B) {                                                \
+    auto k = ffn_pair8_kernel<MODE, DROP, true, B, true>;        \
+    allow_lds(k, lds);                                           \
+    k<<<a.M / V2_ROWS, 512, lds, st>>>(a);                       \
+    return true;                                                 \
+  }
+  NST_FFN_DBG_LIST(NST_FFN_DBG_CASE)
+#undef NST_FFN_DBG_CASE
+  return false;
+}
+#endif
+
 template <int DROP, bool FULL>
 int launch_v2_fwd(const FfnArgs& a, hipStream_t st) {
   constexpr int DBG = 0;
   const int lds = V2_BIAS + a.F * 4;
+#ifdef NST_FFN_ABLATION
+  if constexpr (DROP == 3 && FULL)
+    if (launch_ablation<MODE_FWD, 3>(a, lds, st)) return NST_OK;
+#endif
   if (a.gate_bits) {
     auto k = ffn_pair8_kernel<MODE_FWD, DROP, FULL, 0, true>;
     allow_lds(k, lds);
@@ -793,6 +854,9 @@ int launch_pair_v2_bwd(const FfnArgs& a_in, hipStream_t st) {
   FfnArgs a = a_in;
   a.rot_mode = 0;
   const int lds = V2_BIAS + 16384;   // the eight 2 KB gate regions
+#ifdef NST_FFN_ABLATION
+  if (launch_ablation<MODE_BWD, 0>(a, lds, st)) return NST_OK;
+#endif
   if (a.gate_bits) {
     if (a.M % V2_ROWS == 0) {
       auto k = ffn_pair8_kernel<MODE_BWD, 0, true, 0, true>;

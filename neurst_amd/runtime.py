@@ -277,7 +277,7 @@ KNOWN_SWITCHES = frozenset((
     "NST_TRAIN_GRAPH", "NST_DIST_BACKEND", "NST_DIST_FORCE", "NST_DIST_WIRE", "NST_DIST_NATIVE", "NST_DIST_TIMEOUT_MIN",
     "NST_DIST_BUCKET_MB", "NST_DIST_DEBUG", "NST_RCCL_PATH", "NST_COMM_DEBUG", "NST_BENCH_CHILD", "NST_BENCH_HANG_DUMP_S",
     "NST_BENCH_VERBOSE", "NST_FFN_MIN_ROWS", "NST_ATTN_FUSED_BWD", "NST_ATTN_MI_FWD", "NST_ATTN_MI_DKDV", "NST_ATTN_MI_DQ",
-    "NST_ROW_FUSION", "NST_ROWGEMM_CFG", "NST_TEST_L2_F32", "NST_TEST_L2_BF16"))
+    "NST_ROW_FUSION", "NST_ROWGEMM_CFG", "NST_TEST_L2_F32", "NST_TEST_L2_BF16", "NST_LIBRARY", "NST_FFN_DBG"))
 
 
 def warn_unknown_switches():

@@ -23,7 +23,7 @@ done
 python scripts/summarise_pmc.py --tag $T ${2:+--commit $2} > /dev/null
 python scripts/kernel_resources.py $T > /dev/null 2>&1
 ls -la $P | grep ${T}_ | wc -l
-for f in pmc_group256 pmc_attn attn_bench wgrad_group_bench pmc_whole_step pmc_conv2 pmc_ln hbm_probe pmc_rowgemm rowgemm_bench_warm rowgemm_bench_cold; do
+for f in pmc_group256 pmc_attn attn_bench wgrad_group_bench pmc_whole_step pmc_conv2 pmc_ln hbm_probe pmc_rowgemm rowgemm_bench_warm rowgemm_bench_cold ffn_cost_model ffn_ablation; do
   [ -s $G/${T}_$f.json ] && cp $G/${T}_$f.json $P/${T}_$f.json
 done
 [ -s $G/${T}_two_rank_rehearsal_graph.log ] && cp $G/${T}_two_rank_rehearsal_graph.log $P/${T}_two_rank_rehearsal_graph_final.log

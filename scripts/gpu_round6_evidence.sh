@@ -25,6 +25,8 @@ PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUS
   scripts/pmc_kernel.sh $O/${T}_pmc_ln.json ln_ bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 > $O/${T}_pmc_ln.log 2>&1
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" \
   scripts/pmc_kernel.sh $O/${T}_pmc_rowgemm.json rowgemm_kernel bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 > $O/${T}_pmc_rowgemm.log 2>&1
+timeout 300 python scripts/ffn_cost_model.py ${T} > /dev/null 2>&1
+[ -f neurst_amd/lib/libneurst_hip_ablation.so ] && NST_LIBRARY=$PWD/neurst_amd/lib/libneurst_hip_ablation.so timeout 600 python scripts/ffn_ablation.py ${T} > $O/${T}_ffn_ablation.log 2>&1
 timeout 300 python scripts/rowgemm_bench.py ${T}_warm > /dev/null 2>&1; cp $O/${T}_warm_rowgemm_bench.json $O/${T}_rowgemm_bench_warm.json
 timeout 300 python scripts/rowgemm_bench.py ${T}_cold --cold > /dev/null 2>&1; cp $O/${T}_cold_rowgemm_bench.json $O/${T}_rowgemm_bench_cold.json
 timeout 120 python scripts/hbm_probe.py --out $O/${T}_hbm_probe.json > $O/${T}_hbm_probe.log 2>&1; tail -1 $O/${T}_hbm_probe.log | cut -c1-400
