@@ -71,7 +71,10 @@ def main():
     yn, mean2, rstd2 = K.layernorm_fwd(y2, gam, bet, 1e-6, relu=True)
     dg2, db2n = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     for name, fn, nb in (("conv2_ln_relu_fwd", lambda: K.layernorm_fwd(y2, gam, bet, 1e-6, relu=True), 2 * y2.numel() * 2),
-                         ("conv2_ln_relu_bwd", lambda: K.layernorm_bwd(dy, y2, gam, mean2, rstd2, dg2, db2n, y=yn), 4 * y2.numel() * 2)):
+                         ("conv2_ln_relu_bwd", lambda: K.layernorm_bwd(dy, y2, gam, mean2, rstd2, dg2, db2n, y=yn), 4 * y2.numel() * 2),
+                         # the form the model runs: the gate recomputed from x and the statistics, the saved activation not read
+                         ("conv2_ln_relu_bwd_regate", lambda: K.layernorm_bwd(dy, y2, gam, mean2, rstd2, dg2, db2n, regate_beta=bet),
+                          3 * y2.numel() * 2)):
         us = timed(fn, a.iters)
         res[name] = {"us": us, "tb_per_s": nb / us / 1e6}
         print(name, res[name])
