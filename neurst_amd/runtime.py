@@ -447,15 +447,21 @@ class Runtime(object):
             self._deferred_reports = []
         return stale
 
-    def launch_wgrad_group(self):
-        """One launch, on the current stream, for every weight gradient queued since the last call, then the reports that
-        waited for it.  (Groups that cannot fill the chip on the weight-gradient stream, and one launch per stack, were measured
+    def launch_wgrad_group(self, side=False):
+        """One launch for every weight gradient queued since the last call -- on the current stream, or (side=True) on the
+        weight-gradient stream behind everything queued so far on the current one -- then the reports that waited for it (the
+        reducer orders its exchange behind both streams).  (Groups that cannot fill the chip on the weight-gradient stream, and one launch per stack, were measured
         and lost: DESIGN 5e.)"""
         g = getattr(self, "_wgrad_group", None)
         if g is None:
             return
         if len(g):
-            g.launch()
+            if side:
+                fn, tensors = g.take()
+                self.run_wgrad(fn, *tensors)
+                self.sublayer_boundary(force=True)
+            else:
+                g.launch()
         reports, self._deferred_reports = self._deferred_reports, []
         for r in reports:
             r()

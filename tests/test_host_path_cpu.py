@@ -159,16 +159,19 @@ def test_grouped_cross_attention_projection_equals_per_layer_and_leaves_nothing_
     assert rel_err(model(other, is_training=False).double(), want) < 1e-6
 
 
+@pytest.mark.parametrize("dec_side", [False, True])
 @pytest.mark.parametrize("at", ["end", "encoder"])
-def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_follow_the_launch(cpu_kernels, monkeypatch, at):
+def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_follow_the_launch(cpu_kernels, monkeypatch, at, dec_side):
     """Runtime.wgrad_group / launch_wgrad_group: with the group on, Dense.backward_params only queues its product; the model
-    launches the queue once (behind the encoder stack or at the end).  Same gradients as the per-product schedule (bit-identical over
+    launches the queue once (behind the encoder stack or at the end; dec_side: the decoder stack's products in a launch of their
+    own right behind the decoder's backward -- Runtime.launch_wgrad_group(side=True), the speech models' placement).  Same gradients as the per-product schedule (bit-identical over
     the emulated kernels), nothing left queued after backward(), and a data-parallel report for a layer is delivered only
     AFTER the launch that writes that layer's weight gradients -- in the original order, each exactly once."""
     from neurst_amd import kernels as K
     from neurst_amd.criterions import build_criterion
     monkeypatch.setattr(K.WgradGroup, "MIN_OUTPUTS", 1)
     monkeypatch.setattr("neurst_amd.models.encoder_decoder_model._WGRAD_GROUP_AT", at)
+    monkeypatch.setattr("neurst_amd.models.encoder_decoder_model._WGRAD_DECODER_SIDE", dec_side)
     crit = build_criterion({"criterion.class": "label_smoothed_cross_entropy", "criterion.params": {"label_smoothing": 0.1}})
     grads, reports = [], []
     for grouped in (False, True):
@@ -191,7 +194,7 @@ def test_grouped_weight_gradients_equal_the_per_product_schedule_and_reports_fol
             assert all(pending == 0 for _, pending in seen), "a report ran while its weight gradients were still queued"
             # 2 encoder layers x (qkv, out, ffn1, ffn2) + 2 decoder layers x (qkv, out, q, out, ffn1, ffn2); the cross-attention
             # k|v projections and the front dense layer (long, few tiles) stay on the per-product path
-            assert len(launches) == 1 and sum(launches) == 2 * 4 + 2 * 6, launches
+            assert launches == ([2 * 6, 2 * 4] if dec_side else [2 * 4 + 2 * 6]), launches
     assert torch.equal(grads[0], grads[1])
     assert reports[0] == reports[1]
 
@@ -1201,3 +1204,16 @@ def test_dynamic_loss_scale_together_with_clipping(cpu_kernels, clip):
     step(_speech_inputs(shape, 99))
     model.backward = orig
     assert float(step._ls_state[2]) == 0.0 and torch.equal(model.store.master, before)
+
+
+def test_decoder_group_goes_to_the_weight_gradient_stream_only_when_its_products_are_short(monkeypatch):
+    """encoder_decoder_model._decoder_group_on_side: the rule is rows(decoder) <= rows(encoder) / 2 (speech: 75 target positions
+    against 225 encoder frames per utterance -> yes; text models with equal lengths -> no); tests may pin it."""
+    from neurst_amd.models import encoder_decoder_model as M
+    monkeypatch.setattr(M, "_WGRAD_DECODER_SIDE", None)
+    assert M._decoder_group_on_side(torch.empty(128, 75, 256), torch.empty(128, 225, 256))
+    assert M._decoder_group_on_side(torch.empty(4, 10, 8), torch.empty(4, 20, 8))
+    assert not M._decoder_group_on_side(torch.empty(256, 64, 512), torch.empty(256, 64, 512))
+    assert not M._decoder_group_on_side(torch.empty(4, 11, 8), torch.empty(4, 20, 8))
+    monkeypatch.setattr(M, "_WGRAD_DECODER_SIDE", True)
+    assert M._decoder_group_on_side(torch.empty(256, 64, 512), torch.empty(256, 64, 512))
