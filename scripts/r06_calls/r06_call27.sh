@@ -1,0 +1,9 @@
+#!/bin/bash
+# call 27: decoder weight-gradient group in pieces during the decoder's backward (temporary NST_DEC_GROUP_EVERY = layers per launch)
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out/r06
+ms() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3))"; }
+one() { python bench.py --steps 10 --warmup 3 --no-cpu-baseline --roofline-steps 0 2>/dev/null | ms; }
+for i in 1 2 3; do
+  echo "once: $(one)  every 3: $(NST_DEC_GROUP_EVERY=3 one)  every 2: $(NST_DEC_GROUP_EVERY=2 one)  every 1: $(NST_DEC_GROUP_EVERY=1 one)"
+done | tee gpurun_out/r06/c27_dec_group_pieces.log
