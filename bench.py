@@ -77,6 +77,9 @@ def parse():
                     help="N > 1 only: skip the short child runs that choose {hardware queues per class} x {RCCL channels} x "
                          "{exchange carrier} before the timed run (the variables are read when HIP / RCCL initialise, so each "
                          "candidate needs fresh processes; every candidate and the choice are reported under `autotune`)")
+    ap.add_argument("--caller-stream", action="store_true",
+                    help="call the step from the default stream (a hand-over to the step's stream and back per call) instead of "
+                         "running the loop on the step's stream")
     ap.add_argument("--autotune-budget", type=float, default=240.0, help="wall-clock cap of all autotune child runs, seconds")
     ap.add_argument("--autotune-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -433,6 +436,11 @@ def main():
         main_stream = torch.cuda.Stream(device=dev, priority=args.main_stream_priority)
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)
+    elif step_fn.stream is not None and not args.caller_stream:
+        # the batches are resident: the loop runs ON the step's stream, so a call needs no hand-over between the caller's stream
+        # and the step's (two event waits per step, ~30 us of idle GPU in the trace of round 6); --caller-stream: the old loop
+        step_fn.stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(step_fn.stream)
 
     verbose = os.environ.get("NST_BENCH_VERBOSE", "0") == "1"
     for i in range(args.warmup):

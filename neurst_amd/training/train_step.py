@@ -251,6 +251,13 @@ class TrainStep(object):
             self.optimizer.apply_gradients(grad_scale=scale, lr_t_dev=lr_t_dev)
         return loss_sum / n
 
+    @property
+    def stream(self):
+        """The high-priority stream the step runs on (None: whatever stream is current when the step is called).  A loop whose
+        batches are already resident may make it the CURRENT stream: a call from another stream hands over through two event
+        waits (caller -> step stream -> caller), ~30 us of idle GPU per step in the graph-replayed benchmark loop."""
+        return self._step_stream
+
     def __call__(self, batches):
         """batches: one model-input dict, or a list of `update_cycle` dicts (gradient accumulation: the mean of
         the micro-batch gradients, GradientAccumulator semantics gradaccum_keras_model.py:62-109)."""
