@@ -243,7 +243,7 @@ __device__ __forceinline__ void store_row4(T* row, int d, int dh, const floatx4_
 // forward.  One workgroup = 4 waves = 64*MI queries; wave w owns query blocks {mi*4 + w}.
 // =============================================================================================
 template <typename T, int MI, bool VEC>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
   typedef typename FragT<T>::type Frag;
   constexpr int VS_RS = sizeof(T) == 2 ? 160 : AT<T>::RS;   // V rows: laid out for the transpose reads (see tmul_acc)
   __shared__ __attribute__((aligned(16))) char smem[AT<T>::TILE_BYTES + TR * VS_RS + TR * 4];
@@ -401,6 +401,21 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
       if (g == 0) p.lse[bh * p.Tq + qg] = m_run[mi] * LN2 + logf(l);
     }
   }
+}
+
+template <typename T, int MI, bool VEC>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnParams p) {
+  attn_fwd_body<T, MI, VEC>(p);
+}
+// The same body held to OCC waves per SIMD (round 6).  The kernel is latency bound -- a tile is a chain global load -> LDS ->
+// barrier -> scores -> softmax -> barrier -- so resident waves are what hides it: the compiler's own choice for bf16 / one query
+// block per wave is 148 + 16 registers = three waves; asked for four it finds 122 without a spill and the encoder shape runs
+// 41 -> 38 us, the decoder shapes 11.7 -> 10.4 and 23.1 -> 21.0, the step 12.07 -> 12.01 ms (profiles/r06_history/c31_*, c32_*).
+// Five / six waves (96 / 80 registers) spill 41 - 86 registers and run 84 / 114 us.  Only this instantiation: the float32 and
+// two-block forms spill at 128 registers.
+template <bool VEC, int OCC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) attn_fwd_occ_kernel(AttnParams p) {
+  attn_fwd_body<bf16_t, 1, VEC>(p);
 }
 
 // =============================================================================================
@@ -1247,7 +1262,13 @@ extern "C" int nst_attention_fwd(const NstAttnDesc* d, const void* q, const void
   // one query block per wave (140 registers, three waves per SIMD) measured 0.07 ms per step faster than two (236
   // registers, two waves) at the benchmark shape: the kernel is latency-bound, occupancy beats reuse (NST_ATTN_MI_FWD=2)
   const int mi = pick_mi("NST_ATTN_MI_FWD", d->Tq, (int64_t)d->B * d->H, false);
-  NST_ATTN_DISPATCH(attn_fwd_kernel, d->Tq, mi, vec);
+  if (d->dtype == NST_BF16 && mi == 1) {   // four waves per SIMD instead of the compiler's three (attn_fwd_occ_kernel)
+    const dim3 grid((d->Tq + TR - 1) / TR, d->H, d->B);
+    if (vec) attn_fwd_occ_kernel<true, 4><<<grid, 256, 0, st>>>(p);
+    else attn_fwd_occ_kernel<false, 4><<<grid, 256, 0, st>>>(p);
+  } else {
+    NST_ATTN_DISPATCH(attn_fwd_kernel, d->Tq, mi, vec);
+  }
   NST_CHECK_LAUNCH("attention_fwd");
   return NST_OK;
 }
