@@ -1,4 +1,7 @@
 #!/bin/bash
+# RECORD of a round-6 experiment: the NST_* switch(es) this script sets existed only in the working tree of that experiment
+# (removed with it; the library now warns about them).  Kept for the log under profiles/r06_history/; it does not re-run.
+echo "$0: record of a removed experiment (see the header); not runnable against this tree" >&2; exit 1
 # Round 6, call 10: ablation of the whole-row products with cold caches (NST_ROWGEMM_DBG: 1 = no K loop, 2 = no row phase, 4 = no x prefetch)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 mkdir -p gpurun_out/r06

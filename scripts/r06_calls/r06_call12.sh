@@ -1,4 +1,7 @@
 #!/bin/bash
+# RECORD of a round-6 experiment: the NST_* switch(es) this script sets existed only in the working tree of that experiment
+# (removed with it; the library now warns about them).  Kept for the log under profiles/r06_history/; it does not re-run.
+echo "$0: record of a removed experiment (see the header); not runnable against this tree" >&2; exit 1
 # Round 6, call 12: the two-ring form of the whole-row products (A and weight streams in separate rings / waves): parity with the
 # form forced, cold-cache timings against the first form, step A/B; the split feed-forward pair's tests again
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"

@@ -1,4 +1,7 @@
 #!/bin/bash
+# RECORD of a round-6 experiment: the NST_* switch(es) this script sets existed only in the working tree of that experiment
+# (removed with it; the library now warns about them).  Kept for the log under profiles/r06_history/; it does not re-run.
+echo "$0: record of a removed experiment (see the header); not runnable against this tree" >&2; exit 1
 # call 23: decoder weight-gradient group on the weight-gradient stream behind the decoder: text models, speech_transformer_m, ragged
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/r06
