@@ -232,3 +232,35 @@ def test_capture_survives_garbage_of_an_earlier_captured_step():
     finally:
         gc.set_threshold(*old)
     assert gc.isenabled() and step2.replays >= 1 and all(l == l for l in losses)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--caller-stream"]])
+def test_bench_line_carries_the_contract_fields(extra):
+    """bench.py as the driver runs it (one JSON line on stdout): the fields of the measurement contract, the roofline object of the
+    dominant kernel family measured live, and both loops (on the step's own stream -- the default -- and called from the default
+    stream) complete with a finite loss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
+                          "--no-cpu-baseline", "--roofline-steps", "1"] + extra,
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["unit"] == "frames/s" and d["vs_baseline"] is None
+    assert "speech_transformer_s" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - 128 * 900 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["final_loss"] == d["final_loss"] and 0.0 < d["final_loss"] < 20.0
